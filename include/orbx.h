@@ -1,0 +1,223 @@
+/*
+ * orbx.h — C ABI of the MI355X-native hot path of jurmy24/orb-slam3-rust.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer of
+ * its own: the path sits behind ordinary Rust `pub fn`s whose arguments are OpenCV
+ * wrapper types.  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference crate root); INTEGRATION.md shows the Rust
+ * `extern "C"` block and the shim that re-creates the original signatures on top.
+ *
+ * Conventions
+ *   - return 0 (ORBX_OK) on success, a negative ORBX_ERR_* otherwise;
+ *     orbx_last_error(h) gives a human-readable message for the last failure
+ *     (maps to `anyhow::Error` / `None` on the Rust side).
+ *   - plain pointers and sizes only; no C++ or torch types.
+ *   - the caller owns every buffer; capacities go in, counts come out.
+ *     A result that does not fit its capacity is an error (ORBX_ERR_CAPACITY),
+ *     never a silent truncation.
+ *   - a handle is NOT thread-safe (mirrors `&mut self`, stereo.rs:52); use one
+ *     handle per thread.  Each handle owns one HIP stream on its device.
+ *   - `*_device` entry points take device pointers (memory of the handle's GPU)
+ *     and are asynchronous on the handle's stream unless stated; the others take
+ *     host pointers, copy in/out, and return when the results are in the buffers.
+ *   - there is NO CPU fallback: every entry point fails with ORBX_ERR_NO_DEVICE
+ *     when no gfx950 device can be opened.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_ABI_VERSION 1
+
+enum {
+  ORBX_OK = 0,
+  ORBX_ERR_INVALID = -1,   /* bad argument (null pointer, size out of range)        */
+  ORBX_ERR_NO_DEVICE = -2, /* no usable HIP device / wrong architecture             */
+  ORBX_ERR_HIP = -3,       /* a HIP runtime call failed (see orbx_last_error)       */
+  ORBX_ERR_CAPACITY = -4,  /* a result did not fit the capacity the caller gave     */
+  ORBX_ERR_NUMERIC = -5,   /* BA: reduced system not positive definite (LU failure
+                              in the reference, local_ba_lm.rs:1036-1039)           */
+  ORBX_ERR_EMPTY = -6      /* BA: no parameters or no residuals -> reference returns
+                              None (local_ba_lm.rs:923-925)                         */
+};
+
+/* = tracking::frame::CameraModel, src/tracking/frame/camera.rs:3-10 */
+typedef struct {
+  double fx, fy, cx, cy, baseline;
+} orbx_camera;
+
+/* = the nine cv::ORB::create arguments, src/tracking/frame/stereo.rs:38-48.
+ * Only the reference's configuration is implemented: n_levels <= 8... any
+ * n_features, scale_factor 1.2f, edge_threshold 31, first_level 0, wta_k 2,
+ * score_type 0 (HARRIS_SCORE), patch_size 31; other values -> ORBX_ERR_INVALID. */
+typedef struct {
+  int n_features;
+  float scale_factor;
+  int n_levels, edge_threshold, first_level, wta_k, score_type, patch_size, fast_threshold;
+} orbx_orb_params;
+
+/* = cv::KeyPoint as seen through opencv::core::KeyPoint (28 bytes) */
+typedef struct {
+  float x, y, size, angle, response;
+  int octave, class_id;
+} orbx_keypoint;
+
+/* = cv::DMatch (16 bytes); field order of the Rust struct literal at stereo.rs:149-154 */
+typedef struct {
+  int query_idx, train_idx, img_idx;
+  float distance;
+} orbx_dmatch;
+
+typedef struct orbx_handle orbx_handle;
+
+const char* orbx_version(void);
+const char* orbx_last_error(const orbx_handle* h);
+
+/* Fills *p with the reference's ORB configuration (stereo.rs:38-48) for n_features. */
+void orbx_default_orb_params(int n_features, orbx_orb_params* p);
+
+/* Replaces StereoProcessor::new (stereo.rs:37-50).  `max_batch` = the largest number of
+ * stereo pairs one *_batch_device call will carry (>= 1); max_w/max_h bound image size. */
+int orbx_create(const orbx_camera* cam, const orbx_orb_params* orb, int device, int max_w,
+                int max_h, int max_batch, orbx_handle** out);
+void orbx_destroy(orbx_handle* h);
+
+/* The handle's hipStream_t (as void*), so a host framework can order its own work
+ * (copies, collectives) against the library's. */
+void* orbx_stream(orbx_handle* h);
+int orbx_synchronize(orbx_handle* h);
+
+/* ---- per-frame feature pipeline ------------------------------------------------ */
+
+/* Replaces StereoProcessor::process (stereo.rs:52-66) for one stereo pair held in host
+ * memory: extract L, extract R (cv::ORB::detectAndCompute, stereo.rs:68-78), match
+ * (stereo.rs:80-161), triangulate (stereo.rs:186-216).
+ *   left/right: CV_8UC1 rows of `w` pixels, row strides in bytes.
+ *   kpL/kpR [cap_kp], descL/descR [cap_kp*32], matches [cap_kp], points_cam [cap_kp*3],
+ *   has_point [cap_kp] (1 = Some, 0 = None; points_cam left untouched where 0). */
+int orbx_process_stereo(orbx_handle* h, const uint8_t* left, size_t lstride, const uint8_t* right,
+                        size_t rstride, int w, int h_px, orbx_keypoint* kpL, uint8_t* descL,
+                        int* nL, orbx_keypoint* kpR, uint8_t* descR, int* nR, int cap_kp,
+                        orbx_dmatch* matches, int* n_matches, double* points_cam,
+                        uint8_t* has_point);
+
+/* Same path for `batch` stereo pairs resident in device memory (the throughput form).
+ *   d_images: [batch][2][h_px][stride] u8, left then right of each pair.
+ *   d_kp [batch][2][cap_kp], d_desc [batch][2][cap_kp][32], d_nkp [batch][2],
+ *   d_matches [batch][cap_kp], d_nmatches [batch], d_points [batch][cap_kp][3],
+ *   d_has_point [batch][cap_kp].
+ * Asynchronous; call orbx_check_status (synchronises) before trusting the results. */
+int orbx_process_stereo_batch_device(orbx_handle* h, const uint8_t* d_images, int batch, int w,
+                                     int h_px, size_t stride, orbx_keypoint* d_kp,
+                                     uint8_t* d_desc, int* d_nkp, int cap_kp,
+                                     orbx_dmatch* d_matches, int* d_nmatches, double* d_points,
+                                     uint8_t* d_has_point);
+
+/* Extraction alone (= detect_features, stereo.rs:68-78) for `n_images` device images
+ * [n_images][h_px][stride]; outputs as above with one slot per image. */
+int orbx_extract_batch_device(orbx_handle* h, const uint8_t* d_images, int n_images, int w,
+                              int h_px, size_t stride, orbx_keypoint* d_kp, uint8_t* d_desc,
+                              int* d_nkp, int cap_kp);
+
+/* Synchronises the stream and returns the sticky device-side status of the calls
+ * since the last check (ORBX_OK or ORBX_ERR_CAPACITY ...), then clears it. */
+int orbx_check_status(orbx_handle* h);
+
+/* ---- matchers ------------------------------------------------------------------- */
+
+/* = StereoProcessor::match_features + triangulate (stereo.rs:80-161, 186-216) on feature
+ * sets the caller already has (host memory).  Uses the handle's CameraModel. */
+int orbx_stereo_match(orbx_handle* h, const orbx_keypoint* kpL, const uint8_t* descL, int nL,
+                      const orbx_keypoint* kpR, const uint8_t* descR, int nR,
+                      orbx_dmatch* matches, int* n_matches, double* points_cam,
+                      uint8_t* has_point);
+
+/* Device form, `batch` independent pairs; per-pair slots of cap_kp as in
+ * orbx_process_stereo_batch_device. */
+int orbx_stereo_match_batch_device(orbx_handle* h, int batch, const orbx_keypoint* d_kp,
+                                   const uint8_t* d_desc, const int* d_nkp, int cap_kp,
+                                   orbx_dmatch* d_matches, int* d_nmatches, double* d_points,
+                                   uint8_t* d_has_point);
+
+/* = BFMatcher::new(NORM_HAMMING, crossCheck=true).train_match(query, train)
+ * (src/tracking/tracker.rs:1001-1010): mutual nearest neighbours, ascending query index,
+ * lowest index wins distance ties.  q [nq][32], t [nt][32], out [nq] (host memory). */
+int orbx_hamming_match_crosscheck(orbx_handle* h, const uint8_t* q, int nq, const uint8_t* t,
+                                  int nt, orbx_dmatch* out, int* n_out);
+int orbx_hamming_match_crosscheck_device(orbx_handle* h, const uint8_t* d_q, int nq,
+                                         const uint8_t* d_t, int nt, orbx_dmatch* d_out,
+                                         int* d_n_out);
+
+/* = descriptor_distance (stereo.rs:166-175) over n_pairs rows: out[i] = popcount(a[i]^b[i])
+ * over 32 bytes.  Host memory. */
+int orbx_hamming_batch(orbx_handle* h, const uint8_t* a, const uint8_t* b, int n_pairs,
+                       uint32_t* out);
+int orbx_hamming_batch_device(orbx_handle* h, const uint8_t* d_a, const uint8_t* d_b, int n_pairs,
+                              uint32_t* d_out);
+
+/* ---- local bundle adjustment ------------------------------------------------------ */
+
+/* = LocalBAConfigLM, src/optimizer/local_ba_lm.rs:96-119 */
+typedef struct {
+  int max_iterations;
+  double param_tolerance, gradient_tolerance, huber_threshold;
+  int max_covisible_keyframes;
+} orbx_ba_config;
+
+/* One VisualObservation (local_ba_lm.rs:68-78) after the id -> index re-keying the
+ * reference does at :928-961.  kf_idx >= 0: optimised keyframe (is_kf_optimized);
+ * kf_idx < 0: fixed keyframe `fixed_idx` (fixed_idx < 0 = unknown id -> identity pose,
+ * local_ba_lm.rs:569). */
+typedef struct {
+  int32_t kf_idx, fixed_idx, mp_idx, _pad;
+  double u, v;
+} orbx_ba_obs;
+
+void orbx_default_ba_config(orbx_ba_config* c);
+
+/* = `&dyn Fn() -> bool` of solve_visual_ba; polled once at the top of each LM iteration
+ * (local_ba_lm.rs:1013).  NULL = never stop. */
+typedef int (*orbx_should_stop_fn)(void* user);
+
+/* Collective hook for the point-partitioned multi-GPU form: sum `n`
+ * doubles at device pointer `d_buf` in place over all ranks, ordered on `hip_stream`.
+ * The host framework implements it (torch.distributed / RCCL).  NULL = single GPU. */
+typedef int (*orbx_allreduce_fn)(void* user, void* d_buf, size_t n, void* hip_stream);
+int orbx_ba_set_allreduce(orbx_handle* h, orbx_allreduce_fn fn, void* user);
+
+/* Replaces solve_visual_ba (local_ba_lm.rs:912-1098).
+ *   poses_cw [K][7]  (qw,qx,qy,qz,tx,ty,tz) T_cw of the optimised keyframes (:966-977)
+ *   fixed_poses_cw [F][7]  T_cw of anchor + other fixed observers
+ *   points [M][3] in/out   map-point positions (:980-987 / :1079-1089)
+ *   obs [N]
+ *   poses_wc_out [K][7]    optimised poses inverted back to T_wc (:1062-1077)
+ * Everything is f64.  With an allreduce hook set, `obs` holds this rank's partition of the
+ * observations (all observations of the points it owns); poses, points and the scalars come
+ * out identical on every rank. */
+int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+                         const double* poses_cw, int F, const double* fixed_poses_cw, int M,
+                         double* points, int N, const orbx_ba_obs* obs,
+                         orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
+                         int* iterations, double* initial_error, double* final_error);
+
+/* Per-kernel device time of the last call, for bench.py's roofline block.  Fills up to
+ * `cap` entries; returns the number available.  Times are HIP-event durations on the
+ * handle's stream; profiling must have been switched on with orbx_set_profiling. */
+typedef struct {
+  char name[48];
+  float ms;          /* summed duration of this kernel's launches in the last call */
+  int launches;
+} orbx_kernel_time;
+int orbx_set_profiling(orbx_handle* h, int on);
+int orbx_get_kernel_times(orbx_handle* h, orbx_kernel_time* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,13 @@
+"""orb-slam3-rust_amd — MI355X-native (gfx950) hot path of jurmy24/orb-slam3-rust:
+stereo ORB extract + match + triangulate and visual local bundle adjustment, as hand-written HIP
+kernels behind the C ABI of include/orbx.h.  See DESIGN.md / INTEGRATION.md.
+
+Import as `orb_slam3_rust_amd` (the shim at the repo root maps the hyphenated directory name).
+"""
+from . import synth  # noqa: F401
+from .api import (  # noqa: F401
+    ABI_SYMBOLS, BA_OBS, DMATCH, KEYPOINT, NN_RATIO, TH_HIGH, TH_LOW, CameraModel, FeatureSet, Handle,
+    LocalBAConfigLM, OrbxError, StereoFrame, StereoProcessor, VisualBAProblemData, VisualBAResultData,
+    VisualObservation, bf_match_crosscheck, descriptor_distance, flatten_ba_problem, load_library,
+    solve_visual_ba)
+from .build import LIB_PATH, build  # noqa: F401

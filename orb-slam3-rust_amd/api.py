@@ -1,0 +1,472 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the C ABI.
+
+Rust is not in the toolchain here, so the thin host layer a Rust shim would be is
+written in Python with the reference's own names and argument meaning:
+
+    reference (Rust)                                     here
+    ---------------------------------------------------  -----------------------------------------
+    CameraModel                  camera.rs:3-10          CameraModel
+    StereoProcessor::new/process stereo.rs:37,52         StereoProcessor(camera, n_features).process
+    FeatureSet / StereoFrame     stereo.rs:15-29         FeatureSet / StereoFrame
+    descriptor_distance          stereo.rs:166           descriptor_distance
+    BFMatcher(HAMMING,true)      tracker.rs:1001-1010    bf_match_crosscheck
+    LocalBAConfigLM              local_ba_lm.rs:96-119   LocalBAConfigLM
+    VisualBAProblemData/Result   local_ba_lm.rs:48-93    VisualBAProblemData / VisualBAResultData
+    solve_visual_ba              local_ba_lm.rs:912      solve_visual_ba
+
+Everything computes on the GPU through liborbx_hip.so; there is no CPU fallback, and a missing
+library or device raises.
+"""
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from .build import LIB_PATH
+
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH = np.dtype([("query_idx", "<i4"), ("train_idx", "<i4"), ("img_idx", "<i4"),
+                   ("distance", "<f4")])
+BA_OBS = np.dtype([("kf_idx", "<i4"), ("fixed_idx", "<i4"), ("mp_idx", "<i4"), ("_pad", "<i4"),
+                   ("u", "<f8"), ("v", "<f8")])
+
+ORBX_OK, ORBX_ERR_INVALID, ORBX_ERR_NO_DEVICE, ORBX_ERR_HIP = 0, -1, -2, -3
+ORBX_ERR_CAPACITY, ORBX_ERR_NUMERIC, ORBX_ERR_EMPTY = -4, -5, -6
+
+# ORB-SLAM3 matching thresholds, stereo.rs:10-12
+TH_HIGH, TH_LOW, NN_RATIO = 100, 50, 0.75
+
+# every symbol include/orbx.h declares
+ABI_SYMBOLS = [
+    "orbx_version", "orbx_last_error", "orbx_default_orb_params", "orbx_create", "orbx_destroy",
+    "orbx_stream", "orbx_synchronize", "orbx_process_stereo", "orbx_process_stereo_batch_device",
+    "orbx_extract_batch_device", "orbx_check_status", "orbx_stereo_match",
+    "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
+    "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual",
+    "orbx_set_profiling", "orbx_get_kernel_times",
+]
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Camera(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "baseline")]
+
+
+class _OrbParams(C.Structure):
+    _fields_ = [("n_features", C.c_int), ("scale_factor", C.c_float), ("n_levels", C.c_int),
+                ("edge_threshold", C.c_int), ("first_level", C.c_int), ("wta_k", C.c_int),
+                ("score_type", C.c_int), ("patch_size", C.c_int), ("fast_threshold", C.c_int)]
+
+
+class _BaConfig(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("param_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("huber_threshold", C.c_double),
+                ("max_covisible_keyframes", C.c_int)]
+
+
+class _KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("launches", C.c_int)]
+
+
+SHOULD_STOP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+_lib = None
+
+
+def load_library():
+    """dlopen liborbx_hip.so.  Raises if it has not been built: the product has no other path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "liborbx_hip.so is missing (%s): build it with __graft_entry__.build(); "
+                "this package has no CPU or PyTorch fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.orbx_version.restype = C.c_char_p
+        L.orbx_last_error.restype = C.c_char_p
+        L.orbx_last_error.argtypes = [C.c_void_p]
+        L.orbx_stream.restype = C.c_void_p
+        L.orbx_stream.argtypes = [C.c_void_p]
+        L.orbx_destroy.argtypes = [C.c_void_p]
+        L.orbx_destroy.restype = None
+        for name in ABI_SYMBOLS:
+            getattr(L, name)
+        _lib = L
+    return _lib
+
+
+def _vp(x):
+    """void* from a numpy array, an int device pointer, a torch tensor, or None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data_as(C.c_void_p)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.data_ptr())
+
+
+@dataclass
+class CameraModel:
+    """camera.rs:3-10"""
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    baseline: float
+
+    def _c(self):
+        return _Camera(self.fx, self.fy, self.cx, self.cy, self.baseline)
+
+
+@dataclass
+class LocalBAConfigLM:
+    """local_ba_lm.rs:96-119 (Default impl :109-119)"""
+    max_iterations: int = 10
+    param_tolerance: float = 1e-8
+    gradient_tolerance: float = 1e-8
+    huber_threshold: float = math.sqrt(5.991)
+    max_covisible_keyframes: int = 20
+
+    def _c(self):
+        return _BaConfig(self.max_iterations, self.param_tolerance, self.gradient_tolerance,
+                         self.huber_threshold, self.max_covisible_keyframes)
+
+
+@dataclass
+class FeatureSet:
+    """stereo.rs:15-19: keypoints (KEYPOINT records) + descriptors [N,32] u8"""
+    keypoints: np.ndarray
+    descriptors: np.ndarray
+
+
+@dataclass
+class StereoFrame:
+    """stereo.rs:21-29.  points_cam is [nL,3] f64 with `has_point` as the Option mask."""
+    left_features: FeatureSet
+    right_features: FeatureSet
+    matches_lr: np.ndarray
+    points_cam: np.ndarray
+    has_point: np.ndarray
+    timestamp_ns: int
+
+    def points_cam_options(self) -> List[Optional[np.ndarray]]:
+        return [self.points_cam[i] if self.has_point[i] else None for i in range(len(self.has_point))]
+
+
+class Handle:
+    """Owns one orbx_handle (one HIP stream on one device).  Not thread-safe, like `&mut self`."""
+
+    def __init__(self, camera: CameraModel, n_features: int, device: int = 0, max_w: int = 752,
+                 max_h: int = 480, max_batch: int = 1, orb_params=None):
+        L = load_library()
+        self._L = L
+        p = _OrbParams()
+        L.orbx_default_orb_params(C.c_int(n_features), C.byref(p))
+        if orb_params:
+            for k, v in orb_params.items():
+                setattr(p, k, v)
+        self.orb_params = p
+        self.camera = camera
+        self._h = C.c_void_p()
+        cam = camera._c()
+        rc = L.orbx_create(C.byref(cam), C.byref(p), C.c_int(device), C.c_int(max_w), C.c_int(max_h),
+                           C.c_int(max_batch), C.byref(self._h))
+        if rc != 0:
+            raise OrbxError(rc, L.orbx_last_error(None).decode())
+        self.device = device
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise OrbxError(rc, self._L.orbx_last_error(self._h).decode())
+
+    @property
+    def stream(self):
+        return self._L.orbx_stream(self._h)
+
+    def synchronize(self):
+        self._check(self._L.orbx_synchronize(self._h))
+
+    def check_status(self):
+        self._check(self._L.orbx_check_status(self._h))
+
+    def set_profiling(self, on=True):
+        self._check(self._L.orbx_set_profiling(self._h, C.c_int(1 if on else 0)))
+
+    def kernel_times(self):
+        arr = (_KernelTime * 64)()
+        n = self._L.orbx_get_kernel_times(self._h, arr, C.c_int(64))
+        return {arr[i].name.decode(): (arr[i].ms, arr[i].launches) for i in range(min(n, 64))}
+
+    # ---- host-buffer entry points -------------------------------------------------------------
+    def process_stereo(self, left, right, cap_kp=None):
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        if left.ndim != 2 or left.shape != right.shape:
+            raise ValueError("left/right must be 2-d u8 images of equal size")
+        hh, ww = left.shape
+        cap = cap_kp or (self.orb_params.n_features + 2048)
+        kpL = np.zeros(cap, KEYPOINT); kpR = np.zeros(cap, KEYPOINT)
+        dL = np.zeros((cap, 32), np.uint8); dR = np.zeros((cap, 32), np.uint8)
+        m = np.zeros(cap, DMATCH); pts = np.zeros((cap, 3), np.float64); has = np.zeros(cap, np.uint8)
+        nL = C.c_int(); nR = C.c_int(); nm = C.c_int()
+        self._check(self._L.orbx_process_stereo(
+            self._h, _vp(left), C.c_size_t(left.strides[0]), _vp(right), C.c_size_t(right.strides[0]),
+            C.c_int(ww), C.c_int(hh), _vp(kpL), _vp(dL), C.byref(nL), _vp(kpR), _vp(dR), C.byref(nR),
+            C.c_int(cap), _vp(m), C.byref(nm), _vp(pts), _vp(has)))
+        return (kpL[:nL.value].copy(), dL[:nL.value].copy(), kpR[:nR.value].copy(), dR[:nR.value].copy(),
+                m[:nm.value].copy(), pts[:nL.value].copy(), has[:nL.value].copy())
+
+    def stereo_match(self, kpL, descL, kpR, descR):
+        kpL = np.ascontiguousarray(kpL, KEYPOINT); kpR = np.ascontiguousarray(kpR, KEYPOINT)
+        descL = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+        descR = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+        nL, nR = len(kpL), len(kpR)
+        m = np.zeros(max(nL, 1), DMATCH); pts = np.zeros((max(nL, 1), 3)); has = np.zeros(max(nL, 1), np.uint8)
+        nm = C.c_int()
+        self._check(self._L.orbx_stereo_match(self._h, _vp(kpL), _vp(descL), C.c_int(nL), _vp(kpR),
+                                              _vp(descR), C.c_int(nR), _vp(m), C.byref(nm), _vp(pts), _vp(has)))
+        return m[:nm.value].copy(), pts[:nL].copy(), has[:nL].copy()
+
+    def hamming_match_crosscheck(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros(max(len(q), 1), DMATCH)
+        n = C.c_int()
+        self._check(self._L.orbx_hamming_match_crosscheck(self._h, _vp(q), C.c_int(len(q)), _vp(t),
+                                                          C.c_int(len(t)), _vp(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def hamming_batch(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        if len(a) != len(b):
+            raise ValueError("hamming_batch: row counts differ")
+        out = np.zeros(len(a), np.uint32)
+        self._check(self._L.orbx_hamming_batch(self._h, _vp(a), _vp(b), C.c_int(len(a)), _vp(out)))
+        return out
+
+    # ---- device-resident batch entry points (torch tensors on this handle's GPU) ----------------
+    def alloc_batch_outputs(self, batch, cap_kp):
+        import torch
+        dev = torch.device("cuda", self.device)
+        return dict(
+            kp=torch.zeros((batch, 2, cap_kp, 7), dtype=torch.float32, device=dev),
+            desc=torch.zeros((batch, 2, cap_kp, 32), dtype=torch.uint8, device=dev),
+            nkp=torch.zeros((batch, 2), dtype=torch.int32, device=dev),
+            matches=torch.zeros((batch, cap_kp, 4), dtype=torch.int32, device=dev),
+            nmatches=torch.zeros((batch,), dtype=torch.int32, device=dev),
+            points=torch.zeros((batch, cap_kp, 3), dtype=torch.float64, device=dev),
+            has_point=torch.zeros((batch, cap_kp), dtype=torch.uint8, device=dev),
+            cap_kp=cap_kp, batch=batch)
+
+    def process_stereo_batch_device(self, images, out):
+        """images: torch u8 [batch,2,h,w] on the GPU; out: alloc_batch_outputs().  Asynchronous."""
+        b, two, hh, ww = images.shape
+        assert two == 2 and images.is_contiguous() and b <= out["batch"]
+        self._check(self._L.orbx_process_stereo_batch_device(
+            self._h, _vp(images), C.c_int(b), C.c_int(ww), C.c_int(hh), C.c_size_t(ww), _vp(out["kp"]),
+            _vp(out["desc"]), _vp(out["nkp"]), C.c_int(out["cap_kp"]), _vp(out["matches"]),
+            _vp(out["nmatches"]), _vp(out["points"]), _vp(out["has_point"])))
+
+    def extract_batch_device(self, images, out):
+        """images: torch u8 [n,h,w]; writes out['kp'|'desc'|'nkp'] viewed as n slots."""
+        n, hh, ww = images.shape
+        assert images.is_contiguous() and n <= 2 * out["batch"]
+        self._check(self._L.orbx_extract_batch_device(
+            self._h, _vp(images), C.c_int(n), C.c_int(ww), C.c_int(hh), C.c_size_t(ww), _vp(out["kp"]),
+            _vp(out["desc"]), _vp(out["nkp"]), C.c_int(out["cap_kp"])))
+
+    def stereo_match_batch_device(self, out, batch=None):
+        b = batch or out["batch"]
+        self._check(self._L.orbx_stereo_match_batch_device(
+            self._h, C.c_int(b), _vp(out["kp"]), _vp(out["desc"]), _vp(out["nkp"]), C.c_int(out["cap_kp"]),
+            _vp(out["matches"]), _vp(out["nmatches"]), _vp(out["points"]), _vp(out["has_point"])))
+
+    @staticmethod
+    def unpack_batch_outputs(out, b):
+        """Host copies of pair `b` in the reference's containers (synchronise first)."""
+        nkp = out["nkp"][b].cpu().numpy()
+        kp = out["kp"][b].cpu().numpy()
+        desc = out["desc"][b].cpu().numpy()
+        nm = int(out["nmatches"][b].item())
+        res = []
+        for s in range(2):
+            k = np.ascontiguousarray(kp[s, :nkp[s]]).view(np.uint8).reshape(-1, 28).copy().view(KEYPOINT).reshape(-1)
+            res.append(FeatureSet(k, desc[s, :nkp[s]].copy()))
+        m = np.ascontiguousarray(out["matches"][b, :nm].cpu().numpy()).view(np.uint8).reshape(-1, 16).copy().view(DMATCH).reshape(-1)
+        pts = out["points"][b, :nkp[0]].cpu().numpy()
+        has = out["has_point"][b, :nkp[0]].cpu().numpy()
+        return res[0], res[1], m, pts, has
+
+    # ---- BA -----------------------------------------------------------------------------------------
+    def set_allreduce(self, fn):
+        """fn(dev_ptr:int, n_doubles:int, hip_stream:int) -> None, or None to clear."""
+        if fn is None:
+            self._ar = None
+            self._check(self._L.orbx_ba_set_allreduce(self._h, None, None))
+            return
+
+        def tramp(user, ptr, n, stream):
+            try:
+                fn(int(ptr), int(n), int(stream) if stream else 0)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._ar = ALLREDUCE_FN(tramp)
+        self._check(self._L.orbx_ba_set_allreduce(self._h, self._ar, None))
+
+    def ba_solve_visual(self, camera, cfg, poses_cw, fixed_cw, points, obs, should_stop=None):
+        poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)
+        fixed_cw = np.ascontiguousarray(fixed_cw, np.float64).reshape(-1, 7)
+        pts = np.array(points, np.float64, copy=True).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs, BA_OBS)
+        K, F, M, N = len(poses_cw), len(fixed_cw), len(pts), len(obs)
+        out_wc = np.zeros((max(K, 1), 7))
+        it = C.c_int(); e0 = C.c_double(); e1 = C.c_double()
+        cb = SHOULD_STOP_FN((lambda user: 1 if should_stop() else 0)) if should_stop else C.cast(None, SHOULD_STOP_FN)
+        cam = camera._c(); c = cfg._c()
+        rc = self._L.orbx_ba_solve_visual(self._h, C.byref(cam), C.byref(c), C.c_int(K), _vp(poses_cw),
+                                          C.c_int(F), _vp(fixed_cw), C.c_int(M), _vp(pts), C.c_int(N),
+                                          _vp(obs), cb, None, _vp(out_wc), C.byref(it), C.byref(e0), C.byref(e1))
+        if rc in (ORBX_ERR_EMPTY,):
+            return None                      # reference returns None, local_ba_lm.rs:923-925
+        self._check(rc)
+        return dict(poses_wc=out_wc[:K], points=pts, iterations=it.value, initial_error=e0.value,
+                    final_error=e1.value)
+
+
+class StereoProcessor:
+    """stereo.rs:31-66.  `new` = the constructor; `process` takes two grayscale u8 images."""
+
+    def __init__(self, camera: CameraModel, n_features: int, device: int = 0, max_w: int = 1920,
+                 max_h: int = 1080):
+        self.camera = camera
+        self.handle = Handle(camera, n_features, device=device, max_w=max_w, max_h=max_h, max_batch=1)
+
+    @classmethod
+    def new(cls, camera: CameraModel, n_features: int, **kw):
+        return cls(camera, n_features, **kw)
+
+    def process(self, left, right, timestamp_ns: int) -> StereoFrame:
+        kpL, dL, kpR, dR, m, pts, has = self.handle.process_stereo(left, right)
+        return StereoFrame(FeatureSet(kpL, dL), FeatureSet(kpR, dR), m, pts, has, int(timestamp_ns))
+
+
+_default_handle = None
+
+
+def _handle():
+    global _default_handle
+    if _default_handle is None:
+        from .synth import EUROC_CAMERA
+        _default_handle = Handle(CameraModel(**EUROC_CAMERA), 2000)
+    return _default_handle
+
+
+def descriptor_distance(desc1, desc2) -> int:
+    """stereo.rs:166-175 for one pair of 32-byte rows (computed on the GPU)."""
+    return int(_handle().hamming_batch(np.asarray(desc1, np.uint8).reshape(1, 32),
+                                       np.asarray(desc2, np.uint8).reshape(1, 32))[0])
+
+
+def bf_match_crosscheck(query_descriptors, train_descriptors):
+    """tracker.rs:1001-1010: BFMatcher::new(NORM_HAMMING, true).train_match(query, train)."""
+    return _handle().hamming_match_crosscheck(query_descriptors, train_descriptors)
+
+
+@dataclass
+class VisualObservation:
+    """local_ba_lm.rs:68-78"""
+    kf_id: int
+    mp_id: int
+    observed_uv: tuple
+    is_kf_optimized: bool
+
+
+@dataclass
+class VisualBAProblemData:
+    """local_ba_lm.rs:48-65.  Poses are 7-vectors (qw,qx,qy,qz,tx,ty,tz), T_cw."""
+    local_kf_poses: Dict[int, np.ndarray]
+    local_mp_positions: Dict[int, np.ndarray]
+    fixed_kf_poses: Dict[int, np.ndarray]
+    anchor_kf_id: int
+    observations: List[VisualObservation]
+    optimized_kf_ids: List[int]
+    mp_ids: List[int]
+
+
+@dataclass
+class VisualBAResultData:
+    """local_ba_lm.rs:81-93.  optimized_poses are T_wc."""
+    optimized_poses: Dict[int, np.ndarray] = field(default_factory=dict)
+    optimized_points: Dict[int, np.ndarray] = field(default_factory=dict)
+    iterations: int = 0
+    initial_error: float = 0.0
+    final_error: float = 0.0
+
+
+def flatten_ba_problem(problem: VisualBAProblemData):
+    """The id -> index re-keying of local_ba_lm.rs:928-987 (what the Rust shim does before the FFI
+    call): observations whose map point is unknown are dropped (:947), an optimised-flagged
+    observation whose keyframe is not in optimized_kf_ids, or a fixed one whose id is not in
+    fixed_kf_poses, falls back to the identity pose (:569)."""
+    kf_idx = {k: i for i, k in enumerate(problem.optimized_kf_ids)}
+    mp_idx = {m: i for i, m in enumerate(problem.mp_ids)}
+    fixed_ids = list(problem.fixed_kf_poses.keys())
+    fixed_idx = {k: i for i, k in enumerate(fixed_ids)}
+    ident = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    # :966-977 leaves the parameters of a keyframe without a pose at zero = identity
+    poses = np.array([problem.local_kf_poses.get(k, ident) for k in problem.optimized_kf_ids],
+                     np.float64).reshape(-1, 7)
+    fixed = np.array([problem.fixed_kf_poses[k] for k in fixed_ids], np.float64).reshape(-1, 7)
+    pts = np.array([problem.local_mp_positions.get(m, np.zeros(3)) for m in problem.mp_ids],
+                   np.float64).reshape(-1, 3)
+    rows = []
+    for o in problem.observations:
+        if o.mp_id not in mp_idx:
+            continue
+        if o.is_kf_optimized and o.kf_id in kf_idx:
+            rows.append((kf_idx[o.kf_id], -1, mp_idx[o.mp_id], 0, o.observed_uv[0], o.observed_uv[1]))
+        else:
+            rows.append((-1, fixed_idx.get(o.kf_id, -1), mp_idx[o.mp_id], 0, o.observed_uv[0], o.observed_uv[1]))
+    return poses, fixed, pts, np.array(rows, BA_OBS)
+
+
+def solve_visual_ba(problem: VisualBAProblemData, camera: CameraModel, config: LocalBAConfigLM,
+                    should_stop: Callable[[], bool], handle: Handle = None) -> Optional[VisualBAResultData]:
+    """local_ba_lm.rs:912-1098."""
+    h = handle or _handle()
+    poses, fixed, pts, obs = flatten_ba_problem(problem)
+    r = h.ba_solve_visual(camera, config, poses, fixed, pts, obs, should_stop)
+    if r is None:
+        return None
+    return VisualBAResultData(
+        {k: r["poses_wc"][i] for i, k in enumerate(problem.optimized_kf_ids)},
+        {m: r["points"][i] for i, m in enumerate(problem.mp_ids)},
+        r["iterations"], r["initial_error"], r["final_error"])

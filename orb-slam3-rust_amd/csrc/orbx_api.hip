@@ -1,0 +1,418 @@
+// orbx_api.hip — the C ABI of include/orbx.h: handle lifetime, host<->device staging, status,
+// per-kernel timing.  Host logic only; kernels live in match_kernels.hip / orb_kernels.hip /
+// ba_kernels.hip.  There is no CPU fallback anywhere in this library.
+#include <mutex>
+
+#include "orbx_internal.hpp"
+
+static thread_local std::string g_create_error;
+
+int orbx_fail(orbx_handle* h, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+int orbx_reserve(orbx_handle* h, DevBuf& b, size_t bytes) {
+  if (bytes <= b.bytes) return ORBX_OK;
+  if (b.p) {
+    ORBX_HIP(h, hipStreamSynchronize(h->stream));
+    ORBX_HIP(h, hipFree(b.p));
+    b.p = nullptr; b.bytes = 0;
+  }
+  const size_t want = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+  ORBX_HIP(h, hipMalloc(&b.p, want));
+  b.bytes = want;
+  return ORBX_OK;
+}
+
+// ---- profiling --------------------------------------------------------------------------------------
+static hipEvent_t prof_event(orbx_handle* h) {
+  if (h->event_next == h->event_pool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    h->event_pool.push_back(e);
+  }
+  return h->event_pool[h->event_next++];
+}
+ProfScope::ProfScope(orbx_handle* h_, const char* name) : h(h_), idx(-1) {
+  if (!h->profiling) return;
+  for (size_t i = 0; i < h->timers.size(); ++i)
+    if (h->timers[i].name == name) { idx = (int)i; break; }
+  if (idx < 0) {
+    KernelTimer t;
+    t.name = name;
+    h->timers.push_back(t);
+    idx = (int)h->timers.size() - 1;
+  }
+  hipEvent_t e = prof_event(h);
+  hipEventRecord(e, h->stream);
+  h->timers[idx].ev.push_back(e);
+}
+ProfScope::~ProfScope() {
+  if (idx < 0) return;
+  hipEvent_t e = prof_event(h);
+  hipEventRecord(e, h->stream);
+  h->timers[idx].ev.push_back(e);
+}
+void orbx_prof_begin_call(orbx_handle* h) {
+  if (!h->profiling) return;
+  h->event_next = 0;
+  for (auto& t : h->timers) { t.ev.clear(); t.ms = 0.f; t.launches = 0; }
+}
+void orbx_prof_end_call(orbx_handle* h) { (void)h; }
+
+extern "C" {
+
+const char* orbx_version(void) { return "orbx-mi355x 0.1 (gfx950, abi 1)"; }
+
+const char* orbx_last_error(const orbx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void orbx_default_orb_params(int n_features, orbx_orb_params* p) {
+  // stereo.rs:38-48
+  p->n_features = n_features; p->scale_factor = 1.2f; p->n_levels = 8; p->edge_threshold = 31;
+  p->first_level = 0; p->wta_k = 2; p->score_type = 0; p->patch_size = 31; p->fast_threshold = 20;
+}
+
+void orbx_default_ba_config(orbx_ba_config* c) {
+  // LocalBAConfigLM::default, local_ba_lm.rs:109-119
+  c->max_iterations = 10; c->param_tolerance = 1e-8; c->gradient_tolerance = 1e-8;
+  c->huber_threshold = sqrt(5.991); c->max_covisible_keyframes = 20;
+}
+
+int orbx_create(const orbx_camera* cam, const orbx_orb_params* orb, int device, int max_w, int max_h,
+                int max_batch, orbx_handle** out) {
+  if (!cam || !orb || !out) return orbx_fail(nullptr, ORBX_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (max_w < 64 || max_h < 64 || max_w > 4095 || max_h > 4095 || max_batch < 1)
+    return orbx_fail(nullptr, ORBX_ERR_INVALID, "image bounds must be 64..4095, max_batch >= 1");
+  if (orb->n_levels < 1 || orb->n_levels > ORBX_MAX_LEVELS || orb->edge_threshold != 31 ||
+      orb->first_level != 0 || orb->wta_k != 2 || orb->score_type != 0 || orb->patch_size != 31 ||
+      orb->n_features < 0 || orb->fast_threshold < 1 || orb->fast_threshold > 254 ||
+      !(orb->scale_factor > 1.0f))
+    return orbx_fail(nullptr, ORBX_ERR_INVALID,
+                     "only the reference's ORB configuration is implemented (stereo.rs:38-48): "
+                     "n_levels<=8, edge 31, first_level 0, WTA_K 2, HARRIS_SCORE, patch 31");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return orbx_fail(nullptr, ORBX_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU path");
+  if (device < 0 || device >= ndev)
+    return orbx_fail(nullptr, ORBX_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    return orbx_fail(nullptr, ORBX_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return orbx_fail(nullptr, ORBX_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                     device, prop.gcnArchName);
+  orbx_handle* h = new orbx_handle();
+  h->device = device; h->cam = *cam; h->orb = *orb;
+  h->max_w = max_w; h->max_h = max_h; h->max_batch = max_batch;
+  if (hipSetDevice(device) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&h->d_status, sizeof(unsigned)) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_status, sizeof(unsigned)) != hipSuccess ||
+      hipMemsetAsync(h->d_status, 0, sizeof(unsigned), h->stream) != hipSuccess) {
+    const int rc = orbx_fail(nullptr, ORBX_ERR_HIP, "stream/status allocation failed: %s",
+                             hipGetErrorString(hipGetLastError()));
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return ORBX_OK;
+}
+
+void orbx_destroy(orbx_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->resize_tab, &h->ws_pyr, &h->ws_blur, &h->ws_cand, &h->ws_hist, &h->ws_counts,
+                    &h->ws_sel, &h->ws_sel2, &h->ws_match};
+  for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+  for (DevBuf& b : h->ws_io) if (b.p) hipFree(b.p);
+  for (DevBuf& b : h->ws_ba) if (b.p) hipFree(b.p);
+  for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
+  if (h->d_status) hipFree(h->d_status);
+  if (h->h_status) hipHostFree(h->h_status);
+  hipStreamDestroy(h->stream);
+  delete h;
+}
+
+void* orbx_stream(orbx_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int orbx_synchronize(orbx_handle* h) {
+  if (!h) return ORBX_ERR_INVALID;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  return ORBX_OK;
+}
+
+int orbx_check_status(orbx_handle* h) {
+  if (!h) return ORBX_ERR_INVALID;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  ORBX_HIP(h, hipMemcpyAsync(h->h_status, h->d_status, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipMemsetAsync(h->d_status, 0, sizeof(unsigned), h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  const unsigned st = *h->h_status;
+  if (st & ORBX_ST_KP_OVERFLOW)
+    return orbx_fail(h, ORBX_ERR_CAPACITY, "an image produced more keypoints than cap_kp");
+  if (st) return orbx_fail(h, ORBX_ERR_HIP, "device status 0x%x", st);
+  return ORBX_OK;
+}
+
+int orbx_set_profiling(orbx_handle* h, int on) {
+  if (!h) return ORBX_ERR_INVALID;
+  h->profiling = on != 0;
+  return ORBX_OK;
+}
+
+int orbx_get_kernel_times(orbx_handle* h, orbx_kernel_time* out, int cap) {
+  if (!h) return ORBX_ERR_INVALID;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  int n = 0;
+  for (auto& t : h->timers) {
+    if (t.ev.empty()) continue;
+    t.ms = 0.f;
+    t.launches = (int)t.ev.size() / 2;
+    for (size_t i = 0; i + 1 < t.ev.size(); i += 2) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]);
+      t.ms += ms;
+    }
+    if (n < cap && out) {
+      memset(&out[n], 0, sizeof(out[n]));
+      strncpy(out[n].name, t.name.c_str(), sizeof(out[n].name) - 1);
+      out[n].ms = t.ms;
+      out[n].launches = t.launches;
+    }
+    ++n;
+  }
+  return n;
+}
+
+// ---- matchers -----------------------------------------------------------------------------------------
+
+int orbx_stereo_match_batch_device(orbx_handle* h, int batch, const orbx_keypoint* d_kp,
+                                   const uint8_t* d_desc, const int* d_nkp, int cap_kp,
+                                   orbx_dmatch* d_matches, int* d_nmatches, double* d_points,
+                                   uint8_t* d_has_point) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (batch < 0 || cap_kp < 1 || !d_kp || !d_desc || !d_nkp || !d_matches || !d_nmatches || !d_points || !d_has_point)
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_stereo_match_batch_device: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  return launch_stereo_match(h, batch, d_kp, d_desc, d_nkp, cap_kp, d_matches, d_nmatches, d_points, d_has_point);
+}
+
+int orbx_stereo_match(orbx_handle* h, const orbx_keypoint* kpL, const uint8_t* descL, int nL,
+                      const orbx_keypoint* kpR, const uint8_t* descR, int nR, orbx_dmatch* matches,
+                      int* n_matches, double* points_cam, uint8_t* has_point) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (nL < 0 || nR < 0 || !n_matches || (nL > 0 && (!kpL || !descL || !matches || !points_cam || !has_point)) ||
+      (nR > 0 && (!kpR || !descR)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_stereo_match: bad argument");
+  *n_matches = 0;
+  if (nL == 0) return ORBX_OK;   // stereo.rs:95 loop body never runs
+  ORBX_HIP(h, hipSetDevice(h->device));
+  const int cap = nL > nR ? nL : nR;
+  const size_t kpb = sizeof(orbx_keypoint) * (size_t)cap, db = 32 * (size_t)cap;
+  if (int rc = orbx_reserve(h, h->ws_io[0], 2 * kpb)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[1], 2 * db)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[2], 4 * sizeof(int))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[3], sizeof(orbx_dmatch) * (size_t)cap)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[4], sizeof(double) * 3 * (size_t)cap)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[5], (size_t)cap)) return rc;
+  orbx_keypoint* d_kp = (orbx_keypoint*)h->ws_io[0].p;
+  uint8_t* d_desc = (uint8_t*)h->ws_io[1].p;
+  int* d_n = (int*)h->ws_io[2].p;
+  const int counts[2] = {nL, nR};
+  ORBX_HIP(h, hipMemcpyAsync(d_kp, kpL, sizeof(orbx_keypoint) * (size_t)nL, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_desc, descL, 32 * (size_t)nL, hipMemcpyHostToDevice, h->stream));
+  if (nR > 0) {
+    ORBX_HIP(h, hipMemcpyAsync(d_kp + cap, kpR, sizeof(orbx_keypoint) * (size_t)nR, hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP(h, hipMemcpyAsync(d_desc + db, descR, 32 * (size_t)nR, hipMemcpyHostToDevice, h->stream));
+  }
+  ORBX_HIP(h, hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));  // `counts` is a stack buffer
+  orbx_prof_begin_call(h);
+  if (int rc = launch_stereo_match(h, 1, d_kp, d_desc, d_n, cap, (orbx_dmatch*)h->ws_io[3].p, d_n + 2,
+                                   (double*)h->ws_io[4].p, (uint8_t*)h->ws_io[5].p))
+    return rc;
+  ORBX_HIP(h, hipMemcpyAsync(n_matches, d_n + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(points_cam, h->ws_io[4].p, sizeof(double) * 3 * (size_t)nL, hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(has_point, h->ws_io[5].p, (size_t)nL, hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  if (*n_matches > 0)
+    ORBX_HIP(h, hipMemcpy(matches, h->ws_io[3].p, sizeof(orbx_dmatch) * (size_t)*n_matches, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_hamming_match_crosscheck_device(orbx_handle* h, const uint8_t* d_q, int nq, const uint8_t* d_t,
+                                         int nt, orbx_dmatch* d_out, int* d_n_out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (nq < 0 || nt < 0 || !d_n_out || (nq > 0 && (!d_q || !d_out)) || (nt > 0 && !d_t))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_hamming_match_crosscheck_device: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  return launch_crosscheck(h, d_q, nq, d_t, nt, d_out, d_n_out);
+}
+
+int orbx_hamming_match_crosscheck(orbx_handle* h, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                                  orbx_dmatch* out, int* n_out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (nq < 0 || nt < 0 || !n_out || (nq > 0 && (!q || !out)) || (nt > 0 && !t))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_hamming_match_crosscheck: bad argument");
+  *n_out = 0;
+  if (nq == 0 || nt == 0) return ORBX_OK;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  if (int rc = orbx_reserve(h, h->ws_io[0], 32 * (size_t)nq)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[1], 32 * (size_t)nt)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[2], sizeof(int))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[3], sizeof(orbx_dmatch) * (size_t)nq)) return rc;
+  ORBX_HIP(h, hipMemcpyAsync(h->ws_io[0].p, q, 32 * (size_t)nq, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(h->ws_io[1].p, t, 32 * (size_t)nt, hipMemcpyHostToDevice, h->stream));
+  orbx_prof_begin_call(h);
+  if (int rc = launch_crosscheck(h, (const uint8_t*)h->ws_io[0].p, nq, (const uint8_t*)h->ws_io[1].p, nt,
+                                 (orbx_dmatch*)h->ws_io[3].p, (int*)h->ws_io[2].p))
+    return rc;
+  ORBX_HIP(h, hipMemcpyAsync(n_out, h->ws_io[2].p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  if (*n_out > 0)
+    ORBX_HIP(h, hipMemcpy(out, h->ws_io[3].p, sizeof(orbx_dmatch) * (size_t)*n_out, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_hamming_batch_device(orbx_handle* h, const uint8_t* d_a, const uint8_t* d_b, int n_pairs,
+                              uint32_t* d_out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (n_pairs < 0 || (n_pairs > 0 && (!d_a || !d_b || !d_out)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_hamming_batch_device: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  return launch_hamming_batch(h, d_a, d_b, n_pairs, d_out);
+}
+
+int orbx_hamming_batch(orbx_handle* h, const uint8_t* a, const uint8_t* b, int n_pairs, uint32_t* out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (n_pairs < 0 || (n_pairs > 0 && (!a || !b || !out)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_hamming_batch: bad argument");
+  if (n_pairs == 0) return ORBX_OK;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  const size_t bytes = 32 * (size_t)n_pairs;
+  if (int rc = orbx_reserve(h, h->ws_io[0], bytes)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[1], bytes)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[2], sizeof(uint32_t) * (size_t)n_pairs)) return rc;
+  ORBX_HIP(h, hipMemcpyAsync(h->ws_io[0].p, a, bytes, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(h->ws_io[1].p, b, bytes, hipMemcpyHostToDevice, h->stream));
+  orbx_prof_begin_call(h);
+  if (int rc = launch_hamming_batch(h, (const uint8_t*)h->ws_io[0].p, (const uint8_t*)h->ws_io[1].p, n_pairs,
+                                    (uint32_t*)h->ws_io[2].p))
+    return rc;
+  ORBX_HIP(h, hipMemcpyAsync(out, h->ws_io[2].p, sizeof(uint32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  return ORBX_OK;
+}
+
+// ---- extraction + full per-frame path -------------------------------------------------------------------
+
+int orbx_extract_batch_device(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,
+                              size_t stride, orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp, int cap_kp) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!d_images || !d_kp || !d_desc || !d_nkp || n_images < 0 || cap_kp < 1)
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_extract_batch_device: bad argument");
+  if (w < 64 || h_px < 64 || w > h->max_w || h_px > h->max_h || stride < (size_t)w)
+    return orbx_fail(h, ORBX_ERR_INVALID, "image %dx%d (stride %zu) outside the handle's bounds %dx%d", w, h_px,
+                     stride, h->max_w, h->max_h);
+  if (n_images > 2 * h->max_batch)
+    return orbx_fail(h, ORBX_ERR_INVALID, "n_images %d exceeds 2*max_batch %d", n_images, 2 * h->max_batch);
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  return launch_orb_extract(h, d_images, n_images, w, h_px, stride, d_kp, d_desc, d_nkp, cap_kp);
+}
+
+int orbx_process_stereo_batch_device(orbx_handle* h, const uint8_t* d_images, int batch, int w, int h_px,
+                                     size_t stride, orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp,
+                                     int cap_kp, orbx_dmatch* d_matches, int* d_nmatches, double* d_points,
+                                     uint8_t* d_has_point) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (batch < 0 || batch > h->max_batch)
+    return orbx_fail(h, ORBX_ERR_INVALID, "batch %d outside 0..max_batch %d", batch, h->max_batch);
+  if (!d_matches || !d_nmatches || !d_points || !d_has_point)
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_process_stereo_batch_device: bad argument");
+  if (int rc = orbx_extract_batch_device(h, d_images, 2 * batch, w, h_px, stride, d_kp, d_desc, d_nkp, cap_kp))
+    return rc;
+  return launch_stereo_match(h, batch, d_kp, d_desc, d_nkp, cap_kp, d_matches, d_nmatches, d_points, d_has_point);
+}
+
+int orbx_process_stereo(orbx_handle* h, const uint8_t* left, size_t lstride, const uint8_t* right,
+                        size_t rstride, int w, int h_px, orbx_keypoint* kpL, uint8_t* descL, int* nL,
+                        orbx_keypoint* kpR, uint8_t* descR, int* nR, int cap_kp, orbx_dmatch* matches,
+                        int* n_matches, double* points_cam, uint8_t* has_point) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!left || !right || !kpL || !descL || !nL || !kpR || !descR || !nR || !matches || !n_matches ||
+      !points_cam || !has_point || cap_kp < 1 || lstride < (size_t)w || rstride < (size_t)w)
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_process_stereo: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  const size_t img = (size_t)w * h_px;
+  const size_t kpb = sizeof(orbx_keypoint) * (size_t)cap_kp, db = 32 * (size_t)cap_kp;
+  if (int rc = orbx_reserve(h, h->ws_io[6], 2 * img)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[7], 2 * kpb)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[8], 2 * db)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[9], 4 * sizeof(int))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[10], sizeof(orbx_dmatch) * (size_t)cap_kp)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[11], (sizeof(double) * 3 + 1) * (size_t)cap_kp)) return rc;
+  uint8_t* d_img = (uint8_t*)h->ws_io[6].p;
+  ORBX_HIP(h, hipMemcpy2DAsync(d_img, w, left, lstride, w, h_px, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpy2DAsync(d_img + img, w, right, rstride, w, h_px, hipMemcpyHostToDevice, h->stream));
+  orbx_keypoint* d_kp = (orbx_keypoint*)h->ws_io[7].p;
+  uint8_t* d_desc = (uint8_t*)h->ws_io[8].p;
+  int* d_n = (int*)h->ws_io[9].p;
+  double* d_pts = (double*)h->ws_io[11].p;
+  uint8_t* d_has = (uint8_t*)(d_pts + 3 * (size_t)cap_kp);
+  if (int rc = orbx_process_stereo_batch_device(h, d_img, 1, w, h_px, (size_t)w, d_kp, d_desc, d_n, cap_kp,
+                                                (orbx_dmatch*)h->ws_io[10].p, d_n + 2, d_pts, d_has))
+    return rc;
+  int counts[3];
+  ORBX_HIP(h, hipMemcpyAsync(counts, d_n, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
+  if (int rc = orbx_check_status(h)) return rc;   // synchronises
+  *nL = counts[0]; *nR = counts[1]; *n_matches = counts[2];
+  ORBX_HIP(h, hipMemcpy(kpL, d_kp, sizeof(orbx_keypoint) * (size_t)counts[0], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(descL, d_desc, 32 * (size_t)counts[0], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(kpR, d_kp + cap_kp, sizeof(orbx_keypoint) * (size_t)counts[1], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(descR, d_desc + db, 32 * (size_t)counts[1], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(matches, h->ws_io[10].p, sizeof(orbx_dmatch) * (size_t)counts[2], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(points_cam, d_pts, sizeof(double) * 3 * (size_t)counts[0], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(has_point, d_has, (size_t)counts[0], hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+// ---- local BA ---------------------------------------------------------------------------------------------
+
+int orbx_ba_set_allreduce(orbx_handle* h, orbx_allreduce_fn fn, void* user) {
+  if (!h) return ORBX_ERR_INVALID;
+  h->allreduce = fn;
+  h->allreduce_user = user;
+  return ORBX_OK;
+}
+
+int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+                         const double* poses_cw, int F, const double* fixed_poses_cw, int M,
+                         double* points, int N, const orbx_ba_obs* obs, orbx_should_stop_fn should_stop,
+                         void* user, double* poses_wc_out, int* iterations, double* initial_error,
+                         double* final_error) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || !cfg || K < 0 || F < 0 || M < 0 || N < 0 || !iterations || !initial_error || !final_error ||
+      (K > 0 && (!poses_cw || !poses_wc_out)) || (F > 0 && !fixed_poses_cw) || (M > 0 && !points) ||
+      (N > 0 && !obs))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  return ba_solve_visual(h, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, should_stop, user,
+                         poses_wc_out, iterations, initial_error, final_error);
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// orbx_internal.hpp — shared host-side declarations of the HIP library (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+#define ORBX_MAX_LEVELS 8
+
+// ---- launch descriptors shared by host code and kernels ------------------------------------------
+// Geometry of one pyramid level inside the per-image pyramid / blur buffers.
+struct OrbLevelGeom {
+  int w, h;          // level size
+  int pitch;         // row pitch in bytes inside the pyramid buffers (multiple of 64)
+  int quota;         // n_l, features wanted on this level (Appendix A.3)
+  float scale;       // 1.2^l as f32
+  unsigned off;      // byte offset of the level inside one image's blur-pyramid slot
+  unsigned cand_off; // element offset of the level's candidate region inside one image's slot
+  unsigned cand_cap; // worst-case number of NMS survivors of the level
+  int tiles_x, tiles_y, tile_start;  // FAST/blur tile table: tiles of this level start at tile_start
+};
+struct OrbGeom {
+  int n_levels;
+  int total_tiles;       // sum over levels of tiles_x*tiles_y
+  unsigned pyr_bytes;    // bytes of one image's pyramid slot (levels 0..n-1, level 0 unused in `pyr`)
+  unsigned cand_total;   // candidate slots per image
+  int fast_threshold;
+  int pad_;
+  OrbLevelGeom lv[ORBX_MAX_LEVELS];
+};
+
+// device status word bits (sticky, cleared by orbx_check_status)
+#define ORBX_ST_KP_OVERFLOW 1u   // more keypoints than cap_kp
+#define ORBX_ST_INTERNAL 2u
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct KernelTimer {
+  std::string name;
+  std::vector<hipEvent_t> ev;  // start/stop pairs of the current call
+  float ms = 0.f;
+  int launches = 0;
+};
+
+struct orbx_handle {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  orbx_camera cam{};
+  orbx_orb_params orb{};
+  int max_w = 0, max_h = 0, max_batch = 0;
+  std::string err;
+  unsigned* d_status = nullptr;
+  unsigned* h_status = nullptr;   // pinned
+  // cached level geometry + resize tables for the last image size
+  int geom_w = 0, geom_h = 0;
+  OrbGeom geom{};
+  DevBuf resize_tab;   // per level: xofs,xc1 [w_l] ; yofs,yc1 [h_l]  (int32 each)
+  std::vector<unsigned> resize_tab_off;  // per level element offsets (x table, y table)
+  // grow-only workspaces
+  DevBuf ws_pyr, ws_blur, ws_cand, ws_hist, ws_counts, ws_sel, ws_sel2, ws_match, ws_io[12];
+  DevBuf ws_ba[24];
+  // BA
+  orbx_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<KernelTimer> timers;
+  std::vector<hipEvent_t> event_pool;
+  size_t event_next = 0;
+};
+
+int orbx_fail(orbx_handle* h, int code, const char* fmt, ...);
+int orbx_reserve(orbx_handle* h, DevBuf& b, size_t bytes);
+
+#define ORBX_HIP(h, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return orbx_fail((h), ORBX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                       __FILE__, __LINE__);                                                 \
+  } while (0)
+
+// profiling scope: records a start/stop event pair around a launch when profiling is on
+struct ProfScope {
+  orbx_handle* h;
+  int idx;
+  ProfScope(orbx_handle* h, const char* name);
+  ~ProfScope();
+};
+void orbx_prof_begin_call(orbx_handle* h);
+void orbx_prof_end_call(orbx_handle* h);
+
+// ---- kernel launchers (defined in the .hip files) --------------------------------------------------
+// matcher (match_kernels.hip)
+int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, const uint8_t* d_desc,
+                        const int* d_nkp, int cap_kp, orbx_dmatch* d_matches, int* d_nmatches,
+                        double* d_points, uint8_t* d_has_point);
+int launch_crosscheck(orbx_handle* h, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                      orbx_dmatch* d_out, int* d_n_out);
+int launch_hamming_batch(orbx_handle* h, const uint8_t* d_a, const uint8_t* d_b, int n, uint32_t* d_out);
+// extractor (orb_kernels.hip)
+int orb_prepare_geometry(orbx_handle* h, int w, int h_px);
+int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,
+                       size_t stride, orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp, int cap_kp);
+// BA (ba_kernels.hip)
+int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+                    const double* poses_cw, int F, const double* fixed_poses_cw, int M,
+                    double* points, int N, const orbx_ba_obs* obs, orbx_should_stop_fn should_stop,
+                    void* user, double* poses_wc_out, int* iterations, double* initial_error,
+                    double* final_error);

@@ -1,0 +1,166 @@
+"""Seeded synthetic inputs of the shapes BASELINE.json names.
+
+There is no EuRoC data in the build or on the GPU box, so every test and bench input is
+generated here: EuRoC-shaped stereo pairs (752x480 u8, rectified, cam0 intrinsics), matcher
+descriptor sets, and local-BA windows.  Pure numpy; identical bytes feed the HIP path and the
+CPU oracle.
+"""
+import numpy as np
+
+# Public EuRoC cam0 values; the reference reads them from
+# mav0/cam0/sensor.yaml (src/io/euroc.rs:329-359).
+EUROC_CAMERA = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375, baseline=0.11007)
+
+
+def stereo_pair(seed, frame, w=752, h=480, n_rect=None, n_disc=None):
+    """One rectified stereo pair (left, right) of u8 [h, w] images.
+
+    A mid-grey canvas with random axis-aligned rectangles and discs, each at its own disparity
+    (2..60 px at 752 wide, scaled with width), painted far-to-near so that nearer objects occlude;
+    rows are identical in both views (rectified), per-pixel noise U[-4,4] is independent.
+    """
+    rng = np.random.default_rng([0x5EED, seed, frame])
+    area = (w * h) / (752.0 * 480.0)
+    n_rect = int(600 * area) if n_rect is None else n_rect
+    n_disc = int(300 * area) if n_disc is None else n_disc
+    n = n_rect + n_disc
+    sx = w / 752.0
+    disp = rng.uniform(2.0, 60.0, n) * sx
+    order = np.argsort(disp, kind="stable")          # far first
+    cx = rng.uniform(0, w, n)
+    cy = rng.uniform(0, h, n)
+    sz_w = rng.integers(6, 61, n)
+    sz_h = rng.integers(6, 61, n)
+    gray = rng.integers(0, 256, n)
+    left = np.full((h, w), 128, np.int16)
+    right = np.full((h, w), 128, np.int16)
+    yy, xx = np.mgrid[0:64, 0:64]
+    for i in order:
+        x0 = int(cx[i]) - int(sz_w[i]) // 2
+        y0 = int(cy[i]) - int(sz_h[i]) // 2
+        d = int(round(disp[i]))
+        if i < n_rect:
+            ww, hh = int(sz_w[i]), int(sz_h[i])
+            for img, xs in ((left, x0), (right, x0 - d)):
+                xa, xb = max(xs, 0), min(xs + ww, w)
+                ya, yb = max(y0, 0), min(y0 + hh, h)
+                if xa < xb and ya < yb:
+                    img[ya:yb, xa:xb] = gray[i]
+        else:
+            r = int(sz_w[i]) // 2
+            m = (yy[:2 * r + 1, :2 * r + 1] - r) ** 2 + (xx[:2 * r + 1, :2 * r + 1] - r) ** 2 <= r * r
+            for img, xs in ((left, x0), (right, x0 - d)):
+                xa, xb = max(xs, 0), min(xs + 2 * r + 1, w)
+                ya, yb = max(y0, 0), min(y0 + 2 * r + 1, h)
+                if xa < xb and ya < yb:
+                    sub = m[ya - y0:yb - y0, xa - xs:xb - xs]
+                    img[ya:yb, xa:xb][sub] = gray[i]
+    left += rng.integers(-4, 5, (h, w), dtype=np.int16)
+    right += rng.integers(-4, 5, (h, w), dtype=np.int16)
+    return (np.clip(left, 0, 255).astype(np.uint8), np.clip(right, 0, 255).astype(np.uint8))
+
+
+def stereo_batch(seed, first_frame, batch, w=752, h=480):
+    """[batch, 2, h, w] u8: the layout orbx_process_stereo_batch_device takes."""
+    out = np.empty((batch, 2, h, w), np.uint8)
+    for b in range(batch):
+        out[b, 0], out[b, 1] = stereo_pair(seed, first_frame + b, w, h)
+    return out
+
+
+def matcher_features(seed, n_left, n_right, keypoint_dtype, w=752, h=480):
+    """Feature sets for the matcher microbench (SURVEY.md §8d 'Value distributions'):
+    256 iid Bernoulli(1/2) bits; 70 % of right descriptors are a left one with Binomial(256,0.06)
+    bits flipped, yR = yL + U{-1,0,1}, xR = xL - U[1.3,120]; the rest independent."""
+    rng = np.random.default_rng([0xFEA7, seed])
+    kpL = np.zeros(n_left, keypoint_dtype)
+    kpR = np.zeros(n_right, keypoint_dtype)
+    kpL["x"] = rng.uniform(31, w - 31, n_left).astype(np.float32)
+    kpL["y"] = rng.uniform(31, h - 31, n_left).astype(np.float32)
+    descL = rng.integers(0, 256, (n_left, 32), dtype=np.uint8)
+    descR = rng.integers(0, 256, (n_right, 32), dtype=np.uint8)
+    kpR["x"] = rng.uniform(31, w - 31, n_right).astype(np.float32)
+    kpR["y"] = rng.uniform(31, h - 31, n_right).astype(np.float32)
+    n_corr = min(int(0.7 * n_right), n_left)
+    src = rng.permutation(n_left)[:n_corr]
+    dst = rng.permutation(n_right)[:n_corr]
+    flips = rng.random((n_corr, 256)) < 0.06
+    bits = np.unpackbits(descL[src], axis=1, bitorder="little") ^ flips.astype(np.uint8)
+    descR[dst] = np.packbits(bits, axis=1, bitorder="little")
+    kpR["y"][dst] = kpL["y"][src] + rng.integers(-1, 2, n_corr).astype(np.float32)
+    kpR["x"][dst] = kpL["x"][src] - rng.uniform(1.3, 120.0, n_corr).astype(np.float32)
+    for kp in (kpL, kpR):
+        kp["size"] = 31.0
+        kp["angle"] = rng.uniform(0, 360, len(kp)).astype(np.float32)
+        kp["response"] = rng.uniform(0, 1e-3, len(kp)).astype(np.float32)
+        kp["octave"] = 0
+        kp["class_id"] = -1
+    return kpL, descL, kpR, descR
+
+
+def _quat_from_axis_angle(axis, ang):
+    axis = np.asarray(axis, np.float64)
+    axis = axis / np.linalg.norm(axis)
+    return np.concatenate([[np.cos(ang / 2)], axis * np.sin(ang / 2)])
+
+
+def _quat_mul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def _quat_rot(q, v):
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    return v @ R.T
+
+
+def ba_window(seed, K, M, obs_dtype, n_fixed_extra=0, w=752, h=480, camera=None, noise_px=1.0,
+              perturb=True):
+    """A local-BA window: keyframe k at (0.15k, 0.02 sin k, 0) m with yaw
+    0.01k rad; points U[-6,6]xU[-3,3]xU[3,15] m; an observation wherever the projection lands
+    inside the image; pixel noise N(0, noise_px); initial poses perturbed (rot N(0,0.5 deg), trans
+    N(0,2 cm)), points N(0,3 cm).  Keyframe 0 is the anchor (fixed, fixed_idx 0); the next
+    `n_fixed_extra` keyframes are fixed observers too; the remaining K-1-n_fixed_extra are optimised.
+
+    Returns dict(poses_cw [Kopt,7], fixed_cw [F,7], points [M,3], obs, gt_poses_cw, gt_points).
+    """
+    cam = dict(EUROC_CAMERA if camera is None else camera)
+    rng = np.random.default_rng([0xBA, seed])
+    pts = np.stack([rng.uniform(-6, 6, M), rng.uniform(-3, 3, M), rng.uniform(3, 15, M)], 1)
+    q_wc, t_wc = [], []
+    for k in range(K):
+        q_wc.append(_quat_from_axis_angle([0, 1, 0], 0.01 * k))
+        t_wc.append(np.array([0.15 * k, 0.02 * np.sin(k), 0.0]))
+    poses_cw = []
+    for k in range(K):
+        qi = q_wc[k] * np.array([1, -1, -1, -1.0])
+        ti = -_quat_rot(qi, t_wc[k])
+        poses_cw.append(np.concatenate([qi, ti]))
+    poses_cw = np.array(poses_cw)
+    F = 1 + n_fixed_extra
+    obs = []
+    for k in range(K):
+        pc = _quat_rot(poses_cw[k, :4], pts) + poses_cw[k, 4:]
+        u = cam["fx"] * pc[:, 0] / pc[:, 2] + cam["cx"]
+        v = cam["fy"] * pc[:, 1] / pc[:, 2] + cam["cy"]
+        vis = (pc[:, 2] > 0.1) & (u >= 0) & (u < w) & (v >= 0) & (v < h)
+        nz = rng.normal(0, noise_px, (M, 2)) if noise_px > 0 else np.zeros((M, 2))
+        for j in np.nonzero(vis)[0]:
+            obs.append((k - F if k >= F else -1, k if k < F else -1, j, 0, u[j] + nz[j, 0], v[j] + nz[j, 1]))
+    obs = np.array(obs, dtype=obs_dtype)
+    init = poses_cw[F:].copy()
+    init_pts = pts.copy()
+    if perturb:
+        for i in range(len(init)):
+            ax = rng.normal(0, 1, 3)
+            dq = _quat_from_axis_angle(ax, np.deg2rad(rng.normal(0, 0.5)))
+            init[i, :4] = _quat_mul(dq, init[i, :4])
+            init[i, 4:] += rng.normal(0, 0.02, 3)
+        init_pts += rng.normal(0, 0.03, init_pts.shape)
+    return dict(poses_cw=init, fixed_cw=poses_cw[:F].copy(), points=init_pts, obs=obs,
+                gt_poses_cw=poses_cw[F:].copy(), gt_points=pts, camera=cam)
