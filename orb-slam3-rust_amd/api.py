@@ -92,6 +92,15 @@ def load_library():
             raise RuntimeError(
                 "liborbx_hip.so is missing (%s): build it with __graft_entry__.build(); "
                 "this package has no CPU or PyTorch fallback" % LIB_PATH)
+        if not os.environ.get("ORBX_NO_TORCH_PRELOAD"):
+            # PyTorch-ROCm wheels carry their own libamdhip64.so.7; two HIP runtimes in one process
+            # do not coexist ("No HIP GPUs are available").  Loading torch first makes the dynamic
+            # linker bind this library's libamdhip64.so.7 dependency to the copy torch already
+            # mapped (same soname), so device memory and streams are shared with torch.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.orbx_version.restype = C.c_char_p
         L.orbx_last_error.restype = C.c_char_p

@@ -13,25 +13,35 @@
 #define ORBX_MAX_LEVELS 8
 
 // ---- launch descriptors shared by host code and kernels ------------------------------------------
-// Geometry of one pyramid level inside the per-image pyramid / blur buffers.
+// Geometry of one pyramid level inside the per-image pyramid / blur slots (identical layout).
 struct OrbLevelGeom {
-  int w, h;          // level size
-  int pitch;         // row pitch in bytes inside the pyramid buffers (multiple of 64)
-  int quota;         // n_l, features wanted on this level (Appendix A.3)
-  float scale;       // 1.2^l as f32
-  unsigned off;      // byte offset of the level inside one image's blur-pyramid slot
-  unsigned cand_off; // element offset of the level's candidate region inside one image's slot
-  unsigned cand_cap; // worst-case number of NMS survivors of the level
-  int tiles_x, tiles_y, tile_start;  // FAST/blur tile table: tiles of this level start at tile_start
+  int w, h;            // level size
+  int pitch;           // row pitch in bytes inside the slots (multiple of 64)
+  int quota;           // n_l, features wanted on this level (Appendix A.3)
+  float scale;         // scaleFactor^l as f32
+  unsigned off;        // byte offset of the level inside one image's slot (multiple of 256)
+  unsigned cand_off;   // element offset of the level's candidate region inside one image's slot
+  unsigned cand_cap;   // worst-case number of NMS survivors of the level
+  int btiles_x, btile_start;   // blur tiles (64x16 over the whole level)
+  int ftiles_x, ftile_start;   // FAST tiles (64x16 over the border-filtered region [31,w-31)x[31,h-31))
 };
 struct OrbGeom {
   int n_levels;
-  int total_tiles;       // sum over levels of tiles_x*tiles_y
-  unsigned pyr_bytes;    // bytes of one image's pyramid slot (levels 0..n-1, level 0 unused in `pyr`)
-  unsigned cand_total;   // candidate slots per image
+  int btiles_total, ftiles_total;
   int fast_threshold;
-  int pad_;
+  unsigned slot_bytes;   // bytes of one image's pyramid (and blur) slot
+  unsigned cand_total;   // candidate slots per image (sum of cand_cap)
   OrbLevelGeom lv[ORBX_MAX_LEVELS];
+};
+// Where level images live: level 0 is the caller's image when it is 4-byte aligned with a pitch
+// that is a multiple of 4, otherwise a copy in the pyramid slot; levels >= 1 are in the slot.
+struct OrbSrc {
+  const uint8_t* l0;
+  size_t l0_img_stride;   // bytes between consecutive images at level 0
+  int l0_pitch;
+  int pad_;
+  uint8_t* pyr;
+  uint8_t* blur;
 };
 
 // device status word bits (sticky, cleared by orbx_check_status)
@@ -62,10 +72,10 @@ struct orbx_handle {
   // cached level geometry + resize tables for the last image size
   int geom_w = 0, geom_h = 0;
   OrbGeom geom{};
-  DevBuf resize_tab;   // per level: xofs,xc1 [w_l] ; yofs,yc1 [h_l]  (int32 each)
-  std::vector<unsigned> resize_tab_off;  // per level element offsets (x table, y table)
+  DevBuf resize_tab;                     // per level l>=1: xtab[w_l], ytab[h_l] packed (ofs<<16 | c1)
+  std::vector<unsigned> resize_tab_off;  // element offsets: [2*l] x table, [2*l+1] y table
   // grow-only workspaces
-  DevBuf ws_pyr, ws_blur, ws_cand, ws_hist, ws_counts, ws_sel, ws_sel2, ws_match, ws_io[12];
+  DevBuf ws_pyr, ws_blur, ws_cand, ws_counters, ws_sel, ws_sel2, ws_match, ws_io[12];
   DevBuf ws_ba[24];
   // BA
   orbx_allreduce_fn allreduce = nullptr;
