@@ -217,6 +217,16 @@ typedef struct {
 int orbx_set_profiling(orbx_handle* h, int on);
 int orbx_get_kernel_times(orbx_handle* h, orbx_kernel_time* out, int cap);
 
+/* ---- stage inspection (tests, debugging) ---------------------------------------------------
+ * Read back intermediate results of the LAST extraction call of this handle: one pyramid level
+ * (which = 0) or its blurred version (which = 1) of image `image_index` as w_l*h_l tightly
+ * packed bytes (out may be NULL to query the size), and the FAST+NMS candidates of a level packed
+ * as (score<<24 | y<<12 | x) in no particular order.  Synchronous. */
+int orbx_debug_read_level(orbx_handle* h, int image_index, int level, int which, uint8_t* out,
+                          int* w_l, int* h_l);
+int orbx_debug_read_candidates(orbx_handle* h, int image_index, int level, uint32_t* out, int cap,
+                               int* n);
+
 #ifdef __cplusplus
 }
 #endif

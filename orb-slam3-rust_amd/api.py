@@ -48,7 +48,8 @@ ABI_SYMBOLS = [
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
     "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual",
-    "orbx_set_profiling", "orbx_get_kernel_times",
+    "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
+    "orbx_debug_read_candidates",
 ]
 
 
@@ -330,6 +331,25 @@ class Handle:
         pts = out["points"][b, :nkp[0]].cpu().numpy()
         has = out["has_point"][b, :nkp[0]].cpu().numpy()
         return res[0], res[1], m, pts, has
+
+    # ---- stage inspection -----------------------------------------------------------------------
+    def debug_level(self, image_index, level, blurred=False):
+        w = C.c_int(); hh = C.c_int()
+        self._check(self._L.orbx_debug_read_level(self._h, C.c_int(image_index), C.c_int(level),
+                                                  C.c_int(1 if blurred else 0), None, C.byref(w), C.byref(hh)))
+        out = np.zeros((hh.value, w.value), np.uint8)
+        self._check(self._L.orbx_debug_read_level(self._h, C.c_int(image_index), C.c_int(level),
+                                                  C.c_int(1 if blurred else 0), _vp(out), C.byref(w), C.byref(hh)))
+        return out
+
+    def debug_candidates(self, image_index, level):
+        n = C.c_int()
+        self._check(self._L.orbx_debug_read_candidates(self._h, C.c_int(image_index), C.c_int(level), None,
+                                                       C.c_int(0), C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint32)
+        self._check(self._L.orbx_debug_read_candidates(self._h, C.c_int(image_index), C.c_int(level), _vp(out),
+                                                       C.c_int(len(out)), C.byref(n)))
+        return out[:n.value].copy()
 
     # ---- BA -----------------------------------------------------------------------------------------
     def set_allreduce(self, fn):

@@ -1,6 +1,749 @@
-// placeholder — replaced by the extractor kernels
+// orb_kernels.hip — batched ORB extractor for gfx950: cv::ORB::detectAndCompute as configured by
+// the reference (src/tracking/frame/stereo.rs:38-48, :68-78), restated per SURVEY.md Appendix A.
+//
+// One call processes n_images images (left and right of every stereo pair of a batch); every kernel
+// covers all images, and all pyramid levels where there is no level-to-level dependency:
+//
+//   copy_l0_kernel        (only if the caller's rows are not 4-byte aligned)
+//   resize_kernel  x7     level l from level l-1, INTER_LINEAR_EXACT fixed point           (A.4)
+//   blur_kernel           7x7 sigma-2 fixed-point Gaussian of every level, LDS tile + halo (A.8)
+//   fast_kernel           FAST-9/16 score + 3x3 NMS + border filter, LDS tile + 4px halo;
+//                         per-level candidate lists + score histograms                     (A.5)
+//   harris_select_kernel  retainBest(2 n_l) by FAST score via the histogram, Harris response
+//                         of the survivors                                                  (A.6)
+//   rank_select_kernel    canonical order (response desc, y, x) by rank sort in LDS,
+//                         retainBest(n_l) incl. ties with the n-th                          (A.6)
+//   describe_kernel       one wave per keypoint: 31x31 patch in LDS -> intensity-centroid
+//                         angle; 37x37 blurred patch in LDS -> 256 steered BRIEF tests,
+//                         4 x __ballot = the 32 descriptor bytes                        (A.7, A.8)
+//
+// Everything is integer/byte work except the Harris response, the angle and the pattern rotation,
+// which are f32/f64 written one IEEE operation at a time (no contraction) so that the results are
+// bit-identical to the CPU specification.  HBM-bound stencil/scan work: no MFMA here by design.
+#include <cfloat>
+#include <cmath>
+
 #include "orbx_internal.hpp"
-int orb_prepare_geometry(orbx_handle* h, int, int) { return orbx_fail(h, ORBX_ERR_INVALID, "extractor not built yet"); }
-int launch_orb_extract(orbx_handle* h, const uint8_t*, int, int, int, size_t, orbx_keypoint*, uint8_t*, int*, int) {
-  return orbx_fail(h, ORBX_ERR_INVALID, "extractor not built yet");
+
+namespace {
+
+#include "orb_pattern_31.inc"
+
+constexpr int TILE_W = 64, TILE_H = 16;
+constexpr int EDGE = 31;             // edgeThreshold, stereo.rs:42
+constexpr int HARRIS_CHUNKS = 8;
+
+__constant__ signed char c_pattern[256 * 4];
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ const uint8_t* level_ptr(const OrbSrc& s, const OrbGeom& g, int img, int l,
+                                                    int& pitch) {
+  if (l == 0) { pitch = s.l0_pitch; return s.l0 + (size_t)img * s.l0_img_stride; }
+  pitch = g.lv[l].pitch;
+  return s.pyr + (size_t)img * g.slot_bytes + g.lv[l].off;
+}
+
+// ---- level 0 copy (unaligned caller images only) -------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_l0_kernel(const uint8_t* __restrict__ src, size_t img_stride,
+                                                      size_t row_stride, int w, int h, uint8_t* __restrict__ pyr,
+                                                      unsigned slot, int pitch) {
+  const int img = blockIdx.z;
+  const int y = blockIdx.y;
+  const uint8_t* s = src + (size_t)img * img_stride + (size_t)y * row_stride;
+  uint8_t* d = pyr + (size_t)img * slot + (size_t)y * pitch;
+  for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) d[x] = s[x];
+}
+
+// ---- A.4 resize: 4 destination pixels per thread, one aligned u32 store ----------------------------------
+__global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
+                                                     const unsigned* __restrict__ xtab,
+                                                     const unsigned* __restrict__ ytab) {
+  const int img = blockIdx.z;
+  int sp;
+  const uint8_t* src = level_ptr(s, g, img, l - 1, sp);
+  const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h;
+  const int w = g.lv[l].w, h = g.lv[l].h, dp = g.lv[l].pitch;
+  uint8_t* dst = s.pyr + (size_t)img * g.slot_bytes + g.lv[l].off;
+  const int x0 = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
+  const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (y >= h || x0 >= w) return;
+  const unsigned yt = ytab[y];
+  const int y0 = (int)(yt >> 16), y1 = min(y0 + 1, sh - 1);
+  const unsigned cy1 = yt & 0xffffu, cy0 = 256u - cy1;
+  const uint8_t* r0 = src + (size_t)y0 * sp;
+  const uint8_t* r1 = src + (size_t)y1 * sp;
+  unsigned packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = x0 + k;
+    if (x < w) {
+      const unsigned xt = xtab[x];
+      const int xo = (int)(xt >> 16), x1 = min(xo + 1, sw - 1);
+      const unsigned cx1 = xt & 0xffffu, cx0 = 256u - cx1;
+      const unsigned h0 = cx0 * r0[xo] + cx1 * r0[x1];   // 8.8
+      const unsigned h1 = cx0 * r1[xo] + cx1 * r1[x1];
+      const unsigned v = cy0 * h0 + cy1 * h1;            // 16.16
+      packed |= ((v + 32768u) >> 16) << (8 * k);
+    }
+  }
+  *reinterpret_cast<unsigned*>(dst + (size_t)y * dp + x0) = packed;
+}
+
+__device__ __forceinline__ bool decode_tile(const OrbGeom& g, int tile, bool fast, int& l, int& tx, int& ty) {
+  l = 0;
+#pragma unroll
+  for (int i = 1; i < ORBX_MAX_LEVELS; ++i) {
+    const int start = fast ? g.lv[i].ftile_start : g.lv[i].btile_start;
+    if (i < g.n_levels && tile >= start) l = i;
+  }
+  const int start = fast ? g.lv[l].ftile_start : g.lv[l].btile_start;
+  const int tiles_x = fast ? g.lv[l].ftiles_x : g.lv[l].btiles_x;
+  const int t = tile - start;
+  ty = t / tiles_x;
+  tx = t - ty * tiles_x;
+  return true;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+// ---- A.8 Gaussian blur 7x7 sigma 2, taps {18,34,48,56,48,34,18}/256, 8.8 then 16.16 ------------------
+__global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g) {
+  __shared__ uint8_t sp[TILE_H + 6][72];
+  __shared__ unsigned short shz[TILE_H + 6][TILE_W];
+  const int img = blockIdx.y;
+  int l, tx, ty;
+  decode_tile(g, blockIdx.x, false, l, tx, ty);
+  int pitch;
+  const uint8_t* src = level_ptr(s, g, img, l, pitch);
+  const int w = g.lv[l].w, h = g.lv[l].h;
+  const int x0 = tx * TILE_W, y0 = ty * TILE_H;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (TILE_H + 6) * 70; i += 256) {
+    const int r = i / 70, c = i - r * 70;
+    const int gx = reflect101(x0 - 3 + c, w), gy = reflect101(y0 - 3 + r, h);
+    sp[r][c] = src[(size_t)gy * pitch + gx];
+  }
+  __syncthreads();
+  for (int i = tid; i < (TILE_H + 6) * TILE_W; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const unsigned v = 18u * (sp[r][c] + sp[r][c + 6]) + 34u * (sp[r][c + 1] + sp[r][c + 5]) +
+                       48u * (sp[r][c + 2] + sp[r][c + 4]) + 56u * sp[r][c + 3];
+    shz[r][c] = (unsigned short)v;
+  }
+  __syncthreads();
+  const int c4 = (tid & 15) * 4, r = tid >> 4;
+  if (y0 + r < h && x0 + c4 < w) {
+    unsigned packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c4 + k;
+      const unsigned v = 18u * ((unsigned)shz[r][c] + shz[r + 6][c]) + 34u * ((unsigned)shz[r + 1][c] + shz[r + 5][c]) +
+                         48u * ((unsigned)shz[r + 2][c] + shz[r + 4][c]) + 56u * (unsigned)shz[r + 3][c];
+      packed |= ((v + 32768u) >> 16) << (8 * k);
+    }
+    uint8_t* dst = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
+    *reinterpret_cast<unsigned*>(dst + (size_t)(y0 + r) * g.lv[l].pitch + x0 + c4) = packed;
+  }
+}
+
+// ---- A.5 FAST-9/16 ------------------------------------------------------------------------------------------
+// score = (max over the 16 arcs of 9 contiguous ring pixels of min(centre - ring), or of
+// min(ring - centre)) - 1 when that maximum exceeds the threshold, else 0.  Sliding-window min/max by
+// doubling (windows 2,4,8,9), all 16 ring differences in registers.
+__device__ __forceinline__ int fast_score16(const int (&d)[16], int t) {
+  int mn1[16], mx1[16], mn2[16], mx2[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { mn1[k] = min(d[k], d[(k + 1) & 15]); mx1[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { mn2[k] = min(mn1[k], mn1[(k + 2) & 15]); mx2[k] = max(mx1[k], mx1[(k + 2) & 15]); }
+  int best = -256;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int mn9 = min(min(mn2[k], mn2[(k + 4) & 15]), d[(k + 8) & 15]);
+    const int mx9 = max(max(mx2[k], mx2[(k + 4) & 15]), d[(k + 8) & 15]);
+    best = max(best, max(mn9, -mx9));
+  }
+  return best > t ? best - 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, unsigned* __restrict__ cand,
+                                                   unsigned* __restrict__ cand_count,
+                                                   unsigned* __restrict__ hist) {
+  __shared__ uint8_t sp[TILE_H + 8][TILE_W + 8];     // pixels, halo 4
+  __shared__ uint8_t ss[TILE_H + 2][TILE_W + 4];     // scores, halo 1 (66 used)
+  __shared__ unsigned s_list[TILE_W * TILE_H / 4];
+  __shared__ int s_cnt;
+  __shared__ unsigned s_base;
+  const int img = blockIdx.y;
+  int l, tx, ty;
+  decode_tile(g, blockIdx.x, true, l, tx, ty);
+  int pitch;
+  const uint8_t* src = level_ptr(s, g, img, l, pitch);
+  const int w = g.lv[l].w, h = g.lv[l].h;
+  const int x0 = EDGE + tx * TILE_W, y0 = EDGE + ty * TILE_H;   // first inner pixel of the tile
+  const int tid = threadIdx.x;
+  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < (TILE_H + 8) * (TILE_W + 8); i += 256) {
+    const int r = i / (TILE_W + 8), c = i - r * (TILE_W + 8);
+    const int gx = min(x0 - 4 + c, w - 1), gy = min(y0 - 4 + r, h - 1);
+    sp[r][c] = src[(size_t)gy * pitch + gx];
+  }
+  __syncthreads();
+  const int t = g.fast_threshold;
+  for (int p = tid; p < (TILE_H + 2) * (TILE_W + 2); p += 256) {
+    const int j = p / (TILE_W + 2), i = p - j * (TILE_W + 2);
+    const int cy = j + 3, cx = i + 3;
+    const int v = sp[cy][cx];
+    int d[16];
+    d[0] = v - sp[cy + 3][cx];      d[1] = v - sp[cy + 3][cx + 1];  d[2] = v - sp[cy + 2][cx + 2];
+    d[3] = v - sp[cy + 1][cx + 3];  d[4] = v - sp[cy][cx + 3];      d[5] = v - sp[cy - 1][cx + 3];
+    d[6] = v - sp[cy - 2][cx + 2];  d[7] = v - sp[cy - 3][cx + 1];  d[8] = v - sp[cy - 3][cx];
+    d[9] = v - sp[cy - 3][cx - 1];  d[10] = v - sp[cy - 2][cx - 2]; d[11] = v - sp[cy - 1][cx - 3];
+    d[12] = v - sp[cy][cx - 3];     d[13] = v - sp[cy + 1][cx - 3]; d[14] = v - sp[cy + 2][cx - 2];
+    d[15] = v - sp[cy + 3][cx - 1];
+    ss[j][i] = (uint8_t)fast_score16(d, t);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid & 63, j = (tid >> 6) + 4 * q;
+    const int x = x0 + i, y = y0 + j;
+    const int sc = ss[j + 1][i + 1];
+    if (sc > 0 && x < w - EDGE && y < h - EDGE) {
+      const bool keep = sc > ss[j][i] && sc > ss[j][i + 1] && sc > ss[j][i + 2] && sc > ss[j + 1][i] &&
+                        sc > ss[j + 1][i + 2] && sc > ss[j + 2][i] && sc > ss[j + 2][i + 1] && sc > ss[j + 2][i + 2];
+      if (keep) {
+        const int pos = atomicAdd(&s_cnt, 1);
+        s_list[pos] = ((unsigned)sc << 24) | ((unsigned)y << 12) | (unsigned)x;
+      }
+    }
+  }
+  __syncthreads();
+  const int il = img * g.n_levels + l;
+  if (tid == 0 && s_cnt > 0) s_base = atomicAdd(&cand_count[il], (unsigned)s_cnt);
+  __syncthreads();
+  if (tid < s_cnt) {
+    const unsigned c = s_list[tid];
+    cand[(size_t)img * g.cand_total + g.lv[l].cand_off + s_base + tid] = c;
+    atomicAdd(&hist[(size_t)il * 256 + (c >> 24)], 1u);
+  }
+}
+
+// ---- A.6 Harris response (blockSize 7, k 0.04) of one candidate, one thread ------------------------------
+__device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img, int pitch, int x0, int y0) {
+  int a = 0, b = 0, c = 0;
+  int rowm[9], row0[9], rowp[9];
+  const uint8_t* p = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { rowm[k] = p[k]; row0[k] = p[pitch + k]; }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const uint8_t* pr = p + (size_t)(i + 2) * pitch;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rowp[k] = pr[k];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int Ix = (row0[j + 2] - row0[j]) * 2 + (rowm[j + 2] - rowm[j]) + (rowp[j + 2] - rowp[j]);
+      const int Iy = (rowp[j + 1] - rowm[j + 1]) * 2 + (rowp[j] - rowm[j]) + (rowp[j + 2] - rowm[j + 2]);
+      a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { rowm[k] = row0[k]; row0[k] = rowp[k]; }
+  }
+  const float scale = 1.f / (4 * 7 * 255.f);
+  const float scale_sq_sq = scale * scale * scale * scale;   // folded at compile time, IEEE
+  const float fa = (float)a, fb = (float)b, fc = (float)c;
+  const float t1 = __fmul_rn(fa, fb);
+  const float t2 = __fmul_rn(fc, fc);
+  const float sm = __fadd_rn(fa, fb);
+  const float t3 = __fmul_rn(__fmul_rn(0.04f, sm), sm);
+  float r = __fmul_rn(__fsub_rn(__fsub_rn(t1, t2), t3), scale_sq_sq);
+  if (r == 0.f) r = 0.f;
+  return r;
+}
+
+// float -> u32 whose unsigned order is the float order
+__device__ __forceinline__ unsigned orderable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_orderable(unsigned o) {
+  const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+// retainBest(2*n_l) by FAST score (threshold from the histogram), then Harris of each survivor.
+// key = (~orderable(response) << 32) | y << 16 | x : ascending key = canonical order.
+__global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g, const unsigned* __restrict__ cand,
+                                                            const unsigned* __restrict__ cand_count,
+                                                            const unsigned* __restrict__ hist,
+                                                            unsigned long long* __restrict__ sel,
+                                                            unsigned* __restrict__ sel_count) {
+  __shared__ unsigned sh[256];
+  __shared__ int s_thr;
+  const int il = blockIdx.x;
+  const int img = il / g.n_levels, l = il - img * g.n_levels;
+  const int tid = threadIdx.x;
+  const unsigned count = cand_count[il];
+  const unsigned want = 2u * (unsigned)g.lv[l].quota;
+  sh[tid] = hist[(size_t)il * 256 + tid];
+  __syncthreads();
+  if (tid == 0) {
+    int thr;
+    if (want == 0) thr = 256;               // retainBest(0) clears
+    else if (count <= want) thr = 0;        // nothing to drop
+    else {
+      unsigned acc = 0;
+      thr = 0;
+      for (int sc = 255; sc >= 0; --sc) {
+        acc += sh[sc];
+        if (acc >= want) { thr = sc; break; }   // n-th best score; ties with it are kept
+      }
+    }
+    s_thr = thr;
+  }
+  __syncthreads();
+  const unsigned thr = (unsigned)s_thr;
+  int pitch;
+  const uint8_t* src = level_ptr(s, g, img, l, pitch);
+  const unsigned* cl = cand + (size_t)img * g.cand_total + g.lv[l].cand_off;
+  unsigned long long* out = sel + (size_t)img * g.cand_total + g.lv[l].cand_off;
+  for (unsigned i = blockIdx.y * 256 + tid; i < count; i += gridDim.y * 256) {
+    const unsigned c = cl[i];
+    if ((c >> 24) < thr) continue;
+    const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
+    const float r = harris_response(src, pitch, x, y);
+    const unsigned long long key = ((unsigned long long)(~orderable(r)) << 32) | ((unsigned)y << 16) | (unsigned)x;
+    const unsigned pos = atomicAdd(&sel_count[il], 1u);
+    out[pos] = key;
+  }
+}
+
+// Rank sort of the survivors of one (image, level) + retainBest(n_l) with ties.  keys are unique
+// (x,y differ), so rank = number of smaller keys is a permutation.  E owned keys per thread per pass.
+template <int E>
+__device__ __forceinline__ void rank_pass(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
+                                          unsigned M, unsigned g0, unsigned long long* chunk, int quota, unsigned* s_thr) {
+  constexpr int CH = 2048;
+  const int tid = threadIdx.x;
+  unsigned long long my[E];
+  unsigned rank[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const unsigned idx = g0 + e * 1024 + tid;
+    my[e] = idx < M ? in[idx] : ~0ull;
+    rank[e] = 0;
+  }
+  for (unsigned c0 = 0; c0 < M; c0 += CH) {
+    const unsigned n = min((unsigned)CH, M - c0);
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += 1024) chunk[i] = in[c0 + i];
+    __syncthreads();
+    for (unsigned k = 0; k < n; ++k) {
+      const unsigned long long v = chunk[k];
+#pragma unroll
+      for (int e = 0; e < E; ++e) rank[e] += (v < my[e]) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const unsigned idx = g0 + e * 1024 + tid;
+    if (idx < M) {
+      out[rank[e]] = my[e];
+      if ((int)rank[e] == quota - 1) *s_thr = (unsigned)(my[e] >> 32);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, const unsigned long long* __restrict__ sel,
+                                                           const unsigned* __restrict__ sel_count,
+                                                           unsigned long long* __restrict__ sel2,
+                                                           unsigned* __restrict__ kept) {
+  __shared__ unsigned long long chunk[2048];
+  __shared__ unsigned s_thr, s_keep;
+  const int il = blockIdx.x;
+  const int img = il / g.n_levels, l = il - img * g.n_levels;
+  const int tid = threadIdx.x;
+  const unsigned M = sel_count[il];
+  const int quota = g.lv[l].quota;
+  const unsigned long long* in = sel + (size_t)img * g.cand_total + g.lv[l].cand_off;
+  unsigned long long* out = sel2 + (size_t)img * g.cand_total + g.lv[l].cand_off;
+  if (tid == 0) { s_thr = 0xffffffffu; s_keep = 0; }
+  __syncthreads();
+  if (M == 0 || quota == 0) { if (tid == 0) kept[il] = 0; return; }
+  if (M <= 1024) rank_pass<1>(in, out, M, 0, chunk, quota, &s_thr);
+  else for (unsigned g0 = 0; g0 < M; g0 += 4096) rank_pass<4>(in, out, M, g0, chunk, quota, &s_thr);
+  __syncthreads();
+  if (M <= (unsigned)quota) { if (tid == 0) kept[il] = M; return; }
+  const unsigned thr = s_thr;   // ~orderable(response of the n-th best); keep hi <= thr
+  unsigned cnt = 0;
+  for (unsigned i = tid; i < M; i += 1024) cnt += ((unsigned)(in[i] >> 32) <= thr) ? 1u : 0u;
+  atomicAdd(&s_keep, cnt);
+  __syncthreads();
+  if (tid == 0) kept[il] = s_keep;
+}
+
+// ---- A.7 orientation + A.8 descriptor: one wave per keypoint ---------------------------------------------
+// cv::fastAtan2, scalar form, f32, one IEEE op at a time
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, __fadd_rn(ax, (float)DBL_EPSILON));
+    c2 = __fmul_rn(c, c);
+    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  } else {
+    c = __fdiv_rn(ax, __fadd_rn(ay, (float)DBL_EPSILON));
+    c2 = __fmul_rn(c, c);
+    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+  }
+  if (x < 0) a = __fsub_rn(180.f, a);
+  if (y < 0) a = __fsub_rn(360.f, a);
+  return a;
+}
+
+// cos/sin of the keypoint angle: radians in f32, then a deterministic f64 evaluation (quadrant
+// reduction with a two-part pi/2, Taylor polynomials to r^17 / r^16), rounded to f32.
+__device__ __forceinline__ void sincos_deg(float angle_deg, float& c_out, float& s_out) {
+  const float rad_f = __fmul_rn(angle_deg, (float)(3.14159265358979323846 / 180.f));
+  const double t = (double)rad_f;
+  const int k = (int)__dadd_rn(__dmul_rn(t, 0.63661977236758134308), 0.5);
+  const double kd = (double)k;
+  const double r = __dsub_rn(__dsub_rn(t, __dmul_rn(kd, 1.57079632673412561417e+00)), __dmul_rn(kd, 6.07710050650619224932e-11));
+  const double z = __dmul_rn(r, r);
+  double S = 1.0 / 355687428096000.0;
+  S = __dsub_rn(__dmul_rn(S, z), 1.0 / 1307674368000.0);
+  S = __dadd_rn(__dmul_rn(S, z), 1.0 / 6227020800.0);
+  S = __dsub_rn(__dmul_rn(S, z), 1.0 / 39916800.0);
+  S = __dadd_rn(__dmul_rn(S, z), 1.0 / 362880.0);
+  S = __dsub_rn(__dmul_rn(S, z), 1.0 / 5040.0);
+  S = __dadd_rn(__dmul_rn(S, z), 1.0 / 120.0);
+  S = __dsub_rn(__dmul_rn(S, z), 1.0 / 6.0);
+  const double sr = __dadd_rn(r, __dmul_rn(r, __dmul_rn(z, S)));
+  double C = 1.0 / 20922789888000.0;
+  C = __dsub_rn(__dmul_rn(C, z), 1.0 / 87178291200.0);
+  C = __dadd_rn(__dmul_rn(C, z), 1.0 / 479001600.0);
+  C = __dsub_rn(__dmul_rn(C, z), 1.0 / 3628800.0);
+  C = __dadd_rn(__dmul_rn(C, z), 1.0 / 40320.0);
+  C = __dsub_rn(__dmul_rn(C, z), 1.0 / 720.0);
+  C = __dadd_rn(__dmul_rn(C, z), 1.0 / 24.0);
+  C = __dsub_rn(__dmul_rn(C, z), 0.5);
+  const double cr = __dadd_rn(1.0, __dmul_rn(z, C));
+  double cs, sn;
+  switch (k & 3) {
+    case 0: cs = cr; sn = sr; break;
+    case 1: cs = -sr; sn = cr; break;
+    case 2: cs = -cr; sn = -sr; break;
+    default: cs = sr; sn = -cr; break;
+  }
+  c_out = (float)cs;
+  s_out = (float)sn;
+}
+
+constexpr int PA_ROWS = 31, PA_DW = 9;    // unblurred 31x31 patch, 9 aligned dwords per row
+constexpr int PB_ROWS = 37, PB_DW = 10, PB_PITCH = 11;   // blurred 37x37 patch, 10 dwords loaded, pitch 11
+
+__global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, const unsigned long long* __restrict__ sel2,
+                                                       const unsigned* __restrict__ kept,
+                                                       orbx_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
+                                                       int* __restrict__ nkp, int cap_kp, float patch_size,
+                                                       unsigned* __restrict__ status) {
+  __shared__ unsigned pa[4][PA_ROWS * PA_DW];
+  __shared__ unsigned pb[4][PB_ROWS * PB_PITCH];
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned start[ORBX_MAX_LEVELS + 1];
+  start[0] = 0;
+#pragma unroll
+  for (int l = 0; l < ORBX_MAX_LEVELS; ++l)
+    start[l + 1] = start[l] + (l < g.n_levels ? kept[img * g.n_levels + l] : 0u);
+  const unsigned total = start[ORBX_MAX_LEVELS];
+  const unsigned limit = min(total, (unsigned)cap_kp);
+  if (blockIdx.x == 0 && tid == 0) {
+    nkp[img] = (int)limit;
+    if (total > (unsigned)cap_kp) atomicOr(status, ORBX_ST_KP_OVERFLOW);
+  }
+  const uint8_t* pab = reinterpret_cast<const uint8_t*>(pa[wave]);
+  const uint8_t* pbb = reinterpret_cast<const uint8_t*>(pb[wave]);
+  for (unsigned slot = blockIdx.x * 4 + wave; slot < limit; slot += gridDim.x * 4) {
+    int l = 0;
+    unsigned lbase = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; ++i) if (slot >= start[i]) { l = i; lbase = start[i]; }
+    // (levels beyond n_levels have start == total > slot, so l < n_levels)
+    const unsigned long long key = sel2[(size_t)img * g.cand_total + g.lv[l].cand_off + (slot - lbase)];
+    const int kx = (int)(key & 0xffffu), ky = (int)((key >> 16) & 0xffffu);
+    const float resp = from_orderable(~(unsigned)(key >> 32));
+    int pitch;
+    const uint8_t* src = level_ptr(s, g, img, l, pitch);
+    const uint8_t* blr = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
+    const int bpitch = g.lv[l].pitch;
+    // stage both patches with aligned dword loads
+    const int ax = (kx - 15) & ~3, ma = (kx - 15) - ax;
+    for (int i = lane; i < PA_ROWS * PA_DW; i += 64) {
+      const int r = i / PA_DW, c = i - r * PA_DW;
+      pa[wave][i] = *reinterpret_cast<const unsigned*>(src + (size_t)(ky - 15 + r) * pitch + ax + 4 * c);
+    }
+    const int bx = (kx - 18) & ~3, mb = (kx - 18) - bx;
+    for (int i = lane; i < PB_ROWS * PB_DW; i += 64) {
+      const int r = i / PB_DW, c = i - r * PB_DW;
+      pb[wave][r * PB_PITCH + c] = *reinterpret_cast<const unsigned*>(blr + (size_t)(ky - 18 + r) * bpitch + bx + 4 * c);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);   // staging stores visible to the whole wave before the reads
+    // intensity centroid over the 749-pixel disc (integer, order independent)
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+      const int r = i / 31, c = i - r * 31;
+      const int v = r - 15, u = c - 15;
+      if (abs(u) <= c_umax[abs(v)]) {
+        const int I = pab[r * (PA_DW * 4) + ma + c];
+        m10 += u * I;
+        m01 += v * I;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      m10 += __shfl_xor(m10, off);
+      m01 += __shfl_xor(m01, off);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    float ca, sa;
+    sincos_deg(angle, ca, sa);
+    unsigned long long word[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = q * 64 + lane;
+      const float px0 = (float)c_pattern[4 * j + 0], py0 = (float)c_pattern[4 * j + 1];
+      const float px1 = (float)c_pattern[4 * j + 2], py1 = (float)c_pattern[4 * j + 3];
+      const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, ca), __fmul_rn(py0, sa)));
+      const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, sa), __fmul_rn(py0, ca)));
+      const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, ca), __fmul_rn(py1, sa)));
+      const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, sa), __fmul_rn(py1, ca)));
+      const int t0 = pbb[(iy0 + 18) * (PB_PITCH * 4) + mb + ix0 + 18];
+      const int t1 = pbb[(iy1 + 18) * (PB_PITCH * 4) + mb + ix1 + 18];
+      word[q] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+      const unsigned long long wv = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+      reinterpret_cast<unsigned long long*>(desc_out + ((size_t)img * cap_kp + slot) * 32)[lane] = wv;
+    }
+    if (lane == 0) {
+      const float sc = g.lv[l].scale;
+      orbx_keypoint o;
+      o.x = __fmul_rn((float)kx, sc);
+      o.y = __fmul_rn((float)ky, sc);
+      o.size = __fmul_rn(patch_size, sc);
+      o.angle = angle;
+      o.response = resp;
+      o.octave = l;
+      o.class_id = -1;
+      kp_out[(size_t)img * cap_kp + slot] = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- host: geometry, tables, launch sequence ---------------------------------------------------------------
+
+void build_resize_tab(int src, int dst, std::vector<unsigned>& out) {
+  // f = (d + 0.5) * (src/dst) - 0.5 in f64; i = floor(f); c1 = round-half-even((f - i) * 256)
+  const double inv_scale = (double)dst / (double)src;
+  const double scale = 1.0 / inv_scale;
+  for (int d = 0; d < dst; ++d) {
+    const double f = scale * ((double)d + 0.5) - 0.5;
+    int i = (int)std::floor(f);
+    unsigned ofs, c1;
+    if (i < 0) { ofs = 0; c1 = 0; }
+    else if (i >= src - 1) { ofs = (unsigned)(src - 1); c1 = 0; }
+    else { ofs = (unsigned)i; c1 = (unsigned)lrint((f - (double)i) * 256.0); }
+    out.push_back((ofs << 16) | c1);
+  }
+}
+
+}  // namespace
+
+int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
+  if (h->geom_w == w && h->geom_h == h_px) return ORBX_OK;
+  const orbx_orb_params& p = h->orb;
+  OrbGeom g{};
+  g.n_levels = p.n_levels;
+  g.fast_threshold = p.fast_threshold;
+  // level sizes and quotas: OpenCV orb.cpp (Appendix A.2/A.3)
+  const double sf = (double)p.scale_factor;
+  for (int l = 0; l < p.n_levels; ++l) {
+    g.lv[l].scale = (float)std::pow(sf, (double)(l - p.first_level));
+    g.lv[l].w = (int)lrintf((float)w / g.lv[l].scale);
+    g.lv[l].h = (int)lrintf((float)h_px / g.lv[l].scale);
+  }
+  const float factor = (float)(1.0 / sf);
+  float nper = (float)p.n_features * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.n_levels));
+  int sum = 0;
+  for (int l = 0; l < p.n_levels - 1; ++l) {
+    g.lv[l].quota = (int)lrintf(nper);
+    sum += g.lv[l].quota;
+    nper *= factor;
+  }
+  g.lv[p.n_levels - 1].quota = p.n_features - sum > 0 ? p.n_features - sum : 0;
+  unsigned off = 0, coff = 0;
+  int bt = 0, ft = 0;
+  for (int l = 0; l < p.n_levels; ++l) {
+    OrbLevelGeom& L = g.lv[l];
+    if (L.w < 8 || L.h < 8) return orbx_fail(h, ORBX_ERR_INVALID, "image too small for %d pyramid levels", p.n_levels);
+    L.pitch = (L.w + 63) & ~63;
+    L.off = off;
+    off += (unsigned)(((size_t)L.pitch * L.h + 255) & ~(size_t)255);
+    const int iw = L.w - 2 * EDGE, ih = L.h - 2 * EDGE;   // border-filtered region
+    L.cand_off = coff;
+    L.cand_cap = (iw > 0 && ih > 0) ? (unsigned)(((iw + 1) / 2) * ((ih + 1) / 2)) : 0u;
+    coff += (L.cand_cap + 63u) & ~63u;
+    L.btiles_x = (L.w + TILE_W - 1) / TILE_W;
+    L.btile_start = bt;
+    bt += L.btiles_x * ((L.h + TILE_H - 1) / TILE_H);
+    L.ftiles_x = iw > 0 ? (iw + TILE_W - 1) / TILE_W : 0;
+    L.ftile_start = ft;
+    ft += (iw > 0 && ih > 0) ? L.ftiles_x * ((ih + TILE_H - 1) / TILE_H) : 0;
+    if (L.ftiles_x == 0) L.ftiles_x = 1;
+  }
+  g.slot_bytes = off;
+  g.cand_total = coff;
+  g.btiles_total = bt;
+  g.ftiles_total = ft;
+  // resize tables
+  std::vector<unsigned> tab;
+  h->resize_tab_off.assign(2 * ORBX_MAX_LEVELS, 0);
+  for (int l = 1; l < p.n_levels; ++l) {
+    h->resize_tab_off[2 * l] = (unsigned)tab.size();
+    build_resize_tab(g.lv[l - 1].w, g.lv[l].w, tab);
+    h->resize_tab_off[2 * l + 1] = (unsigned)tab.size();
+    build_resize_tab(g.lv[l - 1].h, g.lv[l].h, tab);
+  }
+  if (int rc = orbx_reserve(h, h->resize_tab, sizeof(unsigned) * (tab.size() + 1))) return rc;
+  ORBX_HIP(h, hipMemcpy(h->resize_tab.p, tab.data(), sizeof(unsigned) * tab.size(), hipMemcpyHostToDevice));
+  static_assert(sizeof(kPattern31) == 256 * 4 * sizeof(int), "pattern table");
+  signed char pat[1024];
+  for (int i = 0; i < 256; ++i)
+    for (int k = 0; k < 4; ++k) pat[4 * i + k] = (signed char)kPattern31[i][k];
+  ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pat, sizeof(pat)));
+  h->geom = g;
+  h->geom_w = w;
+  h->geom_h = h_px;
+  return ORBX_OK;
+}
+
+int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px, size_t stride,
+                       orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp, int cap_kp) {
+  if (n_images <= 0) return ORBX_OK;
+  if (int rc = orb_prepare_geometry(h, w, h_px)) return rc;
+  const OrbGeom& g = h->geom;
+  const int nl = g.n_levels;
+  const size_t n_il = (size_t)n_images * nl;
+  if (int rc = orbx_reserve(h, h->ws_pyr, (size_t)g.slot_bytes * n_images)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_blur, (size_t)g.slot_bytes * n_images)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_cand, sizeof(unsigned) * (size_t)g.cand_total * n_images)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_sel, sizeof(unsigned long long) * (size_t)g.cand_total * n_images)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_sel2, sizeof(unsigned long long) * (size_t)g.cand_total * n_images)) return rc;
+  // counters: cand_count[n_il], sel_count[n_il], kept[n_il], hist[n_il*256]
+  const size_t n_cnt = n_il * (3 + 256);
+  if (int rc = orbx_reserve(h, h->ws_counters, sizeof(unsigned) * n_cnt)) return rc;
+  unsigned* cand_count = (unsigned*)h->ws_counters.p;
+  unsigned* sel_count = cand_count + n_il;
+  unsigned* kept = sel_count + n_il;
+  unsigned* hist = kept + n_il;
+  ORBX_HIP(h, hipMemsetAsync(h->ws_counters.p, 0, sizeof(unsigned) * n_cnt, h->stream));
+
+  OrbSrc s{};
+  s.pyr = (uint8_t*)h->ws_pyr.p;
+  s.blur = (uint8_t*)h->ws_blur.p;
+  const bool aligned = ((uintptr_t)d_images % 4 == 0) && (stride % 4 == 0) && (((size_t)h_px * stride) % 4 == 0);
+  if (aligned) {
+    s.l0 = d_images; s.l0_img_stride = (size_t)h_px * stride; s.l0_pitch = (int)stride;
+  } else {
+    ProfScope ps(h, "copy_l0_kernel");
+    hipLaunchKernelGGL(copy_l0_kernel, dim3(1, h_px, n_images), dim3(256), 0, h->stream, d_images,
+                       (size_t)h_px * stride, stride, w, h_px, s.pyr, g.slot_bytes, g.lv[0].pitch);
+    s.l0 = s.pyr; s.l0_img_stride = g.slot_bytes; s.l0_pitch = g.lv[0].pitch;
+  }
+  const unsigned* tab = (const unsigned*)h->resize_tab.p;
+  {
+    ProfScope ps(h, "resize_kernel");
+    for (int l = 1; l < nl; ++l) {
+      dim3 grid((g.lv[l].w + 63) / 64, (g.lv[l].h + 15) / 16, n_images);
+      hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, h->stream, s, g, l, tab + h->resize_tab_off[2 * l],
+                         tab + h->resize_tab_off[2 * l + 1]);
+    }
+  }
+  {
+    ProfScope ps(h, "blur_kernel");
+    hipLaunchKernelGGL(blur_kernel, dim3(g.btiles_total, n_images), dim3(256), 0, h->stream, s, g);
+  }
+  if (g.ftiles_total > 0) {
+    ProfScope ps(h, "fast_kernel");
+    hipLaunchKernelGGL(fast_kernel, dim3(g.ftiles_total, n_images), dim3(256), 0, h->stream, s, g,
+                       (unsigned*)h->ws_cand.p, cand_count, hist);
+  }
+  {
+    ProfScope ps(h, "harris_select_kernel");
+    hipLaunchKernelGGL(harris_select_kernel, dim3((unsigned)n_il, HARRIS_CHUNKS), dim3(256), 0, h->stream, s, g,
+                       (const unsigned*)h->ws_cand.p, cand_count, hist, (unsigned long long*)h->ws_sel.p, sel_count);
+  }
+  {
+    ProfScope ps(h, "rank_select_kernel");
+    hipLaunchKernelGGL(rank_select_kernel, dim3((unsigned)n_il), dim3(1024), 0, h->stream, g,
+                       (const unsigned long long*)h->ws_sel.p, sel_count, (unsigned long long*)h->ws_sel2.p, kept);
+  }
+  {
+    ProfScope ps(h, "describe_kernel");
+    const int blocks_x = (h->orb.n_features + 64 + 3) / 4;
+    hipLaunchKernelGGL(describe_kernel, dim3(blocks_x, n_images), dim3(256), 0, h->stream, s, g,
+                       (const unsigned long long*)h->ws_sel2.p, kept, d_kp, d_desc, d_nkp, cap_kp,
+                       (float)h->orb.patch_size, h->d_status);
+  }
+  ORBX_HIP(h, hipGetLastError());
+  return ORBX_OK;
+}
+
+// ---- stage inspection --------------------------------------------------------------------------------------
+extern "C" int orbx_debug_read_level(orbx_handle* h, int image_index, int level, int which, uint8_t* out,
+                                     int* w_l, int* h_l) {
+  if (!h || !w_l || !h_l) return ORBX_ERR_INVALID;
+  const OrbGeom& g = h->geom;
+  if (h->geom_w == 0 || level < 0 || level >= g.n_levels || image_index < 0 || (which != 0 && which != 1))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_debug_read_level: nothing extracted yet or bad index");
+  *w_l = g.lv[level].w; *h_l = g.lv[level].h;
+  if (!out) return ORBX_OK;
+  if (which == 0 && level == 0) return orbx_fail(h, ORBX_ERR_INVALID, "level 0 is the caller's image");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  const DevBuf& b = which ? h->ws_blur : h->ws_pyr;
+  if ((size_t)(image_index + 1) * g.slot_bytes > b.bytes) return orbx_fail(h, ORBX_ERR_INVALID, "image index out of range");
+  const uint8_t* src = (const uint8_t*)b.p + (size_t)image_index * g.slot_bytes + g.lv[level].off;
+  ORBX_HIP(h, hipMemcpy2D(out, g.lv[level].w, src, g.lv[level].pitch, g.lv[level].w, g.lv[level].h, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+extern "C" int orbx_debug_read_candidates(orbx_handle* h, int image_index, int level, uint32_t* out, int cap, int* n) {
+  if (!h || !n) return ORBX_ERR_INVALID;
+  const OrbGeom& g = h->geom;
+  if (h->geom_w == 0 || level < 0 || level >= g.n_levels || image_index < 0)
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_debug_read_candidates: nothing extracted yet or bad index");
+  if ((size_t)(image_index + 1) * g.cand_total * sizeof(unsigned) > h->ws_cand.bytes)
+    return orbx_fail(h, ORBX_ERR_INVALID, "image index out of range");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  unsigned cnt = 0;
+  ORBX_HIP(h, hipMemcpy(&cnt, (const unsigned*)h->ws_counters.p + (size_t)image_index * g.n_levels + level, sizeof(cnt), hipMemcpyDeviceToHost));
+  *n = (int)cnt;
+  if (!out) return ORBX_OK;
+  if ((int)cnt > cap) return orbx_fail(h, ORBX_ERR_CAPACITY, "candidate buffer too small: need %u", cnt);
+  ORBX_HIP(h, hipMemcpy(out, (const unsigned*)h->ws_cand.p + (size_t)image_index * g.cand_total + g.lv[level].cand_off,
+                        sizeof(unsigned) * cnt, hipMemcpyDeviceToHost));
+  return ORBX_OK;
 }

@@ -1,0 +1,177 @@
+"""GPU parity of the ORB extractor and of the whole per-frame path (StereoProcessor::process,
+stereo.rs:52-66), through the C ABI, bit-exact against the CPU specification (oracle/orb_ref.cpp,
+SURVEY.md Appendix A; parity with OpenCV itself is unpinned)."""
+import numpy as np
+import pytest
+
+from conftest import records_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _first_diff(a, b):
+    for name in a.dtype.names:
+        bad = np.nonzero(a[name].view(np.uint32) != b[name].view(np.uint32))[0]
+        if len(bad):
+            return "%s differs at %d rows, first %d: %r vs %r" % (name, len(bad), bad[0], a[name][bad[0]], b[name][bad[0]])
+    return "equal"
+
+
+@pytest.fixture(scope="module")
+def h2000(pkg):
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 2000, device=0, max_w=1920, max_h=1080, max_batch=8)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def frame0(pkg, h2000):
+    L, R = pkg.synth.stereo_pair(11, 0)
+    res = h2000.process_stereo(L, R)
+    return L, R, res
+
+
+def test_pyramid_levels_bit_exact(h2000, oracle, frame0):
+    L, R, _ = frame0
+    p = oracle.orb_params(2000)
+    for img_i, img in enumerate((L, R)):
+        for l in range(1, 8):
+            want = oracle.orb_pyramid_level(img, p, l)
+            got = h2000.debug_level(img_i, l)
+            assert got.shape == want.shape
+            assert np.array_equal(got, want), "level %d of image %d: %d pixels differ" % (l, img_i, (got != want).sum())
+
+
+def test_blur_levels_bit_exact(h2000, oracle, frame0):
+    L, R, _ = frame0
+    p = oracle.orb_params(2000)
+    for l in range(8):
+        want = oracle.orb_blur_level(L, p, l)
+        got = h2000.debug_level(0, l, blurred=True)
+        assert np.array_equal(got, want), "blur level %d: %d pixels differ" % (l, (got != want).sum())
+
+
+def test_fast_candidates_bit_exact(h2000, oracle, frame0):
+    L, R, _ = frame0
+    p = oracle.orb_params(2000)
+    for img_i, img in enumerate((L, R)):
+        for l in range(8):
+            want = np.sort(oracle.orb_fast_level(img, p, l))
+            got = np.sort(h2000.debug_candidates(img_i, l))
+            assert np.array_equal(got, want), "FAST level %d: %d vs %d candidates" % (l, len(got), len(want))
+
+
+def test_process_stereo_bit_exact(h2000, oracle, pkg, frame0):
+    L, R, (kpL, dL, kpR, dR, m, pts, has) = frame0
+    p = oracle.orb_params(2000)
+    okL, odL = oracle.orb_extract(L, p)
+    okR, odR = oracle.orb_extract(R, p)
+    assert len(kpL) == len(okL) and len(kpR) == len(okR)
+    assert records_equal(kpL, okL), _first_diff(kpL, okL)
+    assert records_equal(kpR, okR), _first_diff(kpR, okR)
+    assert np.array_equal(dL, odL), "%d descriptor rows differ" % (dL != odL).any(1).sum()
+    assert np.array_equal(dR, odR)
+    cam = oracle.Camera(**pkg.synth.EUROC_CAMERA)
+    m0, p0, h0 = oracle.stereo_match(cam, okL, odL, okR, odR)
+    assert records_equal(m0, m) and np.array_equal(h0, has) and np.array_equal(p0[h0 == 1], pts[has == 1])
+    assert len(m) > 200
+
+
+@pytest.mark.parametrize("n_features,seed", [(1200, 1), (2000, 2), (4000, 3), (500, 4)])
+def test_extract_other_quotas(oracle, pkg, n_features, seed):
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), n_features, device=0, max_w=752, max_h=480, max_batch=1)
+    L, R = pkg.synth.stereo_pair(seed, 5)
+    kpL, dL, kpR, dR, m, pts, has = h.process_stereo(L, R, cap_kp=n_features + 1024)
+    p = oracle.orb_params(n_features)
+    for (k, d, img) in ((kpL, dL, L), (kpR, dR, R)):
+        ok, od = oracle.orb_extract(img, p)
+        assert records_equal(k, ok), _first_diff(k, ok) if len(k) == len(ok) else "%d vs %d" % (len(k), len(ok))
+        assert np.array_equal(d, od)
+    h.close()
+
+
+@pytest.mark.parametrize("w,hh", [(1920, 1080), (640, 480), (333, 257), (752, 480)])
+def test_extract_other_sizes_and_strides(oracle, pkg, w, hh):
+    n = 4000 if w == 1920 else 1500
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), n, device=0, max_w=1920, max_h=1080, max_batch=1)
+    L, R = pkg.synth.stereo_pair(21, 0, w, hh)
+    kpL, dL, kpR, dR, m, pts, has = h.process_stereo(L, R, cap_kp=n + 2048)
+    p = oracle.orb_params(n)
+    ok, od = oracle.orb_extract(L, p)
+    assert records_equal(kpL, ok), _first_diff(kpL, ok) if len(kpL) == len(ok) else "%d vs %d" % (len(kpL), len(ok))
+    assert np.array_equal(dL, od)
+    ok, od = oracle.orb_extract(R, p)
+    assert records_equal(kpR, ok) and np.array_equal(dR, od)
+    h.close()
+
+
+def test_degenerate_images(oracle, pkg):
+    """flat image -> no keypoints; binary dot grid -> all FAST scores tie, every candidate is kept by
+    retainBest's tie rule and the Harris responses tie too (exercises the big rank-sort path)."""
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 300, device=0, max_w=752, max_h=480, max_batch=1)
+    flat = np.full((480, 752), 90, np.uint8)
+    kpL, dL, kpR, dR, m, pts, has = h.process_stereo(flat, flat)
+    assert len(kpL) == 0 and len(kpR) == 0 and len(m) == 0
+    dots = np.full((480, 752), 20, np.uint8)
+    dots[8::12, 8::12] = 240
+    p = oracle.orb_params(300)
+    ok, od = oracle.orb_extract(dots, p)
+    kpL, dL, kpR, dR, m, pts, has = h.process_stereo(dots, dots, cap_kp=len(ok) + 64)
+    assert len(ok) > 1500    # far more than n_features: ties are all kept (keypoint.cpp retainBest)
+    assert records_equal(kpL, ok), _first_diff(kpL, ok) if len(kpL) == len(ok) else "%d vs %d" % (len(kpL), len(ok))
+    assert np.array_equal(dL, od)
+    # capacity too small -> error, never truncation
+    with pytest.raises(pkg.OrbxError) as e:
+        h.process_stereo(dots, dots, cap_kp=1000)
+    assert e.value.code == -4
+    h.close()
+
+
+def test_batch_device_equals_single(h2000, oracle, pkg):
+    """[batch,2,h,w] device-resident form: every pair equals the oracle run on that pair."""
+    import torch
+    B = 6
+    imgs = pkg.synth.stereo_batch(7, 100, B)
+    out = h2000.alloc_batch_outputs(B, 2304)
+    d_imgs = torch.from_numpy(imgs).cuda()
+    h2000.process_stereo_batch_device(d_imgs, out)
+    h2000.check_status()
+    p = oracle.orb_params(2000)
+    cam = oracle.Camera(**pkg.synth.EUROC_CAMERA)
+    for b in range(B):
+        fl, fr, m, pts, has = h2000.unpack_batch_outputs(out, b)
+        okL, odL = oracle.orb_extract(imgs[b, 0], p)
+        okR, odR = oracle.orb_extract(imgs[b, 1], p)
+        assert records_equal(fl.keypoints, okL) and np.array_equal(fl.descriptors, odL)
+        assert records_equal(fr.keypoints, okR) and np.array_equal(fr.descriptors, odR)
+        m0, p0, h0 = oracle.stereo_match(cam, okL, odL, okR, odR)
+        assert records_equal(m0, m) and np.array_equal(h0, has) and np.array_equal(p0[h0 == 1], pts[has == 1])
+
+
+def test_unaligned_rows(oracle, pkg):
+    """caller rows that are not 4-byte aligned go through the level-0 copy"""
+    import torch
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 800, device=0, max_w=752, max_h=480, max_batch=1)
+    L, R = pkg.synth.stereo_pair(31, 2, 333, 257)
+    out = h.alloc_batch_outputs(1, 2048)
+    d = torch.from_numpy(np.stack([L, R])[None]).cuda()     # stride 333: unaligned
+    h.process_stereo_batch_device(d, out)
+    h.check_status()
+    fl, fr, m, pts, has = h.unpack_batch_outputs(out, 0)
+    ok, od = oracle.orb_extract(L, oracle.orb_params(800))
+    assert records_equal(fl.keypoints, ok) and np.array_equal(fl.descriptors, od)
+    h.close()
+
+
+def test_stereo_processor_mirror(pkg, oracle):
+    """the host mirror with the reference's names: StereoProcessor::new / process"""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA)
+    sp = pkg.StereoProcessor.new(cam, 1200)          # main.rs:53 uses 1200
+    L, R = pkg.synth.stereo_pair(1, 1)
+    f = sp.process(L, R, 1403636579763555584)
+    assert f.timestamp_ns == 1403636579763555584
+    assert len(f.left_features.keypoints) == len(f.left_features.descriptors) <= 1200 + 50
+    assert len(f.points_cam_options()) == len(f.left_features.keypoints)
+    assert sum(p is not None for p in f.points_cam_options()) == int(f.has_point.sum())
+    ok, od = oracle.orb_extract(L, oracle.orb_params(1200))
+    assert records_equal(f.left_features.keypoints, ok)
