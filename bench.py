@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X: stereo frames/s of ORB extract + match + triangulate
+at 752x480, 2000 ORB/frame (configs[1]), plus local-BA LM iterations/s (configs[2]) as extra keys.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+
+A "step" is one pass of the hot path (orbx_process_stereo_batch_device) over one batch of B synthetic
+stereo pairs that are already resident in HBM.  For N > 1 the driver launches one rank per GPU
+(torch.distributed.run); frames shard across ranks with no data-path collective, so
+per-GPU work is fixed ("weak" scaling) and value = all ranks' frames / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the `roofline` and `cpu_baseline` objects described in DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# compulsory bytes per stereo frame at 752x480, N=2000
+ALGO_BYTES_PER_FRAME = 2 * 752 * 480 + 2 * 2000 * (28 + 32) + 2 * 2000 * (32 + 8) + 2000 * 16 + 2000 * 25
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_batches(P, torch, dev, seed, batch, n_batches, w, h):
+    """n_batches distinct [batch,2,h,w] u8 device tensors.  32 generated pairs are expanded on the GPU
+    by vertical flips (rows stay rectified) and brightness offsets, so that the working set
+    (n_batches*batch*2*w*h bytes) exceeds the 256 MiB Infinity Cache."""
+    uniq = min(32, batch * n_batches)
+    base = torch.from_numpy(P.synth.stereo_batch(seed, 0, uniq, w, h)).to(dev)
+    out = []
+    k = 0
+    for _ in range(n_batches):
+        items = []
+        for _ in range(batch):
+            img = base[k % uniq]
+            v = k // uniq
+            if v & 1:
+                img = torch.flip(img, dims=[1])
+            off = ((v >> 1) % 5) * 3 - 6
+            if off:
+                img = (img.to(torch.int16) + off).clamp_(0, 255).to(torch.uint8)
+            items.append(img)
+            k += 1
+        out.append(torch.stack(items).contiguous())
+    return out
+
+
+def cpu_baseline(P, frames_mt, frames_1t, w, h, n_features):
+    """The CPU oracle (a restatement of the reference algorithm, kind 'port') on a bounded sample of the
+    same workload, timed on this box's host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.lib()
+    cam = O.Camera(**P.synth.EUROC_CAMERA)
+    p = O.orb_params(n_features)
+    imgs = P.synth.stereo_batch(999, 0, max(frames_mt, frames_1t), w, h)
+
+    def one(b):
+        kl, dl = O.orb_extract(imgs[b, 0], p)
+        kr, dr = O.orb_extract(imgs[b, 1], p)
+        return len(O.stereo_match(cam, kl, dl, kr, dr)[0])
+
+    one(0)
+    t0 = time.perf_counter()
+    for b in range(frames_1t):
+        one(b)
+    t1 = time.perf_counter() - t0
+    cores = min(os.cpu_count() or 1, 16)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:      # ctypes releases the GIL inside the oracle
+        list(ex.map(one, range(frames_mt)))
+    tm = time.perf_counter() - t0
+    return dict(value=round(frames_mt / tm, 3), unit="stereo frames/s", cores=cores, kind="port",
+                sample="%d synthetic 752x480 stereo frames, N=%d, oracle extract+match+triangulate, %d threads "
+                       "(frame-level parallelism); 1 thread: %.3f frames/s on %d frames"
+                       % (frames_mt, n_features, cores, frames_1t / t1, frames_1t),
+                value_1thread=round(frames_1t / t1, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="stereo pairs per step per GPU")
+    ap.add_argument("--n-batches", type=int, default=3)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import orb_slam3_rust_amd as P
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    W, H = 752, 480
+    cam = P.CameraModel(**P.synth.EUROC_CAMERA)
+    h = P.Handle(cam, args.features, device=local_rank, max_w=W, max_h=H, max_batch=args.batch)
+    cap = args.features + 304
+    out = h.alloc_batch_outputs(args.batch, cap)
+    batches = make_batches(P, torch, dev, 1000 * rank + 1, args.batch, args.n_batches, W, H)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        h.process_stereo_batch_device(batches[i % len(batches)], out)
+    h.check_status()
+    h.set_profiling(True)     # HIP events around every launch, on the library's stream
+    barrier(); torch.cuda.synchronize(); h.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        h.process_stereo_batch_device(batches[i % len(batches)], out)
+    h.synchronize(); torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    acc = {k: [v[0], v[1]] for k, v in h.kernel_times().items()}   # durations over the timed region
+    h.set_profiling(False)
+    h.check_status()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_matches = float(out["nmatches"].float().mean().item())
+    n_kp = float(out["nkp"].float().mean().item())
+
+    # roofline of the dominant kernel (largest summed HIP-event duration over the timed region)
+    total_ms = sum(a[0] for a in acc.values())
+    dom = max(acc.items(), key=lambda kv: kv[1][0])
+    dom_name, (dom_ms, dom_launches) = dom
+    # algorithmic bytes per launch of each kernel: per image, x images per launch
+    n_img = 2 * args.batch
+    lv = [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]
+    px = [a * b for a, b in lv]
+    per_launch = {
+        "fast_kernel": n_img * (sum(px) + 4 * 2 * args.features),          # read every level once, write candidates
+        "blur_kernel": n_img * 2 * sum(px),                                # read + write every level
+        "resize_kernel": n_img * (sum(px[:-1]) + sum(px[1:])) / 7.0,       # 7 launches: read l-1, write l
+        "describe_kernel": n_img * args.features * (31 * 31 + 37 * 37 + 28 + 32),
+        "harris_select_kernel": n_img * 2 * args.features * (81 + 4 + 8),
+        "rank_select_kernel": n_img * 2 * args.features * 16,
+        "stereo_match_kernel": args.batch * (2 * args.features * (32 + 8) + args.features * 8),
+        "stereo_compact_kernel": args.batch * args.features * (8 + 16 + 25),
+    }
+    ach = per_launch.get(dom_name, 0) / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = dict(bound="hbm", kernel=dom_name, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                    avg_launch_us=round(dom_ms / max(dom_launches, 1) * 1e3, 2),
+                    kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in sorted(acc.items())},
+                    path_algorithmic_GBps=round(ALGO_BYTES_PER_FRAME * args.batch * world * args.steps / elapsed / 1e9, 3))
+
+    frames = args.batch * args.steps * world
+    value = frames / elapsed
+    res = dict(metric="stereo frames/sec ORB extract+match @752x480", value=round(value, 2), unit="stereo frames/s",
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8", data="synthetic",
+               config=dict(workload="Synthetic 752x480 stereo, 2000 ORB/frame, extract+match+triangulate (BASELINE configs[1])",
+                           image=[W, H], n_features=args.features, batch_pairs_per_gpu=args.batch,
+                           distinct_batches=args.n_batches, parallelism="frames sharded, %d rank(s), no collective" % world,
+                           mean_keypoints_per_image=round(n_kp, 1), mean_matches_per_frame=round(n_matches, 1)),
+               roofline=roofline)
+
+    if not args.no_ba:
+        try:
+            res["local_ba"] = bench_ba(P, h, cam)
+        except Exception as e:  # BA leg must not hide the headline number
+            res["local_ba"] = dict(error=str(e))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(P, 48, 6, W, H, args.features)
+    elif rank == 0:
+        res["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(res))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_ba(P, h, cam):
+    """configs[2]: local BA, 20 keyframes / 2000 map points, LM iterations per second on this GPU."""
+    win = P.synth.ba_window(42, 20, 2000, P.BA_OBS)
+    cfg = P.LocalBAConfigLM()
+    r = h.ba_solve_visual(cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
+    reps = 5
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(reps):
+        r = h.ba_solve_visual(cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
+        its += r["iterations"]
+    dt = time.perf_counter() - t0
+    return dict(workload="synth_ba(seed=42, K=20, M=2000), %d observations" % len(win["obs"]),
+                lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3),
+                iterations=r["iterations"], initial_error_px=round(r["initial_error"], 4),
+                final_error_px=round(r["final_error"], 4))
+
+
+if __name__ == "__main__":
+    main()

@@ -206,12 +206,14 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
                          int* iterations, double* initial_error, double* final_error);
 
-/* Per-kernel device time of the last call, for bench.py's roofline block.  Fills up to
- * `cap` entries; returns the number available.  Times are HIP-event durations on the
- * handle's stream; profiling must have been switched on with orbx_set_profiling. */
+/* Per-kernel device time for bench.py's roofline block.  While profiling is on
+ * (orbx_set_profiling), every launch is bracketed by HIP events on the handle's stream;
+ * orbx_get_kernel_times synchronises, fills up to `cap` entries with the durations summed
+ * over all calls since the previous read (returns the number of kernels seen), and starts a
+ * new accumulation window. */
 typedef struct {
   char name[48];
-  float ms;          /* summed duration of this kernel's launches in the last call */
+  float ms;          /* summed duration of this kernel's launches in the window */
   int launches;
 } orbx_kernel_time;
 int orbx_set_profiling(orbx_handle* h, int on);

@@ -59,11 +59,7 @@ ProfScope::~ProfScope() {
   hipEventRecord(e, h->stream);
   h->timers[idx].ev.push_back(e);
 }
-void orbx_prof_begin_call(orbx_handle* h) {
-  if (!h->profiling) return;
-  h->event_next = 0;
-  for (auto& t : h->timers) { t.ev.clear(); t.ms = 0.f; t.launches = 0; }
-}
+void orbx_prof_begin_call(orbx_handle* h) { (void)h; }   // events accumulate until they are read
 void orbx_prof_end_call(orbx_handle* h) { (void)h; }
 
 extern "C" {
@@ -166,6 +162,8 @@ int orbx_check_status(orbx_handle* h) {
 int orbx_set_profiling(orbx_handle* h, int on) {
   if (!h) return ORBX_ERR_INVALID;
   h->profiling = on != 0;
+  h->event_next = 0;
+  for (auto& t : h->timers) t.ev.clear();
   return ORBX_OK;
 }
 
@@ -191,6 +189,9 @@ int orbx_get_kernel_times(orbx_handle* h, orbx_kernel_time* out, int cap) {
     }
     ++n;
   }
+  // reading resets: the next call starts a new accumulation window
+  h->event_next = 0;
+  for (auto& t : h->timers) t.ev.clear();
   return n;
 }
 
