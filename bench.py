@@ -117,7 +117,8 @@ def main():
     h = P.Handle(cam, args.features, device=local_rank, max_w=W, max_h=H, max_batch=args.batch)
     cap = args.features + 304
     out = h.alloc_batch_outputs(args.batch, cap)
-    batches = make_batches(P, torch, dev, 1000 * rank + 1, args.batch, args.n_batches, W, H)
+    # rank r owns stream r (seed 1000*r+1): frames shard across ranks, no collective
+    batches = make_batches(P, torch, dev, 1000 * P.dist.shard_streams(world, rank, world)[0] + 1, args.batch, args.n_batches, W, H)
     torch.cuda.synchronize()
 
     def barrier():
@@ -138,9 +139,7 @@ def main():
     h.set_profiling(False)
     h.check_status()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = P.dist.allreduce_max_seconds(elapsed, dev)
     n_matches = float(out["nmatches"].float().mean().item())
     n_kp = float(out["nkp"].float().mean().item())
 

@@ -4,7 +4,7 @@ kernels behind the C ABI of include/orbx.h.  See DESIGN.md / INTEGRATION.md.
 
 Import as `orb_slam3_rust_amd` (the shim at the repo root maps the hyphenated directory name).
 """
-from . import synth  # noqa: F401
+from . import dist, synth  # noqa: F401
 from .api import (  # noqa: F401
     ABI_SYMBOLS, BA_OBS, DMATCH, KEYPOINT, NN_RATIO, TH_HIGH, TH_LOW, CameraModel, FeatureSet, Handle,
     LocalBAConfigLM, OrbxError, StereoFrame, StereoProcessor, VisualBAProblemData, VisualBAResultData,

@@ -100,3 +100,53 @@ def test_solve_visual_ba_mirror(gpu_handle, oracle, pkg):
     assert res.iterations == o["iterations"] and set(res.optimized_poses) == set(kf_ids)
     got = np.array([res.optimized_poses[k] for k in kf_ids])
     assert _rel(got, o["poses_wc"]) < POSE_TOL
+
+
+def test_ba_point_partition_two_ranks_one_gpu(oracle, pkg):
+    """Point-partitioned BA on the real kernels: two 'ranks' = two handles driven by two
+    threads in this process, the all-reduce hook sums their device buffers in place.  The result must
+    match the single-handle solve to rounding (summation order differs) and be identical on both."""
+    import threading
+    import torch
+    w = pkg.synth.ba_window(21, 10, 400, pkg.BA_OBS, n_fixed_extra=1)
+    cam = pkg.CameraModel(**w["camera"]); cfg = pkg.LocalBAConfigLM()
+    dev = torch.device("cuda", 0)
+    world = 2
+    hs = [pkg.Handle(cam, 100, device=0) for _ in range(world)]
+    bar = threading.Barrier(world)
+    slots = [None] * world
+    out = [None] * world
+    errs = []
+
+    def hook_for(rank):
+        def hook(ptr, n, stream):
+            torch.cuda.synchronize()
+            slots[rank] = pkg.dist.device_tensor(ptr, n, dev)
+            bar.wait()
+            total = slots[0] + slots[1]
+            torch.cuda.synchronize()
+            bar.wait()
+            slots[rank].copy_(total)
+            torch.cuda.synchronize()
+            bar.wait()
+        return hook
+
+    def run(rank):
+        try:
+            out[rank] = pkg.dist.ba_solve_partitioned(hs[rank], cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"],
+                                                      w["obs"], rank, world, hook_for(rank))
+        except Exception as e:  # pragma: no cover
+            errs.append(e); bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts: t.start()
+    for t in ts: t.join(120)
+    assert not errs, errs
+    single = hs[0].ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+    for r in range(world):
+        assert out[r]["iterations"] == single["iterations"]
+        assert _rel(out[r]["poses_wc"], single["poses_wc"]) < 1e-9
+        assert _rel(out[r]["points"], single["points"]) < 1e-9
+        assert abs(out[r]["final_error"] - single["final_error"]) < 1e-10 * single["final_error"]
+    assert np.array_equal(out[0]["poses_wc"], out[1]["poses_wc"]) and np.array_equal(out[0]["points"], out[1]["points"])
+    for h in hs: h.close()

@@ -1,0 +1,93 @@
+"""world_size-2 gloo tests (CPU) of the N>1 host logic: stream sharding, the BA point partition and
+the all-reduce of the reduced normal equations.  The compute under the collective is
+the oracle's reduced-system builder; the partition / reduce code is the product's (dist.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import orb_slam3_rust_amd as P
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # 1) frame sharding: disjoint, complete
+        mine = P.dist.shard_streams(8, rank, world)
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        assert sorted(sum(allv, [])) == list(range(8))
+        # 2) BA: partial reduced systems of the point partition, summed over ranks == full system
+        w = P.synth.ba_window(11, 6, 120, P.BA_OBS, n_fixed_extra=1)
+        cam = O.Camera(**w["camera"]); cfg = O.ba_config()
+        pp = np.concatenate([O.se3_to_params(p) for p in w["poses_cw"]])
+        local = P.dist.partition_observations(w["obs"], rank, world)
+        owners = P.dist.point_owner(local["mp_idx"], world)
+        assert np.all(owners == rank) and 0 < len(local) < len(w["obs"])
+        U, gp, S, b, chi2 = O.ba_reduced_system(cam, cfg, 1e-3, pp, w["fixed_cw"], w["points"], local)
+        buf = torch.from_numpy(np.concatenate([S.ravel(), U.ravel(), gp, b, [chi2]]))
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        Uf, gpf, Sf, bf, chif = O.ba_reduced_system(cam, cfg, 1e-3, pp, w["fixed_cw"], w["points"], w["obs"])
+        full = np.concatenate([Sf.ravel(), Uf.ravel(), gpf, bf, [chif]])
+        assert np.allclose(buf.numpy(), full, rtol=1e-11, atol=1e-8)
+        # 3) solving the reduced system from the summed buffer gives the same pose step on every rank
+        n = 6 * len(w["poses_cw"])
+        Ssum = buf.numpy()[:n * n].reshape(n, n)
+        Usum = buf.numpy()[n * n:n * n + 36 * (n // 6)].reshape(-1, 6, 6)
+        H = -Ssum.copy()
+        for k in range(n // 6):
+            Ud = Usum[k].copy()
+            Ud[np.diag_indices(6)] += 1e-3 * np.maximum(np.diag(Ud), 1e-6)
+            H[6 * k:6 * k + 6, 6 * k:6 * k + 6] += Ud
+        rhs = -buf.numpy()[n * n + 36 * (n // 6):n * n + 36 * (n // 6) + n] + buf.numpy()[n * n + 36 * (n // 6) + n:n * n + 36 * (n // 6) + 2 * n]
+        dp = np.linalg.solve(H, rhs)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dp.tolist())
+        assert np.array_equal(np.array(gathered[0]), np.array(gathered[1]))
+        # 4) the bench's max-over-ranks timing helper
+        assert P.dist.allreduce_max_seconds(1.0 + rank) == float(world)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_partition_and_reduce():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_partition_properties():
+    sys.path.insert(0, ROOT)
+    import orb_slam3_rust_amd as P
+    w = P.synth.ba_window(5, 8, 500, P.BA_OBS)
+    parts = [P.dist.partition_observations(w["obs"], r, 4) for r in range(4)]
+    assert sum(len(p) for p in parts) == len(w["obs"])
+    for r, p in enumerate(parts):
+        assert np.all(p["mp_idx"] % 4 == r)
+    sizes = [len(p) for p in parts]
+    assert max(sizes) < 1.3 * min(sizes)        # balanced
+    assert P.dist.shard_streams(8, 3, 8) == [3] and P.dist.shard_streams(3, 1, 2) == [1]
