@@ -181,9 +181,9 @@ def main():
 
     if not args.no_ba:
         try:
-            res["local_ba"] = bench_ba(P, h, cam)
+            res["local_ba"] = bench_ba(P, h, cam, rank, world, dev)
         except Exception as e:  # BA leg must not hide the headline number
-            res["local_ba"] = dict(error=str(e))
+            res["local_ba"] = dict(error=repr(e))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(P, 48, 6, W, H, args.features)
     elif rank == 0:
@@ -195,19 +195,35 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_ba(P, h, cam):
-    """configs[2]: local BA, 20 keyframes / 2000 map points, LM iterations per second on this GPU."""
+def bench_ba(P, h, cam, rank=0, world=1, dev=None):
+    """configs[2]: local BA, 20 keyframes / 2000 map points, LM iterations per second.  One GPU: the
+    whole window on this GPU.  N GPUs (configs[3]): the SAME window with its map points partitioned
+    over the ranks and the reduced normal equations all-reduced over RCCL every iteration."""
     win = P.synth.ba_window(42, 20, 2000, P.BA_OBS)
     cfg = P.LocalBAConfigLM()
-    r = h.ba_solve_visual(cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
+    hook = P.dist.make_allreduce_hook(dev) if world > 1 else None
+
+    def solve():
+        if world > 1:
+            return P.dist.ba_solve_partitioned(h, cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"],
+                                               rank, world, hook)
+        return h.ba_solve_visual(cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
+
+    r = solve()
     reps = 5
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     t0 = time.perf_counter()
     its = 0
     for _ in range(reps):
-        r = h.ba_solve_visual(cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
+        r = solve()
         its += r["iterations"]
     dt = time.perf_counter() - t0
-    return dict(workload="synth_ba(seed=42, K=20, M=2000), %d observations" % len(win["obs"]),
+    if world > 1:
+        dt = P.dist.allreduce_max_seconds(dt, dev)
+    return dict(workload="synth_ba(seed=42, K=20, M=2000), %d observations%s" % (
+                    len(win["obs"]), ", points partitioned over %d ranks + RCCL all-reduce" % world if world > 1 else ""),
                 lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3),
                 iterations=r["iterations"], initial_error_px=round(r["initial_error"], 4),
                 final_error_px=round(r["final_error"], 4))

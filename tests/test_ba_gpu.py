@@ -150,3 +150,28 @@ def test_ba_point_partition_two_ranks_one_gpu(oracle, pkg):
         assert abs(out[r]["final_error"] - single["final_error"]) < 1e-10 * single["final_error"]
     assert np.array_equal(out[0]["poses_wc"], out[1]["poses_wc"]) and np.array_equal(out[0]["points"], out[1]["points"])
     for h in hs: h.close()
+
+
+def test_ba_allreduce_hook_rccl_world1(gpu_handle, pkg):
+    """The torch.distributed hook itself (backend nccl = RCCL), world_size 1 on this one GPU: the
+    collective runs on the library's stream through torch.cuda.ExternalStream and must leave the
+    single-rank result unchanged bit for bit."""
+    import os, socket
+    import torch
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        w = pkg.synth.ba_window(9, 7, 250, pkg.BA_OBS)
+        cam = pkg.CameraModel(**w["camera"]); cfg = pkg.LocalBAConfigLM()
+        ref = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+        got = pkg.dist.ba_solve_partitioned(gpu_handle, cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"],
+                                            0, 1, pkg.dist.make_allreduce_hook(dev))
+        assert got["iterations"] == ref["iterations"]
+        assert np.array_equal(got["poses_wc"], ref["poses_wc"]) and np.array_equal(got["points"], ref["points"])
+        assert got["final_error"] == ref["final_error"]
+    finally:
+        dist.destroy_process_group()
