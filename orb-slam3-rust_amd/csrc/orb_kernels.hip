@@ -33,8 +33,22 @@ constexpr int TILE_W = 64, TILE_H = 16;
 constexpr int EDGE = 31;             // edgeThreshold, stereo.rs:42
 constexpr int HARRIS_CHUNKS = 8;
 
-__constant__ signed char c_pattern[256 * 4];
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__constant__ __attribute__((aligned(16))) signed char c_pattern[256 * 4];
+
+// XCD-aware block -> (image, block-within-image) map.  Workgroups are dealt round-robin over the 8
+// XCDs by linear id, so with a 1-D grid of 8*ceil(n_img/8)*per_img blocks, id = (grp*per_img + b)*8 + x
+// puts every block of image grp*8+x on XCD x (whichever physical XCD that is): an image's pyramid
+// (1.2 MB) then stays in ONE 4 MB L2 while its tiles / keypoints are processed, instead of being
+// fetched by up to 8 L2s.  Speed only; any placement gives the same results.
+__device__ __forceinline__ bool xcd_decode(int per_img, int n_img, int& img, int& b) {
+  const unsigned L = blockIdx.x;
+  const unsigned x = L & 7u, slot = L >> 3;
+  const unsigned grp = slot / (unsigned)per_img;
+  b = (int)(slot - grp * (unsigned)per_img);
+  img = (int)(grp * 8u + x);
+  return img < n_img;
+}
+static inline unsigned xcd_grid(int per_img, int n_img) { return 8u * (unsigned)((n_img + 7) / 8) * (unsigned)per_img; }
 
 __device__ __forceinline__ const uint8_t* level_ptr(const OrbSrc& s, const OrbGeom& g, int img, int l,
                                                     int& pitch) {
@@ -55,17 +69,19 @@ __global__ __launch_bounds__(256) void copy_l0_kernel(const uint8_t* __restrict_
 }
 
 // ---- A.4 resize: 4 destination pixels per thread, one aligned u32 store ----------------------------------
-__global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
+__global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l, int n_img, int tiles_x, int tiles_y,
                                                      const unsigned* __restrict__ xtab,
                                                      const unsigned* __restrict__ ytab) {
-  const int img = blockIdx.z;
+  int img, tb;
+  if (!xcd_decode(tiles_x * tiles_y, n_img, img, tb)) return;
+  const int tby = tb / tiles_x, tbx = tb - tby * tiles_x;
   int sp;
   const uint8_t* src = level_ptr(s, g, img, l - 1, sp);
   const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h;
   const int w = g.lv[l].w, h = g.lv[l].h, dp = g.lv[l].pitch;
   uint8_t* dst = s.pyr + (size_t)img * g.slot_bytes + g.lv[l].off;
-  const int x0 = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
-  const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int x0 = tbx * 64 + (threadIdx.x & 15) * 4;
+  const int y = tby * 16 + (threadIdx.x >> 4);
   if (y >= h || x0 >= w) return;
   const unsigned yt = ytab[y];
   const int y0 = (int)(yt >> 16), y1 = min(y0 + 1, sh - 1);
@@ -110,42 +126,87 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 
 // ---- A.8 Gaussian blur 7x7 sigma 2, taps {18,34,48,56,48,34,18}/256, 8.8 then 16.16 ------------------
-__global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g) {
-  __shared__ uint8_t sp[TILE_H + 6][72];
-  __shared__ unsigned short shz[TILE_H + 6][TILE_W];
-  const int img = blockIdx.y;
+// No LDS: a wave owns a 256-px-wide column strip (lane = 4 consecutive pixels = one dword) and walks
+// down BLUR_STRIP rows.  Per input row: one coalesced 256-B dword load per wave, neighbour dwords by
+// DPP wave shifts (+2 edge lanes loading), horizontal taps with v_alignbyte + v_dot4_u32_u8 (8.8 sums),
+// a 7-row ring of those sums in registers, vertical taps as 32-bit mads (16.16), one dword store.
+// Lanes whose 10-px window crosses the image edge rebuild their three dwords bytewise with
+// BORDER_REFLECT_101 (a few lanes per row).
+constexpr int BLUR_W = 256, BLUR_STRIP = 64, BLUR_H = 4 * BLUR_STRIP;
+
+__device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2, unsigned (&hs)[4]) {
+  const unsigned G0 = 18u | (34u << 8) | (48u << 16) | (56u << 24);   // px x-3..x
+  const unsigned G1 = 48u | (34u << 8) | (18u << 16);                 // px x+1..x+3
+  hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), G1,
+                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), G0, 0u, false), false);
+  hs[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), G1,
+                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), G0, 0u, false), false);
+  hs[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), G1,
+                                 __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), G0, 0u, false), false);
+  hs[3] = __builtin_amdgcn_udot4(d2, G1, __builtin_amdgcn_udot4(d1, G0, 0u, false), false);
+}
+
+__device__ __forceinline__ void blur_row(const uint8_t* __restrict__ src, int pitch, int w, int row, int x0, int lane,
+                                         bool slow, unsigned (&hs)[4]) {
+  const uint8_t* rp = src + (size_t)row * pitch;
+  const int xl = min(x0, pitch - 4);
+  unsigned d1 = *reinterpret_cast<const unsigned*>(rp + xl);
+  // edge lanes of the wave fetch the dword their neighbour lane does not exist for
+  unsigned extra = 0;
+  if (lane == 0 && x0 >= 4) extra = *reinterpret_cast<const unsigned*>(rp + x0 - 4);
+  if (lane == 63 && x0 + 8 <= pitch) extra = *reinterpret_cast<const unsigned*>(rp + x0 + 4);
+  unsigned d0 = __builtin_amdgcn_update_dpp(0u, d1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  unsigned d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  if (lane == 0) d0 = extra;
+  if (lane == 63) d2 = extra;
+  if (slow) {
+    unsigned b[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) b[t] = rp[reflect101(x0 - 4 + t, w)];
+    d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+    d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+  }
+  blur_hsum(d0, d1, d2, hs);
+}
+
+__global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_img) {
+  int img, tile;
+  if (!xcd_decode(g.btiles_total, n_img, img, tile)) return;
   int l, tx, ty;
-  decode_tile(g, blockIdx.x, false, l, tx, ty);
+  decode_tile(g, tile, false, l, tx, ty);
   int pitch;
   const uint8_t* src = level_ptr(s, g, img, l, pitch);
   const int w = g.lv[l].w, h = g.lv[l].h;
-  const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < (TILE_H + 6) * 70; i += 256) {
-    const int r = i / 70, c = i - r * 70;
-    const int gx = reflect101(x0 - 3 + c, w), gy = reflect101(y0 - 3 + r, h);
-    sp[r][c] = src[(size_t)gy * pitch + gx];
-  }
-  __syncthreads();
-  for (int i = tid; i < (TILE_H + 6) * TILE_W; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const unsigned v = 18u * (sp[r][c] + sp[r][c + 6]) + 34u * (sp[r][c + 1] + sp[r][c + 5]) +
-                       48u * (sp[r][c + 2] + sp[r][c + 4]) + 56u * sp[r][c + 3];
-    shz[r][c] = (unsigned short)v;
-  }
-  __syncthreads();
-  const int c4 = (tid & 15) * 4, r = tid >> 4;
-  if (y0 + r < h && x0 + c4 < w) {
-    unsigned packed = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ys = ty * BLUR_H + wave * BLUR_STRIP;
+  if (ys >= h) return;                        // wave-uniform
+  const int x0 = tx * BLUR_W + lane * 4;
+  const bool active = x0 < w;
+  const bool slow = active && (x0 < 4 || x0 + 7 > w);
+  const int nrows = min(BLUR_STRIP, h - ys);
+  uint8_t* dst = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
+  const int dpitch = g.lv[l].pitch;
+  unsigned ring[7][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = c4 + k;
-      const unsigned v = 18u * ((unsigned)shz[r][c] + shz[r + 6][c]) + 34u * ((unsigned)shz[r + 1][c] + shz[r + 5][c]) +
-                         48u * ((unsigned)shz[r + 2][c] + shz[r + 4][c]) + 56u * (unsigned)shz[r + 3][c];
-      packed |= ((v + 32768u) >> 16) << (8 * k);
+  for (int i = 0; i < 6; ++i) blur_row(src, pitch, w, reflect101(ys - 3 + i, h), x0, lane, slow, ring[i]);
+  for (int y0 = 0; y0 < nrows; y0 += 7) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int y = y0 + i;
+      if (y < nrows) {   // wave-uniform
+        // ring slot (i+6)%7 receives input row ys+y+3; slots (i..i+6)%7 hold rows y-3..y+3
+        blur_row(src, pitch, w, reflect101(ys + y + 3, h), x0, lane, slow, ring[(i + 6) % 7]);
+        unsigned packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned v = 18u * (ring[i % 7][k] + ring[(i + 6) % 7][k]) + 34u * (ring[(i + 1) % 7][k] + ring[(i + 5) % 7][k]) +
+                             48u * (ring[(i + 2) % 7][k] + ring[(i + 4) % 7][k]) + 56u * ring[(i + 3) % 7][k];
+          packed |= ((v + 32768u) >> 16) << (8 * k);
+        }
+        if (active) *reinterpret_cast<unsigned*>(dst + (size_t)(ys + y) * dpitch + x0) = packed;
+      }
     }
-    uint8_t* dst = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
-    *reinterpret_cast<unsigned*>(dst + (size_t)(y0 + r) * g.lv[l].pitch + x0 + c4) = packed;
   }
 }
 
@@ -169,7 +230,7 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int t) {
   return best > t ? best - 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, unsigned* __restrict__ cand,
+__global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, unsigned* __restrict__ cand,
                                                    unsigned* __restrict__ cand_count,
                                                    unsigned* __restrict__ hist) {
   __shared__ uint8_t sp[TILE_H + 8][TILE_W + 8];     // pixels, halo 4
@@ -177,9 +238,10 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, unsigned
   __shared__ unsigned s_list[TILE_W * TILE_H / 4];
   __shared__ int s_cnt;
   __shared__ unsigned s_base;
-  const int img = blockIdx.y;
+  int img, tile;
+  if (!xcd_decode(g.ftiles_total, n_img, img, tile)) return;
   int l, tx, ty;
-  decode_tile(g, blockIdx.x, true, l, tx, ty);
+  decode_tile(g, tile, true, l, tx, ty);
   int pitch;
   const uint8_t* src = level_ptr(s, g, img, l, pitch);
   const int w = g.lv[l].w, h = g.lv[l].h;
@@ -277,15 +339,17 @@ __device__ __forceinline__ float from_orderable(unsigned o) {
 
 // retainBest(2*n_l) by FAST score (threshold from the histogram), then Harris of each survivor.
 // key = (~orderable(response) << 32) | y << 16 | x : ascending key = canonical order.
-__global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g, const unsigned* __restrict__ cand,
+__global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g, int n_img, const unsigned* __restrict__ cand,
                                                             const unsigned* __restrict__ cand_count,
                                                             const unsigned* __restrict__ hist,
                                                             unsigned long long* __restrict__ sel,
                                                             unsigned* __restrict__ sel_count) {
   __shared__ unsigned sh[256];
   __shared__ int s_thr;
-  const int il = blockIdx.x;
-  const int img = il / g.n_levels, l = il - img * g.n_levels;
+  int img, bb;
+  if (!xcd_decode(g.n_levels * HARRIS_CHUNKS, n_img, img, bb)) return;
+  const int l = bb / HARRIS_CHUNKS, chunk = bb - l * HARRIS_CHUNKS;
+  const int il = img * g.n_levels + l;
   const int tid = threadIdx.x;
   const unsigned count = cand_count[il];
   const unsigned want = 2u * (unsigned)g.lv[l].quota;
@@ -311,7 +375,7 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
   const uint8_t* src = level_ptr(s, g, img, l, pitch);
   const unsigned* cl = cand + (size_t)img * g.cand_total + g.lv[l].cand_off;
   unsigned long long* out = sel + (size_t)img * g.cand_total + g.lv[l].cand_off;
-  for (unsigned i = blockIdx.y * 256 + tid; i < count; i += gridDim.y * 256) {
+  for (unsigned i = chunk * 256 + tid; i < count; i += HARRIS_CHUNKS * 256) {
     const unsigned c = cl[i];
     if ((c >> 24) < thr) continue;
     const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
@@ -358,14 +422,15 @@ __device__ __forceinline__ void rank_pass(const unsigned long long* __restrict__
   }
 }
 
-__global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, const unsigned long long* __restrict__ sel,
+__global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img, const unsigned long long* __restrict__ sel,
                                                            const unsigned* __restrict__ sel_count,
                                                            unsigned long long* __restrict__ sel2,
                                                            unsigned* __restrict__ kept) {
   __shared__ unsigned long long chunk[2048];
   __shared__ unsigned s_thr, s_keep;
-  const int il = blockIdx.x;
-  const int img = il / g.n_levels, l = il - img * g.n_levels;
+  int img, l;
+  if (!xcd_decode(g.n_levels, n_img, img, l)) return;
+  const int il = img * g.n_levels + l;
   const int tid = threadIdx.x;
   const unsigned M = sel_count[il];
   const int quota = g.lv[l].quota;
@@ -450,15 +515,21 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float& c_out, float&
 constexpr int PA_ROWS = 31, PA_DW = 9;    // unblurred 31x31 patch, 9 aligned dwords per row
 constexpr int PB_ROWS = 37, PB_DW = 10, PB_PITCH = 11;   // blurred 37x37 patch, 10 dwords loaded, pitch 11
 
-__global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, const unsigned long long* __restrict__ sel2,
+__global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int n_img, int blocks_per_img,
+                                                       const unsigned long long* __restrict__ sel2,
                                                        const unsigned* __restrict__ kept,
                                                        orbx_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
                                                        int* __restrict__ nkp, int cap_kp, float patch_size,
                                                        unsigned* __restrict__ status) {
   __shared__ unsigned pa[4][PA_ROWS * PA_DW];
   __shared__ unsigned pb[4][PB_ROWS * PB_PITCH];
-  const int img = blockIdx.y;
+  int img, bx;
+  if (!xcd_decode(blocks_per_img, n_img, img, bx)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // this lane's four test pairs (bits lane, lane+64, lane+128, lane+192), one dword each
+  int pat[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pat[q] = reinterpret_cast<const int*>(c_pattern)[q * 64 + lane];
   unsigned start[ORBX_MAX_LEVELS + 1];
   start[0] = 0;
 #pragma unroll
@@ -466,13 +537,13 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, cons
     start[l + 1] = start[l] + (l < g.n_levels ? kept[img * g.n_levels + l] : 0u);
   const unsigned total = start[ORBX_MAX_LEVELS];
   const unsigned limit = min(total, (unsigned)cap_kp);
-  if (blockIdx.x == 0 && tid == 0) {
+  if (bx == 0 && tid == 0) {
     nkp[img] = (int)limit;
     if (total > (unsigned)cap_kp) atomicOr(status, ORBX_ST_KP_OVERFLOW);
   }
   const uint8_t* pab = reinterpret_cast<const uint8_t*>(pa[wave]);
   const uint8_t* pbb = reinterpret_cast<const uint8_t*>(pb[wave]);
-  for (unsigned slot = blockIdx.x * 4 + wave; slot < limit; slot += gridDim.x * 4) {
+  for (unsigned slot = bx * 4 + wave; slot < limit; slot += blocks_per_img * 4) {
     int l = 0;
     unsigned lbase = 0;
 #pragma unroll
@@ -503,7 +574,9 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, cons
     for (int i = lane; i < 31 * 31; i += 64) {
       const int r = i / 31, c = i - r * 31;
       const int v = r - 15, u = c - 15;
-      if (abs(u) <= c_umax[abs(v)]) {
+      // umax[|v|] (Appendix A.7) packed 4 bits per entry: 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3
+      const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * abs(v))) & 15ull);
+      if (abs(u) <= um) {
         const int I = pab[r * (PA_DW * 4) + ma + c];
         m10 += u * I;
         m01 += v * I;
@@ -520,9 +593,8 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, cons
     unsigned long long word[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int j = q * 64 + lane;
-      const float px0 = (float)c_pattern[4 * j + 0], py0 = (float)c_pattern[4 * j + 1];
-      const float px1 = (float)c_pattern[4 * j + 2], py1 = (float)c_pattern[4 * j + 3];
+      const float px0 = (float)(signed char)(pat[q] & 0xff), py0 = (float)(signed char)((pat[q] >> 8) & 0xff);
+      const float px1 = (float)(signed char)((pat[q] >> 16) & 0xff), py1 = (float)(signed char)((pat[q] >> 24) & 0xff);
       const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, ca), __fmul_rn(py0, sa)));
       const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, sa), __fmul_rn(py0, ca)));
       const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, ca), __fmul_rn(py1, sa)));
@@ -604,9 +676,9 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
     L.cand_off = coff;
     L.cand_cap = (iw > 0 && ih > 0) ? (unsigned)(((iw + 1) / 2) * ((ih + 1) / 2)) : 0u;
     coff += (L.cand_cap + 63u) & ~63u;
-    L.btiles_x = (L.w + TILE_W - 1) / TILE_W;
+    L.btiles_x = (L.w + BLUR_W - 1) / BLUR_W;
     L.btile_start = bt;
-    bt += L.btiles_x * ((L.h + TILE_H - 1) / TILE_H);
+    bt += L.btiles_x * ((L.h + BLUR_H - 1) / BLUR_H);
     L.ftiles_x = iw > 0 ? (iw + TILE_W - 1) / TILE_W : 0;
     L.ftile_start = ft;
     ft += (iw > 0 && ih > 0) ? L.ftiles_x * ((ih + TILE_H - 1) / TILE_H) : 0;
@@ -675,34 +747,34 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
   {
     ProfScope ps(h, "resize_kernel");
     for (int l = 1; l < nl; ++l) {
-      dim3 grid((g.lv[l].w + 63) / 64, (g.lv[l].h + 15) / 16, n_images);
-      hipLaunchKernelGGL(resize_kernel, grid, dim3(256), 0, h->stream, s, g, l, tab + h->resize_tab_off[2 * l],
-                         tab + h->resize_tab_off[2 * l + 1]);
+      const int tx = (g.lv[l].w + 63) / 64, ty = (g.lv[l].h + 15) / 16;
+      hipLaunchKernelGGL(resize_kernel, dim3(xcd_grid(tx * ty, n_images)), dim3(256), 0, h->stream, s, g, l, n_images, tx, ty,
+                         tab + h->resize_tab_off[2 * l], tab + h->resize_tab_off[2 * l + 1]);
     }
   }
   {
     ProfScope ps(h, "blur_kernel");
-    hipLaunchKernelGGL(blur_kernel, dim3(g.btiles_total, n_images), dim3(256), 0, h->stream, s, g);
+    hipLaunchKernelGGL(blur_kernel, dim3(xcd_grid(g.btiles_total, n_images)), dim3(256), 0, h->stream, s, g, n_images);
   }
   if (g.ftiles_total > 0) {
     ProfScope ps(h, "fast_kernel");
-    hipLaunchKernelGGL(fast_kernel, dim3(g.ftiles_total, n_images), dim3(256), 0, h->stream, s, g,
+    hipLaunchKernelGGL(fast_kernel, dim3(xcd_grid(g.ftiles_total, n_images)), dim3(256), 0, h->stream, s, g, n_images,
                        (unsigned*)h->ws_cand.p, cand_count, hist);
   }
   {
     ProfScope ps(h, "harris_select_kernel");
-    hipLaunchKernelGGL(harris_select_kernel, dim3((unsigned)n_il, HARRIS_CHUNKS), dim3(256), 0, h->stream, s, g,
+    hipLaunchKernelGGL(harris_select_kernel, dim3(xcd_grid(nl * HARRIS_CHUNKS, n_images)), dim3(256), 0, h->stream, s, g, n_images,
                        (const unsigned*)h->ws_cand.p, cand_count, hist, (unsigned long long*)h->ws_sel.p, sel_count);
   }
   {
     ProfScope ps(h, "rank_select_kernel");
-    hipLaunchKernelGGL(rank_select_kernel, dim3((unsigned)n_il), dim3(1024), 0, h->stream, g,
+    hipLaunchKernelGGL(rank_select_kernel, dim3(xcd_grid(nl, n_images)), dim3(1024), 0, h->stream, g, n_images,
                        (const unsigned long long*)h->ws_sel.p, sel_count, (unsigned long long*)h->ws_sel2.p, kept);
   }
   {
     ProfScope ps(h, "describe_kernel");
     const int blocks_x = (h->orb.n_features + 64 + 3) / 4;
-    hipLaunchKernelGGL(describe_kernel, dim3(blocks_x, n_images), dim3(256), 0, h->stream, s, g,
+    hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid(blocks_x, n_images)), dim3(256), 0, h->stream, s, g, n_images, blocks_x,
                        (const unsigned long long*)h->ws_sel2.p, kept, d_kp, d_desc, d_nkp, cap_kp,
                        (float)h->orb.patch_size, h->d_status);
   }
