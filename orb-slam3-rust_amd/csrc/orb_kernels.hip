@@ -230,13 +230,22 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int t) {
   return best > t ? best - 1 : 0;
 }
 
+// Two-phase per 64x16 tile (+1 score halo, +4 pixel halo):
+//   1. every position: compass pre-test — a 9-arc always contains two adjacent compass points
+//      (0,4,8,12), so a corner needs two adjacent ones both brighter than v+t or both darker than v-t;
+//      survivors (~10 %) are compacted into an LDS list (ballot + one LDS atomic per wave);
+//   2. full arc score only for the listed positions, written into the LDS score tile;
+//   3. 3x3 NMS + border filter over the list, block-aggregated append to the level's candidates.
 __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, unsigned* __restrict__ cand,
                                                    unsigned* __restrict__ cand_count,
                                                    unsigned* __restrict__ hist) {
-  __shared__ uint8_t sp[TILE_H + 8][TILE_W + 8];     // pixels, halo 4
-  __shared__ uint8_t ss[TILE_H + 2][TILE_W + 4];     // scores, halo 1 (66 used)
+  constexpr int SPW = 80;                              // pixel-tile row: 20 aligned dwords
+  constexpr int NPOS = (TILE_H + 2) * (TILE_W + 2);
+  __shared__ __attribute__((aligned(16))) uint8_t sp[TILE_H + 8][SPW];
+  __shared__ __attribute__((aligned(16))) uint8_t ss[TILE_H + 2][TILE_W + 4];   // scores, halo 1 (66 used)
+  __shared__ unsigned short s_pos[NPOS];
   __shared__ unsigned s_list[TILE_W * TILE_H / 4];
-  __shared__ int s_cnt;
+  __shared__ int s_npos, s_cnt;
   __shared__ unsigned s_base;
   int img, tile;
   if (!xcd_decode(g.ftiles_total, n_img, img, tile)) return;
@@ -246,18 +255,47 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   const uint8_t* src = level_ptr(s, g, img, l, pitch);
   const int w = g.lv[l].w, h = g.lv[l].h;
   const int x0 = EDGE + tx * TILE_W, y0 = EDGE + ty * TILE_H;   // first inner pixel of the tile
-  const int tid = threadIdx.x;
-  if (tid == 0) s_cnt = 0;
-  for (int i = tid; i < (TILE_H + 8) * (TILE_W + 8); i += 256) {
-    const int r = i / (TILE_W + 8), c = i - r * (TILE_W + 8);
-    const int gx = min(x0 - 4 + c, w - 1), gy = min(y0 - 4 + r, h - 1);
-    sp[r][c] = src[(size_t)gy * pitch + gx];
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) { s_npos = 0; s_cnt = 0; }
+  // pixel tile: columns [xa, xa+80) with xa = x0-4 rounded down to a dword; pixel x sits at byte x-xa
+  const int xa = (x0 - 4) & ~3, xo = (x0 - 4) - xa;
+  for (int i = tid; i < (TILE_H + 8) * (SPW / 4); i += 256) {
+    const int r = i / (SPW / 4), c = i - r * (SPW / 4);
+    const int gy = min(y0 - 4 + r, h - 1), gx = min(xa + 4 * c, pitch - 4);
+    reinterpret_cast<unsigned*>(&sp[r][0])[c] = *reinterpret_cast<const unsigned*>(src + (size_t)gy * pitch + gx);
   }
+  for (int i = tid; i < (TILE_H + 2) * (TILE_W + 4) / 4; i += 256) reinterpret_cast<unsigned*>(&ss[0][0])[i] = 0u;
   __syncthreads();
   const int t = g.fast_threshold;
-  for (int p = tid; p < (TILE_H + 2) * (TILE_W + 2); p += 256) {
+  // phase 1: compass pre-test
+  for (int p0 = 0; p0 < NPOS; p0 += 256) {
+    const int p = p0 + tid;
+    bool c = false;
+    if (p < NPOS) {
+      const int j = p / (TILE_W + 2), i = p - j * (TILE_W + 2);
+      const int cy = j + 3, cx = i + 3 + xo;
+      const int v = sp[cy][cx];
+      const int hi = v + t, lo = v - t;
+      const int a0 = sp[cy + 3][cx], a4 = sp[cy][cx + 3], a8 = sp[cy - 3][cx], a12 = sp[cy][cx - 3];
+      const bool b0 = a0 > hi, b4 = a4 > hi, b8 = a8 > hi, b12 = a12 > hi;
+      const bool k0 = a0 < lo, k4 = a4 < lo, k8 = a8 < lo, k12 = a12 < lo;
+      c = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0);
+    }
+    const unsigned long long m = __ballot(c);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_npos, __popcll(m));
+      base = __shfl(base, 0);
+      if (c) s_pos[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+    }
+  }
+  __syncthreads();
+  const int npos = s_npos;
+  // phase 2: full score of the pre-test survivors
+  for (int q = tid; q < npos; q += 256) {
+    const int p = s_pos[q];
     const int j = p / (TILE_W + 2), i = p - j * (TILE_W + 2);
-    const int cy = j + 3, cx = i + 3;
+    const int cy = j + 3, cx = i + 3 + xo;
     const int v = sp[cy][cx];
     int d[16];
     d[0] = v - sp[cy + 3][cx];      d[1] = v - sp[cy + 3][cx + 1];  d[2] = v - sp[cy + 2][cx + 2];
@@ -269,14 +307,16 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     ss[j][i] = (uint8_t)fast_score16(d, t);
   }
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = tid & 63, j = (tid >> 6) + 4 * q;
-    const int x = x0 + i, y = y0 + j;
-    const int sc = ss[j + 1][i + 1];
+  // phase 3: NMS (strictly greater than the 8 neighbours) + runByImageBorder, over the list
+  for (int q = tid; q < npos; q += 256) {
+    const int p = s_pos[q];
+    const int j = p / (TILE_W + 2), i = p - j * (TILE_W + 2);
+    if (i < 1 || i > TILE_W || j < 1 || j > TILE_H) continue;      // halo position
+    const int x = x0 + i - 1, y = y0 + j - 1;
+    const int sc = ss[j][i];
     if (sc > 0 && x < w - EDGE && y < h - EDGE) {
-      const bool keep = sc > ss[j][i] && sc > ss[j][i + 1] && sc > ss[j][i + 2] && sc > ss[j + 1][i] &&
-                        sc > ss[j + 1][i + 2] && sc > ss[j + 2][i] && sc > ss[j + 2][i + 1] && sc > ss[j + 2][i + 2];
+      const bool keep = sc > ss[j - 1][i - 1] && sc > ss[j - 1][i] && sc > ss[j - 1][i + 1] && sc > ss[j][i - 1] &&
+                        sc > ss[j][i + 1] && sc > ss[j + 1][i - 1] && sc > ss[j + 1][i] && sc > ss[j + 1][i + 1];
       if (keep) {
         const int pos = atomicAdd(&s_cnt, 1);
         s_list[pos] = ((unsigned)sc << 24) | ((unsigned)y << 12) | (unsigned)x;
