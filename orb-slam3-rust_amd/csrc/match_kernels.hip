@@ -19,7 +19,6 @@ constexpr int kWave = 64;
 constexpr int SM_THREADS = 256;
 constexpr int SM_LEFT_PER_WAVE = 4;
 constexpr int SM_LEFT_PER_BLOCK = SM_LEFT_PER_WAVE * (SM_THREADS / kWave);
-constexpr int SM_RCHUNK = 2048;
 constexpr unsigned TH_HIGH = 100;  // stereo.rs:10
 
 struct Desc256 {
@@ -46,65 +45,104 @@ __device__ __forceinline__ void merge_top2(unsigned& b, int& bi, unsigned& s, un
   s = min(min(s, os), loser);
 }
 
-// One wave = SM_LEFT_PER_WAVE left keypoints; right (x,y) staged through LDS in chunks.
+// --- stereo matcher, bucketed ------------------------------------------------------------------------
+// The reference scans every right keypoint for every left one (stereo.rs:95-141); ~99 % fail the
+// vertical gate |vl - vr| <= 2 (:117).  Here the right keypoints of a pair are first counting-sorted by
+// image row (stereo_bucket_kernel, one block per pair, histogram + scan + scatter in LDS); a left
+// keypoint then examines only the rows floor(vl)-3 .. floor(vl)+3 and applies the reference's exact f32
+// gates to those.  The result is the same set of admissible candidates; best / second / best_idx are
+// order-independent functions of that set (two smallest distances of the multiset, lowest right index
+// among the minima — what the sequential strict '<' scan yields), so the matches are bit-identical.
+// Keypoint coordinates must be finite.
+constexpr int SB_ROWS = 4096;            // row buckets (images are at most 4095 rows, orbx_create)
+constexpr int SB_THREADS = 1024;
+
+__device__ __forceinline__ int row_bucket(float v) {
+  return v >= 0.0f ? (v < (float)(SB_ROWS - 1) ? (int)v : SB_ROWS - 1) : 0;
+}
+
+__global__ __launch_bounds__(SB_THREADS) void stereo_bucket_kernel(const orbx_keypoint* __restrict__ kp,
+                                                                   const int* __restrict__ nkp, int cap,
+                                                                   int* __restrict__ bstart /*[pair][SB_ROWS+1]*/,
+                                                                   int* __restrict__ sidx /*[pair][cap]*/,
+                                                                   float2* __restrict__ sxy /*[pair][cap]*/) {
+  __shared__ int cnt[SB_ROWS];
+  __shared__ int wsum[SB_THREADS / 64];
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const orbx_keypoint* kpR = kp + (size_t)(2 * pair + 1) * cap;
+  const int nR = min(nkp[2 * pair + 1], cap);
+  for (int i = tid; i < SB_ROWS; i += SB_THREADS) cnt[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < nR; i += SB_THREADS) atomicAdd(&cnt[row_bucket(kpR[i].y)], 1);
+  __syncthreads();
+  // exclusive scan of 4096 counters: 4 per thread, wave scan, cross-wave offsets
+  int c[4], tot = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { c[k] = cnt[4 * tid + k]; tot += c[k]; }
+  int inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = inc - tot;
+  for (int wv = 0; wv < wave; ++wv) base += wsum[wv];
+  __syncthreads();
+  int* bs = bstart + (size_t)pair * (SB_ROWS + 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { bs[4 * tid + k] = base; cnt[4 * tid + k] = base; base += c[k]; }
+  if (tid == SB_THREADS - 1) bs[SB_ROWS] = base;
+  __syncthreads();
+  for (int i = tid; i < nR; i += SB_THREADS) {
+    const float x = kpR[i].x, y = kpR[i].y;
+    const int pos = atomicAdd(&cnt[row_bucket(y)], 1);     // order inside a bucket is irrelevant
+    sidx[(size_t)pair * cap + pos] = i;
+    sxy[(size_t)pair * cap + pos] = make_float2(x, y);
+  }
+}
+
+// candidate update that does not depend on visiting order
+__device__ __forceinline__ void push_top2(unsigned& b, int& bi, unsigned& s, unsigned d, int ri) {
+  if (d < b || (d == b && ri < bi)) { s = b; b = d; bi = ri; }
+  else s = min(s, d);
+}
+
+// One wave per left keypoint (SM_LEFT_PER_WAVE in turn), lanes over the right keypoints of its rows.
 __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
     const orbx_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
     const int* __restrict__ nkp, int cap, float max_disp, float min_disp,
+    const int* __restrict__ bstart, const int* __restrict__ sidx, const float2* __restrict__ sxy,
     int2* __restrict__ tmp) {
-  __shared__ float2 sR[SM_RCHUNK];
   const int pair = blockIdx.y;
   const orbx_keypoint* kpL = kp + (size_t)(2 * pair) * cap;
-  const orbx_keypoint* kpR = kpL + cap;
   const uint8_t* dL = desc + (size_t)(2 * pair) * cap * 32;
   const uint8_t* dR = dL + (size_t)cap * 32;
   const int nL = min(nkp[2 * pair], cap), nR = min(nkp[2 * pair + 1], cap);
-  const int l0 = blockIdx.x * SM_LEFT_PER_BLOCK;
-  if (l0 >= nL) return;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-
-  float ul[SM_LEFT_PER_WAVE], vl[SM_LEFT_PER_WAVE], min_u[SM_LEFT_PER_WAVE], max_u[SM_LEFT_PER_WAVE];
-  Desc256 dl[SM_LEFT_PER_WAVE];
-  unsigned best[SM_LEFT_PER_WAVE], second[SM_LEFT_PER_WAVE];
-  int bidx[SM_LEFT_PER_WAVE];
-  bool valid[SM_LEFT_PER_WAVE];
-#pragma unroll
+  const int* bs = bstart + (size_t)pair * (SB_ROWS + 1);
+  const int* si = sidx + (size_t)pair * cap;
+  const float2* sx = sxy + (size_t)pair * cap;
+#pragma unroll 1
   for (int q = 0; q < SM_LEFT_PER_WAVE; ++q) {
-    const int li = l0 + wave * SM_LEFT_PER_WAVE + q;
-    valid[q] = li < nL;
-    const int lc = valid[q] ? li : 0;
-    ul[q] = kpL[lc].x;
-    vl[q] = kpL[lc].y;
-    min_u[q] = fmaxf(ul[q] - max_disp, 0.0f);                             // stereo.rs:100
-    const float lim = ((float)nR * ul[q]) / (float)nL;                    // stereo.rs:102
-    max_u[q] = fminf(ul[q] - min_disp, lim);                              // stereo.rs:101
-    dl[q] = load_desc(dL + (size_t)lc * 32);
-    best[q] = TH_HIGH; second[q] = TH_HIGH; bidx[q] = 0x7fffffff;
-  }
-
-  for (int r0 = 0; r0 < nR; r0 += SM_RCHUNK) {
-    const int cnt = min(SM_RCHUNK, nR - r0);
-    __syncthreads();
-    for (int i = tid; i < cnt; i += SM_THREADS) sR[i] = make_float2(kpR[r0 + i].x, kpR[r0 + i].y);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < SM_LEFT_PER_WAVE; ++q) {
-      if (!valid[q]) continue;  // wave-uniform
-      for (int i = lane; i < cnt; i += kWave) {
-        const float2 r = sR[i];
-        if (fabsf(vl[q] - r.y) > 2.0f) continue;                          // stereo.rs:117
-        if (r.x < min_u[q] || r.x > max_u[q]) continue;                   // stereo.rs:122
-        if (ul[q] <= r.x) continue;                                       // stereo.rs:127
-        const int ri = r0 + i;
-        const unsigned d = hamming(dl[q], load_desc(dR + (size_t)ri * 32));
-        if (d < best[q]) { second[q] = best[q]; best[q] = d; bidx[q] = ri; }   // stereo.rs:135-141
-        else if (d < second[q]) { second[q] = d; }
-      }
+    const int li = blockIdx.x * SM_LEFT_PER_BLOCK + wave * SM_LEFT_PER_WAVE + q;
+    if (li >= nL) return;                                                    // wave-uniform
+    const float ul = kpL[li].x, vl = kpL[li].y;
+    const float min_u = fmaxf(ul - max_disp, 0.0f);                          // stereo.rs:100
+    const float lim = ((float)nR * ul) / (float)nL;                          // stereo.rs:102
+    const float max_u = fminf(ul - min_disp, lim);                           // stereo.rs:101
+    const Desc256 dl = load_desc(dL + (size_t)li * 32);
+    const int rb = row_bucket(vl);
+    const int lo = bs[max(rb - 3, 0)], hi = bs[min(rb + 3, SB_ROWS - 1) + 1];
+    unsigned b = TH_HIGH, s = TH_HIGH;
+    int bi = 0x7fffffff;
+    for (int t = lo + lane; t < hi; t += kWave) {
+      const float2 r = sx[t];
+      if (fabsf(vl - r.y) > 2.0f) continue;                                  // stereo.rs:117
+      if (r.x < min_u || r.x > max_u) continue;                              // stereo.rs:122
+      if (ul <= r.x) continue;                                               // stereo.rs:127
+      const int ri = si[t];
+      const unsigned d = hamming(dl, load_desc(dR + (size_t)ri * 32));      // stereo.rs:132-133
+      if (d < TH_HIGH) push_top2(b, bi, s, d, ri);                           // :135-141 (d >= 100 never enters)
     }
-  }
-#pragma unroll
-  for (int q = 0; q < SM_LEFT_PER_WAVE; ++q) {
-    unsigned b = best[q], s = second[q];
-    int bi = bidx[q];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const unsigned ob = __shfl_xor(b, off);
@@ -112,8 +150,7 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
       const unsigned os = __shfl_xor(s, off);
       merge_top2(b, bi, s, ob, obi, os);
     }
-    if (lane == 0 && valid[q]) {
-      const int li = l0 + wave * SM_LEFT_PER_WAVE + q;
+    if (lane == 0) {
       const bool has = bi != 0x7fffffff;
       const bool emit = has && (((float)b < 0.9f * (float)s) || s == TH_HIGH);   // stereo.rs:145-148
       tmp[(size_t)pair * cap + li] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
@@ -267,20 +304,32 @@ int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, co
                         const int* d_nkp, int cap_kp, orbx_dmatch* d_matches, int* d_nmatches,
                         double* d_points, uint8_t* d_has_point) {
   if (batch <= 0) return ORBX_OK;
-  if (int rc = orbx_reserve(h, h->ws_match, sizeof(int2) * (size_t)batch * cap_kp)) return rc;
+  // workspace: tmp int2[batch*cap] | bstart int[batch*(SB_ROWS+1)] | sidx int[batch*cap] | sxy float2[batch*cap]
+  const size_t n_tmp = (size_t)batch * cap_kp;
+  const size_t bytes = sizeof(int2) * n_tmp + sizeof(int) * (size_t)batch * (SB_ROWS + 1) + sizeof(int) * n_tmp +
+                       sizeof(float2) * n_tmp + 64;
+  if (int rc = orbx_reserve(h, h->ws_match, bytes)) return rc;
+  int2* tmp = (int2*)h->ws_match.p;
+  float2* sxy = (float2*)(tmp + n_tmp);
+  int* sidx = (int*)(sxy + n_tmp);
+  int* bstart = sidx + n_tmp;
   // stereo.rs:84-90: f64 product/quotient, then `as f32`
   const float max_disp = (float)(h->cam.fx * h->cam.baseline / 0.1);
   const float min_disp = (float)(h->cam.fx * h->cam.baseline / 40.0);
   {
+    ProfScope ps(h, "stereo_bucket_kernel");
+    hipLaunchKernelGGL(stereo_bucket_kernel, dim3(batch), dim3(SB_THREADS), 0, h->stream, d_kp, d_nkp, cap_kp, bstart, sidx, sxy);
+  }
+  {
     ProfScope ps(h, "stereo_match_kernel");
     dim3 grid((cap_kp + SM_LEFT_PER_BLOCK - 1) / SM_LEFT_PER_BLOCK, batch);
     hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(SM_THREADS), 0, h->stream, d_kp, d_desc, d_nkp,
-                       cap_kp, max_disp, min_disp, (int2*)h->ws_match.p);
+                       cap_kp, max_disp, min_disp, bstart, sidx, sxy, tmp);
   }
   {
     ProfScope ps(h, "stereo_compact_kernel");
     hipLaunchKernelGGL(stereo_compact_kernel, dim3(batch), dim3(256), 0, h->stream, d_kp, d_nkp, cap_kp,
-                       (const int2*)h->ws_match.p, h->cam, d_matches, d_nmatches, d_points, d_has_point);
+                       (const int2*)tmp, h->cam, d_matches, d_nmatches, d_points, d_has_point);
   }
   ORBX_HIP(h, hipGetLastError());
   return ORBX_OK;
