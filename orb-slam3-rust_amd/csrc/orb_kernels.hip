@@ -552,8 +552,19 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float& c_out, float&
   s_out = (float)sn;
 }
 
-constexpr int PA_ROWS = 31, PA_DW = 9;    // unblurred 31x31 patch, 9 aligned dwords per row
-constexpr int PB_ROWS = 37, PB_DW = 10, PB_PITCH = 11;   // blurred 37x37 patch, 10 dwords loaded, pitch 11
+constexpr int PB_ROWS = 37, PB_DW = 10, PB_PITCH = 11;   // blurred 37x37 patch: 10 dwords per row, LDS pitch 11
+
+// Intensity-centroid weights (Appendix A.7): the 31x31 patch as 31 rows x 8 dwords (task t = r*8 + c,
+// pixel column 4c+b); per task one dword of 0/1 disc-membership bytes and one of (column index)*membership
+// bytes, so that v_dot4_u32_u8 yields sum(I) and sum((u+15) I) of four pixels at once.
+__constant__ unsigned c_ic_ones[256];
+__constant__ unsigned c_ic_col[256];
+
+__device__ __forceinline__ unsigned ld_u32(const uint8_t* p) {   // unaligned dword load (global_load_dword)
+  unsigned v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
 
 __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int n_img, int blocks_per_img,
                                                        const unsigned long long* __restrict__ sel2,
@@ -561,15 +572,19 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
                                                        orbx_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
                                                        int* __restrict__ nkp, int cap_kp, float patch_size,
                                                        unsigned* __restrict__ status) {
-  __shared__ unsigned pa[4][PA_ROWS * PA_DW];
   __shared__ unsigned pb[4][PB_ROWS * PB_PITCH];
   int img, bx;
   if (!xcd_decode(blocks_per_img, n_img, img, bx)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // this lane's four test pairs (bits lane, lane+64, lane+128, lane+192), one dword each
+  // per-lane constants: four rBRIEF test pairs (bits lane, lane+64, ...) and four centroid tasks
   int pat[4];
+  unsigned w_ones[4], w_col[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) pat[q] = reinterpret_cast<const int*>(c_pattern)[q * 64 + lane];
+  for (int q = 0; q < 4; ++q) {
+    pat[q] = reinterpret_cast<const int*>(c_pattern)[q * 64 + lane];
+    w_ones[q] = c_ic_ones[q * 64 + lane];
+    w_col[q] = c_ic_col[q * 64 + lane];
+  }
   unsigned start[ORBX_MAX_LEVELS + 1];
   start[0] = 0;
 #pragma unroll
@@ -581,7 +596,6 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
     nkp[img] = (int)limit;
     if (total > (unsigned)cap_kp) atomicOr(status, ORBX_ST_KP_OVERFLOW);
   }
-  const uint8_t* pab = reinterpret_cast<const uint8_t*>(pa[wave]);
   const uint8_t* pbb = reinterpret_cast<const uint8_t*>(pb[wave]);
   for (unsigned slot = bx * 4 + wave; slot < limit; slot += blocks_per_img * 4) {
     int l = 0;
@@ -596,40 +610,35 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
     const uint8_t* src = level_ptr(s, g, img, l, pitch);
     const uint8_t* blr = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
     const int bpitch = g.lv[l].pitch;
-    // stage both patches with aligned dword loads
-    const int ax = (kx - 15) & ~3, ma = (kx - 15) - ax;
-    for (int i = lane; i < PA_ROWS * PA_DW; i += 64) {
-      const int r = i / PA_DW, c = i - r * PA_DW;
-      pa[wave][i] = *reinterpret_cast<const unsigned*>(src + (size_t)(ky - 15 + r) * pitch + ax + 4 * c);
-    }
-    const int bx = (kx - 18) & ~3, mb = (kx - 18) - bx;
+    // stage the blurred 37x37 patch (rows of 40 bytes starting at kx-18) into LDS
     for (int i = lane; i < PB_ROWS * PB_DW; i += 64) {
       const int r = i / PB_DW, c = i - r * PB_DW;
-      pb[wave][r * PB_PITCH + c] = *reinterpret_cast<const unsigned*>(blr + (size_t)(ky - 18 + r) * bpitch + bx + 4 * c);
+      pb[wave][r * PB_PITCH + c] = ld_u32(blr + (size_t)(ky - 18 + r) * bpitch + (kx - 18) + 4 * c);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);   // staging stores visible to the whole wave before the reads
-    // intensity centroid over the 749-pixel disc (integer, order independent)
-    int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-      const int r = i / 31, c = i - r * 31;
-      const int v = r - 15, u = c - 15;
-      // umax[|v|] (Appendix A.7) packed 4 bits per entry: 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3
-      const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * abs(v))) & 15ull);
-      if (abs(u) <= um) {
-        const int I = pab[r * (PA_DW * 4) + ma + c];
-        m10 += u * I;
-        m01 += v * I;
-      }
+    // intensity centroid over the 749-pixel disc straight from the level image (integer, order independent)
+    int sA = 0, sB = 0, sC = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = q * 64 + lane;
+      const int r = min(t >> 3, 30), c = t & 7;
+      const unsigned px = ld_u32(src + (size_t)(ky - 15 + r) * pitch + (kx - 15) + 4 * c);
+      const unsigned sI = __builtin_amdgcn_udot4(px, w_ones[q], 0u, false);
+      sA += (int)__builtin_amdgcn_udot4(px, w_col[q], 0u, false);
+      sB += (int)sI;
+      sC += (r - 15) * (int)sI;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-      m10 += __shfl_xor(m10, off);
-      m01 += __shfl_xor(m01, off);
+      sA += __shfl_xor(sA, off);
+      sB += __shfl_xor(sB, off);
+      sC += __shfl_xor(sC, off);
     }
+    const int m10 = sA - 15 * sB, m01 = sC;
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     float ca, sa;
     sincos_deg(angle, ca, sa);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);   // staging stores visible to the whole wave before the reads
     unsigned long long word[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -639,8 +648,8 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
       const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, sa), __fmul_rn(py0, ca)));
       const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, ca), __fmul_rn(py1, sa)));
       const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, sa), __fmul_rn(py1, ca)));
-      const int t0 = pbb[(iy0 + 18) * (PB_PITCH * 4) + mb + ix0 + 18];
-      const int t1 = pbb[(iy1 + 18) * (PB_PITCH * 4) + mb + ix1 + 18];
+      const int t0 = pbb[(iy0 + 18) * (PB_PITCH * 4) + ix0 + 18];
+      const int t1 = pbb[(iy1 + 18) * (PB_PITCH * 4) + ix1 + 18];
       word[q] = __ballot(t0 < t1);
     }
     if (lane < 4) {
@@ -744,6 +753,23 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
   for (int i = 0; i < 256; ++i)
     for (int k = 0; k < 4; ++k) pat[4 * i + k] = (signed char)kPattern31[i][k];
   ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pat, sizeof(pat)));
+  // intensity-centroid dot4 weights; umax (Appendix A.7) = half-widths of the 31-px disc
+  static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  unsigned ones[256], colw[256];
+  for (int t = 0; t < 256; ++t) {
+    ones[t] = colw[t] = 0;
+    const int r = t >> 3, c = t & 7;
+    if (r > 30) continue;
+    for (int b = 0; b < 4; ++b) {
+      const int col = 4 * c + b, u = col - 15, v = r - 15;
+      if (col <= 30 && std::abs(u) <= umax[std::abs(v)]) {
+        ones[t] |= 1u << (8 * b);
+        colw[t] |= (unsigned)col << (8 * b);
+      }
+    }
+  }
+  ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_ic_ones), ones, sizeof(ones)));
+  ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_ic_col), colw, sizeof(colw)));
   h->geom = g;
   h->geom_w = w;
   h->geom_h = h_px;
