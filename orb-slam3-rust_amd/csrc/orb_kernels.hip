@@ -69,6 +69,15 @@ __global__ __launch_bounds__(256) void copy_l0_kernel(const uint8_t* __restrict_
 }
 
 // ---- A.4 resize: 4 destination pixels per thread, one aligned u32 store ----------------------------------
+// The four source offsets of a thread span at most 6 bytes (scale 1.2), so each source row is read as
+// one unaligned 8-byte window; a tap pair is (window >> 8*o) and the 8.8 horizontal sum is one
+// v_dot4_u32_u8:  cx0*p0 + cx1*p1 = (cx0-1)*p0 + cx1*p1 + p0  (cx0 = 256-cx1 can be 256, cx0-1 fits a byte).
+__device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
+__device__ __forceinline__ unsigned resize_h(unsigned long long win, int o, unsigned coef) {
+  const unsigned pr = (unsigned)(win >> (8 * o));
+  return __builtin_amdgcn_udot4(pr, coef, pr & 0xffu, false);
+}
+
 __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l, int n_img, int tiles_x, int tiles_y,
                                                      const unsigned* __restrict__ xtab,
                                                      const unsigned* __restrict__ ytab) {
@@ -88,18 +97,36 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
   const unsigned cy1 = yt & 0xffffu, cy0 = 256u - cy1;
   const uint8_t* r0 = src + (size_t)y0 * sp;
   const uint8_t* r1 = src + (size_t)y1 * sp;
+  const uint4 xt4 = *reinterpret_cast<const uint4*>(xtab + x0);      // table padded to a multiple of 4 entries
+  const unsigned xt[4] = {xt4.x, xt4.y, xt4.z, xt4.w};
+  const int xb = (int)(xt[0] >> 16);
   unsigned packed = 0;
+  if (xb + 8 <= sp) {
+    const unsigned long long w0 = (unsigned long long)ld_u32(r0 + xb) | ((unsigned long long)ld_u32(r0 + xb + 4) << 32);
+    const unsigned long long w1 = (unsigned long long)ld_u32(r1 + xb) | ((unsigned long long)ld_u32(r1 + xb + 4) << 32);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int x = x0 + k;
-    if (x < w) {
-      const unsigned xt = xtab[x];
-      const int xo = (int)(xt >> 16), x1 = min(xo + 1, sw - 1);
-      const unsigned cx1 = xt & 0xffffu, cx0 = 256u - cx1;
-      const unsigned h0 = cx0 * r0[xo] + cx1 * r0[x1];   // 8.8
-      const unsigned h1 = cx0 * r1[xo] + cx1 * r1[x1];
-      const unsigned v = cy0 * h0 + cy1 * h1;            // 16.16
-      packed |= ((v + 32768u) >> 16) << (8 * k);
+    for (int k = 0; k < 4; ++k) {
+      if (x0 + k < w) {
+        const int o = (int)(xt[k] >> 16) - xb;             // 0..4; tap o+1 <= 5 (weight 0 when clamped at the edge)
+        const unsigned cx1 = xt[k] & 0xffffu;
+        const unsigned coef = (255u - cx1) | (cx1 << 8);   // (cx0 - 1, cx1)
+        const unsigned h0 = resize_h(w0, o, coef), h1 = resize_h(w1, o, coef);   // 8.8
+        const unsigned v = cy0 * h0 + cy1 * h1;                                  // 16.16
+        packed |= ((v + 32768u) >> 16) << (8 * k);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int x = x0 + k;
+      if (x < w) {
+        const int xo = (int)(xt[k] >> 16), x1 = min(xo + 1, sw - 1);
+        const unsigned cx1 = xt[k] & 0xffffu, cx0 = 256u - cx1;
+        const unsigned h0 = cx0 * r0[xo] + cx1 * r0[x1];
+        const unsigned h1 = cx0 * r1[xo] + cx1 * r1[x1];
+        const unsigned v = cy0 * h0 + cy1 * h1;
+        packed |= ((v + 32768u) >> 16) << (8 * k);
+      }
     }
   }
   *reinterpret_cast<unsigned*>(dst + (size_t)y * dp + x0) = packed;
@@ -334,18 +361,35 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   }
 }
 
+__device__ __forceinline__ unsigned ld_u32(const uint8_t* p) {   // unaligned dword load (global_load_dword)
+  unsigned v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
 // ---- A.6 Harris response (blockSize 7, k 0.04) of one candidate, one thread ------------------------------
 __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img, int pitch, int x0, int y0) {
   int a = 0, b = 0, c = 0;
+  // 9x9 window as 9 rows x 3 unaligned dwords (27 loads instead of 81 byte loads)
   int rowm[9], row0[9], rowp[9];
   const uint8_t* p = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
+  unsigned w[9][3];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { rowm[k] = p[k]; row0[k] = p[pitch + k]; }
+  for (int r = 0; r < 9; ++r) {
+    const uint8_t* pr = p + (size_t)r * pitch;
+    w[r][0] = ld_u32(pr); w[r][1] = ld_u32(pr + 4); w[r][2] = ld_u32(pr + 8);
+  }
+#define ORBX_ROW(dst, r)                                                                    \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                             \
+    dst[k] = (int)((w[r][0] >> (8 * k)) & 0xffu);                                             \
+    dst[4 + k] = (int)((w[r][1] >> (8 * k)) & 0xffu);                                         \
+  }                                                                                           \
+  dst[8] = (int)(w[r][2] & 0xffu);
+  ORBX_ROW(rowm, 0)
+  ORBX_ROW(row0, 1)
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
-    const uint8_t* pr = p + (size_t)(i + 2) * pitch;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) rowp[k] = pr[k];
+    ORBX_ROW(rowp, i + 2)
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const int Ix = (row0[j + 2] - row0[j]) * 2 + (rowm[j + 2] - rowm[j]) + (rowp[j + 2] - rowp[j]);
@@ -355,6 +399,7 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
 #pragma unroll
     for (int k = 0; k < 9; ++k) { rowm[k] = row0[k]; row0[k] = rowp[k]; }
   }
+#undef ORBX_ROW
   const float scale = 1.f / (4 * 7 * 255.f);
   const float scale_sq_sq = scale * scale * scale * scale;   // folded at compile time, IEEE
   const float fa = (float)a, fb = (float)b, fc = (float)c;
@@ -560,12 +605,6 @@ constexpr int PB_ROWS = 37, PB_DW = 10, PB_PITCH = 11;   // blurred 37x37 patch:
 __constant__ unsigned c_ic_ones[256];
 __constant__ unsigned c_ic_col[256];
 
-__device__ __forceinline__ unsigned ld_u32(const uint8_t* p) {   // unaligned dword load (global_load_dword)
-  unsigned v;
-  __builtin_memcpy(&v, p, 4);
-  return v;
-}
-
 __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int n_img, int blocks_per_img,
                                                        const unsigned long long* __restrict__ sel2,
                                                        const unsigned* __restrict__ kept,
@@ -685,8 +724,10 @@ void build_resize_tab(int src, int dst, std::vector<unsigned>& out) {
     if (i < 0) { ofs = 0; c1 = 0; }
     else if (i >= src - 1) { ofs = (unsigned)(src - 1); c1 = 0; }
     else { ofs = (unsigned)i; c1 = (unsigned)lrint((f - (double)i) * 256.0); }
+    if (c1 == 256u) { ofs += 1; c1 = 0; }   // weight (0,256) on (i,i+1) == weight (256,0) on (i+1,i+2): keeps c1 in a byte
     out.push_back((ofs << 16) | c1);
   }
+  while (out.size() % 4) out.push_back(out.back());   // uint4 loads of the x table
 }
 
 }  // namespace
