@@ -257,21 +257,26 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int t) {
   return best > t ? best - 1 : 0;
 }
 
-// Two-phase per 64x16 tile (+1 score halo, +4 pixel halo):
-//   1. every position: compass pre-test — a 9-arc always contains two adjacent compass points
-//      (0,4,8,12), so a corner needs two adjacent ones both brighter than v+t or both darker than v-t;
-//      survivors (~10 %) are compacted into an LDS list (ballot + one LDS atomic per wave);
+// Two-phase per tile.  Score region 64 x 32 positions (inner 62 x 30 + 1-position NMS frame), pixel tile
+// 72 x 38 bytes staged so that position i sits at byte i+4 of its LDS row (dword aligned):
+//   1. every position, 4 per thread from 5 dword LDS reads: compass pre-test — a 9-arc always contains
+//      two adjacent compass points (0,4,8,12), so a corner needs two adjacent ones both brighter than
+//      v+t or both darker than v-t; survivors (~10 %) are compacted into an LDS list;
 //   2. full arc score only for the listed positions, written into the LDS score tile;
 //   3. 3x3 NMS + border filter over the list, block-aggregated append to the level's candidates.
+constexpr int FT_W = 62, FT_H = 30;          // inner tile
+constexpr int FS_W = 64, FS_H = 32;          // score region
+constexpr int FP_PITCH = 72, FP_ROWS = FS_H + 6;
+
+__device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
+
 __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, unsigned* __restrict__ cand,
                                                    unsigned* __restrict__ cand_count,
                                                    unsigned* __restrict__ hist) {
-  constexpr int SPW = 80;                              // pixel-tile row: 20 aligned dwords
-  constexpr int NPOS = (TILE_H + 2) * (TILE_W + 2);
-  __shared__ __attribute__((aligned(16))) uint8_t sp[TILE_H + 8][SPW];
-  __shared__ __attribute__((aligned(16))) uint8_t ss[TILE_H + 2][TILE_W + 4];   // scores, halo 1 (66 used)
-  __shared__ unsigned short s_pos[NPOS];
-  __shared__ unsigned s_list[TILE_W * TILE_H / 4];
+  __shared__ __attribute__((aligned(16))) uint8_t sp[FP_ROWS][FP_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t ss[FS_H][FS_W];
+  __shared__ unsigned short s_pos[FS_W * FS_H];
+  __shared__ unsigned s_list[512];
   __shared__ int s_npos, s_cnt;
   __shared__ unsigned s_base;
   int img, tile;
@@ -281,39 +286,56 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   int pitch;
   const uint8_t* src = level_ptr(s, g, img, l, pitch);
   const int w = g.lv[l].w, h = g.lv[l].h;
-  const int x0 = EDGE + tx * TILE_W, y0 = EDGE + ty * TILE_H;   // first inner pixel of the tile
+  const int x0 = EDGE + tx * FT_W, y0 = EDGE + ty * FT_H;   // first inner pixel; score position (i,j) = pixel (x0-1+i, y0-1+j)
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) { s_npos = 0; s_cnt = 0; }
-  // pixel tile: columns [xa, xa+80) with xa = x0-4 rounded down to a dword; pixel x sits at byte x-xa
-  const int xa = (x0 - 4) & ~3, xo = (x0 - 4) - xa;
-  for (int i = tid; i < (TILE_H + 8) * (SPW / 4); i += 256) {
-    const int r = i / (SPW / 4), c = i - r * (SPW / 4);
-    const int gy = min(y0 - 4 + r, h - 1), gx = min(xa + 4 * c, pitch - 4);
-    reinterpret_cast<unsigned*>(&sp[r][0])[c] = *reinterpret_cast<const unsigned*>(src + (size_t)gy * pitch + gx);
+  // pixel tile: LDS row r = image row y0-4+r, byte b = image column x0-5+b
+  for (int i = tid; i < FP_ROWS * (FP_PITCH / 4); i += 256) {
+    const int r = i / (FP_PITCH / 4), c = i - r * (FP_PITCH / 4);
+    const int gy = min(y0 - 4 + r, h - 1), gx = min(x0 - 5 + 4 * c, pitch - 4);
+    reinterpret_cast<unsigned*>(&sp[r][0])[c] = ld_u32(src + (size_t)gy * pitch + gx);
   }
-  for (int i = tid; i < (TILE_H + 2) * (TILE_W + 4) / 4; i += 256) reinterpret_cast<unsigned*>(&ss[0][0])[i] = 0u;
+  for (int i = tid; i < FS_W * FS_H / 4; i += 256) reinterpret_cast<unsigned*>(&ss[0][0])[i] = 0u;
   __syncthreads();
   const int t = g.fast_threshold;
-  // phase 1: compass pre-test
-  for (int p0 = 0; p0 < NPOS; p0 += 256) {
-    const int p = p0 + tid;
-    bool c = false;
-    if (p < NPOS) {
-      const int j = p / (TILE_W + 2), i = p - j * (TILE_W + 2);
-      const int cy = j + 3, cx = i + 3 + xo;
-      const int v = sp[cy][cx];
+  // phase 1: compass pre-test, 4 positions per task
+#pragma unroll
+  for (int rep = 0; rep < (FS_W / 4) * FS_H / 256; ++rep) {
+    const int task = rep * 256 + tid;
+    const int j = task >> 4, tq = task & 15;
+    const unsigned* rowc = reinterpret_cast<const unsigned*>(&sp[j + 3][0]) + tq;
+    const unsigned c0 = rowc[0], c1 = rowc[1], c2 = rowc[2];
+    const unsigned up = reinterpret_cast<const unsigned*>(&sp[j][0])[tq + 1];       // y-3
+    const unsigned dn = reinterpret_cast<const unsigned*>(&sp[j + 6][0])[tq + 1];   // y+3
+    const unsigned long long lo64 = ((unsigned long long)c1 << 32) | c0;   // bytes 4tq .. 4tq+7
+    const unsigned long long hi64 = ((unsigned long long)c2 << 32) | c1;   // bytes 4tq+4 .. 4tq+11
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = (int)((c1 >> (8 * k)) & 0xffu);
+      const int a12 = (int)((lo64 >> (8 * (k + 1))) & 0xffu);   // x-3
+      const int a4 = (int)((hi64 >> (8 * (k + 3))) & 0xffu);    // x+3
+      const int a8 = (int)((up >> (8 * k)) & 0xffu);
+      const int a0 = (int)((dn >> (8 * k)) & 0xffu);
       const int hi = v + t, lo = v - t;
-      const int a0 = sp[cy + 3][cx], a4 = sp[cy][cx + 3], a8 = sp[cy - 3][cx], a12 = sp[cy][cx - 3];
       const bool b0 = a0 > hi, b4 = a4 > hi, b8 = a8 > hi, b12 = a12 > hi;
       const bool k0 = a0 < lo, k4 = a4 < lo, k8 = a8 < lo, k12 = a12 < lo;
-      c = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0);
+      const bool c = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) || (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0);
+      mask |= (c ? 1u : 0u) << k;
     }
-    const unsigned long long m = __ballot(c);
-    if (m) {
+    const int n = __popc(mask);
+    // wave-level compaction: exclusive prefix of n over the lanes
+    int inc = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+    const int wtot = __shfl(inc, 63);
+    if (wtot) {
       int base = 0;
-      if (lane == 0) base = atomicAdd(&s_npos, __popcll(m));
-      base = __shfl(base, 0);
-      if (c) s_pos[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)p;
+      if (lane == 0) base = atomicAdd(&s_npos, wtot);
+      base = __shfl(base, 0) + inc - n;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (mask & (1u << k)) s_pos[base++] = (unsigned short)(j * FS_W + 4 * tq + k);
     }
   }
   __syncthreads();
@@ -321,8 +343,8 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   // phase 2: full score of the pre-test survivors
   for (int q = tid; q < npos; q += 256) {
     const int p = s_pos[q];
-    const int j = p / (TILE_W + 2), i = p - j * (TILE_W + 2);
-    const int cy = j + 3, cx = i + 3 + xo;
+    const int j = p >> 6, i = p & 63;
+    const int cy = j + 3, cx = i + 4;
     const int v = sp[cy][cx];
     int d[16];
     d[0] = v - sp[cy + 3][cx];      d[1] = v - sp[cy + 3][cx + 1];  d[2] = v - sp[cy + 2][cx + 2];
@@ -337,8 +359,8 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   // phase 3: NMS (strictly greater than the 8 neighbours) + runByImageBorder, over the list
   for (int q = tid; q < npos; q += 256) {
     const int p = s_pos[q];
-    const int j = p / (TILE_W + 2), i = p - j * (TILE_W + 2);
-    if (i < 1 || i > TILE_W || j < 1 || j > TILE_H) continue;      // halo position
+    const int j = p >> 6, i = p & 63;
+    if (i < 1 || i > FT_W || j < 1 || j > FT_H) continue;      // NMS frame position
     const int x = x0 + i - 1, y = y0 + j - 1;
     const int sc = ss[j][i];
     if (sc > 0 && x < w - EDGE && y < h - EDGE) {
@@ -352,11 +374,12 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   }
   __syncthreads();
   const int il = img * g.n_levels + l;
-  if (tid == 0 && s_cnt > 0) s_base = atomicAdd(&cand_count[il], (unsigned)s_cnt);
+  const int cnt = s_cnt;
+  if (tid == 0 && cnt > 0) s_base = atomicAdd(&cand_count[il], (unsigned)cnt);
   __syncthreads();
-  if (tid < s_cnt) {
-    const unsigned c = s_list[tid];
-    cand[(size_t)img * g.cand_total + g.lv[l].cand_off + s_base + tid] = c;
+  for (int q = tid; q < cnt; q += 256) {
+    const unsigned c = s_list[q];
+    cand[(size_t)img * g.cand_total + g.lv[l].cand_off + s_base + q] = c;
     atomicAdd(&hist[(size_t)il * 256 + (c >> 24)], 1u);
   }
 }
@@ -769,9 +792,9 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
     L.btiles_x = (L.w + BLUR_W - 1) / BLUR_W;
     L.btile_start = bt;
     bt += L.btiles_x * ((L.h + BLUR_H - 1) / BLUR_H);
-    L.ftiles_x = iw > 0 ? (iw + TILE_W - 1) / TILE_W : 0;
+    L.ftiles_x = iw > 0 ? (iw + FT_W - 1) / FT_W : 0;
     L.ftile_start = ft;
-    ft += (iw > 0 && ih > 0) ? L.ftiles_x * ((ih + TILE_H - 1) / TILE_H) : 0;
+    ft += (iw > 0 && ih > 0) ? L.ftiles_x * ((ih + FT_H - 1) / FT_H) : 0;
     if (L.ftiles_x == 0) L.ftiles_x = 1;
   }
   g.slot_bytes = off;
