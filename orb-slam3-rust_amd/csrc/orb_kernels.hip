@@ -173,8 +173,8 @@ __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2,
   hs[3] = __builtin_amdgcn_udot4(d2, G1, __builtin_amdgcn_udot4(d1, G0, 0u, false), false);
 }
 
-__device__ __forceinline__ void blur_row(const uint8_t* __restrict__ src, int pitch, int w, int row, int x0, int lane,
-                                         bool slow, unsigned (&hs)[4]) {
+__device__ __forceinline__ void blur_row(const uint8_t* __restrict__ src, int pitch, int row, int x0, int lane,
+                                         bool slow, const int (&col)[12], unsigned (&hs)[4]) {
   const uint8_t* rp = src + (size_t)row * pitch;
   const int xl = min(x0, pitch - 4);
   unsigned d1 = *reinterpret_cast<const unsigned*>(rp + xl);
@@ -186,10 +186,10 @@ __device__ __forceinline__ void blur_row(const uint8_t* __restrict__ src, int pi
   unsigned d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
   if (lane == 0) d0 = extra;
   if (lane == 63) d2 = extra;
-  if (slow) {
+  if (slow) {   // window crosses the image edge: gather the 12 bytes from the precomputed reflected columns
     unsigned b[12];
 #pragma unroll
-    for (int t = 0; t < 12; ++t) b[t] = rp[reflect101(x0 - 4 + t, w)];
+    for (int t = 0; t < 12; ++t) b[t] = rp[col[t]];
     d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
     d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
     d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
@@ -214,16 +214,20 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
   const int nrows = min(BLUR_STRIP, h - ys);
   uint8_t* dst = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
   const int dpitch = g.lv[l].pitch;
+  // BORDER_REFLECT_101 source columns of this lane's 12-byte window (same for every row)
+  int col[12];
+#pragma unroll
+  for (int t = 0; t < 12; ++t) col[t] = slow ? reflect101(x0 - 4 + t, w) : 0;
   unsigned ring[7][4];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) blur_row(src, pitch, w, reflect101(ys - 3 + i, h), x0, lane, slow, ring[i]);
+  for (int i = 0; i < 6; ++i) blur_row(src, pitch, reflect101(ys - 3 + i, h), x0, lane, slow, col, ring[i]);
   for (int y0 = 0; y0 < nrows; y0 += 7) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int y = y0 + i;
       if (y < nrows) {   // wave-uniform
         // ring slot (i+6)%7 receives input row ys+y+3; slots (i..i+6)%7 hold rows y-3..y+3
-        blur_row(src, pitch, w, reflect101(ys + y + 3, h), x0, lane, slow, ring[(i + 6) % 7]);
+        blur_row(src, pitch, reflect101(ys + y + 3, h), x0, lane, slow, col, ring[(i + 6) % 7]);
         unsigned packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
