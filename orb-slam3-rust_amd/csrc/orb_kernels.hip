@@ -159,7 +159,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // a 7-row ring of those sums in registers, vertical taps as 32-bit mads (16.16), one dword store.
 // Lanes whose 10-px window crosses the image edge rebuild their three dwords bytewise with
 // BORDER_REFLECT_101 (a few lanes per row).
-constexpr int BLUR_W = 256, BLUR_STRIP = 64, BLUR_H = 4 * BLUR_STRIP;
+constexpr int BLUR_W = 248, BLUR_STRIP = 64, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo
 
 __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2, unsigned (&hs)[4]) {
   const unsigned G0 = 18u | (34u << 8) | (48u << 16) | (56u << 24);   // px x-3..x
@@ -173,19 +173,12 @@ __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2,
   hs[3] = __builtin_amdgcn_udot4(d2, G1, __builtin_amdgcn_udot4(d1, G0, 0u, false), false);
 }
 
-__device__ __forceinline__ void blur_row(const uint8_t* __restrict__ src, int pitch, int row, int x0, int lane,
-                                         bool slow, const int (&col)[12], unsigned (&hs)[4]) {
-  const uint8_t* rp = src + (size_t)row * pitch;
-  const int xl = min(x0, pitch - 4);
+// rp = row base (wave-uniform), xl = this lane's clamped dword column
+__device__ __forceinline__ void blur_row(const uint8_t* __restrict__ rp, int xl, bool slow, const int (&col)[12],
+                                         unsigned (&hs)[4]) {
   unsigned d1 = *reinterpret_cast<const unsigned*>(rp + xl);
-  // edge lanes of the wave fetch the dword their neighbour lane does not exist for
-  unsigned extra = 0;
-  if (lane == 0 && x0 >= 4) extra = *reinterpret_cast<const unsigned*>(rp + x0 - 4);
-  if (lane == 63 && x0 + 8 <= pitch) extra = *reinterpret_cast<const unsigned*>(rp + x0 + 4);
   unsigned d0 = __builtin_amdgcn_update_dpp(0u, d1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
   unsigned d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-  if (lane == 0) d0 = extra;
-  if (lane == 63) d2 = extra;
   if (slow) {   // window crosses the image edge: gather the 12 bytes from the precomputed reflected columns
     unsigned b[12];
 #pragma unroll
@@ -205,12 +198,14 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
   int pitch;
   const uint8_t* src = level_ptr(s, g, img, l, pitch);
   const int w = g.lv[l].w, h = g.lv[l].h;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row arithmetic stays on the SALU
   const int ys = ty * BLUR_H + wave * BLUR_STRIP;
-  if (ys >= h) return;                        // wave-uniform
-  const int x0 = tx * BLUR_W + lane * 4;
-  const bool active = x0 < w;
+  if (ys >= h) return;
+  const int x0 = tx * BLUR_W + (lane - 1) * 4;
+  const bool active = lane >= 1 && lane <= 62 && x0 < w;
   const bool slow = active && (x0 < 4 || x0 + 7 > w);
+  const int xl = max(0, min(x0, pitch - 4));
   const int nrows = min(BLUR_STRIP, h - ys);
   uint8_t* dst = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
   const int dpitch = g.lv[l].pitch;
@@ -220,14 +215,14 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
   for (int t = 0; t < 12; ++t) col[t] = slow ? reflect101(x0 - 4 + t, w) : 0;
   unsigned ring[7][4];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) blur_row(src, pitch, reflect101(ys - 3 + i, h), x0, lane, slow, col, ring[i]);
+  for (int i = 0; i < 6; ++i) blur_row(src + (size_t)reflect101(ys - 3 + i, h) * pitch, xl, slow, col, ring[i]);
   for (int y0 = 0; y0 < nrows; y0 += 7) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int y = y0 + i;
       if (y < nrows) {   // wave-uniform
         // ring slot (i+6)%7 receives input row ys+y+3; slots (i..i+6)%7 hold rows y-3..y+3
-        blur_row(src, pitch, reflect101(ys + y + 3, h), x0, lane, slow, col, ring[(i + 6) % 7]);
+        blur_row(src + (size_t)reflect101(ys + y + 3, h) * pitch, xl, slow, col, ring[(i + 6) % 7]);
         unsigned packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
