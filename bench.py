@@ -158,12 +158,23 @@ def main():
         "describe_kernel": n_img * args.features * (31 * 31 + 37 * 37 + 28 + 32),
         "harris_select_kernel": n_img * 2 * args.features * (81 + 4 + 8),
         "rank_select_kernel": n_img * 2 * args.features * 16,
+        "stereo_bucket_kernel": args.batch * args.features * (8 + 12),
         "stereo_match_kernel": args.batch * (2 * args.features * (32 + 8) + args.features * 8),
         "stereo_compact_kernel": args.batch * args.features * (8 + 16 + 25),
     }
     ach = per_launch.get(dom_name, 0) / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run
+    # separately: scripts/pmc_summary.py -> profiles/*_pmc_traffic.json); counters cannot be read live here
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pmc.get("batch") == args.batch and pmc.get("n_features") == args.features:
+            traffic = pmc["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
     roofline = dict(bound="hbm", kernel=dom_name, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
+                    algorithmic_bytes_per_launch=int(per_launch.get(dom_name, 0)),
                     avg_launch_us=round(dom_ms / max(dom_launches, 1) * 1e3, 2),
                     kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in sorted(acc.items())},
                     path_algorithmic_GBps=round(ALGO_BYTES_PER_FRAME * args.batch * world * args.steps / elapsed / 1e9, 3))

@@ -315,97 +315,205 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(BaDims d, const double* 
 }
 
 // result block (doubles): [0] chi2  [1] gnorm  [2] chol_ok  [3] |dp|^2  [4] |p_pose|^2
-template <bool LDS>
-__device__ void solve_body(int n, double lambda, const double* __restrict__ rb, int K, double* S, double* b,
+// One workgroup of 256 threads.  S lives in LDS (n <= ~135) or in global memory; the right-hand side always
+// in LDS.  Right-looking Cholesky: 2 barriers per column, trailing update on a 16x16 thread grid; the two
+// triangular solves run in wave 0 alone as row dot products with shuffle reductions (no block barriers).
+constexpr int BA_SOLVE_THREADS = 1024;
+constexpr int BA_TG = 32;                 // trailing update runs on a BA_TG x BA_TG thread grid
+constexpr int BA_TB = 4;                  // entries per thread per row batch (BA_TG*BA_TB = 128 columns)
+constexpr int BA_MAX_N = 768;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// force-inlined into both kernels so that the address space of S (LDS vs global) is known: as an
+// out-of-line function it took a generic pointer and every access became a slow flat_load/flat_store.
+//
+// Factorisation kept in "unscaled column" form: after step c the strict lower part of column c still holds
+// a_rc (not a_rc / L_cc) and srinv[c] = 1 / L_cc; L_rc = S[r][c] * srinv[c] is formed on the fly.  That
+// removes the column-scaling pass and two of the three barriers per column, and the only long-latency
+// scalar op per column is one reciprocal square root.
+// 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps y <- y + y*(1 - x y^2)/2 (full f64 accuracy)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double e = fma(-x * y, y, 1.0);
+    y = fma(y, 0.5 * e, y);
+  }
+  return y;
+}
+
+template <typename SPtr>
+__device__ __forceinline__ void solve_body(int n, double lambda, const double* __restrict__ rb, int K, SPtr S,
                            double* __restrict__ dp, double* __restrict__ res, const double* __restrict__ params) {
-  const int tid = threadIdx.x, nth = blockDim.x;
+  __shared__ double sb[BA_MAX_N];
+  __shared__ double srinv[BA_MAX_N];
+  __shared__ double s_red[BA_SOLVE_THREADS];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, nth = BA_SOLVE_THREADS, lane = tid & 63;
   const size_t nn = (size_t)n * n;
   const double* U = rb + nn;
   const double* gp = U + 36 * (size_t)K;
   const double* bred = gp + n;
-  __shared__ double s_gsq[1024];
-  __shared__ int s_ok;
   if (tid == 0) s_ok = 1;
   // S = blockdiag(U*) - S_red ; b = -g_p + b_red
-  for (size_t idx = tid; idx < nn; idx += nth) {
-    const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
-    double v = -rb[idx];
-    if (i / 6 == j / 6) {
-      double u = U[36 * (size_t)(i / 6) + (i % 6) * 6 + (j % 6)];
-      if (i == j) u += lambda * fmax(u, 1e-6);
-      v += u;
+  for (int i = tid / BA_TG; i < n; i += nth / BA_TG)
+    for (int j = tid % BA_TG; j < n; j += BA_TG) {
+      double v = -rb[(size_t)i * n + j];
+      if (i / 6 == j / 6) {
+        double u = U[36 * (size_t)(i / 6) + (i % 6) * 6 + (j % 6)];
+        if (i == j) u += lambda * fmax(u, 1e-6);
+        v += u;
+      }
+      S[(size_t)i * n + j] = v;
     }
-    S[idx] = v;
-  }
   double gs = 0.0;
-  for (int i = tid; i < n; i += nth) { b[i] = -gp[i] + bred[i]; gs += gp[i] * gp[i]; }
-  s_gsq[tid] = gs;
+  for (int i = tid; i < n; i += nth) { sb[i] = -gp[i] + bred[i]; gs += gp[i] * gp[i]; }
+  s_red[tid] = gs;
   __syncthreads();
-  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_gsq[tid] += s_gsq[tid + s2]; __syncthreads(); }
-  if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(s_gsq[0] + bred[n + 1]); }
+  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_red[tid] += s_red[tid + s2]; __syncthreads(); }
+  if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(s_red[0] + bred[n + 1]); }
   // Cholesky, right-looking, lower triangle
+  const int tr = tid / BA_TG, tc = tid % BA_TG;
+  const size_t dump = (size_t)n * n + tid;     // scratch element behind the matrix, one per thread
   for (int c = 0; c < n; ++c) {
     __syncthreads();
     const double dcc = S[(size_t)c * n + c];
     if (!(dcc > 0.0)) { if (tid == 0) s_ok = 0; break; }   // uniform: every thread reads the same value
-    const double dd = sqrt(dcc);
-    __syncthreads();
-    for (int r = c + tid; r < n; r += nth) S[(size_t)r * n + c] = (r == c) ? dd : S[(size_t)r * n + c] / dd;
-    __syncthreads();
-    const int m = n - c - 1;
-    for (int idx = tid; idx < m * m; idx += nth) {
-      const int r = c + 1 + idx / m, k = c + 1 + idx % m;
-      if (k <= r) S[(size_t)r * n + k] -= S[(size_t)r * n + c] * S[(size_t)k * n + c];
+    const double rinv = rsqrt_nr(dcc);
+    if (tid == 0) srinv[c] = rinv;
+    // trailing update S[r][k] -= L[r][c] L[k][c], c < k <= r < n.  Branch-free: masked-off entries go to a
+    // per-thread dump slot so that no LDS access sits inside a divergent branch.
+    for (int kb = c + 1 + tc; kb < n; kb += BA_TG * BA_TB) {
+      double lk[BA_TB];
+#pragma unroll
+      for (int b = 0; b < BA_TB; ++b) { const int k = min(kb + BA_TG * b, n - 1); lk[b] = S[(size_t)k * n + c] * rinv; }
+      const int rfirst = c + 1 + tr + BA_TG * ((max(kb - (c + 1 + tr), 0) + BA_TG - 1) / BA_TG);
+      const int niter = (n - (c + 1) + BA_TG - 1) / BA_TG;      // uniform trip count; rows >= n are masked
+      for (int it = 0; it < niter; ++it) {
+        const int r = rfirst + BA_TG * it;
+        const bool rok = r < n;
+        size_t idx[BA_TB];
+        double v[BA_TB];
+#pragma unroll
+        for (int b = 0; b < BA_TB; ++b) {
+          const int k = kb + BA_TG * b;
+          idx[b] = (rok && k <= r) ? (size_t)r * n + k : dump;
+        }
+        const double lru = S[(size_t)min(r, n - 1) * n + c];      // one LDS round trip for lr and the batch
+#pragma unroll
+        for (int b = 0; b < BA_TB; ++b) v[b] = S[idx[b]];
+        const double lr = lru * rinv;
+#pragma unroll
+        for (int b = 0; b < BA_TB; ++b) S[idx[b]] = v[b] - lr * lk[b];
+      }
     }
   }
   __syncthreads();
   const int ok = s_ok;
-  if (ok) {
-    // forward L y = b, backward L^T x = y (column oriented, one barrier per column)
-    for (int c = 0; c < n; ++c) {
-      __syncthreads();
-      const double yc = b[c] / S[(size_t)c * n + c];
-      __syncthreads();
-      if (tid == 0) b[c] = yc;
-      for (int r = c + 1 + tid; r < n; r += nth) b[r] -= S[(size_t)r * n + c] * yc;
+  if (ok && tid < 64 && n <= 128) {
+    // forward L y = b then backward L^T x = y, column oriented: lane holds rows `lane` and `lane+64` of the
+    // right-hand side in registers, each step broadcasts one solved entry with v_readlane; the column of the
+    // next step is loaded while the current one is applied
+    const int r0 = min(lane, n - 1), r1 = min(lane + 64, n - 1);
+    double b0 = lane < n ? sb[lane] : 0.0, b1 = lane + 64 < n ? sb[lane + 64] : 0.0;
+    const double ri0 = srinv[r0], ri1 = srinv[r1];
+    constexpr int CH = 8;
+    double l0[CH], l1[CH], rc[CH], l0n[CH], l1n[CH], rcn[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { const int c = min(j, n - 1); l0[j] = S[(size_t)r0 * n + c]; l1[j] = S[(size_t)r1 * n + c]; rc[j] = srinv[c]; }
+    for (int c0 = 0; c0 < n; c0 += CH) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { const int c = min(c0 + CH + j, n - 1); l0n[j] = S[(size_t)r0 * n + c]; l1n[j] = S[(size_t)r1 * n + c]; rcn[j] = srinv[c]; }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int c = c0 + j;
+        if (c < n) {   // uniform
+          const double own = (c < 64) ? b0 : b1;
+          const int src = c & 63;
+          const int lo = __builtin_amdgcn_readlane(__double2loint(own), src), hi = __builtin_amdgcn_readlane(__double2hiint(own), src);
+          const double yc = __hiloint2double(hi, lo) * rc[j];
+          const double f = yc * rc[j];                       // L_rc y_c = a_rc * rinv_c * y_c
+          if (lane > c) b0 = b0 - l0[j] * f; else if (lane == c) b0 = yc;
+          if (lane + 64 > c) b1 = b1 - l1[j] * f; else if (lane + 64 == c) b1 = yc;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { l0[j] = l0n[j]; l1[j] = l1n[j]; rc[j] = rcn[j]; }
     }
-    for (int c = n - 1; c >= 0; --c) {
-      __syncthreads();
-      const double xc = b[c] / S[(size_t)c * n + c];
-      __syncthreads();
-      if (tid == 0) b[c] = xc;
-      for (int r = tid; r < c; r += nth) b[r] -= S[(size_t)c * n + r] * xc;
+    // backward: row c of L is S[c][r] * rinv_r (unscaled column r); chunks run downwards from n-1
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { const int c = max(n - 1 - j, 0); l0[j] = S[(size_t)c * n + r0]; l1[j] = S[(size_t)c * n + r1]; rc[j] = srinv[c]; }
+    for (int c0 = n - 1; c0 >= 0; c0 -= CH) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { const int c = max(c0 - CH - j, 0); l0n[j] = S[(size_t)c * n + r0]; l1n[j] = S[(size_t)c * n + r1]; rcn[j] = srinv[c]; }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int c = c0 - j;
+        if (c >= 0) {   // uniform
+          const double own = (c < 64) ? b0 : b1;
+          const int src = c & 63;
+          const int lo = __builtin_amdgcn_readlane(__double2loint(own), src), hi = __builtin_amdgcn_readlane(__double2hiint(own), src);
+          const double xc = __hiloint2double(hi, lo) * rc[j];
+          if (lane < c) b0 = b0 - (l0[j] * ri0) * xc; else if (lane == c) b0 = xc;
+          if (lane + 64 < c) b1 = b1 - (l1[j] * ri1) * xc; else if (lane + 64 == c) b1 = xc;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { l0[j] = l0n[j]; l1[j] = l1n[j]; rc[j] = rcn[j]; }
     }
-    __syncthreads();
+    if (lane < n) sb[lane] = b0;
+    if (lane + 64 < n) sb[lane + 64] = b1;
+  } else if (ok && tid < 64) {
+    // general n: row dot products with shuffle reductions; L_rk = S[r][k] * srinv[k]
+    for (int r = 0; r < n; ++r) {
+      double acc = 0.0;
+      for (int k = lane; k < r; k += 64) acc += S[(size_t)r * n + k] * srinv[k] * sb[k];
+      acc = wave_sum(acc);
+      if (lane == 0) sb[r] = (sb[r] - acc) * srinv[r];
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int r = n - 1; r >= 0; --r) {
+      double acc = 0.0;
+      for (int k = r + 1 + lane; k < n; k += 64) acc += S[(size_t)k * n + r] * sb[k];
+      acc = wave_sum(acc) * srinv[r];
+      if (lane == 0) sb[r] = (sb[r] - acc) * srinv[r];
+      __builtin_amdgcn_wave_barrier();
+    }
   }
+  __syncthreads();
   double dsq = 0.0, psq = 0.0;
   for (int i = tid; i < n; i += nth) {
-    const double v = ok ? b[i] : 0.0;
+    const double v = ok ? sb[i] : 0.0;
     dp[i] = v;
     dsq += v * v;
     psq += params[i] * params[i];
   }
-  s_gsq[tid] = dsq;
+  s_red[tid] = dsq;
   __syncthreads();
-  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_gsq[tid] += s_gsq[tid + s2]; __syncthreads(); }
-  if (tid == 0) { res[2] = (double)ok; res[3] = s_gsq[0]; }
+  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_red[tid] += s_red[tid + s2]; __syncthreads(); }
+  if (tid == 0) { res[2] = (double)ok; res[3] = s_red[0]; }
   __syncthreads();
-  s_gsq[tid] = psq;
+  s_red[tid] = psq;
   __syncthreads();
-  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_gsq[tid] += s_gsq[tid + s2]; __syncthreads(); }
-  if (tid == 0) res[4] = s_gsq[0];
+  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_red[tid] += s_red[tid + s2]; __syncthreads(); }
+  if (tid == 0) res[4] = s_red[0];
 }
 
-__global__ __launch_bounds__(1024) void ba_solve_lds_kernel(int n, double lambda, const double* __restrict__ rb, int K,
-                                                            double* __restrict__ dp, double* __restrict__ res,
-                                                            const double* __restrict__ params) {
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(int n, double lambda, const double* __restrict__ rb,
+                                                                        int K, double* __restrict__ dp, double* __restrict__ res,
+                                                                        const double* __restrict__ params) {
   extern __shared__ __align__(16) double dyn[];
-  solve_body<true>(n, lambda, rb, K, dyn, dyn + (size_t)n * n, dp, res, params);
+  solve_body(n, lambda, rb, K, dyn, dp, res, params);
 }
-__global__ __launch_bounds__(1024) void ba_solve_gmem_kernel(int n, double lambda, const double* __restrict__ rb, int K,
-                                                             double* __restrict__ Sg, double* __restrict__ dp,
-                                                             double* __restrict__ res, const double* __restrict__ params) {
-  solve_body<false>(n, lambda, rb, K, Sg, Sg + (size_t)n * n, dp, res, params);
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_gmem_kernel(int n, double lambda, const double* __restrict__ rb,
+                                                                         int K, double* __restrict__ Sg, double* __restrict__ dp,
+                                                                         double* __restrict__ res, const double* __restrict__ params) {
+  solve_body(n, lambda, rb, K, Sg, dp, res, params);
 }
 
 // delta_l = V*^-1 (-g_l - sum_k W_kj^T delta_p_k); trial = params + delta; per-point |delta_l|^2, |p_l|^2
@@ -605,7 +713,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
       {B_OA, 96 * (size_t)std::max(N, 1)}, {B_OR, 16 * (size_t)std::max(N, 1)}, {B_OYG, 48 * (size_t)std::max(N, 1)},
       {B_VINV, 72 * (size_t)std::max(M, 1)}, {B_GL, 24 * (size_t)std::max(M, 1)}, {B_PT, 8 * 4 * (size_t)std::max(M, 1)},
       {B_WT, 8 * (size_t)d.rows * d.P}, {B_YT, 8 * (size_t)d.rows * d.P}, {B_PART, 8 * n_upper * d.ksplit * 256},
-      {B_UG, 8 * (size_t)(48 * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 2 * (size_t)n + 32)}, {B_RES, 8 * 16}};
+      {B_UG, 8 * (size_t)(48 * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 2 * (size_t)n + 32 + BA_SOLVE_THREADS)}, {B_RES, 8 * 16}};
   for (auto& nd : need) if (int rc = orbx_reserve(h, h->ws_ba[nd.id], nd.bytes)) return rc;
   auto D = [&](int id) { return (double*)h->ws_ba[id].p; };
   auto I = [&](int id) { return (int*)h->ws_ba[id].p; };
@@ -629,8 +737,9 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   double* res = D(B_RES);
   double hres[16];
 
-  const size_t lds_need = 8 * ((size_t)n * n + n);
-  const bool use_lds = lds_need <= 150 * 1024;
+  if (n > BA_MAX_N) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d optimised keyframes per window", BA_MAX_N / 6);
+  const size_t lds_need = 8 * ((size_t)n * n + BA_SOLVE_THREADS);
+  const bool use_lds = lds_need + 8 * (2 * BA_MAX_N + BA_SOLVE_THREADS) + 64 <= 160 * 1024;
   if (use_lds && n > 0)
     ORBX_HIP(h, hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
 
@@ -703,9 +812,9 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     {
       ProfScope ps(h, "ba_solve_kernel");
       if (use_lds)
-        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(1024), lds_need, st, n, lambda, D(B_RB), K, D(B_SOLVE), res, cur);
+        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_THREADS), lds_need, st, n, lambda, D(B_RB), K, D(B_SOLVE), res, cur);
       else
-        hipLaunchKernelGGL(ba_solve_gmem_kernel, dim3(1), dim3(1024), 0, st, n, lambda, D(B_RB), K, D(B_SOLVE) + ((n + 15) & ~15), D(B_SOLVE), res, cur);
+        hipLaunchKernelGGL(ba_solve_gmem_kernel, dim3(1), dim3(BA_SOLVE_THREADS), 0, st, n, lambda, D(B_RB), K, D(B_SOLVE) + ((n + 15) & ~15), D(B_SOLVE), res, cur);
     }
     {
       ProfScope ps(h, "ba_backsub_kernel");

@@ -20,7 +20,16 @@ def load(path, tag):
         acc[name].append(float(r["Counter_Value"]))
     return acc
 
+import json
 f = load(sys.argv[1], "FETCH_SIZE"); w = load(sys.argv[2], "WRITE_SIZE")
+out = dict(batch=int(sys.argv[3]) if len(sys.argv) > 3 else None, n_features=int(sys.argv[4]) if len(sys.argv) > 4 else None,
+           note="per launch; hbm_bytes = 2*FETCH_SIZE KiB (gfx950 half-count correction, calibrated for wide "
+                "coalesced streams only) + WRITE_SIZE KiB; fetch_raw_bytes is the uncorrected counter", kernels={})
+for k in sorted(f):
+    fm = sum(f[k]) / len(f[k]); wm = sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1)
+    out["kernels"][k] = dict(fetch_raw_bytes=int(fm * 1024), write_bytes=int(wm * 1024), hbm_bytes_per_launch=int((2 * fm + wm) * 1024))
+if len(sys.argv) > 5:
+    json.dump(out, open(sys.argv[5], "w"), indent=1)
 print("%-28s %8s %14s %14s %14s" % ("kernel", "launches", "FETCH KiB", "FETCHx2 MB", "WRITE MB"))
 for k in sorted(f):
     fm = sum(f[k]) / len(f[k]); wm = sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1)

@@ -171,7 +171,9 @@ def test_ba_allreduce_hook_rccl_world1(gpu_handle, pkg):
         got = pkg.dist.ba_solve_partitioned(gpu_handle, cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"],
                                             0, 1, pkg.dist.make_allreduce_hook(dev))
         assert got["iterations"] == ref["iterations"]
-        assert np.array_equal(got["poses_wc"], ref["poses_wc"]) and np.array_equal(got["points"], ref["points"])
+        # poses are bit-identical; points go through the cross-rank merge init + sum(delta), which rounds once more
+        assert np.array_equal(got["poses_wc"], ref["poses_wc"])
+        assert _rel(got["points"], ref["points"]) < 1e-14
         assert got["final_error"] == ref["final_error"]
     finally:
         dist.destroy_process_group()
