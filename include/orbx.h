@@ -161,6 +161,22 @@ int orbx_hamming_batch(orbx_handle* h, const uint8_t* a, const uint8_t* b, int n
 int orbx_hamming_batch_device(orbx_handle* h, const uint8_t* d_a, const uint8_t* d_b, int n_pairs,
                               uint32_t* d_out);
 
+/* Guided matching = FeatureGrid::new + get_features_in_area (src/tracking/tracking_frame.rs:52-128,
+ * 64x48 cells over img_w x img_h) followed by the tracker's descriptor search over the candidates:
+ *   mode 0  track_with_motion_model (src/tracking/tracker.rs:1126-1157): smallest distance < 100;
+ *   mode 1  track_local_map (tracker.rs:880-923): best <= 100 and, with more than one candidate,
+ *           best <= 0.75 * second.
+ * Ties go to the first candidate in the reference's visiting order (cells row-major, keypoint index
+ * ascending inside a cell).  kp/desc: the frame's n features; q_uv [nq][2] f64 projected positions,
+ * q_desc [nq][32] map-point descriptors; out_idx [nq] = keypoint index or -1, out_dist [nq].
+ * Keypoint and query coordinates must be finite.  Host and device forms. */
+int orbx_guided_match(orbx_handle* h, const orbx_keypoint* kp, const uint8_t* desc, int n, double img_w,
+                      double img_h, const double* q_uv, const uint8_t* q_desc, int nq, double radius,
+                      int mode, int* out_idx, uint32_t* out_dist);
+int orbx_guided_match_device(orbx_handle* h, const orbx_keypoint* d_kp, const uint8_t* d_desc, int n,
+                             double img_w, double img_h, const double* d_q_uv, const uint8_t* d_q_desc,
+                             int nq, double radius, int mode, int* d_out_idx, uint32_t* d_out_dist);
+
 /* ---- local bundle adjustment ------------------------------------------------------ */
 
 /* = LocalBAConfigLM, src/optimizer/local_ba_lm.rs:96-119 */

@@ -7,7 +7,12 @@
 //   src/tracking/frame/stereo.rs:166-175  descriptor_distance
 //   src/tracking/frame/stereo.rs:186-216  triangulate
 //   src/tracking/tracker.rs:1001-1010     BFMatcher(NORM_HAMMING, crossCheck=true).train_match
+//   src/tracking/tracking_frame.rs:52-128 FeatureGrid::new / get_features_in_area
+//   src/tracking/tracker.rs:880-923       track_local_map descriptor search (ratio rule)
+//   src/tracking/tracker.rs:1126-1157     track_with_motion_model descriptor search
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -122,6 +127,67 @@ int oracle_crosscheck_match(const uint8_t* q, int nq, const uint8_t* t, int nt, 
     }
   }
   return n;
+}
+
+// ---- guided matching -------------------------------------------------------------------------------------
+// Rust float -> int casts saturate (and NaN -> 0); `as usize` of a negative i32 wraps.
+static inline long long sat_usize(double v) { return (v != v || v <= 0.0) ? 0 : (v >= 9.0e18 ? (long long)9.0e18 : (long long)v); }
+static inline int sat_i32(double v) {
+  if (v != v) return 0;
+  if (v <= -2147483648.0) return INT32_MIN;
+  if (v >= 2147483647.0) return INT32_MAX;
+  return (int)v;
+}
+
+// tracking_frame.rs:52-128 + the two search loops.  mode 0 = track_with_motion_model (:1126-1157): smallest
+// distance < TH_HIGH, first candidate wins ties.  mode 1 = track_local_map (:880-923): best/second over the
+// candidates, reject best > TH_HIGH, and when there is more than one candidate reject best > 0.75*second.
+// out_idx[q] = matched keypoint index or -1; out_dist[q] = its distance.
+void oracle_guided_match(const orbx_keypoint* kp, const uint8_t* desc, int n, double img_w, double img_h,
+                         const double* q_uv, const uint8_t* q_desc, int nq, double radius, int mode,
+                         int* out_idx, uint32_t* out_dist) {
+  const int GC = 64, GR = 48;                                   // tracking_frame.rs:43-44
+  const double winv = (double)GC / (img_w - 0.0), hinv = (double)GR / (img_h - 0.0);   // :58-59
+  std::vector<std::vector<int>> cells((size_t)GC * GR);
+  for (int i = 0; i < n; ++i) {                                 // :65-78
+    const double x = (double)kp[i].x, y = (double)kp[i].y;
+    long long cx = sat_usize((x - 0.0) * winv), cy = sat_usize((y - 0.0) * hinv);
+    if (cx > GC - 1) cx = GC - 1;
+    if (cy > GR - 1) cy = GR - 1;
+    cells[(size_t)cy * GC + cx].push_back(i);
+  }
+  for (int q = 0; q < nq; ++q) {
+    const double x = q_uv[2 * q], y = q_uv[2 * q + 1];
+    // :107-117 — note `(max as usize).min(cols-1)`: a negative max wraps and clamps to the LAST cell
+    const int mnx = sat_i32(std::floor((x - 0.0 - radius) * winv)), mxx = sat_i32(std::ceil((x - 0.0 + radius) * winv));
+    const int mny = sat_i32(std::floor((y - 0.0 - radius) * hinv)), mxy = sat_i32(std::ceil((y - 0.0 + radius) * hinv));
+    const long long x0 = mnx > 0 ? mnx : 0, y0 = mny > 0 ? mny : 0;
+    const long long x1 = (mxx < 0 || mxx > GC - 1) ? GC - 1 : mxx, y1 = (mxy < 0 || mxy > GR - 1) ? GR - 1 : mxy;
+    std::vector<int> cand;
+    for (long long cy = y0; cy <= y1; ++cy)
+      for (long long cx = x0; cx <= x1; ++cx)
+        for (int i : cells[(size_t)cy * GC + cx]) cand.push_back(i);
+    out_idx[q] = -1; out_dist[q] = 0;
+    uint32_t best = 0xffffffffu, second = 0xffffffffu;
+    int bi = -1;
+    if (mode == 0) {
+      for (int i : cand) {
+        const uint32_t d = oracle_hamming256(q_desc + 32 * (size_t)q, desc + 32 * (size_t)i);
+        if (d < best && d < 100) { best = d; bi = i; }          // tracker.rs:1146-1149
+      }
+      if (bi >= 0) { out_idx[q] = bi; out_dist[q] = best; }
+    } else {
+      if (cand.empty()) continue;                               // :884-886
+      for (int i : cand) {
+        const uint32_t d = oracle_hamming256(q_desc + 32 * (size_t)q, desc + 32 * (size_t)i);
+        if (d < best) { second = best; best = d; bi = i; }     // :898-904
+        else if (d < second) second = d;
+      }
+      if (best > 100) continue;                                 // :907-909
+      if (cand.size() > 1 && (float)best > 0.75f * (float)second) continue;   // :911-915
+      out_idx[q] = bi; out_dist[q] = best;
+    }
+  }
 }
 
 }  // extern "C"

@@ -34,6 +34,9 @@ int oracle_stereo_match(const orbx_camera* cam, const orbx_keypoint* kpL, const 
                         int nL, const orbx_keypoint* kpR, const uint8_t* descR, int nR,
                         orbx_dmatch* matches, double* points_cam, uint8_t* has_point);
 int oracle_crosscheck_match(const uint8_t* q, int nq, const uint8_t* t, int nt, orbx_dmatch* out);
+void oracle_guided_match(const orbx_keypoint* kp, const uint8_t* desc, int n, double img_w, double img_h,
+                         const double* q_uv, const uint8_t* q_desc, int nq, double radius, int mode,
+                         int* out_idx, uint32_t* out_dist);
 
 /* ---- ORB extractor (orb_ref.cpp) ---- */
 typedef struct {

@@ -109,6 +109,17 @@ def crosscheck_match(q, t):
     return out[:n].copy()
 
 
+def guided_match(kp, desc, img_w, img_h, q_uv, q_desc, radius, mode):
+    kp = np.ascontiguousarray(kp, KEYPOINT); desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    q_uv = np.ascontiguousarray(q_uv, np.float64).reshape(-1, 2)
+    q_desc = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+    nq = len(q_uv)
+    idx = np.zeros(max(nq, 1), np.int32); dist = np.zeros(max(nq, 1), np.uint32)
+    lib().oracle_guided_match(_p(kp), _p(desc), C.c_int(len(kp)), C.c_double(img_w), C.c_double(img_h), _p(q_uv),
+                              _p(q_desc), C.c_int(nq), C.c_double(radius), C.c_int(mode), _p(idx), _p(dist))
+    return idx[:nq].copy(), dist[:nq].copy()
+
+
 def orb_level_table(w, h, params):
     T = OrbLevels()
     rc = lib().oracle_orb_level_table(C.c_int(w), C.c_int(h), C.byref(params), C.byref(T))

@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
     "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual",
+    "orbx_guided_match", "orbx_guided_match_device",
     "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
     "orbx_debug_read_candidates",
 ]
@@ -269,6 +270,18 @@ class Handle:
         self._check(self._L.orbx_hamming_match_crosscheck(self._h, _vp(q), C.c_int(len(q)), _vp(t),
                                                           C.c_int(len(t)), _vp(out), C.byref(n)))
         return out[:n.value].copy()
+
+    def guided_match(self, kp, desc, img_w, img_h, q_uv, q_desc, radius, mode):
+        """FeatureGrid + descriptor search (tracking_frame.rs:52-128; tracker.rs:880-923 mode 1, :1126-1157 mode 0)."""
+        kp = np.ascontiguousarray(kp, KEYPOINT); desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        q_uv = np.ascontiguousarray(q_uv, np.float64).reshape(-1, 2)
+        q_desc = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        nq = len(q_uv)
+        idx = np.zeros(max(nq, 1), np.int32); dist = np.zeros(max(nq, 1), np.uint32)
+        self._check(self._L.orbx_guided_match(self._h, _vp(kp), _vp(desc), C.c_int(len(kp)), C.c_double(img_w),
+                                              C.c_double(img_h), _vp(q_uv), _vp(q_desc), C.c_int(nq), C.c_double(radius),
+                                              C.c_int(mode), _vp(idx), _vp(dist)))
+        return idx[:nq].copy(), dist[:nq].copy()
 
     def hamming_batch(self, a, b):
         a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)

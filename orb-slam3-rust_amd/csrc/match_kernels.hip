@@ -11,6 +11,9 @@
 // wave with __shfl_xor and reproduce the reference's sequential scan (strict '<': the lowest
 // right index wins a tie, `second` is the second smallest of the multiset).  All of this is
 // integer/byte work bound by L2/HBM reads, not by MFMA.
+#include <algorithm>
+#include <climits>
+
 #include "orbx_internal.hpp"
 
 namespace {
@@ -291,6 +294,118 @@ __global__ __launch_bounds__(256) void crosscheck_compact_kernel(const int* __re
   if (tid == 0) *n_out = running;
 }
 
+// ---- guided matching: FeatureGrid (tracking_frame.rs:52-128) + the tracker's two search rules -----------------
+constexpr int GG_COLS = 64, GG_ROWS = 48, GG_CELLS = GG_COLS * GG_ROWS;   // tracking_frame.rs:43-44
+
+// Rust `f64 as usize`: truncation, negative / NaN -> 0
+__device__ __forceinline__ int sat_cell(double v, int last) {
+  return (v > 0.0) ? (v >= (double)(last + 1) ? last : (int)v) : 0;
+}
+// Rust `f64 as i32`: saturating, NaN -> 0
+__device__ __forceinline__ int sat_i32(double v) {
+  if (v != v) return 0;
+  if (v <= -2147483648.0) return INT_MIN;
+  if (v >= 2147483647.0) return INT_MAX;
+  return (int)v;
+}
+
+// One block: counting sort of the keypoints by grid cell (CSR: cell_start[GG_CELLS+1], sorted_idx[n]) and the
+// cell of every keypoint.  The order inside a cell is irrelevant: ties are broken on (cell, index) explicitly.
+__global__ __launch_bounds__(1024) void grid_build_kernel(const orbx_keypoint* __restrict__ kp, int n, double winv, double hinv,
+                                                          int* __restrict__ cell_start, int* __restrict__ sorted_idx,
+                                                          unsigned short* __restrict__ cell_of) {
+  __shared__ int cnt[GG_CELLS];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < GG_CELLS; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const int cx = sat_cell(((double)kp[i].x - 0.0) * winv, GG_COLS - 1);     // tracking_frame.rs:66-75
+    const int cy = sat_cell(((double)kp[i].y - 0.0) * hinv, GG_ROWS - 1);
+    const int c = cy * GG_COLS + cx;
+    cell_of[i] = (unsigned short)c;
+    atomicAdd(&cnt[c], 1);
+  }
+  __syncthreads();
+  int c3[3], tot = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { c3[k] = cnt[3 * tid + k]; tot += c3[k]; }
+  int inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = inc - tot;
+  for (int wv = 0; wv < wave; ++wv) base += wsum[wv];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { cell_start[3 * tid + k] = base; cnt[3 * tid + k] = base; base += c3[k]; }
+  if (tid == 1023) cell_start[GG_CELLS] = base;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) sorted_idx[atomicAdd(&cnt[cell_of[i]], 1)] = i;
+}
+
+// One wave per query.  key = (distance << 48 | cell << 32 | index): the minimum key is the smallest distance,
+// and among equal distances the first candidate in the reference's visiting order (cells row-major, indices
+// ascending inside a cell).  `second` is the second smallest distance of the multiset.
+__global__ __launch_bounds__(256) void guided_match_kernel(const uint8_t* __restrict__ desc, const int* __restrict__ cell_start,
+                                                           const int* __restrict__ sorted_idx,
+                                                           const unsigned short* __restrict__ cell_of,
+                                                           const double* __restrict__ q_uv, const uint8_t* __restrict__ q_desc,
+                                                           int nq, double radius, double winv, double hinv, int mode,
+                                                           int* __restrict__ out_idx, uint32_t* __restrict__ out_dist) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const double x = q_uv[2 * (size_t)q], y = q_uv[2 * (size_t)q + 1];
+  // tracking_frame.rs:107-117, including `(max as usize).min(cols - 1)`: a negative max wraps -> last cell
+  const int mnx = sat_i32(floor((x - 0.0 - radius) * winv)), mxx = sat_i32(ceil((x - 0.0 + radius) * winv));
+  const int mny = sat_i32(floor((y - 0.0 - radius) * hinv)), mxy = sat_i32(ceil((y - 0.0 + radius) * hinv));
+  const int x0 = max(mnx, 0), y0 = max(mny, 0);
+  const int x1 = (mxx < 0 || mxx > GG_COLS - 1) ? GG_COLS - 1 : mxx;
+  const int y1 = (mxy < 0 || mxy > GG_ROWS - 1) ? GG_ROWS - 1 : mxy;
+  const Desc256 dq = load_desc(q_desc + (size_t)q * 32);
+  unsigned long long bk = ~0ull;
+  unsigned s = 0xffffffffu;
+  int total = 0;
+  if (x0 <= x1) {
+    for (int cy = y0; cy <= y1; ++cy) {
+      const int lo = cell_start[cy * GG_COLS + x0], hi = cell_start[cy * GG_COLS + x1 + 1];
+      total += hi - lo;
+      for (int t = lo + lane; t < hi; t += kWave) {
+        const int i = sorted_idx[t];
+        const unsigned d = hamming(dq, load_desc(desc + (size_t)i * 32));
+        if (mode == 0 && d >= TH_HIGH) continue;                          // tracker.rs:1146
+        const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)cell_of[i] << 32) | (unsigned)i;
+        if (key < bk) { s = min(s, (unsigned)(bk >> 48)); if (bk == ~0ull) s = 0xffffffffu; bk = key; }
+        else s = min(s, d);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long ok = __shfl_xor(bk, off);
+    const unsigned os = __shfl_xor(s, off);
+    const unsigned long long mn = ok < bk ? ok : bk, mx = ok < bk ? bk : ok;
+    unsigned ns = min(s, os);
+    if (mx != ~0ull) ns = min(ns, (unsigned)(mx >> 48));
+    bk = mn; s = ns;
+  }
+  if (lane == 0) {
+    int res = -1;
+    unsigned rd = 0;
+    if (bk != ~0ull) {
+      const unsigned best = (unsigned)(bk >> 48);
+      const int bi = (int)(unsigned)(bk & 0xffffffffull);
+      if (mode == 0) { res = bi; rd = best; }
+      else if (total > 0 && best <= TH_HIGH &&                                        // tracker.rs:884-886, :907-909
+               !(total > 1 && (float)best > 0.75f * (float)s)) { res = bi; rd = best; }   // :911-915
+    }
+    out_idx[q] = res;
+    out_dist[q] = rd;
+  }
+}
+
 __global__ __launch_bounds__(256) void hamming_batch_kernel(const uint8_t* __restrict__ a,
                                                             const uint8_t* __restrict__ b, int n,
                                                             uint32_t* __restrict__ out) {
@@ -365,6 +480,30 @@ int launch_hamming_batch(orbx_handle* h, const uint8_t* d_a, const uint8_t* d_b,
   ProfScope ps(h, "hamming_batch_kernel");
   const int blocks = min((n + 255) / 256, 2048);
   hipLaunchKernelGGL(hamming_batch_kernel, dim3(blocks), dim3(256), 0, h->stream, d_a, d_b, n, d_out);
+  ORBX_HIP(h, hipGetLastError());
+  return ORBX_OK;
+}
+
+int launch_guided_match(orbx_handle* h, const orbx_keypoint* d_kp, const uint8_t* d_desc, int n, double img_w, double img_h,
+                        const double* d_q_uv, const uint8_t* d_q_desc, int nq, double radius, int mode, int* d_out_idx,
+                        uint32_t* d_out_dist) {
+  if (nq <= 0) return ORBX_OK;
+  // workspace: cell_start int[GG_CELLS+1] | sorted_idx int[n] | cell_of u16[n]
+  const size_t bytes = sizeof(int) * (GG_CELLS + 1 + (size_t)std::max(n, 1)) + sizeof(unsigned short) * (size_t)std::max(n, 1) + 64;
+  if (int rc = orbx_reserve(h, h->ws_match, bytes)) return rc;
+  int* cell_start = (int*)h->ws_match.p;
+  int* sorted_idx = cell_start + GG_CELLS + 1;
+  unsigned short* cell_of = (unsigned short*)(sorted_idx + std::max(n, 1));
+  const double winv = (double)GG_COLS / (img_w - 0.0), hinv = (double)GG_ROWS / (img_h - 0.0);   // tracking_frame.rs:58-59
+  {
+    ProfScope ps(h, "grid_build_kernel");
+    hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, h->stream, d_kp, n, winv, hinv, cell_start, sorted_idx, cell_of);
+  }
+  {
+    ProfScope ps(h, "guided_match_kernel");
+    hipLaunchKernelGGL(guided_match_kernel, dim3((nq + 3) / 4), dim3(256), 0, h->stream, d_desc, cell_start, sorted_idx, cell_of,
+                       d_q_uv, d_q_desc, nq, radius, winv, hinv, mode, d_out_idx, d_out_dist);
+  }
   ORBX_HIP(h, hipGetLastError());
   return ORBX_OK;
 }

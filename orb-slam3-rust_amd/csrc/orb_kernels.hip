@@ -29,7 +29,6 @@ namespace {
 
 #include "orb_pattern_31.inc"
 
-constexpr int TILE_W = 64, TILE_H = 16;
 constexpr int EDGE = 31;             // edgeThreshold, stereo.rs:42
 constexpr int HARRIS_CHUNKS = 8;
 

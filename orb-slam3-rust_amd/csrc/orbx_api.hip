@@ -318,6 +318,51 @@ int orbx_hamming_batch(orbx_handle* h, const uint8_t* a, const uint8_t* b, int n
   return ORBX_OK;
 }
 
+int orbx_guided_match_device(orbx_handle* h, const orbx_keypoint* d_kp, const uint8_t* d_desc, int n, double img_w,
+                             double img_h, const double* d_q_uv, const uint8_t* d_q_desc, int nq, double radius, int mode,
+                             int* d_out_idx, uint32_t* d_out_dist) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (n < 0 || nq < 0 || (mode != 0 && mode != 1) || !(img_w > 0.0) || !(img_h > 0.0) || !(radius >= 0.0) ||
+      (n > 0 && (!d_kp || !d_desc)) || (nq > 0 && (!d_q_uv || !d_q_desc || !d_out_idx || !d_out_dist)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_guided_match_device: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  return launch_guided_match(h, d_kp, d_desc, n, img_w, img_h, d_q_uv, d_q_desc, nq, radius, mode, d_out_idx, d_out_dist);
+}
+
+int orbx_guided_match(orbx_handle* h, const orbx_keypoint* kp, const uint8_t* desc, int n, double img_w, double img_h,
+                      const double* q_uv, const uint8_t* q_desc, int nq, double radius, int mode, int* out_idx,
+                      uint32_t* out_dist) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (n < 0 || nq < 0 || (mode != 0 && mode != 1) || !(img_w > 0.0) || !(img_h > 0.0) || !(radius >= 0.0) ||
+      (n > 0 && (!kp || !desc)) || (nq > 0 && (!q_uv || !q_desc || !out_idx || !out_dist)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_guided_match: bad argument");
+  if (nq == 0) return ORBX_OK;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  if (int rc = orbx_reserve(h, h->ws_io[0], sizeof(orbx_keypoint) * nn)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[1], 32 * nn)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[2], 16 * (size_t)nq)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[3], 32 * (size_t)nq)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[4], 8 * (size_t)nq)) return rc;
+  if (n > 0) {
+    ORBX_HIP(h, hipMemcpyAsync(h->ws_io[0].p, kp, sizeof(orbx_keypoint) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP(h, hipMemcpyAsync(h->ws_io[1].p, desc, 32 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  }
+  ORBX_HIP(h, hipMemcpyAsync(h->ws_io[2].p, q_uv, 16 * (size_t)nq, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(h->ws_io[3].p, q_desc, 32 * (size_t)nq, hipMemcpyHostToDevice, h->stream));
+  int* d_idx = (int*)h->ws_io[4].p;
+  uint32_t* d_dist = (uint32_t*)(d_idx + nq);
+  orbx_prof_begin_call(h);
+  if (int rc = launch_guided_match(h, (const orbx_keypoint*)h->ws_io[0].p, (const uint8_t*)h->ws_io[1].p, n, img_w, img_h,
+                                   (const double*)h->ws_io[2].p, (const uint8_t*)h->ws_io[3].p, nq, radius, mode, d_idx, d_dist))
+    return rc;
+  ORBX_HIP(h, hipMemcpyAsync(out_idx, d_idx, 4 * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(out_dist, d_dist, 4 * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  return ORBX_OK;
+}
+
 // ---- extraction + full per-frame path -------------------------------------------------------------------
 
 int orbx_extract_batch_device(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,

@@ -116,6 +116,9 @@ int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, co
 int launch_crosscheck(orbx_handle* h, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                       orbx_dmatch* d_out, int* d_n_out);
 int launch_hamming_batch(orbx_handle* h, const uint8_t* d_a, const uint8_t* d_b, int n, uint32_t* d_out);
+int launch_guided_match(orbx_handle* h, const orbx_keypoint* d_kp, const uint8_t* d_desc, int n, double img_w, double img_h,
+                        const double* d_q_uv, const uint8_t* d_q_desc, int nq, double radius, int mode, int* d_out_idx,
+                        uint32_t* d_out_dist);
 // extractor (orb_kernels.hip)
 int orb_prepare_geometry(orbx_handle* h, int w, int h_px);
 int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,

@@ -110,3 +110,37 @@ def test_batch_device_matches_host_path(gpu_handle, oracle, pkg):
         _, _, m, pts, has = gpu_handle.unpack_batch_outputs(out, b)
         m0, p0, h0 = oracle.stereo_match(cam, *sets[b])
         assert records_equal(m0, m) and np.array_equal(h0, has) and np.array_equal(p0[h0 == 1], pts[has == 1])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n,nq,radius,seed", [(2000, 1500, 15.0, 0), (1200, 3000, 15.0, 1), (300, 64, 40.0, 2), (5, 9, 15.0, 3), (4000, 100, 7.5, 4)])
+def test_guided_match_parity(gpu_handle, oracle, pkg, mode, n, nq, radius, seed):
+    """FeatureGrid + descriptor search (tracking_frame.rs:52-128, tracker.rs:880-923 / :1126-1157), bit-exact"""
+    kp, d, kq, dq = pkg.synth.matcher_features(200 + seed, n, max(nq, 1), pkg.KEYPOINT)
+    rng = np.random.default_rng(seed)
+    uv = np.stack([kq["x"].astype(np.float64) + rng.uniform(-20, 140, len(kq)), kq["y"].astype(np.float64) + rng.uniform(-3, 3, len(kq))], 1)[:nq]
+    uv[::17] = rng.uniform(-200, 1000, (len(uv[::17]), 2))        # queries outside the image: the wrap-around cell quirk
+    i0, d0 = oracle.guided_match(kp, d, 752.0, 480.0, uv, dq[:nq], radius, mode)
+    i1, d1 = gpu_handle.guided_match(kp, d, 752.0, 480.0, uv, dq[:nq], radius, mode)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    if n >= 1000 and nq >= 1000:
+        assert (i0 >= 0).sum() > 50
+
+
+def test_guided_match_ties_and_empty(gpu_handle, oracle, pkg):
+    rng = np.random.default_rng(5)
+    n = 800
+    kp = np.zeros(n, pkg.KEYPOINT)
+    kp["x"] = rng.uniform(0, 752, n).astype(np.float32); kp["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    base = rng.integers(0, 256, (3, 32), dtype=np.uint8)
+    d = base[rng.integers(0, 3, n)]                          # only three distinct descriptors: ties everywhere
+    uv = np.stack([rng.uniform(0, 752, 500), rng.uniform(0, 480, 500)], 1)
+    dq = base[rng.integers(0, 3, 500)].copy(); dq[:, 0] ^= rng.integers(0, 2, 500).astype(np.uint8)
+    for mode in (0, 1):
+        i0, d0 = oracle.guided_match(kp, d, 752.0, 480.0, uv, dq, 15.0, mode)
+        i1, d1 = gpu_handle.guided_match(kp, d, 752.0, 480.0, uv, dq, 15.0, mode)
+        assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    i1, d1 = gpu_handle.guided_match(kp[:0], d[:0], 752.0, 480.0, uv[:4], dq[:4], 15.0, 1)
+    assert np.all(i1 == -1)
+    i1, d1 = gpu_handle.guided_match(kp, d, 752.0, 480.0, uv[:0], dq[:0], 15.0, 0)
+    assert len(i1) == 0

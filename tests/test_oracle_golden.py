@@ -183,3 +183,34 @@ def test_resize_and_blur_invariants(oracle, pkg):
     assert l1.shape == (400, 627)
     # bilinear from a 2x2 neighbourhood: inside [min,max] of the source neighbourhood
     assert abs(float(l1.mean()) - float(L.mean())) < 1.0
+
+
+def test_guided_match_semantics(oracle):
+    """FeatureGrid quirks and the two search rules (tracking_frame.rs:52-128, tracker.rs:880-923, :1126-1157)"""
+    kp = np.zeros(3, oracle.KEYPOINT)
+    kp["x"] = [100.0, 104.0, 700.0]; kp["y"] = [100.0, 101.0, 400.0]
+    d = np.zeros((3, 32), np.uint8); d[1, 0] = 0x01; d[2, 0] = 0xFF
+    q = np.zeros((1, 32), np.uint8)
+    # two candidates at distance 0 and 1: mode 0 takes the closest; mode 1 also passes (0 <= 0.75*1)
+    for mode in (0, 1):
+        i, dist = oracle.guided_match(kp, d, 752.0, 480.0, [[102.0, 100.0]], q, 15.0, mode)
+        assert i[0] == 0 and dist[0] == 0
+    # equal distances: first candidate in visiting order wins in mode 0; mode 1 rejects (best > 0.75*second)
+    d2 = d.copy(); d2[0, 0] = 0x01
+    i, dist = oracle.guided_match(kp, d2, 752.0, 480.0, [[102.0, 100.0]], q, 15.0, 0)
+    assert i[0] == 0 and dist[0] == 1
+    i, _ = oracle.guided_match(kp, d2, 752.0, 480.0, [[102.0, 100.0]], q, 15.0, 1)
+    assert i[0] == -1
+    # single candidate: ratio rule not applied (candidates.len() > 1, tracker.rs:911)
+    i, dist = oracle.guided_match(kp, d, 752.0, 480.0, [[700.0, 400.0]], q, 15.0, 1)
+    assert i[0] == 2 and dist[0] == 8
+    # mode 0 needs d < 100 strictly, mode 1 accepts best <= 100
+    d3 = np.zeros((1, 32), np.uint8); d3[0, :12] = 0xFF; d3[0, 12] = 0x0F      # distance 100
+    k1 = kp[:1]
+    assert oracle.guided_match(k1, d3, 752.0, 480.0, [[100.0, 100.0]], q, 15.0, 0)[0][0] == -1
+    assert oracle.guided_match(k1, d3, 752.0, 480.0, [[100.0, 100.0]], q, 15.0, 1)[0][0] == 0
+    # `(max_cell as usize).min(cols-1)` (tracking_frame.rs:113-116): a query left of the image wraps to ALL columns
+    i, dist = oracle.guided_match(kp, d, 752.0, 480.0, [[-100.0, 100.0]], q, 15.0, 0)
+    assert i[0] == 0
+    # a query right of the image gives an empty range
+    assert oracle.guided_match(kp, d, 752.0, 480.0, [[2000.0, 100.0]], q, 15.0, 0)[0][0] == -1
