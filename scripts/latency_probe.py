@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Single stereo pair through the host-buffer drop-in entry point (PCIe-inclusive latency) and
+throughput as a function of batch size (device-resident)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import orb_slam3_rust_amd as P
+cam = P.CameraModel(**P.synth.EUROC_CAMERA)
+h = P.Handle(cam, 2000, max_batch=256)
+L, R = P.synth.stereo_pair(1, 0)
+for _ in range(5):
+    h.process_stereo(L, R)
+t0 = time.perf_counter()
+for _ in range(50):
+    h.process_stereo(L, R)
+print("orbx_process_stereo (host buffers, 1 pair, PCIe + sync inclusive): %.3f ms/frame" % ((time.perf_counter() - t0) / 50 * 1e3))
+imgs = torch.from_numpy(P.synth.stereo_batch(2, 0, 32)).cuda()
+for b in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+    x = imgs.repeat((b + 31) // 32, 1, 1, 1)[:b].contiguous()
+    out = h.alloc_batch_outputs(b, 2304)
+    for _ in range(3):
+        h.process_stereo_batch_device(x, out)
+    h.synchronize()
+    t0 = time.perf_counter()
+    n = max(5, 200 // b)
+    for _ in range(n):
+        h.process_stereo_batch_device(x, out)
+    h.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("batch %4d: %8.3f ms/step  %9.1f frames/s" % (b, dt * 1e3, b / dt))
