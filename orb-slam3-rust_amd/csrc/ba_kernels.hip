@@ -329,13 +329,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// force-inlined into both kernels so that the address space of S (LDS vs global) is known: as an
-// out-of-line function it took a generic pointer and every access became a slow flat_load/flat_store.
-//
-// Factorisation kept in "unscaled column" form: after step c the strict lower part of column c still holds
-// a_rc (not a_rc / L_cc) and srinv[c] = 1 / L_cc; L_rc = S[r][c] * srinv[c] is formed on the fly.  That
-// removes the column-scaling pass and two of the three barriers per column, and the only long-latency
-// scalar op per column is one reciprocal square root.
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps y <- y + y*(1 - x y^2)/2 (full f64 accuracy)
 __device__ __forceinline__ double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -347,19 +340,28 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return y;
 }
 
+// force-inlined into both kernels so that the address space of S (LDS vs global) is known: as an
+// out-of-line function it took a generic pointer and every access became a slow flat_load/flat_store.
+//
+// Blocked left-looking Cholesky, panels of BA_NB columns:
+//   (a) panel update  A[r][c0+j] -= sum_{k<c0} L[r][k] L[c0+j][k]   — one independent dot product per
+//       (row, panel column), all threads, 4 accumulators each: the n^3/3 flops live here with full ILP;
+//   (b) every row thread factors the BA_NB x BA_NB diagonal block redundantly in registers (no broadcast
+//       barrier) and solves its own row against it; one reciprocal square root per column.
+// Two barriers per panel (30 for n = 114) instead of two or three per column.  srinv[c] = 1 / L_cc.
+constexpr int BA_NB = 8;
+
 template <typename SPtr>
 __device__ __forceinline__ void solve_body(int n, double lambda, const double* __restrict__ rb, int K, SPtr S,
                            double* __restrict__ dp, double* __restrict__ res, const double* __restrict__ params) {
   __shared__ double sb[BA_MAX_N];
   __shared__ double srinv[BA_MAX_N];
   __shared__ double s_red[BA_SOLVE_THREADS];
-  __shared__ int s_ok;
   const int tid = threadIdx.x, nth = BA_SOLVE_THREADS, lane = tid & 63;
   const size_t nn = (size_t)n * n;
   const double* U = rb + nn;
   const double* gp = U + 36 * (size_t)K;
   const double* bred = gp + n;
-  if (tid == 0) s_ok = 1;
   // S = blockdiag(U*) - S_red ; b = -g_p + b_red
   for (int i = tid / BA_TG; i < n; i += nth / BA_TG)
     for (int j = tid % BA_TG; j < n; j += BA_TG) {
@@ -377,51 +379,89 @@ __device__ __forceinline__ void solve_body(int n, double lambda, const double* _
   __syncthreads();
   for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_red[tid] += s_red[tid + s2]; __syncthreads(); }
   if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(s_red[0] + bred[n + 1]); }
-  // Cholesky, right-looking, lower triangle
-  const int tr = tid / BA_TG, tc = tid % BA_TG;
-  const size_t dump = (size_t)n * n + tid;     // scratch element behind the matrix, one per thread
-  for (int c = 0; c < n; ++c) {
+  int ok = 1;
+  for (int c0 = 0; c0 < n && ok; c0 += BA_NB) {
+    const int nb = min(BA_NB, n - c0);
     __syncthreads();
-    const double dcc = S[(size_t)c * n + c];
-    if (!(dcc > 0.0)) { if (tid == 0) s_ok = 0; break; }   // uniform: every thread reads the same value
-    const double rinv = rsqrt_nr(dcc);
-    if (tid == 0) srinv[c] = rinv;
-    // trailing update S[r][k] -= L[r][c] L[k][c], c < k <= r < n.  Branch-free: masked-off entries go to a
-    // per-thread dump slot so that no LDS access sits inside a divergent branch.
-    for (int kb = c + 1 + tc; kb < n; kb += BA_TG * BA_TB) {
-      double lk[BA_TB];
-#pragma unroll
-      for (int b = 0; b < BA_TB; ++b) { const int k = min(kb + BA_TG * b, n - 1); lk[b] = S[(size_t)k * n + c] * rinv; }
-      const int rfirst = c + 1 + tr + BA_TG * ((max(kb - (c + 1 + tr), 0) + BA_TG - 1) / BA_TG);
-      const int niter = (n - (c + 1) + BA_TG - 1) / BA_TG;      // uniform trip count; rows >= n are masked
-      for (int it = 0; it < niter; ++it) {
-        const int r = rfirst + BA_TG * it;
-        const bool rok = r < n;
-        size_t idx[BA_TB];
-        double v[BA_TB];
-#pragma unroll
-        for (int b = 0; b < BA_TB; ++b) {
-          const int k = kb + BA_TG * b;
-          idx[b] = (rok && k <= r) ? (size_t)r * n + k : dump;
+    // (a) panel update with everything to the left of the panel
+    if (c0 > 0) {
+      for (int idx = tid; idx < (n - c0) * BA_NB; idx += nth) {
+        const int r = c0 + idx / BA_NB, j = idx % BA_NB;
+        if (j < nb && c0 + j <= r) {
+          const size_t ro = (size_t)r * n, co = (size_t)(c0 + j) * n;
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          int k = 0;
+          for (; k + 4 <= c0; k += 4) {
+            a0 = fma(S[ro + k], S[co + k], a0);
+            a1 = fma(S[ro + k + 1], S[co + k + 1], a1);
+            a2 = fma(S[ro + k + 2], S[co + k + 2], a2);
+            a3 = fma(S[ro + k + 3], S[co + k + 3], a3);
+          }
+          for (; k < c0; ++k) a0 = fma(S[ro + k], S[co + k], a0);
+          S[ro + c0 + j] -= (a0 + a1) + (a2 + a3);
         }
-        const double lru = S[(size_t)min(r, n - 1) * n + c];      // one LDS round trip for lr and the batch
+      }
+      __syncthreads();
+    }
+    // (b) diagonal block (redundantly per thread) + this thread's row of the panel
+    const int r = c0 + tid;
+    double L[BA_NB][BA_NB], rinv[BA_NB];
 #pragma unroll
-        for (int b = 0; b < BA_TB; ++b) v[b] = S[idx[b]];
-        const double lr = lru * rinv;
+    for (int i = 0; i < BA_NB; ++i)
 #pragma unroll
-        for (int b = 0; b < BA_TB; ++b) S[idx[b]] = v[b] - lr * lk[b];
+      for (int j = 0; j <= i; ++j) L[i][j] = (i < nb) ? S[(size_t)(c0 + i) * n + c0 + j] : (i == j ? 1.0 : 0.0);
+    __syncthreads();   // every wave has read the block before the block's own rows overwrite it with the factor
+#pragma unroll
+    for (int j = 0; j < BA_NB; ++j) {
+      double d = L[j][j];
+#pragma unroll
+      for (int i = 0; i < j; ++i) d = fma(-L[j][i], L[j][i], d);
+      if (j < nb && !(d > 0.0)) ok = 0;                 // same value in every thread
+      const double ri = rsqrt_nr(ok ? d : 1.0);
+      rinv[j] = ri;
+      L[j][j] = d * ri;                                  // sqrt(d)
+#pragma unroll
+      for (int i = j + 1; i < BA_NB; ++i) {
+        double v = L[i][j];
+#pragma unroll
+        for (int t = 0; t < j; ++t) v = fma(-L[i][t], L[j][t], v);
+        L[i][j] = v * ri;
+      }
+    }
+    if (ok && r < n) {
+      if (tid < nb) {
+        // a row of the diagonal block: write the factor
+#pragma unroll
+        for (int i = 0; i < BA_NB; ++i)
+          if (i == tid) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) S[(size_t)r * n + c0 + j] = L[i][j];
+            srinv[r] = rinv[i];
+          }
+      } else {
+        // a row below the block: x = a L11^-T
+        double x[BA_NB];
+#pragma unroll
+        for (int j = 0; j < BA_NB; ++j) x[j] = (j < nb) ? S[(size_t)r * n + c0 + j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < BA_NB; ++j) {
+          double v = x[j];
+#pragma unroll
+          for (int t = 0; t < j; ++t) v = fma(-x[t], L[j][t], v);
+          x[j] = v * rinv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BA_NB; ++j) if (j < nb) S[(size_t)r * n + c0 + j] = x[j];
       }
     }
   }
   __syncthreads();
-  const int ok = s_ok;
   if (ok && tid < 64 && n <= 128) {
     // forward L y = b then backward L^T x = y, column oriented: lane holds rows `lane` and `lane+64` of the
-    // right-hand side in registers, each step broadcasts one solved entry with v_readlane; the column of the
-    // next step is loaded while the current one is applied
+    // right-hand side in registers, each step broadcasts one solved entry with v_readlane; columns are
+    // fetched in chunks of 8 one chunk ahead
     const int r0 = min(lane, n - 1), r1 = min(lane + 64, n - 1);
     double b0 = lane < n ? sb[lane] : 0.0, b1 = lane + 64 < n ? sb[lane + 64] : 0.0;
-    const double ri0 = srinv[r0], ri1 = srinv[r1];
     constexpr int CH = 8;
     double l0[CH], l1[CH], rc[CH], l0n[CH], l1n[CH], rcn[CH];
 #pragma unroll
@@ -437,15 +477,14 @@ __device__ __forceinline__ void solve_body(int n, double lambda, const double* _
           const int src = c & 63;
           const int lo = __builtin_amdgcn_readlane(__double2loint(own), src), hi = __builtin_amdgcn_readlane(__double2hiint(own), src);
           const double yc = __hiloint2double(hi, lo) * rc[j];
-          const double f = yc * rc[j];                       // L_rc y_c = a_rc * rinv_c * y_c
-          if (lane > c) b0 = b0 - l0[j] * f; else if (lane == c) b0 = yc;
-          if (lane + 64 > c) b1 = b1 - l1[j] * f; else if (lane + 64 == c) b1 = yc;
+          if (lane > c) b0 = fma(-l0[j], yc, b0); else if (lane == c) b0 = yc;
+          if (lane + 64 > c) b1 = fma(-l1[j], yc, b1); else if (lane + 64 == c) b1 = yc;
         }
       }
 #pragma unroll
       for (int j = 0; j < CH; ++j) { l0[j] = l0n[j]; l1[j] = l1n[j]; rc[j] = rcn[j]; }
     }
-    // backward: row c of L is S[c][r] * rinv_r (unscaled column r); chunks run downwards from n-1
+    // backward: row c of L, chunks run downwards from n-1
 #pragma unroll
     for (int j = 0; j < CH; ++j) { const int c = max(n - 1 - j, 0); l0[j] = S[(size_t)c * n + r0]; l1[j] = S[(size_t)c * n + r1]; rc[j] = srinv[c]; }
     for (int c0 = n - 1; c0 >= 0; c0 -= CH) {
@@ -459,8 +498,8 @@ __device__ __forceinline__ void solve_body(int n, double lambda, const double* _
           const int src = c & 63;
           const int lo = __builtin_amdgcn_readlane(__double2loint(own), src), hi = __builtin_amdgcn_readlane(__double2hiint(own), src);
           const double xc = __hiloint2double(hi, lo) * rc[j];
-          if (lane < c) b0 = b0 - (l0[j] * ri0) * xc; else if (lane == c) b0 = xc;
-          if (lane + 64 < c) b1 = b1 - (l1[j] * ri1) * xc; else if (lane + 64 == c) b1 = xc;
+          if (lane < c) b0 = fma(-l0[j], xc, b0); else if (lane == c) b0 = xc;
+          if (lane + 64 < c) b1 = fma(-l1[j], xc, b1); else if (lane + 64 == c) b1 = xc;
         }
       }
 #pragma unroll
@@ -469,18 +508,18 @@ __device__ __forceinline__ void solve_body(int n, double lambda, const double* _
     if (lane < n) sb[lane] = b0;
     if (lane + 64 < n) sb[lane + 64] = b1;
   } else if (ok && tid < 64) {
-    // general n: row dot products with shuffle reductions; L_rk = S[r][k] * srinv[k]
+    // general n: row dot products with shuffle reductions
     for (int r = 0; r < n; ++r) {
       double acc = 0.0;
-      for (int k = lane; k < r; k += 64) acc += S[(size_t)r * n + k] * srinv[k] * sb[k];
+      for (int k = lane; k < r; k += 64) acc = fma(S[(size_t)r * n + k], sb[k], acc);
       acc = wave_sum(acc);
       if (lane == 0) sb[r] = (sb[r] - acc) * srinv[r];
       __builtin_amdgcn_wave_barrier();
     }
     for (int r = n - 1; r >= 0; --r) {
       double acc = 0.0;
-      for (int k = r + 1 + lane; k < n; k += 64) acc += S[(size_t)k * n + r] * sb[k];
-      acc = wave_sum(acc) * srinv[r];
+      for (int k = r + 1 + lane; k < n; k += 64) acc = fma(S[(size_t)k * n + r], sb[k], acc);
+      acc = wave_sum(acc);
       if (lane == 0) sb[r] = (sb[r] - acc) * srinv[r];
       __builtin_amdgcn_wave_barrier();
     }
