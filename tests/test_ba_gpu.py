@@ -177,3 +177,16 @@ def test_ba_allreduce_hook_rccl_world1(gpu_handle, pkg):
         assert got["final_error"] == ref["final_error"]
     finally:
         dist.destroy_process_group()
+
+
+def test_ba_config5_size(gpu_handle, oracle, pkg):
+    """BASELINE configs[4]: 50 keyframes / 8000 points (n = 294: global-memory factorisation, 19x19 MFMA tiles).
+    Three LM iterations keep the CPU oracle's share of the test short."""
+    w = pkg.synth.ba_window(43, 50, 8000, pkg.BA_OBS)
+    cam = pkg.CameraModel(**w["camera"]); ocam = oracle.Camera(**w["camera"])
+    cfg = pkg.LocalBAConfigLM(max_iterations=3); ocfg = oracle.ba_config(); ocfg.max_iterations = 3
+    g = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+    o = oracle.ba_solve_schur(ocam, ocfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+    assert g["iterations"] == o["iterations"] == 3 and len(w["obs"]) > 150000
+    assert abs(g["final_error"] - o["final_error"]) < 1e-8 * o["final_error"]
+    assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL
