@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # compulsory bytes per stereo frame at 752x480, N=2000
-ALGO_BYTES_PER_FRAME = 2 * 752 * 480 + 2 * 2000 * (28 + 32) + 2 * 2000 * (32 + 8) + 2000 * 16 + 2000 * 25
+def algo_bytes_per_frame(w, h, n):
+    return 2 * w * h + 2 * n * (28 + 32) + 2 * n * (32 + 8) + n * 16 + n * 25
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -81,9 +82,9 @@ def cpu_baseline(P, frames_mt, frames_1t, w, h, n_features):
         list(ex.map(one, range(frames_mt)))
     tm = time.perf_counter() - t0
     return dict(value=round(frames_mt / tm, 3), unit="stereo frames/s", cores=cores, kind="port",
-                sample="%d synthetic 752x480 stereo frames, N=%d, oracle extract+match+triangulate, %d threads "
+                sample="%d synthetic %dx%d stereo frames, N=%d, oracle extract+match+triangulate, %d threads "
                        "(frame-level parallelism); 1 thread: %.3f frames/s on %d frames"
-                       % (frames_mt, n_features, cores, frames_1t / t1, frames_1t),
+                       % (frames_mt, w, h, n_features, cores, frames_1t / t1, frames_1t),
                 value_1thread=round(frames_1t / t1, 3))
 
 
@@ -95,6 +96,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="stereo pairs per step per GPU")
     ap.add_argument("--n-batches", type=int, default=3)
     ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--width", type=int, default=752)
+    ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     args = ap.parse_args()
@@ -112,7 +115,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    W, H = 752, 480
+    W, H = args.width, args.height     # default = BASELINE configs[1]; 1920x1080 --features 4000 = configs[4]
     cam = P.CameraModel(**P.synth.EUROC_CAMERA)
     h = P.Handle(cam, args.features, device=local_rank, max_w=W, max_h=H, max_batch=args.batch)
     cap = args.features + 304
@@ -149,7 +152,8 @@ def main():
     dom_name, (dom_ms, dom_launches) = dom
     # algorithmic bytes per launch of each kernel: per image, x images per launch
     n_img = 2 * args.batch
-    lv = [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]
+    sc = [float(np.float32(np.float64(np.float32(1.2)) ** l)) for l in range(8)]       # level sizes as orb.cpp
+    lv = [(int(np.rint(np.float32(W) / np.float32(s))), int(np.rint(np.float32(H) / np.float32(s)))) for s in sc]
     px = [a * b for a, b in lv]
     per_launch = {
         "fast_kernel": n_img * (sum(px) + 4 * 2 * args.features),          # read every level once, write candidates
@@ -177,14 +181,15 @@ def main():
                     algorithmic_bytes_per_launch=int(per_launch.get(dom_name, 0)),
                     avg_launch_us=round(dom_ms / max(dom_launches, 1) * 1e3, 2),
                     kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in sorted(acc.items())},
-                    path_algorithmic_GBps=round(ALGO_BYTES_PER_FRAME * args.batch * world * args.steps / elapsed / 1e9, 3))
+                    path_algorithmic_GBps=round(algo_bytes_per_frame(W, H, args.features) * args.batch * world * args.steps / elapsed / 1e9, 3))
 
     frames = args.batch * args.steps * world
     value = frames / elapsed
     res = dict(metric="stereo frames/sec ORB extract+match @752x480", value=round(value, 2), unit="stereo frames/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8", data="synthetic",
-               config=dict(workload="Synthetic 752x480 stereo, 2000 ORB/frame, extract+match+triangulate (BASELINE configs[1])",
+               config=dict(workload="Synthetic %dx%d stereo, %d ORB/frame, extract+match+triangulate (BASELINE configs[%d])"
+                                    % (W, H, args.features, 1 if (W, H, args.features) == (752, 480, 2000) else 4),
                            image=[W, H], n_features=args.features, batch_pairs_per_gpu=args.batch,
                            distinct_batches=args.n_batches, parallelism="frames sharded, %d rank(s), no collective" % world,
                            mean_keypoints_per_image=round(n_kp, 1), mean_matches_per_frame=round(n_matches, 1)),
@@ -196,7 +201,8 @@ def main():
         except Exception as e:  # BA leg must not hide the headline number
             res["local_ba"] = dict(error=repr(e))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(P, 48, 6, W, H, args.features)
+        big = W * H > 752 * 480
+        res["cpu_baseline"] = cpu_baseline(P, 16 if big else 48, 2 if big else 6, W, H, args.features)
     elif rank == 0:
         res["cpu_baseline"] = None
     if rank == 0:

@@ -320,7 +320,6 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(BaDims d, const double* 
 // triangular solves run in wave 0 alone as row dot products with shuffle reductions (no block barriers).
 constexpr int BA_SOLVE_THREADS = 1024;
 constexpr int BA_TG = 32;                 // trailing update runs on a BA_TG x BA_TG thread grid
-constexpr int BA_TB = 4;                  // entries per thread per row batch (BA_TG*BA_TB = 128 columns)
 constexpr int BA_MAX_N = 768;
 
 __device__ __forceinline__ double wave_sum(double v) {
