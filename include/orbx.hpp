@@ -1,0 +1,250 @@
+// orbx.hpp — C++17 host-side mirror of the reference crate's interface for the hot path, header-only, on top
+// of the C ABI (orbx.h).  The reference is compiled Rust and Rust is not in this toolchain, so this is the
+// compiled-language form of the thin shim INTEGRATION.md describes: same names, argument meaning and error
+// behaviour as the reference (file:line relative to the reference crate root):
+//
+//   orbx::CameraModel                       src/tracking/frame/camera.rs:3-10
+//   orbx::FeatureSet / StereoFrame          src/tracking/frame/stereo.rs:15-29
+//   orbx::StereoProcessor::create/process   stereo.rs:37-66     (`new` is a keyword in C++)
+//   orbx::descriptor_distance               stereo.rs:166-175
+//   orbx::bf_match_crosscheck               src/tracking/tracker.rs:1001-1010
+//   orbx::FeatureGrid-guided search         src/tracking/tracking_frame.rs:52-128, tracker.rs:880-923, :1126-1157
+//   orbx::SE3                               src/geometry/se3.rs:5-8 (unit quaternion w,x,y,z + translation)
+//   orbx::LocalBAConfigLM                   src/optimizer/local_ba_lm.rs:96-119
+//   orbx::VisualObservation/ProblemData/ResultData   local_ba_lm.rs:48-93
+//   orbx::solve_visual_ba                   local_ba_lm.rs:912-1098
+//
+// Errors: the reference propagates `anyhow::Error` with `?` — here orbx::Error is thrown; where the
+// reference returns `None` (solve_visual_ba) std::nullopt is returned.  Everything computes on the GPU.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "orbx.h"
+
+namespace orbx {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error("orbx error " + std::to_string(c) + ": " + m), code(c) {}
+};
+
+// ORB-SLAM3 matching thresholds, stereo.rs:10-12
+constexpr uint32_t TH_HIGH = 100, TH_LOW = 50;
+constexpr float NN_RATIO = 0.75f;
+
+struct CameraModel {   // camera.rs:3-10
+  double fx, fy, cx, cy, baseline;
+  orbx_camera c() const { return orbx_camera{fx, fy, cx, cy, baseline}; }
+};
+
+using KeyPoint = orbx_keypoint;
+using DMatch = orbx_dmatch;
+
+struct FeatureSet {   // stereo.rs:15-19
+  std::vector<KeyPoint> keypoints;
+  std::vector<uint8_t> descriptors;   // keypoints.size() rows of 32 bytes
+};
+
+struct StereoFrame {   // stereo.rs:21-29
+  FeatureSet left_features, right_features;
+  std::vector<DMatch> matches_lr;
+  std::vector<std::optional<std::array<double, 3>>> points_cam;   // per left keypoint
+  uint64_t timestamp_ns = 0;
+};
+
+// RAII owner of one orbx_handle (one HIP stream on one device).  Not thread-safe, like `&mut self`.
+class Handle {
+ public:
+  Handle(const CameraModel& cam, int n_features, int device = 0, int max_w = 1920, int max_h = 1080, int max_batch = 1) {
+    orbx_orb_params p;
+    orbx_default_orb_params(n_features, &p);
+    const orbx_camera c = cam.c();
+    const int rc = orbx_create(&c, &p, device, max_w, max_h, max_batch, &h_);
+    if (rc != ORBX_OK) throw Error(rc, orbx_last_error(nullptr));
+    n_features_ = n_features;
+  }
+  Handle(const Handle&) = delete;
+  Handle& operator=(const Handle&) = delete;
+  Handle(Handle&& o) noexcept : h_(o.h_), n_features_(o.n_features_) { o.h_ = nullptr; }
+  ~Handle() { if (h_) orbx_destroy(h_); }
+  orbx_handle* get() const { return h_; }
+  int n_features() const { return n_features_; }
+  void check(int rc) const { if (rc != ORBX_OK) throw Error(rc, orbx_last_error(h_)); }
+
+ private:
+  orbx_handle* h_ = nullptr;
+  int n_features_ = 0;
+};
+
+class StereoProcessor {   // stereo.rs:31-66
+ public:
+  // = StereoProcessor::new(camera, n_features) -> Result<Self>
+  static StereoProcessor create(const CameraModel& camera, int n_features, int device = 0) {
+    return StereoProcessor(camera, n_features, device);
+  }
+  // = process(&mut self, left: &Mat, right: &Mat, timestamp_ns) -> Result<StereoFrame>; images are CV_8UC1 rows
+  StereoFrame process(const uint8_t* left, size_t lstride, const uint8_t* right, size_t rstride, int w, int h,
+                      uint64_t timestamp_ns) {
+    const size_t cap = (size_t)handle_.n_features() + 2048;
+    StereoFrame f;
+    f.left_features.keypoints.resize(cap); f.right_features.keypoints.resize(cap);
+    f.left_features.descriptors.resize(cap * 32); f.right_features.descriptors.resize(cap * 32);
+    f.matches_lr.resize(cap);
+    std::vector<double> pts(cap * 3);
+    std::vector<uint8_t> has(cap);
+    int nl = 0, nr = 0, nm = 0;
+    handle_.check(orbx_process_stereo(handle_.get(), left, lstride, right, rstride, w, h, f.left_features.keypoints.data(),
+                                      f.left_features.descriptors.data(), &nl, f.right_features.keypoints.data(),
+                                      f.right_features.descriptors.data(), &nr, (int)cap, f.matches_lr.data(), &nm,
+                                      pts.data(), has.data()));
+    f.left_features.keypoints.resize(nl); f.left_features.descriptors.resize((size_t)nl * 32);
+    f.right_features.keypoints.resize(nr); f.right_features.descriptors.resize((size_t)nr * 32);
+    f.matches_lr.resize(nm);
+    f.points_cam.resize(nl);
+    for (int i = 0; i < nl; ++i)
+      if (has[i]) f.points_cam[i] = std::array<double, 3>{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    f.timestamp_ns = timestamp_ns;
+    return f;
+  }
+  Handle& handle() { return handle_; }
+
+ private:
+  StereoProcessor(const CameraModel& camera, int n_features, int device) : handle_(camera, n_features, device) {}
+  Handle handle_;
+};
+
+// stereo.rs:166-175
+inline uint32_t descriptor_distance(Handle& h, const uint8_t* desc1, const uint8_t* desc2) {
+  uint32_t d = 0;
+  h.check(orbx_hamming_batch(h.get(), desc1, desc2, 1, &d));
+  return d;
+}
+
+// tracker.rs:1001-1010: BFMatcher::new(NORM_HAMMING, true).train_match(query, train)
+inline std::vector<DMatch> bf_match_crosscheck(Handle& h, const std::vector<uint8_t>& query, const std::vector<uint8_t>& train) {
+  const int nq = (int)(query.size() / 32), nt = (int)(train.size() / 32);
+  std::vector<DMatch> out((size_t)std::max(nq, 1));
+  int n = 0;
+  h.check(orbx_hamming_match_crosscheck(h.get(), query.data(), nq, train.data(), nt, out.data(), &n));
+  out.resize(n);
+  return out;
+}
+
+// FeatureGrid::get_features_in_area + descriptor search.  mode 0 = track_with_motion_model, 1 = track_local_map.
+// Returns per query the matched keypoint index or -1.
+inline std::vector<int> guided_match(Handle& h, const FeatureSet& frame, double img_w, double img_h,
+                                     const std::vector<std::array<double, 2>>& uv, const std::vector<uint8_t>& q_desc,
+                                     double radius, int mode) {
+  const int nq = (int)uv.size();
+  std::vector<int> idx((size_t)std::max(nq, 1));
+  std::vector<uint32_t> dist((size_t)std::max(nq, 1));
+  h.check(orbx_guided_match(h.get(), frame.keypoints.data(), frame.descriptors.data(), (int)frame.keypoints.size(), img_w, img_h,
+                            nq ? &uv[0][0] : nullptr, q_desc.data(), nq, radius, mode, idx.data(), dist.data()));
+  idx.resize(nq);
+  return idx;
+}
+
+struct SE3 {   // se3.rs:5-8; rotation as unit quaternion (w, x, y, z)
+  std::array<double, 4> rotation{1, 0, 0, 0};
+  std::array<double, 3> translation{0, 0, 0};
+};
+
+struct LocalBAConfigLM {   // local_ba_lm.rs:96-119, Default :109-119
+  int max_iterations = 10;
+  double param_tolerance = 1e-8, gradient_tolerance = 1e-8, huber_threshold = std::sqrt(5.991);
+  int max_covisible_keyframes = 20;
+};
+
+using KeyFrameId = uint64_t;   // atlas/map/types.rs:9
+using MapPointId = uint64_t;   // atlas/map/types.rs:29
+
+struct VisualObservation {   // local_ba_lm.rs:68-78
+  KeyFrameId kf_id;
+  MapPointId mp_id;
+  std::array<double, 2> observed_uv;
+  bool is_kf_optimized;
+};
+
+struct VisualBAProblemData {   // local_ba_lm.rs:48-65; poses are T_cw
+  std::unordered_map<KeyFrameId, SE3> local_kf_poses;
+  std::unordered_map<MapPointId, std::array<double, 3>> local_mp_positions;
+  std::unordered_map<KeyFrameId, SE3> fixed_kf_poses;
+  KeyFrameId anchor_kf_id = 0;
+  std::vector<VisualObservation> observations;
+  std::vector<KeyFrameId> optimized_kf_ids;
+  std::vector<MapPointId> mp_ids;
+};
+
+struct VisualBAResultData {   // local_ba_lm.rs:81-93; optimized_poses are T_wc
+  std::unordered_map<KeyFrameId, SE3> optimized_poses;
+  std::unordered_map<MapPointId, std::array<double, 3>> optimized_points;
+  size_t iterations = 0;
+  double initial_error = 0, final_error = 0;
+};
+
+// local_ba_lm.rs:912-1098.  The id -> index re-keying is the reference's own (:928-987).
+inline std::optional<VisualBAResultData> solve_visual_ba(Handle& h, const VisualBAProblemData& problem, const CameraModel& camera,
+                                                         const LocalBAConfigLM& config, const std::function<bool()>& should_stop) {
+  std::unordered_map<KeyFrameId, int> kf_idx, fixed_idx;
+  std::unordered_map<MapPointId, int> mp_idx;
+  for (size_t i = 0; i < problem.optimized_kf_ids.size(); ++i) kf_idx[problem.optimized_kf_ids[i]] = (int)i;   // :928-933
+  for (size_t i = 0; i < problem.mp_ids.size(); ++i) mp_idx[problem.mp_ids[i]] = (int)i;                       // :935-940
+  std::vector<double> poses, fixed, points;
+  auto push7 = [](std::vector<double>& v, const SE3& p) {
+    v.insert(v.end(), p.rotation.begin(), p.rotation.end());
+    v.insert(v.end(), p.translation.begin(), p.translation.end());
+  };
+  for (KeyFrameId id : problem.optimized_kf_ids) {                       // :966-977 (missing pose -> zero params = identity)
+    auto it = problem.local_kf_poses.find(id);
+    push7(poses, it != problem.local_kf_poses.end() ? it->second : SE3{});
+  }
+  for (const auto& kv : problem.fixed_kf_poses) { fixed_idx[kv.first] = (int)fixed_idx.size(); push7(fixed, kv.second); }
+  for (MapPointId id : problem.mp_ids) {                                 // :980-987
+    auto it = problem.local_mp_positions.find(id);
+    const std::array<double, 3> p = it != problem.local_mp_positions.end() ? it->second : std::array<double, 3>{0, 0, 0};
+    points.insert(points.end(), p.begin(), p.end());
+  }
+  std::vector<orbx_ba_obs> obs;
+  for (const VisualObservation& o : problem.observations) {              // :943-961
+    auto m = mp_idx.find(o.mp_id);
+    if (m == mp_idx.end()) continue;                                     // :947
+    orbx_ba_obs b{};
+    b.mp_idx = m->second; b.u = o.observed_uv[0]; b.v = o.observed_uv[1];
+    auto k = o.is_kf_optimized ? kf_idx.find(o.kf_id) : kf_idx.end();
+    if (k != kf_idx.end()) { b.kf_idx = k->second; b.fixed_idx = -1; }
+    else { auto f = fixed_idx.find(o.kf_id); b.kf_idx = -1; b.fixed_idx = f != fixed_idx.end() ? f->second : -1; }   // :569 identity
+    obs.push_back(b);
+  }
+  const int K = (int)problem.optimized_kf_ids.size(), F = (int)fixed_idx.size(), M = (int)problem.mp_ids.size();
+  std::vector<double> out((size_t)std::max(K, 1) * 7);
+  int it = 0;
+  double e0 = 0, e1 = 0;
+  const orbx_camera c = camera.c();
+  const orbx_ba_config cfg{config.max_iterations, config.param_tolerance, config.gradient_tolerance, config.huber_threshold,
+                           config.max_covisible_keyframes};
+  auto tramp = [](void* user) -> int { return (*static_cast<const std::function<bool()>*>(user))() ? 1 : 0; };
+  const int rc = orbx_ba_solve_visual(h.get(), &c, &cfg, K, poses.data(), F, fixed.data(), M, points.data(), (int)obs.size(),
+                                      obs.data(), should_stop ? +tramp : nullptr, const_cast<std::function<bool()>*>(&should_stop),
+                                      out.data(), &it, &e0, &e1);
+  if (rc != ORBX_OK) return std::nullopt;                                // :923-925 and every failure -> None
+  VisualBAResultData r;
+  for (int i = 0; i < K; ++i) {
+    SE3 p;
+    for (int q = 0; q < 4; ++q) p.rotation[q] = out[7 * (size_t)i + q];
+    for (int q = 0; q < 3; ++q) p.translation[q] = out[7 * (size_t)i + 4 + q];
+    r.optimized_poses[problem.optimized_kf_ids[i]] = p;                  // T_wc, :1076
+  }
+  for (int j = 0; j < M; ++j) r.optimized_points[problem.mp_ids[j]] = {points[3 * (size_t)j], points[3 * (size_t)j + 1], points[3 * (size_t)j + 2]};
+  r.iterations = (size_t)it; r.initial_error = e0; r.final_error = e1;
+  return r;
+}
+
+}  // namespace orbx

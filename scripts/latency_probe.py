@@ -28,3 +28,26 @@ for b in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     h.synchronize()
     dt = (time.perf_counter() - t0) / n
     print("batch %4d: %8.3f ms/step  %9.1f frames/s" % (b, dt * 1e3, b / dt))
+
+# PCIe-inclusive batched form: pinned host images -> HBM -> process -> all results back to pinned host memory
+for b in (8, 64):
+    host_in = torch.from_numpy(P.synth.stereo_batch(3, 0, min(b, 16))).repeat((b + 15) // 16, 1, 1, 1)[:b].contiguous().pin_memory()
+    out = h.alloc_batch_outputs(b, 2304)
+    host_out = {k: torch.empty_like(v, device="cpu").pin_memory() for k, v in out.items() if hasattr(v, "shape")}
+    dev_in = torch.empty_like(host_in, device="cuda")
+    ext = torch.cuda.ExternalStream(h.stream)
+    def step():
+        with torch.cuda.stream(ext):
+            dev_in.copy_(host_in, non_blocking=True)
+            h.process_stereo_batch_device(dev_in, out)
+            for k, v in host_out.items():
+                v.copy_(out[k], non_blocking=True)
+        h.synchronize()
+    for _ in range(3):
+        step()
+    t0 = time.perf_counter()
+    n = 20
+    for _ in range(n):
+        step()
+    dt = (time.perf_counter() - t0) / n
+    print("PCIe-inclusive batch %3d (H2D images + process + D2H of every output buffer at full capacity, serial): %7.3f ms/step  %9.1f frames/s" % (b, dt * 1e3, b / dt))

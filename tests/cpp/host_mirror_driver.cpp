@@ -1,0 +1,101 @@
+// Compiled-host test driver for include/orbx.hpp: runs StereoProcessor::process and solve_visual_ba through the
+// C++ mirror of the reference's interface on inputs written by tests/test_cpp_host_mirror.py and writes the
+// results back for comparison with the oracle.  usage: driver <in_dir> <out_dir>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "orbx.hpp"
+
+static std::vector<uint8_t> slurp(const std::string& p) {
+  FILE* f = fopen(p.c_str(), "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", p.c_str()); exit(2); }
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> b((size_t)n);
+  if (fread(b.data(), 1, (size_t)n, f) != (size_t)n) exit(2);
+  fclose(f);
+  return b;
+}
+template <class T> static void put(FILE* f, const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  const std::string in = argv[1], out = argv[2];
+  const orbx::CameraModel cam{458.654, 457.296, 367.215, 248.375, 0.11007};   // EuRoC cam0
+  try {
+    // ---- StereoProcessor::new + process (stereo.rs:37-66) -------------------------------------------------
+    std::vector<uint8_t> s = slurp(in + "/stereo.bin");
+    const int w = ((int*)s.data())[0], h = ((int*)s.data())[1], nfeat = ((int*)s.data())[2];
+    const uint8_t* left = s.data() + 12;
+    const uint8_t* right = left + (size_t)w * h;
+    orbx::StereoProcessor sp = orbx::StereoProcessor::create(cam, nfeat);
+    orbx::StereoFrame f = sp.process(left, (size_t)w, right, (size_t)w, w, h, 1403636579763555584ull);
+    FILE* fo = fopen((out + "/stereo_out.bin").c_str(), "wb");
+    const int counts[3] = {(int)f.left_features.keypoints.size(), (int)f.right_features.keypoints.size(), (int)f.matches_lr.size()};
+    put(fo, counts, 3);
+    put(fo, f.left_features.keypoints.data(), f.left_features.keypoints.size());
+    put(fo, f.left_features.descriptors.data(), f.left_features.descriptors.size());
+    put(fo, f.right_features.keypoints.data(), f.right_features.keypoints.size());
+    put(fo, f.right_features.descriptors.data(), f.right_features.descriptors.size());
+    put(fo, f.matches_lr.data(), f.matches_lr.size());
+    for (size_t i = 0; i < f.points_cam.size(); ++i) {
+      const uint8_t has = f.points_cam[i].has_value();
+      const double z[3] = {0, 0, 0};
+      put(fo, &has, 1);
+      put(fo, has ? f.points_cam[i]->data() : z, 3);
+    }
+    fclose(fo);
+    // descriptor_distance + cross-check matcher on the extracted descriptors
+    const uint32_t d01 = orbx::descriptor_distance(sp.handle(), f.left_features.descriptors.data(), f.left_features.descriptors.data() + 32);
+    std::vector<orbx::DMatch> cc = orbx::bf_match_crosscheck(sp.handle(), f.left_features.descriptors, f.right_features.descriptors);
+    fo = fopen((out + "/match_out.bin").c_str(), "wb");
+    const int nc = (int)cc.size();
+    put(fo, &d01, 1); put(fo, &nc, 1); put(fo, cc.data(), cc.size());
+    fclose(fo);
+
+    // ---- solve_visual_ba (local_ba_lm.rs:912-1098) through VisualBAProblemData keyed by ids -----------------
+    std::vector<uint8_t> b = slurp(in + "/ba.bin");
+    const int* hd = (const int*)b.data();
+    const int K = hd[0], F = hd[1], M = hd[2], N = hd[3], stop_after = hd[4];
+    const double* dp = (const double*)(b.data() + 32);
+    const double* poses = dp; const double* fixed = poses + 7 * (size_t)K; const double* pts = fixed + 7 * (size_t)F;
+    const double* ob = pts + 3 * (size_t)M;   // N x (kf_idx, fixed_idx, mp_idx, u, v) as doubles
+    orbx::VisualBAProblemData prob;
+    auto se3 = [](const double* p) { orbx::SE3 s; for (int i = 0; i < 4; ++i) s.rotation[i] = p[i]; for (int i = 0; i < 3; ++i) s.translation[i] = p[4 + i]; return s; };
+    for (int k = 0; k < K; ++k) { const orbx::KeyFrameId id = 1000 + 7 * (uint64_t)k; prob.optimized_kf_ids.push_back(id); prob.local_kf_poses[id] = se3(poses + 7 * (size_t)k); }
+    for (int k = 0; k < F; ++k) prob.fixed_kf_poses[10 + (uint64_t)k] = se3(fixed + 7 * (size_t)k);
+    prob.anchor_kf_id = 10;
+    for (int j = 0; j < M; ++j) { const orbx::MapPointId id = 5000 + 3 * (uint64_t)j; prob.mp_ids.push_back(id); prob.local_mp_positions[id] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]}; }
+    for (int i = 0; i < N; ++i) {
+      const double* o = ob + 5 * (size_t)i;
+      const int kf = (int)o[0], fx = (int)o[1], mp = (int)o[2];
+      orbx::VisualObservation v;
+      v.is_kf_optimized = kf >= 0;
+      v.kf_id = kf >= 0 ? 1000 + 7 * (uint64_t)kf : 10 + (uint64_t)fx;
+      v.mp_id = 5000 + 3 * (uint64_t)mp;
+      v.observed_uv = {o[3], o[4]};
+      prob.observations.push_back(v);
+    }
+    int calls = 0;
+    auto res = orbx::solve_visual_ba(sp.handle(), prob, cam, orbx::LocalBAConfigLM{}, [&]() { return stop_after >= 0 && calls++ >= stop_after; });
+    fo = fopen((out + "/ba_out.bin").c_str(), "wb");
+    const int ok = res.has_value();
+    put(fo, &ok, 1);
+    if (ok) {
+      const int it = (int)res->iterations;
+      put(fo, &it, 1);
+      put(fo, &res->initial_error, 1); put(fo, &res->final_error, 1);
+      for (orbx::KeyFrameId id : prob.optimized_kf_ids) { const orbx::SE3& p = res->optimized_poses.at(id); put(fo, p.rotation.data(), 4); put(fo, p.translation.data(), 3); }
+      for (orbx::MapPointId id : prob.mp_ids) put(fo, res->optimized_points.at(id).data(), 3);
+    }
+    fclose(fo);
+    // an empty problem is None, as local_ba_lm.rs:923-925
+    orbx::VisualBAProblemData empty;
+    if (orbx::solve_visual_ba(sp.handle(), empty, cam, orbx::LocalBAConfigLM{}, nullptr).has_value()) return 3;
+  } catch (const orbx::Error& e) {
+    fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  printf("HOST_MIRROR_OK\n");
+  return 0;
+}

@@ -1,0 +1,78 @@
+"""The compiled host-side mirror (include/orbx.hpp: StereoProcessor, descriptor_distance, bf_match_crosscheck,
+VisualBAProblemData / solve_visual_ba with the reference's names) — built with g++ against liborbx_hip.so.
+CPU: it compiles and links.  GPU: its results equal the oracle's."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import records_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "orb-slam3-rust_amd")
+
+
+def _build(tmp):
+    exe = os.path.join(tmp, "host_mirror_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "host_mirror_driver.cpp"), "-o", exe,
+                    "-L", LIBDIR, "-lorbx_hip", "-Wl,-rpath," + LIBDIR], check=True)
+    return exe
+
+
+def test_cpp_mirror_compiles_and_links(pkg, tmp_path):
+    pkg.load_library()          # the .so must exist (built by __graft_entry__.build())
+    assert os.path.exists(_build(str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
+    tmp = str(tmp_path)
+    exe = _build(tmp)
+    nfeat = 1200                                                       # main.rs:53
+    L, R = pkg.synth.stereo_pair(17, 4)
+    with open(os.path.join(tmp, "stereo.bin"), "wb") as f:
+        f.write(struct.pack("<iii", 752, 480, nfeat)); f.write(L.tobytes()); f.write(R.tobytes())
+    w = pkg.synth.ba_window(13, 7, 150, pkg.BA_OBS, n_fixed_extra=1)
+    K, F, M, N = len(w["poses_cw"]), len(w["fixed_cw"]), len(w["points"]), len(w["obs"])
+    ob = np.stack([w["obs"]["kf_idx"], w["obs"]["fixed_idx"], w["obs"]["mp_idx"], w["obs"]["u"], w["obs"]["v"]], 1).astype(np.float64)
+    with open(os.path.join(tmp, "ba.bin"), "wb") as f:
+        f.write(struct.pack("<iiiiiiii", K, F, M, N, -1, 0, 0, 0))
+        for a in (w["poses_cw"], w["fixed_cw"], w["points"], ob):
+            f.write(np.ascontiguousarray(a, np.float64).tobytes())
+    env = dict(os.environ); env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe, tmp, tmp], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "HOST_MIRROR_OK" in r.stdout, (r.stdout, r.stderr)
+    # --- StereoFrame
+    buf = open(os.path.join(tmp, "stereo_out.bin"), "rb").read()
+    nl, nr, nm = struct.unpack_from("<iii", buf, 0)
+    off = 12
+    def take(dtype, n):
+        nonlocal off
+        a = np.frombuffer(buf, dtype, n, off); off += a.nbytes; return a
+    kl = take(pkg.KEYPOINT, nl); dl = take(np.uint8, nl * 32).reshape(-1, 32)
+    kr = take(pkg.KEYPOINT, nr); dr = take(np.uint8, nr * 32).reshape(-1, 32)
+    m = take(pkg.DMATCH, nm)
+    pc = np.frombuffer(buf, np.dtype([("has", "u1"), ("p", "<f8", 3)]), nl, off)
+    p = oracle.orb_params(nfeat)
+    okl, odl = oracle.orb_extract(L, p); okr, odr = oracle.orb_extract(R, p)
+    assert records_equal(kl, okl) and np.array_equal(dl, odl) and records_equal(kr, okr) and np.array_equal(dr, odr)
+    m0, p0, h0 = oracle.stereo_match(oracle.Camera(**pkg.synth.EUROC_CAMERA), okl, odl, okr, odr)
+    assert records_equal(m, m0) and np.array_equal(pc["has"], h0) and np.array_equal(pc["p"][h0 == 1], p0[h0 == 1])
+    # --- descriptor_distance + BFMatcher cross-check
+    mb = open(os.path.join(tmp, "match_out.bin"), "rb").read()
+    d01, nc = struct.unpack_from("<Ii", mb, 0)
+    assert d01 == oracle.hamming_batch(odl[0], odl[1])[0]
+    assert records_equal(np.frombuffer(mb, pkg.DMATCH, nc, 8), oracle.crosscheck_match(odl, odr))
+    # --- solve_visual_ba through VisualBAProblemData keyed by ids
+    bb = open(os.path.join(tmp, "ba_out.bin"), "rb").read()
+    ok, it = struct.unpack_from("<ii", bb, 0)
+    e0, e1 = struct.unpack_from("<dd", bb, 8)
+    poses = np.frombuffer(bb, np.float64, 7 * K, 24).reshape(K, 7)
+    pts = np.frombuffer(bb, np.float64, 3 * M, 24 + 56 * K).reshape(M, 3)
+    o = oracle.ba_solve_dense(oracle.Camera(**w["camera"]), oracle.ba_config(), w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+    assert ok == 1 and it == o["iterations"] and abs(e1 - o["final_error"]) < 1e-8 * o["final_error"]
+    rel = lambda a, b: np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))
+    assert rel(poses, o["poses_wc"]) < 1e-6 and rel(pts, o["points"]) < 1e-6
