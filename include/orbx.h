@@ -119,6 +119,18 @@ int orbx_process_stereo_batch_device(orbx_handle* h, const uint8_t* d_images, in
                                      orbx_dmatch* d_matches, int* d_nmatches, double* d_points,
                                      uint8_t* d_has_point);
 
+/* The same path for `batch` stereo pairs held in HOST memory (layouts as above, all arrays on the host).
+ * The batch is cut into chunks of at most `max_batch` pairs; the upload of chunk i+1, the kernels of chunk i and
+ * the download of chunk i-1 run concurrently on three HIP streams (double-buffered device staging).  The copies
+ * only overlap when the host buffers are page-locked: allocate them with orbx_host_alloc (or register them).
+ * Synchronous: returns when every result is in the host arrays. */
+int orbx_process_stereo_batch(orbx_handle* h, const uint8_t* images, int batch, int w, int h_px,
+                              size_t stride, orbx_keypoint* kp, uint8_t* desc, int* nkp, int cap_kp,
+                              orbx_dmatch* matches, int* nmatches, double* points, uint8_t* has_point);
+/* Page-locked host memory for the call above (hipHostMalloc / hipHostFree). */
+void* orbx_host_alloc(size_t bytes);
+void orbx_host_free(void* p);
+
 /* Extraction alone (= detect_features, stereo.rs:68-78) for `n_images` device images
  * [n_images][h_px][stride]; outputs as above with one slot per image. */
 int orbx_extract_batch_device(orbx_handle* h, const uint8_t* d_images, int n_images, int w,

@@ -17,9 +17,11 @@ written in Python with the reference's own names and argument meaning:
 Everything computes on the GPU through liborbx_hip.so; there is no CPU fallback, and a missing
 library or device raises.
 """
+import atexit
 import ctypes as C
 import math
 import os
+import weakref
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional
 
@@ -44,6 +46,7 @@ TH_HIGH, TH_LOW, NN_RATIO = 100, 50, 0.75
 ABI_SYMBOLS = [
     "orbx_version", "orbx_last_error", "orbx_default_orb_params", "orbx_create", "orbx_destroy",
     "orbx_stream", "orbx_synchronize", "orbx_process_stereo", "orbx_process_stereo_batch_device",
+    "orbx_process_stereo_batch", "orbx_host_alloc", "orbx_host_free",
     "orbx_extract_batch_device", "orbx_check_status", "orbx_stereo_match",
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
@@ -84,6 +87,17 @@ SHOULD_STOP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 _lib = None
+_live_handles = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_handles():
+    # destroy handles while the HIP runtime is still loaded (interpreter teardown order is arbitrary)
+    for h in list(_live_handles):
+        try:
+            h.close()
+        except Exception:
+            pass
 
 
 def load_library():
@@ -198,6 +212,7 @@ class Handle:
             raise OrbxError(rc, L.orbx_last_error(None).decode())
         self.device = device
         self._keep = []
+        _live_handles.add(self)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -314,6 +329,25 @@ class Handle:
             self._h, _vp(images), C.c_int(b), C.c_int(ww), C.c_int(hh), C.c_size_t(ww), _vp(out["kp"]),
             _vp(out["desc"]), _vp(out["nkp"]), C.c_int(out["cap_kp"]), _vp(out["matches"]),
             _vp(out["nmatches"]), _vp(out["points"]), _vp(out["has_point"])))
+
+    def process_stereo_batch_host(self, images, out):
+        """Pipelined host-buffer form: `images` and every tensor of `out` are (ideally pinned) CPU torch tensors with
+        the layouts of alloc_batch_outputs.  Synchronous."""
+        b, two, hh, ww = images.shape
+        assert two == 2 and images.is_contiguous() and not images.is_cuda and b <= out["batch"]
+        self._check(self._L.orbx_process_stereo_batch(
+            self._h, _vp(images), C.c_int(b), C.c_int(ww), C.c_int(hh), C.c_size_t(ww), _vp(out["kp"]),
+            _vp(out["desc"]), _vp(out["nkp"]), C.c_int(out["cap_kp"]), _vp(out["matches"]),
+            _vp(out["nmatches"]), _vp(out["points"]), _vp(out["has_point"])))
+
+    @staticmethod
+    def alloc_host_outputs(batch, cap_kp, pin=True):
+        import torch
+        mk = lambda shape, dt: (torch.zeros(shape, dtype=dt).pin_memory() if pin else torch.zeros(shape, dtype=dt))
+        return dict(kp=mk((batch, 2, cap_kp, 7), torch.float32), desc=mk((batch, 2, cap_kp, 32), torch.uint8),
+                    nkp=mk((batch, 2), torch.int32), matches=mk((batch, cap_kp, 4), torch.int32),
+                    nmatches=mk((batch,), torch.int32), points=mk((batch, cap_kp, 3), torch.float64),
+                    has_point=mk((batch, cap_kp), torch.uint8), cap_kp=cap_kp, batch=batch)
 
     def extract_batch_device(self, images, out):
         """images: torch u8 [n,h,w]; writes out['kp'|'desc'|'nkp'] viewed as n slots."""

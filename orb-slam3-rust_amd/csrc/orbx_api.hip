@@ -130,6 +130,10 @@ void orbx_destroy(orbx_handle* h) {
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (DevBuf& b : h->ws_io) if (b.p) hipFree(b.p);
   for (DevBuf& b : h->ws_ba) if (b.p) hipFree(b.p);
+  for (auto& set : h->ws_pipe) for (DevBuf& b : set) if (b.p) hipFree(b.p);
+  for (int i = 0; i < 2; ++i) { if (h->ev_in[i]) hipEventDestroy(h->ev_in[i]); if (h->ev_comp[i]) hipEventDestroy(h->ev_comp[i]); if (h->ev_out[i]) hipEventDestroy(h->ev_out[i]); }
+  if (h->s_in) hipStreamDestroy(h->s_in);
+  if (h->s_out) hipStreamDestroy(h->s_out);
   for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
   if (h->d_status) hipFree(h->d_status);
   if (h->h_status) hipHostFree(h->h_status);
@@ -434,6 +438,66 @@ int orbx_process_stereo(orbx_handle* h, const uint8_t* left, size_t lstride, con
   ORBX_HIP(h, hipMemcpy(points_cam, d_pts, sizeof(double) * 3 * (size_t)counts[0], hipMemcpyDeviceToHost));
   ORBX_HIP(h, hipMemcpy(has_point, d_has, (size_t)counts[0], hipMemcpyDeviceToHost));
   return ORBX_OK;
+}
+
+void* orbx_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  return hipHostMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+}
+void orbx_host_free(void* p) { if (p) hipHostFree(p); }
+
+int orbx_process_stereo_batch(orbx_handle* h, const uint8_t* images, int batch, int w, int h_px, size_t stride,
+                              orbx_keypoint* kp, uint8_t* desc, int* nkp, int cap_kp, orbx_dmatch* matches, int* nmatches,
+                              double* points, uint8_t* has_point) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (batch < 0 || cap_kp < 1 || !images || !kp || !desc || !nkp || !matches || !nmatches || !points || !has_point ||
+      stride < (size_t)w)
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_process_stereo_batch: bad argument");
+  if (batch == 0) return ORBX_OK;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  if (!h->s_in) {
+    ORBX_HIP(h, hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    ORBX_HIP(h, hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      ORBX_HIP(h, hipEventCreateWithFlags(&h->ev_in[i], hipEventDisableTiming));
+      ORBX_HIP(h, hipEventCreateWithFlags(&h->ev_comp[i], hipEventDisableTiming));
+      ORBX_HIP(h, hipEventCreateWithFlags(&h->ev_out[i], hipEventDisableTiming));
+    }
+  }
+  const int C = h->max_batch < 32 ? h->max_batch : 32;   // pairs per chunk
+  const size_t img_b = (size_t)h_px * stride * 2;          // one pair
+  const size_t sz[8] = {img_b * C, sizeof(orbx_keypoint) * 2 * (size_t)cap_kp * C, 64 * (size_t)cap_kp * C, sizeof(int) * 2 * (size_t)C,
+                        sizeof(orbx_dmatch) * (size_t)cap_kp * C, sizeof(int) * (size_t)C, 24 * (size_t)cap_kp * C, (size_t)cap_kp * C};
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < 8; ++i) if (int rc = orbx_reserve(h, h->ws_pipe[b][i], sz[i])) return rc;
+  // workspaces of the extractor are sized before the pipeline starts (orbx_reserve may synchronise)
+  const int n_chunks = (batch + C - 1) / C;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int b = c & 1, p0 = c * C, np = (batch - p0 < C) ? batch - p0 : C;
+    DevBuf* d = h->ws_pipe[b];
+    if (c >= 2) ORBX_HIP(h, hipStreamWaitEvent(h->s_in, h->ev_comp[b], 0));    // image buffer b is free again
+    ORBX_HIP(h, hipMemcpyAsync(d[0].p, images + (size_t)p0 * img_b, img_b * np, hipMemcpyHostToDevice, h->s_in));
+    ORBX_HIP(h, hipEventRecord(h->ev_in[b], h->s_in));
+    ORBX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_in[b], 0));
+    if (c >= 2) ORBX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_out[b], 0));  // output buffers b have been downloaded
+    if (int rc = orbx_process_stereo_batch_device(h, (const uint8_t*)d[0].p, np, w, h_px, stride, (orbx_keypoint*)d[1].p,
+                                                  (uint8_t*)d[2].p, (int*)d[3].p, cap_kp, (orbx_dmatch*)d[4].p, (int*)d[5].p,
+                                                  (double*)d[6].p, (uint8_t*)d[7].p))
+      return rc;
+    ORBX_HIP(h, hipEventRecord(h->ev_comp[b], h->stream));
+    ORBX_HIP(h, hipStreamWaitEvent(h->s_out, h->ev_comp[b], 0));
+    const size_t cp = (size_t)cap_kp;
+    ORBX_HIP(h, hipMemcpyAsync(kp + 2 * cp * p0, d[1].p, sizeof(orbx_keypoint) * 2 * cp * np, hipMemcpyDeviceToHost, h->s_out));
+    ORBX_HIP(h, hipMemcpyAsync(desc + 64 * cp * p0, d[2].p, 64 * cp * np, hipMemcpyDeviceToHost, h->s_out));
+    ORBX_HIP(h, hipMemcpyAsync(nkp + 2 * (size_t)p0, d[3].p, sizeof(int) * 2 * np, hipMemcpyDeviceToHost, h->s_out));
+    ORBX_HIP(h, hipMemcpyAsync(matches + cp * p0, d[4].p, sizeof(orbx_dmatch) * cp * np, hipMemcpyDeviceToHost, h->s_out));
+    ORBX_HIP(h, hipMemcpyAsync(nmatches + p0, d[5].p, sizeof(int) * np, hipMemcpyDeviceToHost, h->s_out));
+    ORBX_HIP(h, hipMemcpyAsync(points + 3 * cp * p0, d[6].p, 24 * cp * np, hipMemcpyDeviceToHost, h->s_out));
+    ORBX_HIP(h, hipMemcpyAsync(has_point + cp * p0, d[7].p, cp * np, hipMemcpyDeviceToHost, h->s_out));
+    ORBX_HIP(h, hipEventRecord(h->ev_out[b], h->s_out));
+  }
+  ORBX_HIP(h, hipStreamSynchronize(h->s_out));
+  return orbx_check_status(h);
 }
 
 // ---- local BA ---------------------------------------------------------------------------------------------

@@ -77,6 +77,10 @@ struct orbx_handle {
   // grow-only workspaces
   DevBuf ws_pyr, ws_blur, ws_cand, ws_counters, ws_sel, ws_sel2, ws_match, ws_io[12];
   DevBuf ws_ba[24];
+  // pipelined host-batch path: copy streams, events, double-buffered staging
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+  DevBuf ws_pipe[2][8];
   // BA
   orbx_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;

@@ -51,3 +51,17 @@ for b in (8, 64):
         step()
     dt = (time.perf_counter() - t0) / n
     print("PCIe-inclusive batch %3d (H2D images + process + D2H of every output buffer at full capacity, serial): %7.3f ms/step  %9.1f frames/s" % (b, dt * 1e3, b / dt))
+
+# pipelined host form (orbx_process_stereo_batch): three streams, chunks of 32 pairs
+hp = P.Handle(cam, 2000, max_batch=32)
+for b in (64, 256):
+    host_in = torch.from_numpy(P.synth.stereo_batch(3, 0, 16)).repeat((b + 15) // 16, 1, 1, 1)[:b].contiguous().pin_memory()
+    hout = hp.alloc_host_outputs(b, 2304)
+    for _ in range(2):
+        hp.process_stereo_batch_host(host_in, hout)
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        hp.process_stereo_batch_host(host_in, hout)
+    dt = (time.perf_counter() - t0) / n
+    print("PCIe-inclusive pipelined batch %3d (orbx_process_stereo_batch, pinned host buffers): %7.3f ms  %9.1f frames/s" % (b, dt * 1e3, b / dt))

@@ -175,3 +175,36 @@ def test_stereo_processor_mirror(pkg, oracle):
     assert sum(p is not None for p in f.points_cam_options()) == int(f.has_point.sum())
     ok, od = oracle.orb_extract(L, oracle.orb_params(1200))
     assert records_equal(f.left_features.keypoints, ok)
+
+
+def test_pipelined_host_batch_equals_device_batch(pkg):
+    """orbx_process_stereo_batch (three-stream pipelined host form, chunks of max_batch) == the device form"""
+    import torch
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 1000, device=0, max_w=752, max_h=480, max_batch=3)
+    B, cap = 8, 1304                         # 3 chunks: 3 + 3 + 2 pairs, both staging buffers reused
+    imgs = pkg.synth.stereo_batch(41, 0, B)
+    host_in = torch.from_numpy(imgs).pin_memory()
+    hout = h.alloc_host_outputs(B, cap)
+    h.process_stereo_batch_host(host_in, hout)
+    h2 = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 1000, device=0, max_w=752, max_h=480, max_batch=B)
+    dout = h2.alloc_batch_outputs(B, cap)
+    h2.process_stereo_batch_device(torch.from_numpy(imgs).cuda(), dout)
+    h2.check_status()
+    nk = dout["nkp"].cpu()
+    assert torch.equal(hout["nkp"], nk) and torch.equal(hout["nmatches"], dout["nmatches"].cpu())
+    for b in range(B):
+        for s in range(2):
+            n = int(nk[b, s])
+            assert torch.equal(hout["kp"][b, s, :n].view(torch.int32), dout["kp"][b, s, :n].cpu().view(torch.int32))
+            assert torch.equal(hout["desc"][b, s, :n], dout["desc"][b, s, :n].cpu())
+        nm = int(hout["nmatches"][b])
+        assert torch.equal(hout["matches"][b, :nm], dout["matches"][b, :nm].cpu())
+        nl = int(nk[b, 0])
+        hp = dout["has_point"][b, :nl].cpu()
+        assert torch.equal(hout["has_point"][b, :nl], hp)
+        assert torch.equal(hout["points"][b, :nl][hp.bool()], dout["points"][b, :nl].cpu()[hp.bool()])
+    # pageable host memory works too (no overlap, same results)
+    hout2 = h.alloc_host_outputs(B, cap, pin=False)
+    h.process_stereo_batch_host(torch.from_numpy(imgs), hout2)
+    assert torch.equal(hout2["nkp"], nk) and torch.equal(hout2["desc"], hout["desc"])
+    h.close(); h2.close()
