@@ -35,14 +35,14 @@ for b in (8, 64):
     out = h.alloc_batch_outputs(b, 2304)
     host_out = {k: torch.empty_like(v, device="cpu").pin_memory() for k, v in out.items() if hasattr(v, "shape")}
     dev_in = torch.empty_like(host_in, device="cuda")
-    ext = torch.cuda.ExternalStream(h.stream)
-    def step():
-        with torch.cuda.stream(ext):
-            dev_in.copy_(host_in, non_blocking=True)
-            h.process_stereo_batch_device(dev_in, out)
-            for k, v in host_out.items():
-                v.copy_(out[k], non_blocking=True)
+    def step():      # serial: upload, kernels, download, each fenced (no overlap)
+        dev_in.copy_(host_in, non_blocking=True)
+        torch.cuda.synchronize()
+        h.process_stereo_batch_device(dev_in, out)
         h.synchronize()
+        for k, v in host_out.items():
+            v.copy_(out[k], non_blocking=True)
+        torch.cuda.synchronize()
     for _ in range(3):
         step()
     t0 = time.perf_counter()
