@@ -57,7 +57,12 @@ def cpu_baseline(P, frames_mt, frames_1t, w, h, n_features):
     same workload, timed on this box's host cores."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
-    O.lib()
+    flags = "-O2 (portable build)"
+    try:
+        O.use_native_build()          # g++ -O3 -march=native on this box (BASELINE.md §3)
+        flags = "-O3 -march=native"
+    except Exception:
+        O.lib()
     cam = O.Camera(**P.synth.EUROC_CAMERA)
     p = O.orb_params(n_features)
     imgs = P.synth.stereo_batch(999, 0, max(frames_mt, frames_1t), w, h)
@@ -82,9 +87,9 @@ def cpu_baseline(P, frames_mt, frames_1t, w, h, n_features):
         list(ex.map(one, range(frames_mt)))
     tm = time.perf_counter() - t0
     return dict(value=round(frames_mt / tm, 3), unit="stereo frames/s", cores=cores, kind="port",
-                sample="%d synthetic %dx%d stereo frames, N=%d, oracle extract+match+triangulate, %d threads "
+                sample="%d synthetic %dx%d stereo frames, N=%d, oracle extract+match+triangulate (g++ %s), %d threads "
                        "(frame-level parallelism); 1 thread: %.3f frames/s on %d frames"
-                       % (frames_mt, w, h, n_features, cores, frames_1t / t1, frames_1t),
+                       % (frames_mt, w, h, n_features, flags, cores, frames_1t / t1, frames_1t),
                 value_1thread=round(frames_1t / t1, 3))
 
 

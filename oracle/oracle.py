@@ -51,6 +51,24 @@ def ba_config():
     return BaConfig(10, 1e-8, 1e-8, float(np.sqrt(5.991)), 20)
 
 
+def use_native_build():
+    """Rebuild the oracle with -O3 -march=native on THIS machine and use it from now on (bench.py's cpu_baseline;
+    the portable -O2 build travels between machines, a -march=native one must not).  Same results, faster."""
+    global _lib
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), "liborbx_oracle_native_%d.so" % os.getuid())
+    srcs = [os.path.join(_HERE, f) for f in ("match_ref.cpp", "orb_ref.cpp", "ba_ref.cpp")]
+    subprocess.run(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                    "-pthread", "-shared", "-o", out] + srcs, check=True)
+    L = C.CDLL(out)
+    L.oracle_hamming256.restype = C.c_uint32
+    L.oracle_fast_atan2.restype = C.c_float
+    L.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+    L.oracle_sincos_deg.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    _lib = L
+    return out
+
+
 def build(asan=False):
     target = "liborbx_oracle_asan.so" if asan else "liborbx_oracle.so"
     subprocess.run(["make", "-s", "-C", _HERE, target], check=True)
