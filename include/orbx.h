@@ -18,7 +18,10 @@
  *   - a handle is NOT thread-safe (mirrors `&mut self`, stereo.rs:52); use one
  *     handle per thread.  Each handle owns one HIP stream on its device.
  *   - `*_device` entry points take device pointers (memory of the handle's GPU)
- *     and are asynchronous on the handle's stream unless stated; the others take
+ *     and are asynchronous on the handle's stream unless stated.  That stream is
+ *     non-blocking: inputs produced on another stream must be complete (or ordered
+ *     with an event against orbx_stream()) before the call, and must stay allocated
+ *     until the work has run; the others take
  *     host pointers, copy in/out, and return when the results are in the buffers.
  *   - there is NO CPU fallback: every entry point fails with ORBX_ERR_NO_DEVICE
  *     when no gfx950 device can be opened.

@@ -212,9 +212,23 @@ class Handle:
             raise OrbxError(rc, L.orbx_last_error(None).decode())
         self.device = device
         self._keep = []
+        self._ext_stream = None
         _live_handles.add(self)
 
+    def _after_torch(self, *tensors):
+        """Order the library's (non-blocking) stream after whatever torch has queued on its current stream — the
+        caller's tensors may still be being written there — and keep the inputs alive until the next synchronise."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        if self._ext_stream is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.stream, device=torch.device("cuda", self.device))
+        self._ext_stream.wait_event(ev)
+        self._keep.extend(tensors)
+
     def close(self):
+        self._ext_stream = None
+        self._keep = []
         if getattr(self, "_h", None) and self._h.value:
             self._L.orbx_destroy(self._h)
             self._h = C.c_void_p()
@@ -235,9 +249,12 @@ class Handle:
 
     def synchronize(self):
         self._check(self._L.orbx_synchronize(self._h))
+        self._keep = []
 
     def check_status(self):
-        self._check(self._L.orbx_check_status(self._h))
+        rc = self._L.orbx_check_status(self._h)
+        self._keep = []
+        self._check(rc)
 
     def set_profiling(self, on=True):
         self._check(self._L.orbx_set_profiling(self._h, C.c_int(1 if on else 0)))
@@ -325,6 +342,7 @@ class Handle:
         """images: torch u8 [batch,2,h,w] on the GPU; out: alloc_batch_outputs().  Asynchronous."""
         b, two, hh, ww = images.shape
         assert two == 2 and images.is_contiguous() and b <= out["batch"]
+        self._after_torch(images)
         self._check(self._L.orbx_process_stereo_batch_device(
             self._h, _vp(images), C.c_int(b), C.c_int(ww), C.c_int(hh), C.c_size_t(ww), _vp(out["kp"]),
             _vp(out["desc"]), _vp(out["nkp"]), C.c_int(out["cap_kp"]), _vp(out["matches"]),
@@ -353,12 +371,14 @@ class Handle:
         """images: torch u8 [n,h,w]; writes out['kp'|'desc'|'nkp'] viewed as n slots."""
         n, hh, ww = images.shape
         assert images.is_contiguous() and n <= 2 * out["batch"]
+        self._after_torch(images)
         self._check(self._L.orbx_extract_batch_device(
             self._h, _vp(images), C.c_int(n), C.c_int(ww), C.c_int(hh), C.c_size_t(ww), _vp(out["kp"]),
             _vp(out["desc"]), _vp(out["nkp"]), C.c_int(out["cap_kp"])))
 
     def stereo_match_batch_device(self, out, batch=None):
         b = batch or out["batch"]
+        self._after_torch()
         self._check(self._L.orbx_stereo_match_batch_device(
             self._h, C.c_int(b), _vp(out["kp"]), _vp(out["desc"]), _vp(out["nkp"]), C.c_int(out["cap_kp"]),
             _vp(out["matches"]), _vp(out["nmatches"]), _vp(out["points"]), _vp(out["has_point"])))

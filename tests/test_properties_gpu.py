@@ -1,0 +1,110 @@
+"""Size-independent properties at the full bench size (128 stereo pairs of 752x480, 2000 ORB): determinism,
+independence of a pair from its batch neighbours, orderings, and consistency between entry points."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_batch(pkg):
+    import torch
+    B, cap = 128, 2304
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 2000, device=0, max_w=752, max_h=480, max_batch=B)
+    base = torch.from_numpy(pkg.synth.stereo_batch(77, 0, 16)).cuda()
+    imgs = torch.cat([base, torch.flip(base, dims=[2]), (base.to(torch.int16) + 5).clamp_(0, 255).to(torch.uint8),
+                      torch.flip(base, dims=[2, 3])[:, [1, 0]]] * 2)[:B].contiguous()
+    out = h.alloc_batch_outputs(B, cap)
+    h.process_stereo_batch_device(imgs, out)
+    h.check_status()
+    snap = {k: v.clone() for k, v in out.items() if hasattr(v, "shape")}
+    yield h, imgs, out, snap, B, cap
+    h.close()
+
+
+def test_rerun_is_bitwise_identical(full_batch):
+    import torch
+    h, imgs, out, snap, B, cap = full_batch
+    for _ in range(2):
+        h.process_stereo_batch_device(imgs, out)
+        h.check_status()
+        for k, v in snap.items():
+            if k in ("kp", "desc", "matches", "points", "has_point"):
+                continue   # compared below up to the valid counts (slots beyond the counts are scratch)
+            assert torch.equal(out[k], v), k
+        nk = snap["nkp"].cpu().numpy(); nm = snap["nmatches"].cpu().numpy()
+        for b in (0, 17, 64, 127):
+            for s in range(2):
+                assert torch.equal(out["kp"][b, s, :nk[b, s]].view(torch.int32), snap["kp"][b, s, :nk[b, s]].view(torch.int32))
+                assert torch.equal(out["desc"][b, s, :nk[b, s]], snap["desc"][b, s, :nk[b, s]])
+            assert torch.equal(out["matches"][b, :nm[b]], snap["matches"][b, :nm[b]])
+
+
+def test_pair_result_independent_of_batch_position(full_batch, pkg):
+    """reversing the batch order permutes the results and nothing else (no cross-talk through shared workspaces,
+    the XCD-aware block mapping or the atomically appended candidate lists)"""
+    import torch
+    h, imgs, out, snap, B, cap = full_batch
+    out2 = h.alloc_batch_outputs(B, cap)
+    h.process_stereo_batch_device(torch.flip(imgs, dims=[0]).contiguous(), out2)
+    h.check_status()
+    assert torch.equal(torch.flip(out2["nkp"], dims=[0]), snap["nkp"])
+    assert torch.equal(torch.flip(out2["nmatches"], dims=[0]), snap["nmatches"])
+    nk = snap["nkp"].cpu().numpy(); nm = snap["nmatches"].cpu().numpy()
+    for b in range(0, B, 7):
+        r = B - 1 - b
+        for s in range(2):
+            n = nk[b, s]
+            assert torch.equal(out2["kp"][r, s, :n].view(torch.int32), snap["kp"][b, s, :n].view(torch.int32))
+            assert torch.equal(out2["desc"][r, s, :n], snap["desc"][b, s, :n])
+        assert torch.equal(out2["matches"][r, :nm[b]], snap["matches"][b, :nm[b]])
+        hp = snap["has_point"][b, :nk[b, 0]].bool()
+        assert torch.equal(out2["points"][r, :nk[b, 0]][hp], snap["points"][b, :nk[b, 0]][hp])
+
+
+def test_output_orderings_and_ranges(full_batch, pkg):
+    h, imgs, out, snap, B, cap = full_batch
+    for b in (0, 31, 100):
+        fl, fr, m, pts, has = h.unpack_batch_outputs(out, b)
+        for f in (fl, fr):
+            k = f.keypoints
+            assert np.all(np.diff(k["octave"]) >= 0)                         # levels concatenated 0..7
+            for l in range(8):
+                r = k["response"][k["octave"] == l]
+                assert np.all(r[:-1] >= r[1:])                               # canonical order inside a level
+            assert np.all((k["angle"] >= 0) & (k["angle"] <= 360.0)) and np.all(k["class_id"] == -1)
+            assert k["x"].min() >= 31 and k["x"].max() < 752 - 31 + 1 and k["y"].min() >= 31 and k["y"].max() < 480 - 31 + 1
+        assert np.all(np.diff(m["query_idx"]) > 0)                           # ascending, one match per left keypoint
+        assert np.all((m["distance"] >= 0) & (m["distance"] < 100)) and np.all(m["img_idx"] == 0)
+        kl, kr = fl.keypoints, fr.keypoints
+        assert np.all(np.abs(kl["y"][m["query_idx"]] - kr["y"][m["train_idx"]]) <= 2.0)      # stereo.rs:117
+        assert np.all(kl["x"][m["query_idx"]] > kr["x"][m["train_idx"]])                      # stereo.rs:127
+        # matched distance = Hamming distance of the two rows (recomputed on the GPU through another entry point)
+        d = h.hamming_batch(fl.descriptors[m["query_idx"]], fr.descriptors[m["train_idx"]])
+        assert np.array_equal(d.astype(np.float32), m["distance"])
+        # every triangulated point re-projects onto its left keypoint (stereo.rs:204-211 inverted)
+        cam = pkg.synth.EUROC_CAMERA
+        q = has == 1
+        u = cam["fx"] * pts[q, 0] / pts[q, 2] + cam["cx"]; v = cam["fy"] * pts[q, 1] / pts[q, 2] + cam["cy"]
+        assert np.allclose(u, kl["x"][q], atol=1e-6) and np.allclose(v, kl["y"][q], atol=1e-6) and np.all(pts[q, 2] > 0)
+        assert q.sum() <= len(m)
+
+
+def test_hamming_metric_properties(gpu_handle):
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (4096, 32), dtype=np.uint8); b = rng.integers(0, 256, (4096, 32), dtype=np.uint8)
+    c = rng.integers(0, 256, (4096, 32), dtype=np.uint8)
+    dab, dba, dac, dcb = (gpu_handle.hamming_batch(x, y) for x, y in ((a, b), (b, a), (a, c), (c, b)))
+    assert np.array_equal(dab, dba) and np.all(gpu_handle.hamming_batch(a, a) == 0)
+    assert np.all(dab <= dac + dcb) and np.all(gpu_handle.hamming_batch(a, 255 - a) == 256)
+
+
+def test_large_odd_image(oracle, pkg):
+    """a size near the handle bound with pitches that are not multiples of anything convenient"""
+    w, hh, n = 2047, 1153, 3000
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), n, device=0, max_w=2048, max_h=1200, max_batch=1)
+    L, R = pkg.synth.stereo_pair(91, 0, w, hh)
+    kpL, dL, kpR, dR, m, pts, has = h.process_stereo(L, R, cap_kp=n + 1024)
+    ok, od = oracle.orb_extract(L, oracle.orb_params(n))
+    assert kpL.tobytes() == ok.tobytes() and np.array_equal(dL, od)
+    h.close()
