@@ -41,6 +41,17 @@ struct BaDims {
 
 struct BaCam { double fx, fy, cx, cy, huber; };
 
+// Levenberg-Marquardt state kept on the device (local_ba_lm.rs:1004-1056): the host only polls should_stop and
+// enqueues; accept/reject, lambda, the stop tests and the iteration count are decided by ba_decide_kernel, and
+// every kernel of an iteration returns at once when `done` is set.  sel picks which of the two parameter buffers
+// is "current" (the other one receives the trial step).
+struct BaState {
+  double lambda, cur_sq, final_sq, gtol, ptol;
+  int done, iters, sel, pad;
+};
+__device__ __forceinline__ double* ba_cur(const BaState* S, double* P0, double* P1) { return S->sel ? P1 : P0; }
+__device__ __forceinline__ double* ba_trial(const BaState* S, double* P0, double* P1) { return S->sel ? P0 : P1; }
+
 // ---- small device math ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
   const double w = q[0], i = q[1], j = q[2], k = q[3];
@@ -53,9 +64,13 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
 }
 
 // local_ba_lm.rs:648-662 then R|t (12 doubles)
-__global__ void ba_pose_kernel(const double* __restrict__ params, int K, double* __restrict__ Rt) {
+__global__ void ba_pose_kernel(BaState* S, double* P0, double* P1, int which /*0 cur, 1 trial*/, int iter, int K,
+                               double* __restrict__ Rt) {
+  if (S->done) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0 && which == 0 && iter >= 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
   if (k >= K) return;
+  const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
   const double* p = params + 6 * (size_t)k;
   double q[4];
   const double angle = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
@@ -118,13 +133,16 @@ __device__ __forceinline__ double group_sum32(double v) {
 }
 
 // One 32-lane group per point (2 points per wave).  Observations are stored point-major (CSR).
-__global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, double lambda,
-    const double* __restrict__ params, const double* __restrict__ Rt_opt, const double* __restrict__ Rt_fix,
+__global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, const BaState* S, double* P0, double* P1,
+    const double* __restrict__ Rt_opt, const double* __restrict__ Rt_fix,
     const int* __restrict__ pt_start, const int* __restrict__ o_kf, const int* __restrict__ o_fix,
     const double* __restrict__ o_uv, double* __restrict__ oA /*N*12*/, double* __restrict__ oR /*N*2*/,
     double* __restrict__ oYg /*N*6*/, double* __restrict__ Vinv /*M*9*/, double* __restrict__ gl /*M*3*/,
     double* __restrict__ pt_chi2 /*M*/, double* __restrict__ pt_glsq /*M*/, double* __restrict__ WT,
     double* __restrict__ YT) {
+  if (S->done) return;
+  const double lambda = S->lambda;
+  const double* params = ba_cur(S, P0, P1);
   const int lane32 = threadIdx.x & 31;
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   if (j >= d.M) return;   // whole 32-lane group leaves together
@@ -200,14 +218,17 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, doub
   }
 }
 
-// One block per optimised keyframe: U_k (36), g_p (6), b_red (6) over its observations, fixed order.
-__global__ __launch_bounds__(256) void ba_kf_kernel(BaDims d, const int* __restrict__ kf_start, const int* __restrict__ kf_obs,
+constexpr int BA_KFSPLIT = 8;
+// BA_KFSPLIT blocks per optimised keyframe: partial U_k (21 unique), g_p (6), b_red (6) over a slice of its
+// observations; the gather kernel adds the partials in a fixed order.
+__global__ __launch_bounds__(256) void ba_kf_kernel(BaDims d, const BaState* S, const int* __restrict__ kf_start, const int* __restrict__ kf_obs,
                                                     const double* __restrict__ oA, const double* __restrict__ oR,
-                                                    const double* __restrict__ oYg, double* __restrict__ U,
-                                                    double* __restrict__ gp, double* __restrict__ bred) {
+                                                    const double* __restrict__ oYg, double* __restrict__ kfpart /*[K][BA_KFSPLIT][33]*/) {
   __shared__ double red[4][33];
-  const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s = kf_start[k], e = kf_start[k + 1];
+  if (S->done) return;
+  const int k = blockIdx.x / BA_KFSPLIT, sp = blockIdx.x % BA_KFSPLIT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = kf_start[k], len = kf_start[k + 1] - s0;
+  const int s = s0 + (int)((long long)len * sp / BA_KFSPLIT), e = s0 + (int)((long long)len * (sp + 1) / BA_KFSPLIT);
   double acc[33];   // 21 unique U entries, 6 g_p, 6 b_red
 #pragma unroll
   for (int a = 0; a < 33; ++a) acc[a] = 0.0;
@@ -235,22 +256,14 @@ __global__ __launch_bounds__(256) void ba_kf_kernel(BaDims d, const int* __restr
     if (lane == 0) red[wave][a] = v;
   }
   __syncthreads();
-  if (tid < 33) {
-    const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-    if (tid < 21) {
-      int a = 0, b = 0, q = tid;
-      for (a = 0; a < 6; ++a) { if (q < 6 - a) { b = a + q; break; } q -= 6 - a; }
-      U[36 * (size_t)k + a * 6 + b] = v;
-      U[36 * (size_t)k + b * 6 + a] = v;
-    } else if (tid < 27) gp[6 * (size_t)k + tid - 21] = v;
-    else bred[6 * (size_t)k + tid - 27] = v;
-  }
+  if (tid < 33) kfpart[((size_t)k * BA_KFSPLIT + sp) * 33 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
 // S_red partials: one wave per (upper tile, k-split).  A[i][k] = YT[k][i0+i], B[k][j] = WT[k][j0+j].
 // v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4], B[l>>4][l&15]; D[(l>>4)+4r][l&15], r = 0..3.
-__global__ __launch_bounds__(256) void ba_schur_kernel(BaDims d, const double* __restrict__ YT,
+__global__ __launch_bounds__(256) void ba_schur_kernel(BaDims d, const BaState* S, const double* __restrict__ YT,
                                                        const double* __restrict__ WT, double* __restrict__ part) {
+  if (S->done) return;
   const int lane = threadIdx.x & 63;
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_upper = d.ntile * (d.ntile + 1) / 2;
@@ -265,10 +278,19 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BaDims d, const double* _
   const double* b_ptr = WT + (size_t)(k0 + (lane >> 4)) * d.P + tj * 16 + (lane & 15);
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   const size_t step = 4 * (size_t)d.P;
-#pragma unroll 4
-  for (int k = 0; k < krows; k += 4) {
-    const double a = *a_ptr, b = *b_ptr;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  int k = 0;
+  // 8 k-steps of operands in flight before the dependent MFMA chain (the plain loop did not unroll and every
+  // MFMA waited for its own pair of L2 loads)
+  for (; k + 32 <= krows; k += 32) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = a_ptr[u * step]; b[u] = b_ptr[u * step]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    a_ptr += 8 * step; b_ptr += 8 * step;
+  }
+  for (; k < krows; k += 4) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(*a_ptr, *b_ptr, acc, 0, 0, 0);
     a_ptr += step; b_ptr += step;
   }
   double* o = part + ((size_t)tile * d.ksplit + ks) * 256;
@@ -277,10 +299,10 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BaDims d, const double* _
 }
 
 // reduce-buffer layout (doubles): [Sred n*n | U 36K | gp n | bred n | chi2 | glsq], n = 6K
-__global__ __launch_bounds__(256) void ba_gather_kernel(BaDims d, const double* __restrict__ part,
-                                                        const double* __restrict__ U, const double* __restrict__ gp,
-                                                        const double* __restrict__ bred, const double* __restrict__ pt_chi2,
+__global__ __launch_bounds__(256) void ba_gather_kernel(BaDims d, const BaState* S, const double* __restrict__ part,
+                                                        const double* __restrict__ kfpart, const double* __restrict__ pt_chi2,
                                                         const double* __restrict__ pt_glsq, double* __restrict__ rb) {
+  if (S->done) return;
   const int n = 6 * d.K;
   const size_t nn = (size_t)n * n;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
@@ -295,10 +317,20 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(BaDims d, const double* 
     for (int ks = 0; ks < d.ksplit; ++ks) s += p[(size_t)ks * 256];
     rb[idx] = s;
   }
-  double* q = rb + nn;
-  for (int i = tid; i < 36 * d.K; i += nth) q[i] = U[i];
+  double* q = rb + nn;                 // U [36K] | gp [n] | bred [n] | chi2 | glsq
+  for (int i = tid; i < 33 * d.K; i += nth) {
+    const int k = i / 33, a = i - 33 * k;
+    double v = 0.0;
+    for (int sp = 0; sp < BA_KFSPLIT; ++sp) v += kfpart[((size_t)k * BA_KFSPLIT + sp) * 33 + a];
+    if (a < 21) {
+      int r = 0, c = 0, t = a;
+      for (r = 0; r < 6; ++r) { if (t < 6 - r) { c = r + t; break; } t -= 6 - r; }
+      q[36 * (size_t)k + r * 6 + c] = v;
+      q[36 * (size_t)k + c * 6 + r] = v;
+    } else if (a < 27) q[36 * (size_t)d.K + 6 * (size_t)k + (a - 21)] = v;
+    else q[36 * (size_t)d.K + n + 6 * (size_t)k + (a - 27)] = v;
+  }
   q += 36 * (size_t)d.K;
-  for (int i = tid; i < n; i += nth) { q[i] = gp[i]; q[n + i] = bred[i]; }
   if (blockIdx.x == 0) {
     // chi2 and |g_l|^2 over the points, fixed order (one block, tree over 256 partials)
     __shared__ double sh[2][256];
@@ -351,8 +383,11 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 constexpr int BA_NB = 8;
 
 template <typename SPtr>
-__device__ __forceinline__ void solve_body(int n, double lambda, const double* __restrict__ rb, int K, SPtr S,
-                           double* __restrict__ dp, double* __restrict__ res, const double* __restrict__ params) {
+__device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0, double* P1, const double* __restrict__ rb, int K, SPtr S,
+                           double* __restrict__ dp, double* __restrict__ res) {
+  if (St->done) return;
+  const double lambda = St->lambda;
+  const double* params = ba_cur(St, P0, P1);
   __shared__ double sb[BA_MAX_N];
   __shared__ double srinv[BA_MAX_N];
   __shared__ double s_red[BA_SOLVE_THREADS];
@@ -542,41 +577,55 @@ __device__ __forceinline__ void solve_body(int n, double lambda, const double* _
   if (tid == 0) res[4] = s_red[0];
 }
 
-__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(int n, double lambda, const double* __restrict__ rb,
-                                                                        int K, double* __restrict__ dp, double* __restrict__ res,
-                                                                        const double* __restrict__ params) {
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(int n, const BaState* St, double* P0, double* P1,
+                                                                        const double* __restrict__ rb, int K,
+                                                                        double* __restrict__ dp, double* __restrict__ res) {
   extern __shared__ __align__(16) double dyn[];
-  solve_body(n, lambda, rb, K, dyn, dp, res, params);
+  solve_body(n, St, P0, P1, rb, K, dyn, dp, res);
 }
-__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_gmem_kernel(int n, double lambda, const double* __restrict__ rb,
-                                                                         int K, double* __restrict__ Sg, double* __restrict__ dp,
-                                                                         double* __restrict__ res, const double* __restrict__ params) {
-  solve_body(n, lambda, rb, K, Sg, dp, res, params);
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_gmem_kernel(int n, const BaState* St, double* P0, double* P1,
+                                                                         const double* __restrict__ rb, int K,
+                                                                         double* __restrict__ Sg, double* __restrict__ dp,
+                                                                         double* __restrict__ res) {
+  solve_body(n, St, P0, P1, rb, K, Sg, dp, res);
 }
 
-// delta_l = V*^-1 (-g_l - sum_k W_kj^T delta_p_k); trial = params + delta; per-point |delta_l|^2, |p_l|^2
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims d, const double* __restrict__ params, const double* __restrict__ dp,
+// delta_l = V*^-1 (-g_l - sum_k W_kj^T delta_p_k); trial = params + delta; per-point |delta_l|^2, |p_l|^2.
+// One 32-lane group per point: lanes take the point's observations, fixed shuffle tree for the three sums.
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims d, const BaState* S, double* P0, double* P1, const double* __restrict__ dp,
                                                          const int* __restrict__ pt_start, const int* __restrict__ o_kf,
                                                          const double* __restrict__ WT, const double* __restrict__ Vinv,
-                                                         const double* __restrict__ gl, double* __restrict__ trial,
+                                                         const double* __restrict__ gl,
                                                          double* __restrict__ pt_dsq, double* __restrict__ pt_psq,
                                                          int owned_only) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < 6 * d.K) trial[j] = params[j] + dp[j];
-  if (j >= d.M) return;
-  double rhs[3] = {-gl[3 * (size_t)j], -gl[3 * (size_t)j + 1], -gl[3 * (size_t)j + 2]};
-  for (int i = pt_start[j]; i < pt_start[j + 1]; ++i) {
+  if (S->done) return;
+  const double* params = ba_cur(S, P0, P1);
+  double* trial = ba_trial(S, P0, P1);
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gtid < 6 * d.K) trial[gtid] = params[gtid] + dp[gtid];
+  const int lane32 = threadIdx.x & 31;
+  const int j = gtid >> 5;
+  if (j >= d.M) return;     // whole 32-lane group
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) {
     const int k = o_kf[i];
     if (k < 0) continue;
+    double dk[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) dk[a] = dp[6 * (size_t)k + a];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double* w = WT + (3 * (size_t)j + c) * d.P + 6 * (size_t)k;
-      double s = 0.0;
+      double sum = 0.0;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) s += w[a] * dp[6 * (size_t)k + a];
-      rhs[c] -= s;
+      for (int a = 0; a < 6; ++a) sum += w[a] * dk[a];
+      acc[c] += sum;
     }
   }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) acc[c] = group_sum32(acc[c]);
+  if (lane32 != 0) return;
+  const double rhs[3] = {-gl[3 * (size_t)j] - acc[0], -gl[3 * (size_t)j + 1] - acc[1], -gl[3 * (size_t)j + 2] - acc[2]};
   const double* I = Vinv + 9 * (size_t)j;
   double dsq = 0.0, psq = 0.0;
 #pragma unroll
@@ -597,11 +646,13 @@ __global__ void ba_diff_kernel(size_t n, const double* __restrict__ a, const dou
 }
 
 // chi2 of a parameter vector: per-point partial sums (fixed order)
-__global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const double* __restrict__ params,
+__global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const BaState* S, double* P0, double* P1, int which,
                                                       const double* __restrict__ Rt_opt, const double* __restrict__ Rt_fix,
                                                       const int* __restrict__ pt_start, const int* __restrict__ o_kf,
                                                       const int* __restrict__ o_fix, const double* __restrict__ o_uv,
                                                       double* __restrict__ pt_chi2) {
+  if (S->done) return;
+  const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= d.M) return;
   const double X[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1],
@@ -618,9 +669,10 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const
 }
 
 // out[0..2] = sums over points of up to three per-point arrays, one block, fixed tree
-__global__ __launch_bounds__(256) void ba_sum3_kernel(int M, const double* __restrict__ a, const double* __restrict__ b,
+__global__ __launch_bounds__(256) void ba_sum3_kernel(const BaState* S, int M, const double* __restrict__ a, const double* __restrict__ b,
                                                       const double* __restrict__ c, double* __restrict__ out) {
   __shared__ double sh[3][256];
+  if (S->done) return;
   double x = 0.0, y = 0.0, z = 0.0;
   for (int j = threadIdx.x; j < M; j += 256) { x += a[j]; if (b) y += b[j]; if (c) z += c[j]; }
   sh[0][threadIdx.x] = x; sh[1][threadIdx.x] = y; sh[2][threadIdx.x] = z;
@@ -632,6 +684,26 @@ __global__ __launch_bounds__(256) void ba_sum3_kernel(int M, const double* __res
     __syncthreads();
   }
   if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
+}
+
+// The tail of one LM iteration, local_ba_lm.rs:1022-1055, on the device.  res: [0] chi2(cur) [1] |g| [2] chol ok
+// [3] |dp|^2 [4] |p_pose|^2 [5] chi2(trial) [6] |dl|^2 [7] |p_points|^2.
+__global__ void ba_decide_kernel(BaState* S, const double* __restrict__ res) {
+  if (S->done) return;
+  const double cur_sq = res[0];
+  S->cur_sq = cur_sq;
+  S->final_sq = cur_sq;
+  if (res[1] < S->gtol) { S->done = 1; return; }                                  // :1027-1029
+  if (res[2] == 0.0) { S->done = 1; return; }                                     // :1036-1039
+  const double dnorm = sqrt(res[3] + res[6]), pnorm = sqrt(res[4] + res[7]);
+  if (dnorm < S->ptol * (pnorm + S->ptol)) { S->done = 1; return; }               // :1041-1044
+  if (res[5] < cur_sq) {                                                          // :1050-1055
+    S->sel ^= 1;
+    S->final_sq = res[5];
+    S->lambda = fmax(S->lambda * 0.1, 1e-10);
+  } else {
+    S->lambda = fmin(S->lambda * 10.0, 1e10);
+  }
 }
 
 // ---- host helpers -----------------------------------------------------------------------------------------------
@@ -751,7 +823,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
       {B_OA, 96 * (size_t)std::max(N, 1)}, {B_OR, 16 * (size_t)std::max(N, 1)}, {B_OYG, 48 * (size_t)std::max(N, 1)},
       {B_VINV, 72 * (size_t)std::max(M, 1)}, {B_GL, 24 * (size_t)std::max(M, 1)}, {B_PT, 8 * 4 * (size_t)std::max(M, 1)},
       {B_WT, 8 * (size_t)d.rows * d.P}, {B_YT, 8 * (size_t)d.rows * d.P}, {B_PART, 8 * n_upper * d.ksplit * 256},
-      {B_UG, 8 * (size_t)(48 * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 2 * (size_t)n + 32 + BA_SOLVE_THREADS)}, {B_RES, 8 * 16}};
+      {B_UG, 8 * (size_t)(33 * BA_KFSPLIT * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 2 * (size_t)n + 32 + BA_SOLVE_THREADS)}, {B_RES, 8 * 16}};
   for (auto& nd : need) if (int rc = orbx_reserve(h, h->ws_ba[nd.id], nd.bytes)) return rc;
   auto D = [&](int id) { return (double*)h->ws_ba[id].p; };
   auto I = [&](int id) { return (int*)h->ws_ba[id].p; };
@@ -771,7 +843,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   ORBX_HIP(h, hipMemsetAsync(D(B_YT), 0, 8 * (size_t)d.rows * d.P, st));
   double* pt_chi2 = D(B_PT); double* pt_glsq = pt_chi2 + std::max(M, 1);
   double* pt_dsq = pt_glsq + std::max(M, 1); double* pt_psq = pt_dsq + std::max(M, 1);
-  double* Ud = D(B_UG); double* gpd = Ud + 36 * (size_t)std::max(K, 1); double* bredd = gpd + 6 * (size_t)std::max(K, 1);
+  double* kfpart = D(B_UG);
   double* res = D(B_RES);
   double hres[16];
 
@@ -781,17 +853,28 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   if (use_lds && n > 0)
     ORBX_HIP(h, hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
 
-  auto chi2_of = [&](double* p, double* out_sum3) -> int {   // out_sum3[0] = chi2 (local partition)
-    if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, p, K, D(B_RTOPT));
-    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M + 255) / 256), dim3(256), 0, st, d, bc, p, D(B_RTOPT), D(B_RTFIX),
-                                  I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
-    hipLaunchKernelGGL(ba_sum3_kernel, dim3(1), dim3(256), 0, st, M, pt_chi2, (const double*)nullptr, (const double*)nullptr, out_sum3);
-    return ORBX_OK;
-  };
+  // device-side LM state
+  if (int rc = orbx_reserve(h, h->ws_ba[23], sizeof(BaState))) return rc;
+  BaState* S = (BaState*)h->ws_ba[23].p;
+  {
+    BaState s0{};
+    s0.lambda = 1e-3;                                                  // :1006-1010
+    s0.gtol = cfg->gradient_tolerance; s0.ptol = cfg->param_tolerance;
+    ORBX_HIP(h, hipMemcpyAsync(S, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+    ORBX_HIP(h, hipStreamSynchronize(st));                             // s0 is a stack object
+  }
+  double* P0 = D(B_PARAMS);
+  double* P1 = D(B_TRIAL);
   auto allreduce = [&](double* dptr, size_t cnt) -> int {
     if (!dist) return ORBX_OK;
     if (h->allreduce(h->allreduce_user, dptr, cnt, (void*)st) != 0) return orbx_fail(h, ORBX_ERR_HIP, "all-reduce hook failed");
     return ORBX_OK;
+  };
+  auto chi2_of = [&](int which, int iter, double* out_sum3, const double* b2, const double* c2) {
+    if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, which, iter, K, D(B_RTOPT));
+    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTOPT), D(B_RTFIX),
+                                  I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
+    hipLaunchKernelGGL(ba_sum3_kernel, dim3(1), dim3(256), 0, st, S, M, pt_chi2, b2, c2, out_sum3);
   };
   // total residual count over all ranks (for the RMS error): all-reduce one double when partitioned
   double n_res = 2.0 * (double)N;
@@ -804,92 +887,76 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     if (n_res == 0.0) return orbx_fail(h, ORBX_ERR_EMPTY, "no residuals on any rank");
   }
 
-  double* cur = D(B_PARAMS);
-  double* trial = D(B_TRIAL);
-  // initial error (:1000-1001)
+  // initial error (:1000-1001) -> res[12]
   {
     ProfScope ps(h, "ba_chi2");
-    chi2_of(cur, res + 5);
+    chi2_of(0, -1, res + 12, nullptr, nullptr);
   }
-  if (int rc = allreduce(res + 5, 1)) return rc;
-  ORBX_HIP(h, hipMemcpyAsync(hres, res, 8 * 16, hipMemcpyDeviceToHost, st));
-  ORBX_HIP(h, hipStreamSynchronize(st));
-  *initial_error = std::sqrt(hres[5]) / std::sqrt(n_res);
-  double final_sq = hres[5];
+  if (int rc = allreduce(res + 12, 1)) return rc;
 
-  double lambda = 1e-3;                                              // :1006-1010
-  int iters = 0;
+  // The loop only polls should_stop (:1013) and enqueues; nothing below waits for the GPU.
   for (int iter = 0; iter < cfg->max_iterations; ++iter) {           // :1012
     if (should_stop && should_stop(user)) break;                     // :1013
-    iters = iter + 1;                                                // :1017
     {
       ProfScope ps(h, "ba_pose_kernel");
-      if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, cur, K, D(B_RTOPT));
+      if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, 0, iter, K, D(B_RTOPT));
+      else hipLaunchKernelGGL(ba_pose_kernel, dim3(1), dim3(64), 0, st, S, P0, P1, 0, iter, 0, D(B_RTOPT));   // iteration counter
     }
     {
       ProfScope ps(h, "ba_build_kernel");
-      if (M > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, lambda, cur, D(B_RTOPT),
+      if (M > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, D(B_RTOPT),
                                     D(B_RTFIX), I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), D(B_OA), D(B_OR), D(B_OYG),
                                     D(B_VINV), D(B_GL), pt_chi2, pt_glsq, D(B_WT), D(B_YT));
     }
     {
       ProfScope ps(h, "ba_kf_kernel");
-      if (K > 0) hipLaunchKernelGGL(ba_kf_kernel, dim3(K), dim3(256), 0, st, d, I(B_KFSTART), I(B_KFOBS), D(B_OA), D(B_OR), D(B_OYG), Ud, gpd, bredd);
+      if (K > 0) hipLaunchKernelGGL(ba_kf_kernel, dim3(K * BA_KFSPLIT), dim3(256), 0, st, d, S, I(B_KFSTART), I(B_KFOBS), D(B_OA), D(B_OR), D(B_OYG), kfpart);
     }
     if (K > 0) {
       ProfScope ps(h, "ba_schur_kernel");
       const int units = (int)n_upper * d.ksplit;
-      hipLaunchKernelGGL(ba_schur_kernel, dim3((units + 3) / 4), dim3(256), 0, st, d, D(B_YT), D(B_WT), D(B_PART));
+      hipLaunchKernelGGL(ba_schur_kernel, dim3((units + 3) / 4), dim3(256), 0, st, d, S, D(B_YT), D(B_WT), D(B_PART));
     }
     {
       ProfScope ps(h, "ba_gather_kernel");
       const int blocks = std::max(1, std::min(256, (n * n + 255) / 256));
-      hipLaunchKernelGGL(ba_gather_kernel, dim3(blocks), dim3(256), 0, st, d, D(B_PART), Ud, gpd, bredd, pt_chi2, pt_glsq, D(B_RB));
+      hipLaunchKernelGGL(ba_gather_kernel, dim3(blocks), dim3(256), 0, st, d, S, D(B_PART), kfpart, pt_chi2, pt_glsq, D(B_RB));
     }
     if (int rc = allreduce(D(B_RB), rb_len)) return rc;
     {
       ProfScope ps(h, "ba_solve_kernel");
       if (use_lds)
-        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_THREADS), lds_need, st, n, lambda, D(B_RB), K, D(B_SOLVE), res, cur);
+        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_THREADS), lds_need, st, n, S, P0, P1, D(B_RB), K, D(B_SOLVE), res);
       else
-        hipLaunchKernelGGL(ba_solve_gmem_kernel, dim3(1), dim3(BA_SOLVE_THREADS), 0, st, n, lambda, D(B_RB), K, D(B_SOLVE) + ((n + 15) & ~15), D(B_SOLVE), res, cur);
+        hipLaunchKernelGGL(ba_solve_gmem_kernel, dim3(1), dim3(BA_SOLVE_THREADS), 0, st, n, S, P0, P1, D(B_RB), K, D(B_SOLVE) + ((n + 15) & ~15), D(B_SOLVE), res);
     }
     {
       ProfScope ps(h, "ba_backsub_kernel");
-      const int cnt = std::max(M, n);
-      hipLaunchKernelGGL(ba_backsub_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, d, cur, D(B_SOLVE), I(B_PTSTART), I(B_OKF), D(B_WT),
-                         D(B_VINV), D(B_GL), trial, pt_dsq, pt_psq, dist ? 1 : 0);
+      const int cnt = std::max(32 * M, n);
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, d, S, P0, P1, D(B_SOLVE), I(B_PTSTART), I(B_OKF), D(B_WT),
+                         D(B_VINV), D(B_GL), pt_dsq, pt_psq, dist ? 1 : 0);
     }
     {
       ProfScope ps(h, "ba_chi2");
       // trial residuals (:1047-1048): res[5] = chi2(trial), res[6] = |delta_l|^2, res[7] = |p_l|^2
-      if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, trial, K, D(B_RTOPT));
-      if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M + 255) / 256), dim3(256), 0, st, d, bc, trial, D(B_RTOPT), D(B_RTFIX),
-                                    I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
-      hipLaunchKernelGGL(ba_sum3_kernel, dim3(1), dim3(256), 0, st, M, pt_chi2, pt_dsq, pt_psq, res + 5);
+      chi2_of(1, -1, res + 5, pt_dsq, pt_psq);
     }
     if (int rc = allreduce(res + 5, 3)) return rc;
-    ORBX_HIP(h, hipMemcpyAsync(hres, res, 8 * 16, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(h, hipStreamSynchronize(st));
-    ORBX_HIP(h, hipGetLastError());
-    const double cur_sq = hres[0], gnorm = hres[1];
-    final_sq = cur_sq;
-    if (gnorm < cfg->gradient_tolerance) break;                      // :1027-1029
-    if (hres[2] == 0.0) break;                                       // solve failed (:1036-1039)
-    const double dnorm = std::sqrt(hres[3] + hres[6]);
-    const double pnorm = std::sqrt(hres[4] + hres[7]);
-    if (dnorm < cfg->param_tolerance * (pnorm + cfg->param_tolerance)) break;   // :1041-1044
-    const double trial_sq = hres[5];
-    if (trial_sq < cur_sq) {                                         // :1050-1055
-      std::swap(cur, trial);
-      final_sq = trial_sq;
-      lambda = std::max(lambda * 0.1, 1e-10);
-    } else {
-      lambda = std::min(lambda * 10.0, 1e10);
+    {
+      ProfScope ps(h, "ba_decide_kernel");
+      hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(1), 0, st, S, res);
     }
   }
-  *iterations = iters;
+  BaState sh{};
+  ORBX_HIP(h, hipMemcpyAsync(hres, res, 8 * 16, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(h, hipMemcpyAsync(&sh, S, sizeof(sh), hipMemcpyDeviceToHost, st));
+  ORBX_HIP(h, hipStreamSynchronize(st));
+  ORBX_HIP(h, hipGetLastError());
+  *initial_error = std::sqrt(hres[12]) / std::sqrt(n_res);
+  *iterations = sh.iters;
+  const double final_sq = sh.iters > 0 ? sh.final_sq : hres[12];
   *final_error = std::sqrt(final_sq) / std::sqrt(n_res);            // :1059-1060
+  double* cur = sh.sel ? P1 : P0;
   std::vector<double> init_pts;
   if (dist && M > 0) {
     // every point moved only on the rank that owns it: sum the per-rank updates
