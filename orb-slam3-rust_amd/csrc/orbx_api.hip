@@ -135,6 +135,7 @@ void orbx_destroy(orbx_handle* h) {
   if (h->s_in) hipStreamDestroy(h->s_in);
   if (h->s_out) hipStreamDestroy(h->s_out);
   for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
+  if (h->h_stage) hipHostFree(h->h_stage);
   if (h->d_status) hipFree(h->d_status);
   if (h->h_status) hipHostFree(h->h_status);
   hipStreamDestroy(h->stream);
@@ -407,36 +408,50 @@ int orbx_process_stereo(orbx_handle* h, const uint8_t* left, size_t lstride, con
       !points_cam || !has_point || cap_kp < 1 || lstride < (size_t)w || rstride < (size_t)w)
     return orbx_fail(h, ORBX_ERR_INVALID, "orbx_process_stereo: bad argument");
   ORBX_HIP(h, hipSetDevice(h->device));
-  const size_t img = (size_t)w * h_px;
-  const size_t kpb = sizeof(orbx_keypoint) * (size_t)cap_kp, db = 32 * (size_t)cap_kp;
+  const size_t img = (size_t)w * h_px, cp = (size_t)cap_kp;
+  // every output of the pair in ONE device block (and one pinned host mirror): a single D2H copy and a single
+  // synchronisation per frame instead of one blocking copy per array
+  const size_t o_pts = 0;                                   // double[cp*3]
+  const size_t o_kp = o_pts + 24 * cp;                      // orbx_keypoint[2*cp]
+  const size_t o_m = o_kp + sizeof(orbx_keypoint) * 2 * cp; // orbx_dmatch[cp]
+  const size_t o_cnt = o_m + sizeof(orbx_dmatch) * cp;      // int nkp[2], nmatches, status
+  const size_t o_desc = o_cnt + 16;                         // u8[2*cp*32]
+  const size_t o_has = o_desc + 64 * cp;                    // u8[cp]
+  const size_t total = (o_has + cp + 63) & ~(size_t)63;
   if (int rc = orbx_reserve(h, h->ws_io[6], 2 * img)) return rc;
-  if (int rc = orbx_reserve(h, h->ws_io[7], 2 * kpb)) return rc;
-  if (int rc = orbx_reserve(h, h->ws_io[8], 2 * db)) return rc;
-  if (int rc = orbx_reserve(h, h->ws_io[9], 4 * sizeof(int))) return rc;
-  if (int rc = orbx_reserve(h, h->ws_io[10], sizeof(orbx_dmatch) * (size_t)cap_kp)) return rc;
-  if (int rc = orbx_reserve(h, h->ws_io[11], (sizeof(double) * 3 + 1) * (size_t)cap_kp)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[7], total)) return rc;
+  if (h->h_stage_bytes < total) {
+    if (h->h_stage) ORBX_HIP(h, hipHostFree(h->h_stage));
+    h->h_stage = nullptr; h->h_stage_bytes = 0;
+    ORBX_HIP(h, hipHostMalloc((void**)&h->h_stage, total));
+    h->h_stage_bytes = total;
+  }
   uint8_t* d_img = (uint8_t*)h->ws_io[6].p;
+  uint8_t* d_out = (uint8_t*)h->ws_io[7].p;
   ORBX_HIP(h, hipMemcpy2DAsync(d_img, w, left, lstride, w, h_px, hipMemcpyHostToDevice, h->stream));
   ORBX_HIP(h, hipMemcpy2DAsync(d_img + img, w, right, rstride, w, h_px, hipMemcpyHostToDevice, h->stream));
-  orbx_keypoint* d_kp = (orbx_keypoint*)h->ws_io[7].p;
-  uint8_t* d_desc = (uint8_t*)h->ws_io[8].p;
-  int* d_n = (int*)h->ws_io[9].p;
-  double* d_pts = (double*)h->ws_io[11].p;
-  uint8_t* d_has = (uint8_t*)(d_pts + 3 * (size_t)cap_kp);
-  if (int rc = orbx_process_stereo_batch_device(h, d_img, 1, w, h_px, (size_t)w, d_kp, d_desc, d_n, cap_kp,
-                                                (orbx_dmatch*)h->ws_io[10].p, d_n + 2, d_pts, d_has))
+  int* d_cnt = (int*)(d_out + o_cnt);
+  if (int rc = orbx_process_stereo_batch_device(h, d_img, 1, w, h_px, (size_t)w, (orbx_keypoint*)(d_out + o_kp), d_out + o_desc,
+                                                d_cnt, cap_kp, (orbx_dmatch*)(d_out + o_m), d_cnt + 2, (double*)(d_out + o_pts),
+                                                d_out + o_has))
     return rc;
-  int counts[3];
-  ORBX_HIP(h, hipMemcpyAsync(counts, d_n, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
-  if (int rc = orbx_check_status(h)) return rc;   // synchronises
-  *nL = counts[0]; *nR = counts[1]; *n_matches = counts[2];
-  ORBX_HIP(h, hipMemcpy(kpL, d_kp, sizeof(orbx_keypoint) * (size_t)counts[0], hipMemcpyDeviceToHost));
-  ORBX_HIP(h, hipMemcpy(descL, d_desc, 32 * (size_t)counts[0], hipMemcpyDeviceToHost));
-  ORBX_HIP(h, hipMemcpy(kpR, d_kp + cap_kp, sizeof(orbx_keypoint) * (size_t)counts[1], hipMemcpyDeviceToHost));
-  ORBX_HIP(h, hipMemcpy(descR, d_desc + db, 32 * (size_t)counts[1], hipMemcpyDeviceToHost));
-  ORBX_HIP(h, hipMemcpy(matches, h->ws_io[10].p, sizeof(orbx_dmatch) * (size_t)counts[2], hipMemcpyDeviceToHost));
-  ORBX_HIP(h, hipMemcpy(points_cam, d_pts, sizeof(double) * 3 * (size_t)counts[0], hipMemcpyDeviceToHost));
-  ORBX_HIP(h, hipMemcpy(has_point, d_has, (size_t)counts[0], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_status, sizeof(unsigned), hipMemcpyDeviceToDevice, h->stream));
+  ORBX_HIP(h, hipMemsetAsync(h->d_status, 0, sizeof(unsigned), h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(h->h_stage, d_out, total, hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  const uint8_t* S = h->h_stage;
+  const int* cnt = (const int*)(S + o_cnt);
+  const unsigned st = (unsigned)cnt[3];
+  if (st & ORBX_ST_KP_OVERFLOW) return orbx_fail(h, ORBX_ERR_CAPACITY, "an image produced more keypoints than cap_kp");
+  if (st) return orbx_fail(h, ORBX_ERR_HIP, "device status 0x%x", st);
+  *nL = cnt[0]; *nR = cnt[1]; *n_matches = cnt[2];
+  memcpy(kpL, S + o_kp, sizeof(orbx_keypoint) * (size_t)cnt[0]);
+  memcpy(kpR, S + o_kp + sizeof(orbx_keypoint) * cp, sizeof(orbx_keypoint) * (size_t)cnt[1]);
+  memcpy(descL, S + o_desc, 32 * (size_t)cnt[0]);
+  memcpy(descR, S + o_desc + 32 * cp, 32 * (size_t)cnt[1]);
+  memcpy(matches, S + o_m, sizeof(orbx_dmatch) * (size_t)cnt[2]);
+  memcpy(points_cam, S + o_pts, 24 * (size_t)cnt[0]);
+  memcpy(has_point, S + o_has, (size_t)cnt[0]);
   return ORBX_OK;
 }
 

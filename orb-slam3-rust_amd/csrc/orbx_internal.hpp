@@ -69,6 +69,8 @@ struct orbx_handle {
   std::string err;
   unsigned* d_status = nullptr;
   unsigned* h_status = nullptr;   // pinned
+  uint8_t* h_stage = nullptr;     // pinned mirror of the single-pair output block (orbx_process_stereo)
+  size_t h_stage_bytes = 0;
   // cached level geometry + resize tables for the last image size
   int geom_w = 0, geom_h = 0;
   OrbGeom geom{};
