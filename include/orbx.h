@@ -56,9 +56,10 @@ typedef struct {
 } orbx_camera;
 
 /* = the nine cv::ORB::create arguments, src/tracking/frame/stereo.rs:38-48.
- * Only the reference's configuration is implemented: n_levels <= 8... any
- * n_features, scale_factor 1.2f, edge_threshold 31, first_level 0, wta_k 2,
- * score_type 0 (HARRIS_SCORE), patch_size 31; other values -> ORBX_ERR_INVALID. */
+ * The reference's configuration and its neighbourhood are implemented: any n_features,
+ * 1 <= n_levels <= 8, scale_factor in (1, 1.5], fast_threshold 1..254; edge_threshold 31,
+ * first_level 0, wta_k 2, score_type 0 (HARRIS_SCORE), patch_size 31 are fixed;
+ * other values -> ORBX_ERR_INVALID. */
 typedef struct {
   int n_features;
   float scale_factor;

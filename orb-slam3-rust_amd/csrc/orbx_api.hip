@@ -89,10 +89,10 @@ int orbx_create(const orbx_camera* cam, const orbx_orb_params* orb, int device, 
   if (orb->n_levels < 1 || orb->n_levels > ORBX_MAX_LEVELS || orb->edge_threshold != 31 ||
       orb->first_level != 0 || orb->wta_k != 2 || orb->score_type != 0 || orb->patch_size != 31 ||
       orb->n_features < 0 || orb->fast_threshold < 1 || orb->fast_threshold > 254 ||
-      !(orb->scale_factor > 1.0f))
+      !(orb->scale_factor > 1.0f) || orb->scale_factor > 1.5f)
     return orbx_fail(nullptr, ORBX_ERR_INVALID,
                      "only the reference's ORB configuration is implemented (stereo.rs:38-48): "
-                     "n_levels<=8, edge 31, first_level 0, WTA_K 2, HARRIS_SCORE, patch 31");
+                     "n_levels<=8, scale factor in (1, 1.5], edge 31, first_level 0, WTA_K 2, HARRIS_SCORE, patch 31");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return orbx_fail(nullptr, ORBX_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU path");

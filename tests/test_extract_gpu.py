@@ -208,3 +208,20 @@ def test_pipelined_host_batch_equals_device_batch(pkg):
     h.process_stereo_batch_host(torch.from_numpy(imgs), hout2)
     assert torch.equal(hout2["nkp"], nk) and torch.equal(hout2["desc"], hout["desc"])
     h.close(); h2.close()
+
+
+@pytest.mark.parametrize("over", [dict(n_levels=4), dict(fast_threshold=10), dict(fast_threshold=45, n_levels=6),
+                                  dict(scale_factor=1.3), dict(scale_factor=1.5, n_levels=5), dict(n_levels=1)])
+def test_orb_parameter_variations(oracle, pkg, over):
+    """the ORB parameters the ABI lets vary (levels, scale factor, FAST threshold) — still bit-exact"""
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 900, device=0, max_w=752, max_h=480, max_batch=1, orb_params=over)
+    p = oracle.orb_params(900)
+    for k, v in over.items():
+        setattr(p, k, v)
+    L, R = pkg.synth.stereo_pair(61, 3)
+    kpL, dL, kpR, dR, m, pts, has = h.process_stereo(L, R)
+    ok, od = oracle.orb_extract(L, p)
+    assert records_equal(kpL, ok), _first_diff(kpL, ok) if len(kpL) == len(ok) else "%d vs %d" % (len(kpL), len(ok))
+    assert np.array_equal(dL, od) and len(ok) > 300
+    assert int(kpL["octave"].max()) == p.n_levels - 1
+    h.close()
