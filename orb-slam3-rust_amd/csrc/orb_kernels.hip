@@ -626,25 +626,30 @@ constexpr int PB_ROWS = 37, PB_DW = 10, PB_PITCH = 11;   // blurred 37x37 patch:
 __constant__ unsigned c_ic_ones[256];
 __constant__ unsigned c_ic_col[256];
 
+// Four keypoints per wave, 16 lanes each: the per-keypoint work that every lane would otherwise repeat (slot and
+// key decode, the three centroid reductions, fastAtan2, the f64 sin/cos) is shared by 4 keypoints per instruction.
+// Lane li of a group owns centroid tasks t = it*16 + li and descriptor bits r*16 + li (it, r = 0..15); a ballot
+// delivers 16 bits of each of the four descriptors at once.
+constexpr int DG_LANES = 16, DG_PER_WAVE = 4, DG_PER_BLOCK = 16;
+
 __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int n_img, int blocks_per_img,
                                                        const unsigned long long* __restrict__ sel2,
                                                        const unsigned* __restrict__ kept,
                                                        orbx_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
                                                        int* __restrict__ nkp, int cap_kp, float patch_size,
                                                        unsigned* __restrict__ status) {
-  __shared__ unsigned pb[4][PB_ROWS * PB_PITCH];
+  __shared__ unsigned pb[DG_PER_BLOCK][PB_ROWS * PB_PITCH];
   int img, bx;
   if (!xcd_decode(blocks_per_img, n_img, img, bx)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // per-lane constants: four rBRIEF test pairs (bits lane, lane+64, ...) and four centroid tasks
-  int pat[4];
-  unsigned w_ones[4], w_col[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    pat[q] = reinterpret_cast<const int*>(c_pattern)[q * 64 + lane];
-    w_ones[q] = c_ic_ones[q * 64 + lane];
-    w_col[q] = c_ic_col[q * 64 + lane];
-  }
+  const int grp = lane >> 4, li = lane & 15;
+  // block-wide tables in LDS (registers are better spent on occupancy): 256 rBRIEF test pairs, 256 centroid tasks
+  __shared__ int s_pat[256];
+  __shared__ unsigned s_ones[256], s_col[256];
+  s_pat[tid] = reinterpret_cast<const int*>(c_pattern)[tid];
+  s_ones[tid] = c_ic_ones[tid];
+  s_col[tid] = c_ic_col[tid];
+  __syncthreads();
   unsigned start[ORBX_MAX_LEVELS + 1];
   start[0] = 0;
 #pragma unroll
@@ -656,8 +661,12 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
     nkp[img] = (int)limit;
     if (total > (unsigned)cap_kp) atomicOr(status, ORBX_ST_KP_OVERFLOW);
   }
-  const uint8_t* pbb = reinterpret_cast<const uint8_t*>(pb[wave]);
-  for (unsigned slot = bx * 4 + wave; slot < limit; slot += blocks_per_img * 4) {
+  unsigned* myp = pb[wave * DG_PER_WAVE + grp];
+  const uint8_t* pbb = reinterpret_cast<const uint8_t*>(myp);
+  for (unsigned base = (bx * 4 + wave) * DG_PER_WAVE; base < limit; base += blocks_per_img * DG_PER_BLOCK) {
+    const unsigned slot_raw = base + grp;
+    const bool active = slot_raw < limit;
+    const unsigned slot = active ? slot_raw : base;        // idle groups shadow the wave's first keypoint
     int l = 0;
     unsigned lbase = 0;
 #pragma unroll
@@ -670,25 +679,31 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
     const uint8_t* src = level_ptr(s, g, img, l, pitch);
     const uint8_t* blr = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
     const int bpitch = g.lv[l].pitch;
-    // stage the blurred 37x37 patch (rows of 40 bytes starting at kx-18) into LDS
-    for (int i = lane; i < PB_ROWS * PB_DW; i += 64) {
-      const int r = i / PB_DW, c = i - r * PB_DW;
-      pb[wave][r * PB_PITCH + c] = ld_u32(blr + (size_t)(ky - 18 + r) * bpitch + (kx - 18) + 4 * c);
+    // stage the blurred 37x37 patch (rows of 40 bytes starting at kx-18) into this group's LDS patch
+    {
+      const uint8_t* b0 = blr + (size_t)(ky - 18) * bpitch + (kx - 18);
+      for (int i = li; i < PB_ROWS * PB_DW; i += DG_LANES) {
+        const int r = i / PB_DW, c = i - r * PB_DW;
+        myp[r * PB_PITCH + c] = ld_u32(b0 + (size_t)r * bpitch + 4 * c);
+      }
     }
     // intensity centroid over the 749-pixel disc straight from the level image (integer, order independent)
     int sA = 0, sB = 0, sC = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int t = q * 64 + lane;
-      const int r = min(t >> 3, 30), c = t & 7;
-      const unsigned px = ld_u32(src + (size_t)(ky - 15 + r) * pitch + (kx - 15) + 4 * c);
-      const unsigned sI = __builtin_amdgcn_udot4(px, w_ones[q], 0u, false);
-      sA += (int)__builtin_amdgcn_udot4(px, w_col[q], 0u, false);
-      sB += (int)sI;
-      sC += (r - 15) * (int)sI;
+    {
+      const uint8_t* a0 = src + (size_t)(ky - 15) * pitch + (kx - 15);
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int t = it * 16 + li;
+        const int r = min(t >> 3, 30), c = t & 7;
+        const unsigned px = ld_u32(a0 + (size_t)r * pitch + 4 * c);
+        const unsigned sI = __builtin_amdgcn_udot4(px, s_ones[t], 0u, false);
+        sA += (int)__builtin_amdgcn_udot4(px, s_col[t], 0u, false);
+        sB += (int)sI;
+        sC += (r - 15) * (int)sI;
+      }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 8; off >= 1; off >>= 1) {
       sA += __shfl_xor(sA, off);
       sB += __shfl_xor(sB, off);
       sC += __shfl_xor(sC, off);
@@ -699,24 +714,29 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
     sincos_deg(angle, ca, sa);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);   // staging stores visible to the whole wave before the reads
-    unsigned long long word[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float px0 = (float)(signed char)(pat[q] & 0xff), py0 = (float)(signed char)((pat[q] >> 8) & 0xff);
-      const float px1 = (float)(signed char)((pat[q] >> 16) & 0xff), py1 = (float)(signed char)((pat[q] >> 24) & 0xff);
+    unsigned long long word[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+      const int pr = s_pat[r * 16 + li];
+      const float px0 = (float)(signed char)(pr & 0xff), py0 = (float)(signed char)((pr >> 8) & 0xff);
+      const float px1 = (float)(signed char)((pr >> 16) & 0xff), py1 = (float)(signed char)((pr >> 24) & 0xff);
       const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, ca), __fmul_rn(py0, sa)));
       const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, sa), __fmul_rn(py0, ca)));
       const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, ca), __fmul_rn(py1, sa)));
       const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, sa), __fmul_rn(py1, ca)));
       const int t0 = pbb[(iy0 + 18) * (PB_PITCH * 4) + ix0 + 18];
       const int t1 = pbb[(iy1 + 18) * (PB_PITCH * 4) + ix1 + 18];
-      word[q] = __ballot(t0 < t1);
+      const unsigned long long bal = __ballot(t0 < t1);
+      const unsigned long long chunk = (bal >> (16 * grp)) & 0xffffull;     // this keypoint's bits 16r .. 16r+15
+      const unsigned long long sh = chunk << (16 * (r & 3));
+      word[0] |= (r >> 2) == 0 ? sh : 0ull; word[1] |= (r >> 2) == 1 ? sh : 0ull;
+      word[2] |= (r >> 2) == 2 ? sh : 0ull; word[3] |= (r >> 2) == 3 ? sh : 0ull;
     }
-    if (lane < 4) {
-      const unsigned long long wv = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
-      reinterpret_cast<unsigned long long*>(desc_out + ((size_t)img * cap_kp + slot) * 32)[lane] = wv;
+    if (active && li < 4) {
+      const unsigned long long wv = li == 0 ? word[0] : li == 1 ? word[1] : li == 2 ? word[2] : word[3];
+      reinterpret_cast<unsigned long long*>(desc_out + ((size_t)img * cap_kp + slot) * 32)[li] = wv;
     }
-    if (lane == 0) {
+    if (active && li == 4) {
       const float sc = g.lv[l].scale;
       orbx_keypoint o;
       o.x = __fmul_rn((float)kx, sc);
@@ -901,7 +921,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
   }
   {
     ProfScope ps(h, "describe_kernel");
-    const int blocks_x = (h->orb.n_features + 64 + 3) / 4;
+    const int blocks_x = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block
     hipLaunchKernelGGL(describe_kernel, dim3(xcd_grid(blocks_x, n_images)), dim3(256), 0, h->stream, s, g, n_images, blocks_x,
                        (const unsigned long long*)h->ws_sel2.p, kept, d_kp, d_desc, d_nkp, cap_kp,
                        (float)h->orb.patch_size, h->d_status);
