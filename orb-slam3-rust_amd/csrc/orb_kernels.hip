@@ -255,6 +255,36 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int t) {
   return best > t ? best - 1 : 0;
 }
 
+// The same score on packed 16-bit pairs (v_pk_min_i16 / v_pk_max_i16 / v_alignbit): P[j] = (d[2j], d[2j+1]).
+typedef short fast_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int fast_score16_pk(int v, const int (&r)[16], int t) {
+  fast_s2 P[8], Q[8], MN[8], MX[8], A[8], B[8];
+  const unsigned vv = (unsigned)v | ((unsigned)v << 16);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned rp = (unsigned)r[2 * j] | ((unsigned)r[2 * j + 1] << 16);
+    P[j] = __builtin_bit_cast(fast_s2, vv) - __builtin_bit_cast(fast_s2, rp);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) Q[j] = __builtin_shufflevector(P[j], P[(j + 1) & 7], 1, 2);            // (d[2j+1], d[2j+2])
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { MN[j] = __builtin_elementwise_min(P[j], Q[j]); MX[j] = __builtin_elementwise_max(P[j], Q[j]); }   // window 2
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { A[j] = __builtin_elementwise_min(MN[j], MN[(j + 1) & 7]); B[j] = __builtin_elementwise_max(MX[j], MX[(j + 1) & 7]); }   // 4
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { MN[j] = __builtin_elementwise_min(A[j], A[(j + 2) & 7]); MX[j] = __builtin_elementwise_max(B[j], B[(j + 2) & 7]); }     // 8
+  fast_s2 best = {-256, -256};
+  const fast_s2 zero = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const fast_s2 mn9 = __builtin_elementwise_min(MN[j], P[(j + 4) & 7]);                                 // 9
+    const fast_s2 mx9 = __builtin_elementwise_max(MX[j], P[(j + 4) & 7]);
+    best = __builtin_elementwise_max(best, __builtin_elementwise_max(mn9, zero - mx9));
+  }
+  const int b = max((int)best[0], (int)best[1]);
+  return b > t ? b - 1 : 0;
+}
+
 // Two-phase per tile.  Score region 64 x 32 positions (inner 62 x 30 + 1-position NMS frame), pixel tile
 // 72 x 38 bytes staged so that position i sits at byte i+4 of its LDS row (dword aligned):
 //   1. every position, 4 per thread from 5 dword LDS reads: compass pre-test — a 9-arc always contains
@@ -344,14 +374,14 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     const int j = p >> 6, i = p & 63;
     const int cy = j + 3, cx = i + 4;
     const int v = sp[cy][cx];
-    int d[16];
-    d[0] = v - sp[cy + 3][cx];      d[1] = v - sp[cy + 3][cx + 1];  d[2] = v - sp[cy + 2][cx + 2];
-    d[3] = v - sp[cy + 1][cx + 3];  d[4] = v - sp[cy][cx + 3];      d[5] = v - sp[cy - 1][cx + 3];
-    d[6] = v - sp[cy - 2][cx + 2];  d[7] = v - sp[cy - 3][cx + 1];  d[8] = v - sp[cy - 3][cx];
-    d[9] = v - sp[cy - 3][cx - 1];  d[10] = v - sp[cy - 2][cx - 2]; d[11] = v - sp[cy - 1][cx - 3];
-    d[12] = v - sp[cy][cx - 3];     d[13] = v - sp[cy + 1][cx - 3]; d[14] = v - sp[cy + 2][cx - 2];
-    d[15] = v - sp[cy + 3][cx - 1];
-    ss[j][i] = (uint8_t)fast_score16(d, t);
+    int r[16];
+    r[0] = sp[cy + 3][cx];      r[1] = sp[cy + 3][cx + 1];  r[2] = sp[cy + 2][cx + 2];
+    r[3] = sp[cy + 1][cx + 3];  r[4] = sp[cy][cx + 3];      r[5] = sp[cy - 1][cx + 3];
+    r[6] = sp[cy - 2][cx + 2];  r[7] = sp[cy - 3][cx + 1];  r[8] = sp[cy - 3][cx];
+    r[9] = sp[cy - 3][cx - 1];  r[10] = sp[cy - 2][cx - 2]; r[11] = sp[cy - 1][cx - 3];
+    r[12] = sp[cy][cx - 3];     r[13] = sp[cy + 1][cx - 3]; r[14] = sp[cy + 2][cx - 2];
+    r[15] = sp[cy + 3][cx - 1];
+    ss[j][i] = (uint8_t)fast_score16_pk(v, r, t);
   }
   __syncthreads();
   // phase 3: NMS (strictly greater than the 8 neighbours) + runByImageBorder, over the list
