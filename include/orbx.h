@@ -104,7 +104,7 @@ int orbx_synchronize(orbx_handle* h);
  * (stereo.rs:80-161), triangulate (stereo.rs:186-216).
  *   left/right: CV_8UC1 rows of `w` pixels, row strides in bytes.
  *   kpL/kpR [cap_kp], descL/descR [cap_kp*32], matches [cap_kp], points_cam [cap_kp*3],
- *   has_point [cap_kp] (1 = Some, 0 = None; points_cam left untouched where 0). */
+ *   has_point [cap_kp] (1 = Some, 0 = None; points_cam is (0,0,0) where 0). */
 int orbx_process_stereo(orbx_handle* h, const uint8_t* left, size_t lstride, const uint8_t* right,
                         size_t rstride, int w, int h_px, orbx_keypoint* kpL, uint8_t* descL,
                         int* nL, orbx_keypoint* kpR, uint8_t* descR, int* nR, int cap_kp,

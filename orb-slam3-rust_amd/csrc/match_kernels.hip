@@ -204,6 +204,10 @@ __global__ __launch_bounds__(256) void stereo_compact_kernel(
           hp = 1;
         }
       }
+      if (!hp) {   // None: defined contents (zeros) so that outputs are reproducible byte for byte
+        double* P = points + ((size_t)pair * cap + li) * 3;
+        P[0] = 0.0; P[1] = 0.0; P[2] = 0.0;
+      }
       has_point[(size_t)pair * cap + li] = hp;
     }
     __syncthreads();

@@ -1,6 +1,7 @@
 // orbx_api.hip — the C ABI of include/orbx.h: handle lifetime, host<->device staging, status,
 // per-kernel timing.  Host logic only; kernels live in match_kernels.hip / orb_kernels.hip /
 // ba_kernels.hip.  There is no CPU fallback anywhere in this library.
+#include <cstdlib>
 #include <mutex>
 
 #include "orbx_internal.hpp"
@@ -135,6 +136,7 @@ void orbx_destroy(orbx_handle* h) {
   if (h->s_in) hipStreamDestroy(h->s_in);
   if (h->s_out) hipStreamDestroy(h->s_out);
   for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
+  if (h->pair_graph) hipGraphExecDestroy(h->pair_graph);
   if (h->h_stage) hipHostFree(h->h_stage);
   if (h->d_status) hipFree(h->d_status);
   if (h->h_status) hipHostFree(h->h_status);
@@ -431,12 +433,48 @@ int orbx_process_stereo(orbx_handle* h, const uint8_t* left, size_t lstride, con
   ORBX_HIP(h, hipMemcpy2DAsync(d_img, w, left, lstride, w, h_px, hipMemcpyHostToDevice, h->stream));
   ORBX_HIP(h, hipMemcpy2DAsync(d_img + img, w, right, rstride, w, h_px, hipMemcpyHostToDevice, h->stream));
   int* d_cnt = (int*)(d_out + o_cnt);
-  if (int rc = orbx_process_stereo_batch_device(h, d_img, 1, w, h_px, (size_t)w, (orbx_keypoint*)(d_out + o_kp), d_out + o_desc,
-                                                d_cnt, cap_kp, (orbx_dmatch*)(d_out + o_m), d_cnt + 2, (double*)(d_out + o_pts),
-                                                d_out + o_has))
-    return rc;
-  ORBX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_status, sizeof(unsigned), hipMemcpyDeviceToDevice, h->stream));
-  ORBX_HIP(h, hipMemsetAsync(h->d_status, 0, sizeof(unsigned), h->stream));
+  auto enqueue_device_part = [&]() -> int {
+    if (int rc = orbx_process_stereo_batch_device(h, d_img, 1, w, h_px, (size_t)w, (orbx_keypoint*)(d_out + o_kp), d_out + o_desc,
+                                                  d_cnt, cap_kp, (orbx_dmatch*)(d_out + o_m), d_cnt + 2, (double*)(d_out + o_pts),
+                                                  d_out + o_has))
+      return rc;
+    ORBX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_status, sizeof(unsigned), hipMemcpyDeviceToDevice, h->stream));
+    ORBX_HIP(h, hipMemsetAsync(h->d_status, 0, sizeof(unsigned), h->stream));
+    return ORBX_OK;
+  };
+  // The device part (memset + ~20 short kernels) is launch-bound for one pair: after two eager calls with an
+  // unchanged configuration (all workspaces allocated, tables uploaded) it is captured into a hipGraph once and
+  // replayed with a single launch per frame.  ORBX_NO_GRAPH=1 or profiling keeps the eager path.
+  static const bool no_graph = getenv("ORBX_NO_GRAPH") != nullptr;
+  const bool same = h->pg_w == w && h->pg_h == h_px && h->pg_cap == cap_kp && h->pg_img == (void*)d_img && h->pg_out == (void*)d_out;
+  if (!same) {
+    if (h->pair_graph) { hipGraphExecDestroy(h->pair_graph); h->pair_graph = nullptr; }
+    h->pg_w = w; h->pg_h = h_px; h->pg_cap = cap_kp; h->pg_img = d_img; h->pg_out = d_out; h->pg_calls = 0;
+  }
+  if (no_graph || h->profiling) {
+    if (int rc = enqueue_device_part()) return rc;
+  } else if (h->pair_graph) {
+    ORBX_HIP(h, hipGraphLaunch(h->pair_graph, h->stream));
+  } else if (h->pg_calls < 2) {
+    ++h->pg_calls;
+    if (int rc = enqueue_device_part()) return rc;
+  } else {
+    hipGraph_t graph = nullptr;
+    ORBX_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_device_part();
+    const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc != ORBX_OK || e != hipSuccess || !graph) {
+      if (graph) hipGraphDestroy(graph);
+      h->pg_calls = -1000000;      // capture is not possible here: stay eager
+      (void)hipGetLastError();
+      if (int rc2 = enqueue_device_part()) return rc2;
+    } else {
+      const hipError_t ei = hipGraphInstantiate(&h->pair_graph, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (ei != hipSuccess) { h->pair_graph = nullptr; h->pg_calls = -1000000; (void)hipGetLastError(); if (int rc2 = enqueue_device_part()) return rc2; }
+      else ORBX_HIP(h, hipGraphLaunch(h->pair_graph, h->stream));
+    }
+  }
   ORBX_HIP(h, hipMemcpyAsync(h->h_stage, d_out, total, hipMemcpyDeviceToHost, h->stream));
   ORBX_HIP(h, hipStreamSynchronize(h->stream));
   const uint8_t* S = h->h_stage;

@@ -71,6 +71,12 @@ struct orbx_handle {
   unsigned* h_status = nullptr;   // pinned
   uint8_t* h_stage = nullptr;     // pinned mirror of the single-pair output block (orbx_process_stereo)
   size_t h_stage_bytes = 0;
+  // hipGraph of the device part of orbx_process_stereo (launch-bound: ~20 short launches per frame); valid for
+  // one (w, h, cap, buffer addresses) configuration, re-captured when any of them changes
+  hipGraphExec_t pair_graph = nullptr;
+  int pg_w = 0, pg_h = 0, pg_cap = 0, pg_calls = 0;
+  void* pg_img = nullptr;
+  void* pg_out = nullptr;
   // cached level geometry + resize tables for the last image size
   int geom_w = 0, geom_h = 0;
   OrbGeom geom{};
