@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(BaDims d, const BaState*
 }
 
 // result block (doubles): [0] chi2  [1] gnorm  [2] chol_ok  [3] |dp|^2  [4] |p_pose|^2
-// One workgroup of 256 threads.  S lives in LDS (n <= ~135) or in global memory; the right-hand side always
-// in LDS.  Right-looking Cholesky: 2 barriers per column, trailing update on a 16x16 thread grid; the two
+// One workgroup.  S lives in LDS (n <= ~135; larger systems take the multi-kernel path below); the right-hand
+// side always in LDS.  Right-looking Cholesky: 2 barriers per column, trailing update on a 16x16 thread grid; the two
 // triangular solves run in wave 0 alone as row dot products with shuffle reductions (no block barriers).
 constexpr int BA_SOLVE_THREADS = 1024;
 constexpr int BA_TG = 32;                 // trailing update runs on a BA_TG x BA_TG thread grid
@@ -583,11 +583,197 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(int n, c
   extern __shared__ __align__(16) double dyn[];
   solve_body(n, St, P0, P1, rb, K, dyn, dp, res);
 }
-__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_gmem_kernel(int n, const BaState* St, double* P0, double* P1,
-                                                                         const double* __restrict__ rb, int K,
-                                                                         double* __restrict__ Sg, double* __restrict__ dp,
-                                                                         double* __restrict__ res) {
-  solve_body(n, St, P0, P1, rb, K, Sg, dp, res);
+
+// ---- large reduced systems (n > ~135: S does not fit LDS) -------------------------------------------------------
+// Right-looking blocked Cholesky over several launches, panels of 16 columns, S in global memory (L2 resident):
+//   ba_big_assemble_kernel   S = blockdiag(U*) - S_red, b, |g|                                   (many blocks)
+//   per panel:  ba_big_panel_kernel   16x16 diagonal block in LDS, rows below solved against it   (1 block)
+//               ba_big_update_kernel  trailing  S22 -= L21 L21^T : one wave per lower 16x16 tile, four
+//                                     v_mfma_f64_16x16x4_f64 (rank-16 update)                     (many waves)
+//   ba_big_subst_kernel      panel-blocked forward / backward substitution, |dp|^2, |p|^2         (1 block)
+constexpr int BB_NB = 16;
+
+__global__ __launch_bounds__(256) void ba_big_assemble_kernel(int n, const BaState* St, double* P0, double* P1,
+                                                              const double* __restrict__ rb, int K, double* __restrict__ Sg,
+                                                              double* __restrict__ bvec, double* __restrict__ res) {
+  if (St->done) return;
+  const double lambda = St->lambda;
+  const size_t nn = (size_t)n * n;
+  const double* U = rb + nn;
+  const double* gp = U + 36 * (size_t)K;
+  const double* bred = gp + n;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  for (size_t idx = gt; idx < nn; idx += nth) {
+    const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
+    double v = -rb[idx];
+    if (i / 6 == j / 6) {
+      double u = U[36 * (size_t)(i / 6) + (i % 6) * 6 + (j % 6)];
+      if (i == j) u += lambda * fmax(u, 1e-6);
+      v += u;
+    }
+    Sg[idx] = v;
+  }
+  for (int i = gt; i < n; i += nth) bvec[i] = -gp[i] + bred[i];
+  if (blockIdx.x == 0) {
+    __shared__ double sh[256];
+    double gs = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) gs += gp[i] * gp[i];
+    sh[threadIdx.x] = gs;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) { if ((int)threadIdx.x < s2) sh[threadIdx.x] += sh[threadIdx.x + s2]; __syncthreads(); }
+    if (threadIdx.x == 0) { res[0] = bred[n]; res[1] = sqrt(sh[0] + bred[n + 1]); res[2] = 1.0; }
+  }
+}
+
+__global__ __launch_bounds__(256) void ba_big_panel_kernel(int n, int c0, const BaState* St, double* __restrict__ Sg,
+                                                           double* __restrict__ ginv, double* __restrict__ res) {
+  __shared__ double D[BB_NB][BB_NB + 1];
+  __shared__ double rinv[BB_NB];
+  __shared__ int s_ok;
+  if (St->done || res[2] == 0.0) return;
+  const int tid = threadIdx.x, nb = min(BB_NB, n - c0);
+  if (tid == 0) s_ok = 1;
+  {
+    const int i = tid / BB_NB, j = tid % BB_NB;
+    D[i][j] = (i < nb && j <= i) ? Sg[(size_t)(c0 + i) * n + c0 + j] : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    const double d = D[j][j];
+    if (!(d > 0.0)) { if (tid == 0) s_ok = 0; break; }   // uniform
+    const double ri = rsqrt_nr(d);
+    __syncthreads();
+    if (tid == 0) { rinv[j] = ri; D[j][j] = d * ri; }
+    if (tid > j && tid < nb) D[tid][j] *= ri;
+    __syncthreads();
+    const int i = tid / BB_NB, k = tid % BB_NB;
+    if (k > j && k <= i && i < nb) D[i][k] = fma(-D[i][j], D[k][j], D[i][k]);
+    __syncthreads();
+  }
+  __syncthreads();
+  if (!s_ok) { if (tid == 0) res[2] = 0.0; return; }
+  // factored block and 1/L_jj back to global
+  {
+    const int i = tid / BB_NB, j = tid % BB_NB;
+    if (i < nb && j <= i) Sg[(size_t)(c0 + i) * n + c0 + j] = D[i][j];
+    if (tid < nb) ginv[c0 + tid] = rinv[tid];
+  }
+  // rows below the block: x = a L11^-T
+  for (int r = c0 + BB_NB + tid; r < n; r += 256) {
+    double x[BB_NB];
+    double* row = Sg + (size_t)r * n + c0;
+#pragma unroll
+    for (int j = 0; j < BB_NB; ++j) x[j] = row[j];
+#pragma unroll
+    for (int j = 0; j < BB_NB; ++j) {
+      double v = x[j];
+#pragma unroll
+      for (int t = 0; t < j; ++t) v = fma(-x[t], D[j][t], v);
+      x[j] = v * rinv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BB_NB; ++j) row[j] = x[j];
+  }
+}
+
+// one wave per lower 16x16 tile (ti >= tj) of the trailing matrix [c1, n) x [c1, n), c1 = c0 + 16
+__global__ __launch_bounds__(256) void ba_big_update_kernel(int n, int c0, const BaState* St, double* __restrict__ Sg,
+                                                            const double* __restrict__ res) {
+  if (St->done || res[2] == 0.0) return;
+  const int lane = threadIdx.x & 63;
+  const int c1 = c0 + BB_NB, m = n - c1;
+  if (m <= 0) return;
+  const int nt = (m + 15) / 16;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= nt * (nt + 1) / 2) return;
+  int ti = 0, rem = unit;
+  while (rem > ti) { rem -= ti + 1; ++ti; }      // unit = ti (ti + 1) / 2 + tj, tj <= ti
+  const int tj = rem;
+  const int ra = min(c1 + 16 * ti + (lane & 15), n - 1), rb_ = min(c1 + 16 * tj + (lane & 15), n - 1);
+  const double* pa = Sg + (size_t)ra * n + c0 + (lane >> 4);
+  const double* pb = Sg + (size_t)rb_ * n + c0 + (lane >> 4);
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  double av[4], bv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { av[q] = pa[4 * q]; bv[q] = pb[4 * q]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+  const int col = c1 + 16 * tj + (lane & 15);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = c1 + 16 * ti + (lane >> 4) + 4 * q;
+    if (row < n && col <= row) Sg[(size_t)row * n + col] -= acc[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void ba_big_subst_kernel(int n, const BaState* St, double* P0, double* P1,
+                                                           const double* __restrict__ Sg, const double* __restrict__ ginv,
+                                                           const double* __restrict__ bvec, double* __restrict__ dp,
+                                                           double* __restrict__ res) {
+  __shared__ double sb[BA_MAX_N];
+  __shared__ double y[BB_NB];
+  __shared__ double red[256];
+  if (St->done) return;
+  const double* params = ba_cur(St, P0, P1);
+  const int tid = threadIdx.x;
+  const int ok = res[2] != 0.0;
+  if (ok) {
+    for (int i = tid; i < n; i += 256) sb[i] = bvec[i];
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += BB_NB) {            // forward: L y = b
+      const int nb = min(BB_NB, n - c0);
+      if (tid == 0) {
+        for (int j = 0; j < nb; ++j) {
+          double v = sb[c0 + j];
+          for (int i = 0; i < j; ++i) v = fma(-Sg[(size_t)(c0 + j) * n + c0 + i], y[i], v);
+          y[j] = v * ginv[c0 + j];
+          sb[c0 + j] = y[j];
+        }
+      }
+      __syncthreads();
+      for (int r = c0 + nb + tid; r < n; r += 256) {
+        const double* row = Sg + (size_t)r * n + c0;
+        double v = sb[r];
+        for (int j = 0; j < nb; ++j) v = fma(-row[j], y[j], v);
+        sb[r] = v;
+      }
+      __syncthreads();
+    }
+    for (int c0 = ((n - 1) / BB_NB) * BB_NB; c0 >= 0; c0 -= BB_NB) {   // backward: L^T x = y
+      const int nb = min(BB_NB, n - c0);
+      if (tid == 0) {
+        for (int j = nb - 1; j >= 0; --j) {
+          double v = sb[c0 + j];
+          for (int i = j + 1; i < nb; ++i) v = fma(-Sg[(size_t)(c0 + i) * n + c0 + j], y[i], v);
+          y[j] = v * ginv[c0 + j];
+          sb[c0 + j] = y[j];
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < c0; i += 256) {
+        double v = sb[i];
+        for (int j = 0; j < nb; ++j) v = fma(-Sg[(size_t)(c0 + j) * n + i], y[j], v);
+        sb[i] = v;
+      }
+      __syncthreads();
+    }
+  }
+  double dsq = 0.0, psq = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double v = ok ? sb[i] : 0.0;
+    dp[i] = v;
+    dsq += v * v;
+    psq += params[i] * params[i];
+  }
+  red[tid] = dsq;
+  __syncthreads();
+  for (int s2 = 128; s2 >= 1; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+  if (tid == 0) res[3] = red[0];
+  __syncthreads();
+  red[tid] = psq;
+  __syncthreads();
+  for (int s2 = 128; s2 >= 1; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+  if (tid == 0) res[4] = red[0];
 }
 
 // delta_l = V*^-1 (-g_l - sum_k W_kj^T delta_p_k); trial = params + delta; per-point |delta_l|^2, |p_l|^2.
@@ -823,7 +1009,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
       {B_OA, 96 * (size_t)std::max(N, 1)}, {B_OR, 16 * (size_t)std::max(N, 1)}, {B_OYG, 48 * (size_t)std::max(N, 1)},
       {B_VINV, 72 * (size_t)std::max(M, 1)}, {B_GL, 24 * (size_t)std::max(M, 1)}, {B_PT, 8 * 4 * (size_t)std::max(M, 1)},
       {B_WT, 8 * (size_t)d.rows * d.P}, {B_YT, 8 * (size_t)d.rows * d.P}, {B_PART, 8 * n_upper * d.ksplit * 256},
-      {B_UG, 8 * (size_t)(33 * BA_KFSPLIT * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 2 * (size_t)n + 32 + BA_SOLVE_THREADS)}, {B_RES, 8 * 16}};
+      {B_UG, 8 * (size_t)(33 * BA_KFSPLIT * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 4 * (size_t)n + 64 + BA_SOLVE_THREADS)}, {B_RES, 8 * 16}};
   for (auto& nd : need) if (int rc = orbx_reserve(h, h->ws_ba[nd.id], nd.bytes)) return rc;
   auto D = [&](int id) { return (double*)h->ws_ba[id].p; };
   auto I = [&](int id) { return (int*)h->ws_ba[id].p; };
@@ -925,10 +1111,25 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     if (int rc = allreduce(D(B_RB), rb_len)) return rc;
     {
       ProfScope ps(h, "ba_solve_kernel");
-      if (use_lds)
+      if (use_lds) {
         hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_THREADS), lds_need, st, n, S, P0, P1, D(B_RB), K, D(B_SOLVE), res);
-      else
-        hipLaunchKernelGGL(ba_solve_gmem_kernel, dim3(1), dim3(BA_SOLVE_THREADS), 0, st, n, S, P0, P1, D(B_RB), K, D(B_SOLVE) + ((n + 15) & ~15), D(B_SOLVE), res);
+      } else {
+        // B_SOLVE layout: dp [n pad 16] | S [n*n] | b [n] | 1/L_jj [n]
+        double* dpv = D(B_SOLVE);
+        double* Sg = dpv + ((n + 15) & ~15);
+        double* bvec = Sg + (size_t)n * n;
+        double* ginv = bvec + n;
+        hipLaunchKernelGGL(ba_big_assemble_kernel, dim3(std::min(512, (n * n + 255) / 256)), dim3(256), 0, st, n, S, P0, P1, D(B_RB), K, Sg, bvec, res);
+        for (int c0 = 0; c0 < n; c0 += BB_NB) {
+          hipLaunchKernelGGL(ba_big_panel_kernel, dim3(1), dim3(256), 0, st, n, c0, S, Sg, ginv, res);
+          const int m = n - c0 - BB_NB;
+          if (m > 0) {
+            const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2;
+            hipLaunchKernelGGL(ba_big_update_kernel, dim3((units + 3) / 4), dim3(256), 0, st, n, c0, S, Sg, res);
+          }
+        }
+        hipLaunchKernelGGL(ba_big_subst_kernel, dim3(1), dim3(256), 0, st, n, S, P0, P1, Sg, ginv, bvec, dpv, res);
+      }
     }
     {
       ProfScope ps(h, "ba_backsub_kernel");
