@@ -20,6 +20,9 @@ int orbx_fail(orbx_handle* h, int code, const char* fmt, ...) {
 
 int orbx_reserve(orbx_handle* h, DevBuf& b, size_t bytes) {
   if (bytes <= b.bytes) return ORBX_OK;
+  // any captured graph holds the addresses of the workspaces: a re-allocation invalidates it
+  if (h->pair_graph) { hipGraphExecDestroy(h->pair_graph); h->pair_graph = nullptr; }
+  h->pg_calls = 0;
   if (b.p) {
     ORBX_HIP(h, hipStreamSynchronize(h->stream));
     ORBX_HIP(h, hipFree(b.p));

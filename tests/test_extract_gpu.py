@@ -225,3 +225,20 @@ def test_orb_parameter_variations(oracle, pkg, over):
     assert np.array_equal(dL, od) and len(ok) > 300
     assert int(kpL["octave"].max()) == p.n_levels - 1
     h.close()
+
+
+def test_graph_replay_survives_workspace_growth(oracle, pkg):
+    """the captured single-pair graph must be dropped when a larger batch call re-allocates the workspaces"""
+    import torch
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 700, device=0, max_w=752, max_h=480, max_batch=6)
+    L, R = pkg.synth.stereo_pair(71, 0)
+    first = [h.process_stereo(L, R) for _ in range(4)]            # eager, eager, capture, replay
+    out = h.alloc_batch_outputs(6, 1004)
+    h.process_stereo_batch_device(torch.from_numpy(pkg.synth.stereo_batch(72, 0, 6)).cuda(), out)   # grows every workspace
+    h.check_status()
+    again = [h.process_stereo(L, R) for _ in range(4)]
+    for r in first[1:] + again:
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(first[0], r))
+    ok, od = oracle.orb_extract(L, oracle.orb_params(700))
+    assert records_equal(first[0][0], ok) and np.array_equal(first[0][1], od)
+    h.close()
