@@ -193,6 +193,20 @@ int orbx_guided_match_device(orbx_handle* h, const orbx_keypoint* d_kp, const ui
                              double img_w, double img_h, const double* d_q_uv, const uint8_t* d_q_desc,
                              int nq, double radius, int mode, int* d_out_idx, uint32_t* d_out_dist);
 
+/* = search_for_triangulation (src/local_mapping/triangulation.rs:401-527): matches between the features of two
+ * keyframes that have no map point yet, inside a 100-px grid neighbourhood (32-px cells), gated by the distance to
+ * the epipole (features without stereo depth) and to the epipolar line (chi2 3.84), smallest Hamming distance
+ * < max_dist, greedy one-to-one in ascending index of keyframe 1.
+ *   mp1 [n1] / mp2 [n2]: 1 = the feature already has a map point; stereo1 [n1]: 1 = points_cam is Some;
+ *   pose1_wc / pose2_wc: 7 doubles (qw,qx,qy,qz,tx,ty,tz), camera-to-world as the Map stores them;
+ *   out_pairs [n1][2] = (idx1, idx2) ascending idx1.  Host memory.  Uses the camera given here (image size is
+ *   2cx x 2cy as in the reference, :434-435). */
+int orbx_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const orbx_keypoint* kp1,
+                                  const uint8_t* desc1, const uint8_t* mp1, const uint8_t* stereo1, int n1,
+                                  const orbx_keypoint* kp2, const uint8_t* desc2, const uint8_t* mp2, int n2,
+                                  const double* pose1_wc, const double* pose2_wc, unsigned max_dist,
+                                  int* out_pairs, int* n_out);
+
 /* ---- local bundle adjustment ------------------------------------------------------ */
 
 /* = LocalBAConfigLM, src/optimizer/local_ba_lm.rs:96-119 */

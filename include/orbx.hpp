@@ -157,6 +157,26 @@ struct SE3 {   // se3.rs:5-8; rotation as unit quaternion (w, x, y, z)
   std::array<double, 3> translation{0, 0, 0};
 };
 
+// triangulation.rs:401-527.  has_map_point1/2: the `map_point_ids[i].is_some()` flags; has_point_cam1: the
+// `points_cam1[i].is_some()` flags.  Returns (idx1, idx2) pairs in ascending idx1.
+inline std::vector<std::pair<size_t, size_t>> search_for_triangulation(
+    Handle& h, const FeatureSet& f1, const std::vector<uint8_t>& has_map_point1, const std::vector<uint8_t>& has_point_cam1,
+    const FeatureSet& f2, const std::vector<uint8_t>& has_map_point2, const SE3& pose1, const SE3& pose2,
+    const CameraModel& camera, uint32_t max_dist) {
+  const int n1 = (int)f1.keypoints.size(), n2 = (int)f2.keypoints.size();
+  const double p1[7] = {pose1.rotation[0], pose1.rotation[1], pose1.rotation[2], pose1.rotation[3], pose1.translation[0], pose1.translation[1], pose1.translation[2]};
+  const double p2[7] = {pose2.rotation[0], pose2.rotation[1], pose2.rotation[2], pose2.rotation[3], pose2.translation[0], pose2.translation[1], pose2.translation[2]};
+  std::vector<int> pairs((size_t)std::max(n1, 1) * 2);
+  int n = 0;
+  const orbx_camera cam = camera.c();
+  h.check(orbx_search_for_triangulation(h.get(), &cam, f1.keypoints.data(), f1.descriptors.data(), has_map_point1.data(),
+                                        has_point_cam1.data(), n1, f2.keypoints.data(), f2.descriptors.data(),
+                                        has_map_point2.data(), n2, p1, p2, max_dist, pairs.data(), &n));
+  std::vector<std::pair<size_t, size_t>> out((size_t)n);
+  for (int i = 0; i < n; ++i) out[(size_t)i] = {(size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]};
+  return out;
+}
+
 struct LocalBAConfigLM {   // local_ba_lm.rs:96-119, Default :109-119
   int max_iterations = 10;
   double param_tolerance = 1e-8, gradient_tolerance = 1e-8, huber_threshold = std::sqrt(5.991);

@@ -10,6 +10,7 @@
 //   src/tracking/tracking_frame.rs:52-128 FeatureGrid::new / get_features_in_area
 //   src/tracking/tracker.rs:880-923       track_local_map descriptor search (ratio rule)
 //   src/tracking/tracker.rs:1126-1157     track_with_motion_model descriptor search
+//   src/local_mapping/triangulation.rs:339-527, 661-705   search_for_triangulation (grid, epipolar gate, greedy)
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -188,6 +189,128 @@ void oracle_guided_match(const orbx_keypoint* kp, const uint8_t* desc, int n, do
       out_idx[q] = bi; out_dist[q] = best;
     }
   }
+}
+
+// ---- search_for_triangulation (src/local_mapping/triangulation.rs:401-527) ------------------------------------
+namespace {
+struct Q { double w, x, y, z; };
+inline void q_rot(const Q& q, const double* v, double* o) {            // nalgebra UnitQuaternion * Vector3
+  const double t[3] = {2.0 * (q.y * v[2] - q.z * v[1]), 2.0 * (q.z * v[0] - q.x * v[2]), 2.0 * (q.x * v[1] - q.y * v[0])};
+  const double c[3] = {q.y * t[2] - q.z * t[1], q.z * t[0] - q.x * t[2], q.x * t[1] - q.y * t[0]};
+  for (int i = 0; i < 3; ++i) o[i] = t[i] * q.w + c[i] + v[i];
+}
+inline Q q_mul(const Q& a, const Q& b) {                                // nalgebra Quaternion * Quaternion
+  return Q{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+           a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+inline void q_to_R(const Q& q, double* R) {
+  const double w = q.w, i = q.x, j = q.y, k = q.z;
+  const double ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+  const double ij = i * j * 2.0, wk = w * k * 2.0, wj = w * j * 2.0, ik = i * k * 2.0, jk = j * k * 2.0, wi = w * i * 2.0;
+  R[0] = ww + ii - jj - kk; R[1] = ij - wk; R[2] = wj + ik;
+  R[3] = wk + ij; R[4] = ww - ii + jj - kk; R[5] = jk - wi;
+  R[6] = ik - wj; R[7] = wi + jk; R[8] = ww - ii - jj + kk;
+}
+inline void mat3_mul(const double* A, const double* B, double* C) {     // row-major, k accumulated in order
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j];
+}
+inline long long f32_as_usize(float v) { return (v != v || v <= 0.0f) ? 0 : (v >= 9.0e18f ? (long long)9.0e18 : (long long)v); }
+}  // namespace
+
+// epipole (x,y) and fundamental matrix F (row-major) as the reference computes them (:418-431, :661-683)
+void oracle_triangulation_geometry(const orbx_camera* cam, const double* pose1_wc, const double* pose2_wc, double* epipole2,
+                                   double* F9) {
+  const Q q1{pose1_wc[0], pose1_wc[1], pose1_wc[2], pose1_wc[3]}, q2{pose2_wc[0], pose2_wc[1], pose2_wc[2], pose2_wc[3]};
+  const double* t1 = pose1_wc + 4;
+  const double* t2 = pose2_wc + 4;
+  const Q q2i{q2.w, -q2.x, -q2.y, -q2.z};                               // pose2.inverse() (se3.rs:56-63)
+  double r[3];
+  q_rot(q2i, t2, r);
+  const double t2i[3] = {-r[0], -r[1], -r[2]};
+  double c1[3];
+  q_rot(q2i, t1, c1);                                                   // pose2_inv.transform_point(c1_world) (:420-421)
+  c1[0] += t2i[0]; c1[1] += t2i[1]; c1[2] += t2i[2];
+  epipole2[0] = cam->fx * c1[0] / c1[2] + cam->cx;                      // :422-426
+  epipole2[1] = cam->fy * c1[1] / c1[2] + cam->cy;
+  double rt[3];
+  q_rot(q2i, t1, rt);
+  const double t12[3] = {t2i[0] - rt[0], t2i[1] - rt[1], t2i[2] - rt[2]};   // :429
+  const Q q1i{q1.w, -q1.x, -q1.y, -q1.z};
+  const Q r12 = q_mul(q2i, q1i);                                        // :430
+  const double tsk[9] = {0.0, -t12[2], t12[1], t12[2], 0.0, -t12[0], -t12[1], t12[0], 0.0};   // :697-703
+  double R[9], E[9], KiT[9], T[9];
+  q_to_R(r12, R);
+  mat3_mul(tsk, R, E);                                                  // :670-672
+  const double Ki[9] = {1.0 / cam->fx, 0.0, -cam->cx / cam->fx, 0.0, 1.0 / cam->fy, -cam->cy / cam->fy, 0.0, 0.0, 1.0};
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) KiT[i * 3 + j] = Ki[j * 3 + i];
+  mat3_mul(KiT, E, T);                                                  // :681 (left to right)
+  mat3_mul(T, Ki, F9);
+}
+
+// out: pairs (idx1, idx2) in ascending idx1; returns the count.  mp1/mp2: 1 = already has a map point;
+// stereo1: 1 = points_cam1[idx1] is Some.  Poses are T_wc (pose.translation = camera centre, :418).
+int oracle_search_for_triangulation(const orbx_camera* cam, const orbx_keypoint* kp1, const uint8_t* desc1, const uint8_t* mp1,
+                                    const uint8_t* stereo1, int n1, const orbx_keypoint* kp2, const uint8_t* desc2,
+                                    const uint8_t* mp2, int n2, const double* pose1_wc, const double* pose2_wc,
+                                    unsigned max_dist, int* out_pairs) {
+  double ep[2], F[9];
+  oracle_triangulation_geometry(cam, pose1_wc, pose2_wc, ep, F);
+  const float CELL = 32.0f;                                              // :339
+  auto f64_as_u32 = [](double v) -> unsigned { return v > 0 ? (v >= 4294967295.0 ? 4294967295u : (unsigned)v) : 0u; };
+  const unsigned iw2 = f64_as_u32(cam->cx * 2.0), ih2 = f64_as_u32(cam->cy * 2.0);      // :434-435
+  long long cols = f32_as_usize(std::ceil((float)iw2 / CELL)), rows = f32_as_usize(std::ceil((float)ih2 / CELL));   // :437-438
+  if (cols > 64) cols = 64;
+  if (rows > 64) rows = 64;
+  if (cols < 1 || rows < 1) return 0;
+  std::vector<std::vector<int>> grid((size_t)(cols * rows));
+  for (int i = 0; i < n2; ++i) {                                         // :356-361
+    long long c = f32_as_usize(kp2[i].x / CELL), r = f32_as_usize(kp2[i].y / CELL);
+    if (c > cols - 1) c = cols - 1;
+    if (r > rows - 1) r = rows - 1;
+    grid[(size_t)(r * cols + c)].push_back(i);
+  }
+  std::vector<uint8_t> matched2((size_t)n2, 0);
+  const float radius = 100.0f;                                           // :442
+  int n_out = 0;
+  for (int i1 = 0; i1 < n1; ++i1) {
+    if (mp1[i1]) continue;                                               // :449-452
+    unsigned best = max_dist;
+    int best2 = -1;
+    const float x = kp1[i1].x, y = kp1[i1].y;
+    const long long c0 = f32_as_usize(std::fmax(std::floor((x - radius) / CELL), 0.0f));   // :376-379
+    long long c1 = f32_as_usize(std::ceil((x + radius) / CELL));
+    const long long r0 = f32_as_usize(std::fmax(std::floor((y - radius) / CELL), 0.0f));
+    long long r1 = f32_as_usize(std::ceil((y + radius) / CELL));
+    if (c1 > cols - 1) c1 = cols - 1;
+    if (r1 > rows - 1) r1 = rows - 1;
+    // epipolar line of kp1 in image 2: l2 = F p1 (:685-687)
+    const double p1[3] = {(double)x, (double)y, 1.0};
+    const double l2[3] = {F[0] * p1[0] + F[1] * p1[1] + F[2] * p1[2], F[3] * p1[0] + F[4] * p1[1] + F[5] * p1[2],
+                          F[6] * p1[0] + F[7] * p1[1] + F[8] * p1[2]};
+    const double den = std::sqrt(l2[0] * l2[0] + l2[1] * l2[1]);        // :692
+    for (long long r = r0; r <= r1; ++r)
+      for (long long c = c0; c <= c1; ++c)
+        for (int i2 : grid[(size_t)(r * cols + c)]) {
+          if (matched2[i2] || mp2[i2]) continue;                         // :479-481
+          const double x2 = (double)kp2[i2].x, y2 = (double)kp2[i2].y;
+          if (!stereo1[i1]) {                                            // :489-497
+            const double dx = ep[0] - x2, dy = ep[1] - y2;
+            if (dx * dx + dy * dy < 100.0 * 1.0) continue;
+          }
+          if (den < 1e-10) continue;                                     // :694-696
+          const double num = std::fabs(l2[0] * x2 + l2[1] * y2 + l2[2] * 1.0);   // :691
+          const double dist_l = num / den;
+          if (!(dist_l * dist_l < 3.84 * 1.0)) continue;                 // :698-702
+          const unsigned d = oracle_hamming256(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+          if (d < best && d <= max_dist) { best2 = i2; best = d; }       // :516-519
+        }
+    if (best2 >= 0) {                                                    // :522-525
+      out_pairs[2 * n_out] = i1; out_pairs[2 * n_out + 1] = best2; ++n_out;
+      matched2[best2] = 1;
+    }
+  }
+  return n_out;
 }
 
 }  // extern "C"

@@ -38,6 +38,13 @@ void oracle_guided_match(const orbx_keypoint* kp, const uint8_t* desc, int n, do
                          const double* q_uv, const uint8_t* q_desc, int nq, double radius, int mode,
                          int* out_idx, uint32_t* out_dist);
 
+void oracle_triangulation_geometry(const orbx_camera* cam, const double* pose1_wc, const double* pose2_wc,
+                                   double* epipole2, double* F9);
+int oracle_search_for_triangulation(const orbx_camera* cam, const orbx_keypoint* kp1, const uint8_t* desc1,
+                                    const uint8_t* mp1, const uint8_t* stereo1, int n1, const orbx_keypoint* kp2,
+                                    const uint8_t* desc2, const uint8_t* mp2, int n2, const double* pose1_wc,
+                                    const double* pose2_wc, unsigned max_dist, int* out_pairs);
+
 /* ---- ORB extractor (orb_ref.cpp) ---- */
 typedef struct {
   int n_levels;

@@ -138,6 +138,17 @@ def guided_match(kp, desc, img_w, img_h, q_uv, q_desc, radius, mode):
     return idx[:nq].copy(), dist[:nq].copy()
 
 
+def search_for_triangulation(cam, kp1, desc1, mp1, stereo1, kp2, desc2, mp2, pose1_wc, pose2_wc, max_dist=50):
+    kp1 = np.ascontiguousarray(kp1, KEYPOINT); kp2 = np.ascontiguousarray(kp2, KEYPOINT)
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    mp1 = np.ascontiguousarray(mp1, np.uint8); mp2 = np.ascontiguousarray(mp2, np.uint8); stereo1 = np.ascontiguousarray(stereo1, np.uint8)
+    p1 = np.ascontiguousarray(pose1_wc, np.float64); p2 = np.ascontiguousarray(pose2_wc, np.float64)
+    out = np.zeros((max(len(kp1), 1), 2), np.int32)
+    n = lib().oracle_search_for_triangulation(C.byref(cam), _p(kp1), _p(desc1), _p(mp1), _p(stereo1), C.c_int(len(kp1)), _p(kp2),
+                                              _p(desc2), _p(mp2), C.c_int(len(kp2)), _p(p1), _p(p2), C.c_uint(max_dist), _p(out))
+    return out[:n].copy()
+
+
 def orb_level_table(w, h, params):
     T = OrbLevels()
     rc = lib().oracle_orb_level_table(C.c_int(w), C.c_int(h), C.byref(params), C.byref(T))

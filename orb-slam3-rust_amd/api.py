@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
     "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual",
-    "orbx_guided_match", "orbx_guided_match_device",
+    "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation",
     "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
     "orbx_debug_read_candidates",
 ]
@@ -314,6 +314,21 @@ class Handle:
                                               C.c_double(img_h), _vp(q_uv), _vp(q_desc), C.c_int(nq), C.c_double(radius),
                                               C.c_int(mode), _vp(idx), _vp(dist)))
         return idx[:nq].copy(), dist[:nq].copy()
+
+    def search_for_triangulation(self, camera, kp1, desc1, mp1, stereo1, kp2, desc2, mp2, pose1_wc, pose2_wc, max_dist=50):
+        """triangulation.rs:401-527.  Returns [(idx1, idx2)] as an int32 [n,2] array, ascending idx1."""
+        kp1 = np.ascontiguousarray(kp1, KEYPOINT); kp2 = np.ascontiguousarray(kp2, KEYPOINT)
+        desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        mp1 = np.ascontiguousarray(mp1, np.uint8); mp2 = np.ascontiguousarray(mp2, np.uint8)
+        stereo1 = np.ascontiguousarray(stereo1, np.uint8)
+        p1 = np.ascontiguousarray(pose1_wc, np.float64); p2 = np.ascontiguousarray(pose2_wc, np.float64)
+        out = np.zeros((max(len(kp1), 1), 2), np.int32)
+        n = C.c_int()
+        cam = camera._c()
+        self._check(self._L.orbx_search_for_triangulation(
+            self._h, C.byref(cam), _vp(kp1), _vp(desc1), _vp(mp1), _vp(stereo1), C.c_int(len(kp1)), _vp(kp2), _vp(desc2),
+            _vp(mp2), C.c_int(len(kp2)), _vp(p1), _vp(p2), C.c_uint(max_dist), _vp(out), C.byref(n)))
+        return out[:n.value].copy()
 
     def hamming_batch(self, a, b):
         a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)

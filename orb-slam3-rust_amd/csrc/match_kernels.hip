@@ -13,6 +13,7 @@
 // integer/byte work bound by L2/HBM reads, not by MFMA.
 #include <algorithm>
 #include <climits>
+#include <cmath>
 
 #include "orbx_internal.hpp"
 
@@ -410,6 +411,196 @@ __global__ __launch_bounds__(256) void guided_match_kernel(const uint8_t* __rest
   }
 }
 
+// ---- search_for_triangulation (src/local_mapping/triangulation.rs:339-527, 661-705) -----------------------------
+// Epipolar-gated, grid-limited, greedy one-to-one matching between two keyframes.  The reference walks the
+// features of keyframe 1 in index order and removes every matched feature of keyframe 2 from later searches
+// (a serial dictatorship).  Exact parallel form: (1) every feature of keyframe 1 proposes its best admissible
+// partner in parallel, ignoring the others; (2) one block walks the proposals in index order — a proposal whose
+// partner is still free is final; one whose partner was taken by an earlier feature is recomputed cooperatively
+// by the whole block against the current `taken` set, then the walk continues.  Only conflicts cost extra work.
+struct TriArgs {
+  double F[9];                 // fundamental matrix, row-major (host, triangulation.rs:670-683)
+  double epx, epy;             // epipole of camera 1 in image 2 (:418-426)
+  int cols, rows;              // 32-px grid over image 2 (:339-346, :437-438)
+  unsigned max_dist;
+  int n1, n2;
+  const orbx_keypoint* kp1; const uint8_t* desc1; const uint8_t* mp1; const uint8_t* stereo1;
+  const orbx_keypoint* kp2; const uint8_t* desc2;
+  const int* cell_start; const int* sorted_idx; const unsigned short* cell_of;
+  uint8_t* taken;              // per feature of keyframe 2: has a map point (mp2) or has been matched
+};
+
+__device__ __forceinline__ int f32_as_cell(float v, int last) {          // Rust `f32 as usize` then .min(last)
+  return (v > 0.0f) ? (v >= (float)(last + 1) ? last : (int)v) : 0;
+}
+
+__global__ __launch_bounds__(1024) void tri_grid_build_kernel(const orbx_keypoint* __restrict__ kp, int n, int cols, int rows,
+                                                              const uint8_t* __restrict__ mp2, int* __restrict__ cell_start,
+                                                              int* __restrict__ sorted_idx, unsigned short* __restrict__ cell_of,
+                                                              uint8_t* __restrict__ taken) {
+  __shared__ int cnt[4096];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncell = cols * rows;
+  for (int i = tid; i < 4096; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const int c = f32_as_cell(kp[i].x / 32.0f, cols - 1), r = f32_as_cell(kp[i].y / 32.0f, rows - 1);   // :357-358
+    const int cell = r * cols + c;
+    cell_of[i] = (unsigned short)cell;
+    taken[i] = mp2[i];
+    atomicAdd(&cnt[cell], 1);
+  }
+  __syncthreads();
+  int c4[4], tot = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { c4[k] = cnt[4 * tid + k]; tot += c4[k]; }
+  int inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = inc - tot;
+  for (int wv = 0; wv < wave; ++wv) base += wsum[wv];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (4 * tid + k <= ncell) cell_start[4 * tid + k] = base; cnt[4 * tid + k] = base; base += c4[k]; }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) sorted_idx[atomicAdd(&cnt[cell_of[i]], 1)] = i;
+}
+
+// best admissible partner of feature i1 over the candidates this thread visits (t, t+stride, ...):
+// key = (distance << 48 | cell << 32 | index), ~0 = none.  Ties go to the first candidate in the reference's
+// visiting order (cells row-major, indices ascending inside a cell).
+template <typename TakenPtr>
+__device__ __forceinline__ unsigned long long tri_scan(const TriArgs& A, TakenPtr taken, int i1, int t, int stride) {
+  const float x = A.kp1[i1].x, y = A.kp1[i1].y;
+  const int c0 = f32_as_cell(fmaxf(floorf((x - 100.0f) / 32.0f), 0.0f), 1 << 30);   // :376-379, radius 100 (:442)
+  const int c1 = min(f32_as_cell(ceilf((x + 100.0f) / 32.0f), 1 << 30), A.cols - 1);
+  const int r0 = f32_as_cell(fmaxf(floorf((y - 100.0f) / 32.0f), 0.0f), 1 << 30);
+  const int r1 = min(f32_as_cell(ceilf((y + 100.0f) / 32.0f), 1 << 30), A.rows - 1);
+  unsigned long long best = ~0ull;
+  if (c0 > c1) return best;
+  const double p0 = (double)x, p1 = (double)y;
+  const double l0 = A.F[0] * p0 + A.F[1] * p1 + A.F[2] * 1.0;           // l2 = F p1 (:685-687)
+  const double l1 = A.F[3] * p0 + A.F[4] * p1 + A.F[5] * 1.0;
+  const double l2 = A.F[6] * p0 + A.F[7] * p1 + A.F[8] * 1.0;
+  const double den = sqrt(l0 * l0 + l1 * l1);                            // :692
+  if (den < 1e-10) return best;                                          // :694-696
+  const bool mono = A.stereo1[i1] == 0;
+  const Desc256 d1 = load_desc(A.desc1 + (size_t)i1 * 32);
+  for (int r = r0; r <= r1; ++r) {
+    const int lo = A.cell_start[r * A.cols + c0], hi = A.cell_start[r * A.cols + c1 + 1];
+    for (int p = lo + t; p < hi; p += stride) {
+      const int i2 = A.sorted_idx[p];
+      if (taken[i2]) continue;                                           // :479-481
+      const double x2 = (double)A.kp2[i2].x, y2 = (double)A.kp2[i2].y;
+      if (mono) {                                                        // :489-497
+        const double dx = A.epx - x2, dy = A.epy - y2;
+        if (dx * dx + dy * dy < 100.0) continue;
+      }
+      const double num = fabs(l0 * x2 + l1 * y2 + l2 * 1.0);             // :691
+      const double dl = num / den;
+      if (!(dl * dl < 3.84)) continue;                                   // :698-702
+      const unsigned d = hamming(d1, load_desc(A.desc2 + (size_t)i2 * 32));
+      if (d >= A.max_dist) continue;                                     // :516 with best_dist starting at max_dist
+      const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)A.cell_of[i2] << 32) | (unsigned)i2;
+      best = key < best ? key : best;
+    }
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256) void tri_propose_kernel(TriArgs A, int* __restrict__ prop) {
+  const int lane = threadIdx.x & 63;
+  const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i1 >= A.n1) return;
+  if (A.mp1[i1]) { if (lane == 0) prop[i1] = -1; return; }               // :449-452
+  unsigned long long key = tri_scan(A, (const uint8_t*)A.taken, i1, lane, kWave);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o = __shfl_xor(key, off); key = o < key ? o : key; }
+  if (lane == 0) prop[i1] = key == ~0ull ? -1 : (int)(unsigned)(key & 0xffffffffull);
+}
+
+// Ordered resolve.  A round looks at the next 256 features at once: a proposal is safe when its partner is free
+// and no earlier feature of the round wants the same partner (owner[] = smallest proposing index, atomicMin).
+// Everything before the first unsafe feature f is committed in order; f is recomputed by the whole block against
+// the current `taken` set and committed; the next round starts at f+1.  Rounds = ceil(n1/256) + #conflicts.
+// owner[] entries left behind by features that are re-examined later stay valid: a feature only changes its
+// proposal when it is the first unsafe one, and then its old partner is already taken.
+template <bool kLds>
+__global__ __launch_bounds__(256) void tri_resolve_kernel(TriArgs A, int* __restrict__ prop, int* __restrict__ owner_g,
+                                                          int* __restrict__ pairs, int* __restrict__ n_out) {
+  extern __shared__ __align__(16) unsigned char tri_smem[];
+  __shared__ int s_i1, s_n, s_first[4], s_cnt[4];
+  __shared__ unsigned long long red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* owner_l = (int*)tri_smem;
+  uint8_t* taken_l = tri_smem + sizeof(int) * (size_t)A.n2;
+  if (kLds) {
+    for (int i = tid; i < A.n2; i += 256) { owner_l[i] = INT_MAX; taken_l[i] = A.taken[i]; }
+  } else {
+    for (int i = tid; i < A.n2; i += 256) owner_g[i] = INT_MAX;
+  }
+  if (tid == 0) { s_i1 = 0; s_n = 0; }
+  __syncthreads();
+  for (;;) {
+    const int base = s_i1, nbase = s_n;
+    if (base >= A.n1) break;
+    const int i = base + tid;
+    const int p = i < A.n1 ? prop[i] : -1;
+    const bool want = p >= 0;
+    bool fre = false;
+    if (want) {
+      fre = kLds ? taken_l[p] == 0 : A.taken[p] == 0;
+      if (fre) { if (kLds) atomicMin(&owner_l[p], i); else atomicMin(&owner_g[p], i); }
+    }
+    __syncthreads();
+    const bool unsafe = want && (!fre || (kLds ? owner_l[p] : owner_g[p]) != i);
+    const unsigned long long ub = __ballot(unsafe), wb = __ballot(want);
+    if (lane == 0) s_first[wave] = ub ? wave * 64 + __ffsll((long long)ub) - 1 : 256;
+    __syncthreads();
+    const int f = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));
+    // ordered commit of the safe prefix [0, f)
+    const unsigned long long pre = wave * 64 >= f ? 0ull : (f - wave * 64 >= 64 ? wb : wb & ((1ull << (f - wave * 64)) - 1ull));
+    if (lane == 0) s_cnt[wave] = __popcll(pre);
+    __syncthreads();
+    int off = nbase;
+    for (int w = 0; w < wave; ++w) off += s_cnt[w];
+    if (want && tid < f) {
+      const int o = off + __popcll(pre & ((1ull << lane) - 1ull));
+      pairs[2 * o] = i; pairs[2 * o + 1] = p;                              // :522-525
+      if (kLds) taken_l[p] = 1; else A.taken[p] = 1;
+    }
+    const int ncommit = nbase + s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+    if (f >= 256) {
+      if (tid == 0) { s_i1 = base + 256; s_n = ncommit; }
+      __syncthreads();
+      continue;
+    }
+    const int i1 = base + f;                       // its partner went to an earlier feature: recompute
+    unsigned long long key = kLds ? tri_scan(A, (const uint8_t*)taken_l, i1, tid, 256) : tri_scan(A, (const uint8_t*)A.taken, i1, tid, 256);
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) { const unsigned long long o = __shfl_xor(key, o2); key = o < key ? o : key; }
+    if (lane == 0) red[wave] = key;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long k = red[0];
+      for (int w = 1; w < 4; ++w) k = red[w] < k ? red[w] : k;
+      int n = ncommit;
+      if (k != ~0ull) {
+        const int q = (int)(unsigned)(k & 0xffffffffull);
+        pairs[2 * n] = i1; pairs[2 * n + 1] = q; ++n;
+        if (kLds) taken_l[q] = 1; else A.taken[q] = 1;
+      }
+      s_i1 = i1 + 1; s_n = n;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *n_out = s_n;
+}
+
 __global__ __launch_bounds__(256) void hamming_batch_kernel(const uint8_t* __restrict__ a,
                                                             const uint8_t* __restrict__ b, int n,
                                                             uint32_t* __restrict__ out) {
@@ -507,6 +698,60 @@ int launch_guided_match(orbx_handle* h, const orbx_keypoint* d_kp, const uint8_t
     ProfScope ps(h, "guided_match_kernel");
     hipLaunchKernelGGL(guided_match_kernel, dim3((nq + 3) / 4), dim3(256), 0, h->stream, d_desc, cell_start, sorted_idx, cell_of,
                        d_q_uv, d_q_desc, nq, radius, winv, hinv, mode, d_out_idx, d_out_dist);
+  }
+  ORBX_HIP(h, hipGetLastError());
+  return ORBX_OK;
+}
+
+int launch_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const double* F9, const double* epipole,
+                                    const orbx_keypoint* d_kp1, const uint8_t* d_desc1, const uint8_t* d_mp1,
+                                    const uint8_t* d_stereo1, int n1, const orbx_keypoint* d_kp2, const uint8_t* d_desc2,
+                                    const uint8_t* d_mp2, int n2, unsigned max_dist, int* d_pairs, int* d_n_out) {
+  if (n1 <= 0 || n2 <= 0) {
+    ORBX_HIP(h, hipMemsetAsync(d_n_out, 0, sizeof(int), h->stream));
+    return ORBX_OK;
+  }
+  auto f64_as_u32 = [](double v) -> unsigned { return v > 0 ? (v >= 4294967295.0 ? 4294967295u : (unsigned)v) : 0u; };
+  const unsigned iw = f64_as_u32(cam->cx * 2.0), ih = f64_as_u32(cam->cy * 2.0);               // triangulation.rs:434-435
+  const float fc = std::ceil((float)iw / 32.0f), fr = std::ceil((float)ih / 32.0f);
+  const int cols = (int)std::min(64.0f, std::max(fc, 0.0f)), rows = (int)std::min(64.0f, std::max(fr, 0.0f));   // :437-438
+  if (cols < 1 || rows < 1) {
+    ORBX_HIP(h, hipMemsetAsync(d_n_out, 0, sizeof(int), h->stream));
+    return ORBX_OK;
+  }
+  // workspace: cell_start int[4100] | sorted_idx int[n2] | prop int[n1] | owner int[n2] | cell_of u16[n2] | taken u8[n2]
+  const size_t bytes = sizeof(int) * (4100 + 2 * (size_t)n2 + (size_t)n1) + 2 * (size_t)n2 + (size_t)n2 + 64;
+  if (int rc = orbx_reserve(h, h->ws_match, bytes)) return rc;
+  int* cell_start = (int*)h->ws_match.p;
+  int* sorted_idx = cell_start + 4100;
+  int* prop = sorted_idx + n2;
+  int* owner = prop + n1;
+  unsigned short* cell_of = (unsigned short*)(owner + n2);
+  uint8_t* taken = (uint8_t*)(cell_of + n2);
+  TriArgs A{};
+  for (int i = 0; i < 9; ++i) A.F[i] = F9[i];
+  A.epx = epipole[0]; A.epy = epipole[1];
+  A.cols = cols; A.rows = rows; A.max_dist = max_dist; A.n1 = n1; A.n2 = n2;
+  A.kp1 = d_kp1; A.desc1 = d_desc1; A.mp1 = d_mp1; A.stereo1 = d_stereo1; A.kp2 = d_kp2; A.desc2 = d_desc2;
+  A.cell_start = cell_start; A.sorted_idx = sorted_idx; A.cell_of = cell_of; A.taken = taken;
+  {
+    ProfScope ps(h, "tri_grid_build_kernel");
+    hipLaunchKernelGGL(tri_grid_build_kernel, dim3(1), dim3(1024), 0, h->stream, d_kp2, n2, cols, rows, d_mp2, cell_start, sorted_idx, cell_of, taken);
+  }
+  {
+    ProfScope ps(h, "tri_propose_kernel");
+    hipLaunchKernelGGL(tri_propose_kernel, dim3((n1 + 3) / 4), dim3(256), 0, h->stream, A, prop);
+  }
+  {
+    ProfScope ps(h, "tri_resolve_kernel");
+    const size_t lds = 5 * (size_t)n2 + 16;
+    if (lds <= 150 * 1024) {
+      if (lds > 64 * 1024)   // more than 64 KB of dynamic LDS needs the opt-in
+        ORBX_HIP(h, hipFuncSetAttribute((const void*)tri_resolve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      hipLaunchKernelGGL(tri_resolve_kernel<true>, dim3(1), dim3(256), lds, h->stream, A, prop, owner, d_pairs, d_n_out);
+    } else {
+      hipLaunchKernelGGL(tri_resolve_kernel<false>, dim3(1), dim3(256), 0, h->stream, A, prop, owner, d_pairs, d_n_out);
+    }
   }
   ORBX_HIP(h, hipGetLastError());
   return ORBX_OK;

@@ -373,6 +373,84 @@ int orbx_guided_match(orbx_handle* h, const orbx_keypoint* kp, const uint8_t* de
   return ORBX_OK;
 }
 
+namespace {
+struct Quat { double w, x, y, z; };
+void quat_rotate(const Quat& q, const double* v, double* o) {            // nalgebra UnitQuaternion * Vector3
+  const double t[3] = {2.0 * (q.y * v[2] - q.z * v[1]), 2.0 * (q.z * v[0] - q.x * v[2]), 2.0 * (q.x * v[1] - q.y * v[0])};
+  const double c[3] = {q.y * t[2] - q.z * t[1], q.z * t[0] - q.x * t[2], q.x * t[1] - q.y * t[0]};
+  for (int i = 0; i < 3; ++i) o[i] = t[i] * q.w + c[i] + v[i];
+}
+void mat3_mul(const double* A, const double* B, double* C) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+// epipole of camera 1 in image 2 and F = K^-T [t12]x R12 K^-1, exactly as triangulation.rs:418-431, :661-683
+void triangulation_geometry(const orbx_camera& cam, const double* p1, const double* p2, double* ep, double* F) {
+  const Quat q1{p1[0], p1[1], p1[2], p1[3]}, q2{p2[0], p2[1], p2[2], p2[3]};
+  const Quat q2i{q2.w, -q2.x, -q2.y, -q2.z}, q1i{q1.w, -q1.x, -q1.y, -q1.z};
+  double r[3], c1[3], rt[3];
+  quat_rotate(q2i, p2 + 4, r);
+  const double t2i[3] = {-r[0], -r[1], -r[2]};                           // pose2.inverse().translation (se3.rs:56-63)
+  quat_rotate(q2i, p1 + 4, c1);
+  c1[0] += t2i[0]; c1[1] += t2i[1]; c1[2] += t2i[2];
+  ep[0] = cam.fx * c1[0] / c1[2] + cam.cx;
+  ep[1] = cam.fy * c1[1] / c1[2] + cam.cy;
+  quat_rotate(q2i, p1 + 4, rt);
+  const double t12[3] = {t2i[0] - rt[0], t2i[1] - rt[1], t2i[2] - rt[2]};
+  const Quat r12{q2i.w * q1i.w - q2i.x * q1i.x - q2i.y * q1i.y - q2i.z * q1i.z, q2i.w * q1i.x + q2i.x * q1i.w + q2i.y * q1i.z - q2i.z * q1i.y,
+                 q2i.w * q1i.y - q2i.x * q1i.z + q2i.y * q1i.w + q2i.z * q1i.x, q2i.w * q1i.z + q2i.x * q1i.y - q2i.y * q1i.x + q2i.z * q1i.w};
+  const double w = r12.w, i = r12.x, j = r12.y, k = r12.z;
+  const double ww = w * w, ii = i * i, jj = j * j, kk = k * k, ij = i * j * 2.0, wk = w * k * 2.0, wj = w * j * 2.0, ik = i * k * 2.0,
+               jk = j * k * 2.0, wi = w * i * 2.0;
+  const double R[9] = {ww + ii - jj - kk, ij - wk, wj + ik, wk + ij, ww - ii + jj - kk, jk - wi, ik - wj, wi + jk, ww - ii - jj + kk};
+  const double tsk[9] = {0.0, -t12[2], t12[1], t12[2], 0.0, -t12[0], -t12[1], t12[0], 0.0};
+  const double Ki[9] = {1.0 / cam.fx, 0.0, -cam.cx / cam.fx, 0.0, 1.0 / cam.fy, -cam.cy / cam.fy, 0.0, 0.0, 1.0};
+  double E[9], KiT[9], T[9];
+  mat3_mul(tsk, R, E);
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) KiT[a * 3 + b] = Ki[b * 3 + a];
+  mat3_mul(KiT, E, T);
+  mat3_mul(T, Ki, F);
+}
+}  // namespace
+
+int orbx_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const orbx_keypoint* kp1, const uint8_t* desc1,
+                                  const uint8_t* mp1, const uint8_t* stereo1, int n1, const orbx_keypoint* kp2,
+                                  const uint8_t* desc2, const uint8_t* mp2, int n2, const double* pose1_wc,
+                                  const double* pose2_wc, unsigned max_dist, int* out_pairs, int* n_out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || n1 < 0 || n2 < 0 || n2 > 65535 * 64 || !pose1_wc || !pose2_wc || !n_out || max_dist > 256 ||
+      (n1 > 0 && (!kp1 || !desc1 || !mp1 || !stereo1 || !out_pairs)) || (n2 > 0 && (!kp2 || !desc2 || !mp2)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_search_for_triangulation: bad argument");
+  *n_out = 0;
+  if (n1 == 0 || n2 == 0) return ORBX_OK;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  double ep[2], F[9];
+  triangulation_geometry(*cam, pose1_wc, pose2_wc, ep, F);
+  const size_t s1 = sizeof(orbx_keypoint) * (size_t)n1, s2 = sizeof(orbx_keypoint) * (size_t)n2;
+  if (int rc = orbx_reserve(h, h->ws_io[0], s1 + s2)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[1], 32 * ((size_t)n1 + n2))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[2], 2 * (size_t)n1 + n2)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[3], sizeof(int) * (2 * (size_t)n1 + 4))) return rc;
+  orbx_keypoint* d_kp1 = (orbx_keypoint*)h->ws_io[0].p; orbx_keypoint* d_kp2 = d_kp1 + n1;
+  uint8_t* d_d1 = (uint8_t*)h->ws_io[1].p; uint8_t* d_d2 = d_d1 + 32 * (size_t)n1;
+  uint8_t* d_mp1 = (uint8_t*)h->ws_io[2].p; uint8_t* d_st1 = d_mp1 + n1; uint8_t* d_mp2 = d_st1 + n1;
+  int* d_pairs = (int*)h->ws_io[3].p; int* d_n = d_pairs + 2 * (size_t)n1;
+  ORBX_HIP(h, hipMemcpyAsync(d_kp1, kp1, s1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_kp2, kp2, s2, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_d1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_d2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_mp1, mp1, (size_t)n1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_st1, stereo1, (size_t)n1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_mp2, mp2, (size_t)n2, hipMemcpyHostToDevice, h->stream));
+  orbx_prof_begin_call(h);
+  if (int rc = launch_search_for_triangulation(h, cam, F, ep, d_kp1, d_d1, d_mp1, d_st1, n1, d_kp2, d_d2, d_mp2, n2, max_dist, d_pairs, d_n))
+    return rc;
+  ORBX_HIP(h, hipMemcpyAsync(n_out, d_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  if (*n_out > 0) ORBX_HIP(h, hipMemcpy(out_pairs, d_pairs, sizeof(int) * 2 * (size_t)*n_out, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
 // ---- extraction + full per-frame path -------------------------------------------------------------------
 
 int orbx_extract_batch_device(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,

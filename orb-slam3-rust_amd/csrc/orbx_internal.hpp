@@ -131,6 +131,10 @@ int launch_hamming_batch(orbx_handle* h, const uint8_t* d_a, const uint8_t* d_b,
 int launch_guided_match(orbx_handle* h, const orbx_keypoint* d_kp, const uint8_t* d_desc, int n, double img_w, double img_h,
                         const double* d_q_uv, const uint8_t* d_q_desc, int nq, double radius, int mode, int* d_out_idx,
                         uint32_t* d_out_dist);
+int launch_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const double* F9, const double* epipole,
+                                    const orbx_keypoint* d_kp1, const uint8_t* d_desc1, const uint8_t* d_mp1,
+                                    const uint8_t* d_stereo1, int n1, const orbx_keypoint* d_kp2, const uint8_t* d_desc2,
+                                    const uint8_t* d_mp2, int n2, unsigned max_dist, int* d_pairs, int* d_n_out);
 // extractor (orb_kernels.hip)
 int orb_prepare_geometry(orbx_handle* h, int w, int h_px);
 int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,

@@ -164,3 +164,47 @@ def ba_window(seed, K, M, obs_dtype, n_fixed_extra=0, w=752, h=480, camera=None,
         init_pts += rng.normal(0, 0.03, init_pts.shape)
     return dict(poses_cw=init, fixed_cw=poses_cw[:F].copy(), points=init_pts, obs=obs,
                 gt_poses_cw=poses_cw[F:].copy(), gt_points=pts, camera=cam)
+
+
+def two_view_features(seed, n_points, keypoint_dtype, n_distractors=300, camera=None, dup=0.0):
+    """Two keyframes looking at the same 3D points (for search_for_triangulation): returns
+    dict(kp1, desc1, mp1, stereo1, kp2, desc2, mp2, pose1_wc, pose2_wc, camera).  Shared points get descriptors
+    that differ in a few bits; `dup` > 0 makes that fraction of the descriptors identical copies (ties and
+    competition for the same partner); flags are random."""
+    cam = dict(EUROC_CAMERA if camera is None else camera)
+    rng = np.random.default_rng([0x7F1, seed])
+    w, h = 2.0 * cam["cx"], 2.0 * cam["cy"]
+    X = np.stack([rng.uniform(-5, 5, n_points), rng.uniform(-3, 3, n_points), rng.uniform(4, 14, n_points)], 1)
+    pose1 = np.concatenate([_quat_from_axis_angle([0, 1, 0], 0.02), [0.0, 0.0, 0.0]])
+    pose2 = np.concatenate([_quat_from_axis_angle([0.1, 1, 0.05], -0.03), [0.45, 0.03, 0.05]])
+
+    def project(pose_wc):
+        qi = pose_wc[:4] * np.array([1, -1, -1, -1.0])
+        pc = _quat_rot(qi, X - pose_wc[4:])
+        return np.stack([cam["fx"] * pc[:, 0] / pc[:, 2] + cam["cx"], cam["fy"] * pc[:, 1] / pc[:, 2] + cam["cy"]], 1), pc[:, 2]
+
+    uv1, z1 = project(pose1)
+    uv2, z2 = project(pose2)
+    ok = (z1 > 0.5) & (z2 > 0.5) & (uv1[:, 0] > 0) & (uv1[:, 0] < w) & (uv1[:, 1] > 0) & (uv1[:, 1] < h) & \
+         (uv2[:, 0] > 0) & (uv2[:, 0] < w) & (uv2[:, 1] > 0) & (uv2[:, 1] < h)
+    uv1, uv2 = uv1[ok], uv2[ok]
+    m = len(uv1)
+    d = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    if dup > 0:
+        k = int(dup * m)
+        d[rng.permutation(m)[:k]] = d[rng.integers(0, max(m // 20, 1), k)]
+    flips = rng.random((m, 256)) < 0.03
+    d2 = np.packbits(np.unpackbits(d, axis=1, bitorder="little") ^ flips.astype(np.uint8), axis=1, bitorder="little")
+    out = {}
+    for name, uv, dd in (("1", uv1, d), ("2", uv2, d2)):
+        nd = n_distractors
+        kp = np.zeros(m + nd, keypoint_dtype)
+        kp["x"] = np.concatenate([uv[:, 0] + rng.normal(0, 0.4, m), rng.uniform(0, w, nd)]).astype(np.float32)
+        kp["y"] = np.concatenate([uv[:, 1] + rng.normal(0, 0.4, m), rng.uniform(0, h, nd)]).astype(np.float32)
+        desc = np.concatenate([dd, rng.integers(0, 256, (nd, 32), dtype=np.uint8)])
+        perm = rng.permutation(m + nd)
+        out["kp" + name] = kp[perm]; out["desc" + name] = desc[perm]
+        out["mp" + name] = (rng.random(m + nd) < 0.3).astype(np.uint8)
+    out["stereo1"] = (rng.random(len(out["kp1"])) < 0.5).astype(np.uint8)
+    out["pose1_wc"] = pose1; out["pose2_wc"] = pose2; out["camera"] = cam
+    return out

@@ -53,6 +53,23 @@ int main(int argc, char** argv) {
     put(fo, &d01, 1); put(fo, &nc, 1); put(fo, cc.data(), cc.size());
     fclose(fo);
 
+    // search_for_triangulation (triangulation.rs:401-527): left/right feature sets as two keyframes
+    {
+      const size_t n1 = f.left_features.keypoints.size(), n2 = f.right_features.keypoints.size();
+      std::vector<uint8_t> mp1(n1), st1(n1), mp2(n2);
+      for (size_t i = 0; i < n1; ++i) { mp1[i] = i % 3 == 0; st1[i] = f.points_cam[i].has_value(); }
+      for (size_t i = 0; i < n2; ++i) mp2[i] = i % 4 == 0;
+      orbx::SE3 p1, p2;
+      p2.rotation = {0.9998000066665778, 0.0, 0.01999866669333308, 0.0};
+      p2.translation = {0.11007, 0.01, 0.02};
+      auto pairs = orbx::search_for_triangulation(sp.handle(), f.left_features, mp1, st1, f.right_features, mp2, p1, p2, cam, 50);
+      fo = fopen((out + "/tri_out.bin").c_str(), "wb");
+      const int np = (int)pairs.size();
+      put(fo, &np, 1);
+      for (auto& pr : pairs) { const int v[2] = {(int)pr.first, (int)pr.second}; put(fo, v, 2); }
+      fclose(fo);
+    }
+
     // ---- solve_visual_ba (local_ba_lm.rs:912-1098) through VisualBAProblemData keyed by ids -----------------
     std::vector<uint8_t> b = slurp(in + "/ba.bin");
     const int* hd = (const int*)b.data();

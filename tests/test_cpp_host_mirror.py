@@ -66,6 +66,14 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
     d01, nc = struct.unpack_from("<Ii", mb, 0)
     assert d01 == oracle.hamming_batch(odl[0], odl[1])[0]
     assert records_equal(np.frombuffer(mb, pkg.DMATCH, nc, 8), oracle.crosscheck_match(odl, odr))
+    # --- search_for_triangulation on the two feature sets
+    tb = open(os.path.join(tmp, "tri_out.bin"), "rb").read()
+    (npairs,) = struct.unpack_from("<i", tb, 0)
+    mp1 = (np.arange(len(okl)) % 3 == 0).astype(np.uint8); mp2 = (np.arange(len(okr)) % 4 == 0).astype(np.uint8)
+    want = oracle.search_for_triangulation(oracle.Camera(**pkg.synth.EUROC_CAMERA), okl, odl, mp1, h0.astype(np.uint8), okr, odr, mp2,
+                                           np.array([1.0, 0, 0, 0, 0, 0, 0]),
+                                           np.array([0.9998000066665778, 0.0, 0.01999866669333308, 0.0, 0.11007, 0.01, 0.02]), 50)
+    assert np.array_equal(np.frombuffer(tb, np.int32, 2 * npairs, 4).reshape(-1, 2), want)
     # --- solve_visual_ba through VisualBAProblemData keyed by ids
     bb = open(os.path.join(tmp, "ba_out.bin"), "rb").read()
     ok, it = struct.unpack_from("<ii", bb, 0)
