@@ -207,6 +207,20 @@ int orbx_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const 
                                   const double* pose1_wc, const double* pose2_wc, unsigned max_dist,
                                   int* out_pairs, int* n_out);
 
+/* = the search of fuse_points_into_keyframes (src/local_mapping/search_in_neighbors.rs:273-343, with
+ * KeyFrame::get_features_in_area, src/atlas/map/keyframe.rs:408-443) for every (map point, target keyframe) pair:
+ * project the point with the keyframe's inverse pose, skip it behind the camera or outside [0,2cx)x[0,2cy), radius
+ * = clamp(radius_scale * depth / fx, 10, 50), best = smallest Hamming distance < desc_threshold among the keyframe's
+ * keypoints inside the circle (lowest index on ties).  The map mutation that consumes the result (:345-383) stays
+ * on the host; it changes neither positions nor descriptors, so all pairs can be searched up front.
+ *   positions [P][3], mp_desc [P][32]; kf_poses_wc [T][7] (qw,qx,qy,qz,tx,ty,tz; the Map's camera-to-world pose);
+ *   kf_feat_offset [T+1]: keyframe t owns kps/descs[kf_feat_offset[t] .. kf_feat_offset[t+1]);
+ *   radius_scale = config.radius_factor * scale_factor.powi(num_levels - 1) (:303);
+ *   out_idx [P][T] = feature index inside the keyframe or -1; out_dist [P][T] (0 where -1).  Host memory. */
+int orbx_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* positions, const uint8_t* mp_desc, int P,
+                     const double* kf_poses_wc, const int* kf_feat_offset, const orbx_keypoint* kps, const uint8_t* descs,
+                     int T, double radius_scale, unsigned desc_threshold, int* out_idx, uint32_t* out_dist);
+
 /* ---- local bundle adjustment ------------------------------------------------------ */
 
 /* = LocalBAConfigLM, src/optimizer/local_ba_lm.rs:96-119 */

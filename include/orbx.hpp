@@ -177,6 +177,35 @@ inline std::vector<std::pair<size_t, size_t>> search_for_triangulation(
   return out;
 }
 
+// The search of fuse_points_into_keyframes (search_in_neighbors.rs:273-343) for every (map point, keyframe) pair.
+// keyframes[t] = (pose, features); returns best feature index per pair, row-major [point][keyframe], -1 = none.
+inline std::vector<int> fuse_search(Handle& h, const std::vector<std::array<double, 3>>& positions, const std::vector<uint8_t>& mp_descriptors,
+                                    const std::vector<std::pair<SE3, const FeatureSet*>>& keyframes, const CameraModel& camera,
+                                    double radius_factor = 3.0, uint32_t desc_threshold = 50) {
+  const int P = (int)positions.size(), T = (int)keyframes.size();
+  std::vector<double> poses(7 * (size_t)T);
+  std::vector<int> off((size_t)T + 1, 0);
+  std::vector<KeyPoint> kps;
+  std::vector<uint8_t> descs;
+  for (int t = 0; t < T; ++t) {
+    const SE3& s = keyframes[(size_t)t].first;
+    for (int i = 0; i < 4; ++i) poses[7 * (size_t)t + i] = s.rotation[i];
+    for (int i = 0; i < 3; ++i) poses[7 * (size_t)t + 4 + i] = s.translation[i];
+    const FeatureSet& f = *keyframes[(size_t)t].second;
+    kps.insert(kps.end(), f.keypoints.begin(), f.keypoints.end());
+    descs.insert(descs.end(), f.descriptors.begin(), f.descriptors.end());
+    off[(size_t)t + 1] = (int)kps.size();
+  }
+  double s7 = 1.2;                       // scale_factor.powi(num_levels - 1) with num_levels = 8 (:248-249, :303)
+  { const double a2 = 1.2 * 1.2, a4 = a2 * a2; s7 = (1.2 * a2) * a4; }
+  std::vector<int> idx((size_t)P * T, -1);
+  std::vector<uint32_t> dist((size_t)P * T, 0);
+  const orbx_camera cam = camera.c();
+  h.check(orbx_fuse_search(h.get(), &cam, P ? positions[0].data() : nullptr, mp_descriptors.data(), P, poses.data(), off.data(),
+                           kps.data(), descs.data(), T, radius_factor * s7, desc_threshold, idx.data(), dist.data()));
+  return idx;
+}
+
 struct LocalBAConfigLM {   // local_ba_lm.rs:96-119, Default :109-119
   int max_iterations = 10;
   double param_tolerance = 1e-8, gradient_tolerance = 1e-8, huber_threshold = std::sqrt(5.991);

@@ -314,3 +314,49 @@ int oracle_search_for_triangulation(const orbx_camera* cam, const orbx_keypoint*
 }
 
 }  // extern "C"
+
+// ---- fuse_points_into_keyframes: the projection + descriptor search of every (map point, target keyframe) pair
+// (src/local_mapping/search_in_neighbors.rs:273-343; KeyFrame::get_features_in_area, src/atlas/map/keyframe.rs:408-443).
+// The map mutation that follows (:345-383) consumes these results on the host and does not change positions,
+// descriptors or features, so the search of all pairs is a pure function of its inputs.
+//   radius_scale = config.radius_factor * scale_factor.powi(num_levels - 1)  (:303, left to the caller so that the
+//   caller's own powi rounding is what is used).  out_idx[p*T + t] = best feature index or -1.
+void oracle_fuse_search(const orbx_camera* cam, const double* positions, const uint8_t* mp_desc, int P,
+                        const double* kf_poses_wc, const int* kf_feat_offset, const orbx_keypoint* kps,
+                        const uint8_t* descs, int T, double radius_scale, unsigned desc_threshold, int* out_idx,
+                        uint32_t* out_dist) {
+  for (int t = 0; t < T; ++t) {
+    const double* pw = kf_poses_wc + 7 * (size_t)t;
+    const Q q{pw[0], pw[1], pw[2], pw[3]};
+    const Q qi{q.w, -q.x, -q.y, -q.z};                                   // se3.rs:57
+    double r[3];
+    q_rot(qi, pw + 4, r);
+    const double ti[3] = {-r[0], -r[1], -r[2]};                            // se3.rs:58
+    const int f0 = kf_feat_offset[t], f1 = kf_feat_offset[t + 1];
+    for (int p = 0; p < P; ++p) {
+      int best_idx = -1;
+      uint32_t best = 0xffffffffu;                                         // :320
+      double pc[3];
+      q_rot(qi, positions + 3 * (size_t)p, pc);                            // transform_point (se3.rs:74-76)
+      pc[0] += ti[0]; pc[1] += ti[1]; pc[2] += ti[2];
+      if (!(pc[2] <= 0.0)) {                                               // :286
+        const double u = cam->fx * pc[0] / pc[2] + cam->cx;               // :291-292
+        const double v = cam->fy * pc[1] / pc[2] + cam->cy;
+        const double width = cam->cx * 2.0, height = cam->cy * 2.0;       // :295-296
+        if (!(u < 0.0 || u >= width || v < 0.0 || v >= height)) {
+          const double radius = radius_scale * pc[2] / cam->fx;           // :303
+          const double sr = std::max(std::min(radius, 50.0), 10.0);       // :304  radius.min(50.0).max(10.0)
+          const double r2 = sr * sr;                                       // keyframe.rs:417
+          for (int i = f0; i < f1; ++i) {
+            const double du = (double)kps[i].x - u, dv = (double)kps[i].y - v;   // keyframe.rs:435-437
+            if (!(du * du + dv * dv <= r2)) continue;
+            const uint32_t d = oracle_hamming256(mp_desc + 32 * (size_t)p, descs + 32 * (size_t)i);
+            if (d < best && d < desc_threshold) { best = d; best_idx = i - f0; }   // :336
+          }
+        }
+      }
+      out_idx[(size_t)p * T + t] = best_idx;
+      out_dist[(size_t)p * T + t] = best_idx >= 0 ? best : 0u;
+    }
+  }
+}

@@ -45,6 +45,11 @@ int oracle_search_for_triangulation(const orbx_camera* cam, const orbx_keypoint*
                                     const uint8_t* desc2, const uint8_t* mp2, int n2, const double* pose1_wc,
                                     const double* pose2_wc, unsigned max_dist, int* out_pairs);
 
+void oracle_fuse_search(const orbx_camera* cam, const double* positions, const uint8_t* mp_desc, int P,
+                        const double* kf_poses_wc, const int* kf_feat_offset, const orbx_keypoint* kps,
+                        const uint8_t* descs, int T, double radius_scale, unsigned desc_threshold, int* out_idx,
+                        uint32_t* out_dist);
+
 /* ---- ORB extractor (orb_ref.cpp) ---- */
 typedef struct {
   int n_levels;

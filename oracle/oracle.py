@@ -149,6 +149,19 @@ def search_for_triangulation(cam, kp1, desc1, mp1, stereo1, kp2, desc2, mp2, pos
     return out[:n].copy()
 
 
+def fuse_search(cam, positions, mp_desc, kf_poses_wc, kf_feat_offset, kps, descs, radius_scale, desc_threshold=50):
+    positions = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+    poses = np.ascontiguousarray(kf_poses_wc, np.float64).reshape(-1, 7)
+    off = np.ascontiguousarray(kf_feat_offset, np.int32)
+    kps = np.ascontiguousarray(kps, KEYPOINT); descs = np.ascontiguousarray(descs, np.uint8).reshape(-1, 32)
+    P, T = len(positions), len(poses)
+    idx = np.full((P, T), -1, np.int32); dist = np.zeros((P, T), np.uint32)
+    lib().oracle_fuse_search(C.byref(cam), _p(positions), _p(mp_desc), C.c_int(P), _p(poses), _p(off), _p(kps), _p(descs),
+                             C.c_int(T), C.c_double(radius_scale), C.c_uint(desc_threshold), _p(idx), _p(dist))
+    return idx, dist
+
+
 def orb_level_table(w, h, params):
     T = OrbLevels()
     rc = lib().oracle_orb_level_table(C.c_int(w), C.c_int(h), C.byref(params), C.byref(T))

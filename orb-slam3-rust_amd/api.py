@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
     "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual",
-    "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation",
+    "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_fuse_search",
     "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
     "orbx_debug_read_candidates",
 ]
@@ -329,6 +329,23 @@ class Handle:
             self._h, C.byref(cam), _vp(kp1), _vp(desc1), _vp(mp1), _vp(stereo1), C.c_int(len(kp1)), _vp(kp2), _vp(desc2),
             _vp(mp2), C.c_int(len(kp2)), _vp(p1), _vp(p2), C.c_uint(max_dist), _vp(out), C.byref(n)))
         return out[:n.value].copy()
+
+    def fuse_search(self, camera, positions, mp_desc, kf_poses_wc, kf_feat_offset, kps, descs, radius_scale, desc_threshold=TH_LOW):
+        """search_in_neighbors.rs:273-343 for every (map point, keyframe) pair -> (idx [P,T] int32, dist [P,T] uint32)."""
+        positions = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        poses = np.ascontiguousarray(kf_poses_wc, np.float64).reshape(-1, 7)
+        off = np.ascontiguousarray(kf_feat_offset, np.int32)
+        kps = np.ascontiguousarray(kps, KEYPOINT); descs = np.ascontiguousarray(descs, np.uint8).reshape(-1, 32)
+        P, T = len(positions), len(poses)
+        if len(off) != T + 1 or len(mp_desc) != P or len(kps) != len(descs):
+            raise ValueError("fuse_search: inconsistent array lengths")
+        idx = np.full((P, T), -1, np.int32); dist = np.zeros((P, T), np.uint32)
+        cam = camera._c()
+        self._check(self._L.orbx_fuse_search(self._h, C.byref(cam), _vp(positions), _vp(mp_desc), C.c_int(P), _vp(poses), _vp(off),
+                                             _vp(kps), _vp(descs), C.c_int(T), C.c_double(radius_scale), C.c_uint(desc_threshold),
+                                             _vp(idx), _vp(dist)))
+        return idx, dist
 
     def hamming_batch(self, a, b):
         a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)

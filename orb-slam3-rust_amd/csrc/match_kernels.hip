@@ -601,6 +601,100 @@ __global__ __launch_bounds__(256) void tri_resolve_kernel(TriArgs A, int* __rest
   if (tid == 0) *n_out = s_n;
 }
 
+// ---- fuse search (src/local_mapping/search_in_neighbors.rs:273-343, src/atlas/map/keyframe.rs:408-443) ---------
+// Every (map point, target keyframe) pair: project, clamp the depth-scaled radius to [10, 50] px, scan the
+// keyframe's keypoints inside the circle, keep the smallest Hamming distance below the threshold (lowest index on
+// ties).  Block = 256 map points x one keyframe; the keyframe's keypoint coordinates stream through LDS and every
+// thread tests all of them (the reference's linear scan, O(P*T*N), in f64 so that the <= r^2 gate is exact).
+#define FUSE_CHUNK 2048
+#define FUSE_THREADS 128
+__global__ __launch_bounds__(FUSE_THREADS) void fuse_search_kernel(orbx_camera cam, const double* __restrict__ positions,
+                                                          const uint8_t* __restrict__ mp_desc, int P,
+                                                          const double* __restrict__ kf_pose_cw, const int* __restrict__ kf_off,
+                                                          const orbx_keypoint* __restrict__ kps, const uint8_t* __restrict__ descs,
+                                                          int T, double radius_scale, unsigned thr, int* __restrict__ out_idx,
+                                                          uint32_t* __restrict__ out_dist) {
+  __shared__ double2 xy[FUSE_CHUNK];   // widened once per block: the circle test is f64 (keyframe.rs:435-437)
+  const int t = blockIdx.y, p = blockIdx.x * FUSE_THREADS + threadIdx.x;
+  const int f0 = kf_off[t], n = kf_off[t + 1] - f0;
+  bool valid = p < P;
+  double u = 0.0, v = 0.0, r2 = -1.0;
+  Desc256 dq{};
+  if (valid) {
+    const double* q = kf_pose_cw + 7 * (size_t)t;                          // inverse pose from the host (se3.rs:56-63)
+    const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    const double px = positions[3 * (size_t)p], py = positions[3 * (size_t)p + 1], pz = positions[3 * (size_t)p + 2];
+    const double t0 = 2.0 * (qy * pz - qz * py), t1 = 2.0 * (qz * px - qx * pz), t2 = 2.0 * (qx * py - qy * px);
+    const double c0 = qy * t2 - qz * t1, c1 = qz * t0 - qx * t2, c2 = qx * t1 - qy * t0;
+    const double x = (t0 * qw + c0 + px) + q[4], y = (t1 * qw + c1 + py) + q[5], z = (t2 * qw + c2 + pz) + q[6];
+    valid = !(z <= 0.0);                                                   // :286
+    if (valid) {
+      u = cam.fx * x / z + cam.cx;                                         // :291-292
+      v = cam.fy * y / z + cam.cy;
+      const double width = cam.cx * 2.0, height = cam.cy * 2.0;
+      valid = !(u < 0.0 || u >= width || v < 0.0 || v >= height);          // :297
+      const double radius = radius_scale * z / cam.fx;                     // :303
+      const double sr = fmax(fmin(radius, 50.0), 10.0);                    // :304
+      r2 = sr * sr;
+      dq = load_desc(mp_desc + 32 * (size_t)p);
+    }
+  }
+  // Hits are rare (about one per query) but each costs a dependent 32-byte global load; they are parked in a
+  // 4-entry list (LDS, one column per thread) and scored together so that a wave stalls once per flush instead of
+  // once per hit.  The scan itself is unrolled by 8 so that the LDS reads and the f64 chains of 8 tests overlap.
+  __shared__ unsigned short hits[4][FUSE_THREADS];
+  unsigned long long best = ~0ull;
+  int nh = 0, cbase = 0;
+  auto flush = [&]() {
+    Desc256 dd[4];
+    int id[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nh) { id[k] = cbase + hits[k][threadIdx.x]; dd[k] = load_desc(descs + 32 * (size_t)(f0 + id[k])); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < nh) {
+        const unsigned d = hamming(dq, dd[k]);
+        if (d < thr) {                                                     // :336
+          const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)id[k];
+          best = key < best ? key : best;
+        }
+      }
+    }
+    nh = 0;
+  };
+  for (int c = 0; c < n; c += FUSE_CHUNK) {
+    const int m = min(FUSE_CHUNK, n - c);
+    if (nh) flush();                                                       // list entries are relative to cbase
+    cbase = c;
+    __syncthreads();
+    for (int i = threadIdx.x; i < FUSE_CHUNK; i += FUSE_THREADS)
+      xy[i] = i < m ? make_double2((double)kps[f0 + c + i].x, (double)kps[f0 + c + i].y) : make_double2(1e300, 1e300);
+    __syncthreads();
+    if (valid) {
+      for (int i = 0; i < m; i += 8) {                                     // padding entries never pass the gate
+        unsigned mask = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const double2 q = xy[i + k];
+          const double du = q.x - u, dv = q.y - v;
+          mask |= (du * du + dv * dv <= r2 ? 1u : 0u) << k;
+        }
+        while (mask) {
+          const int k = __ffs(mask) - 1;
+          mask &= mask - 1;
+          hits[nh][threadIdx.x] = (unsigned short)(i + k);
+          if (++nh == 4) flush();
+        }
+      }
+    }
+  }
+  if (nh) flush();
+  if (p < P) {
+    out_idx[(size_t)p * T + t] = best == ~0ull ? -1 : (int)(unsigned)(best & 0xffffffffull);
+    out_dist[(size_t)p * T + t] = best == ~0ull ? 0u : (unsigned)(best >> 32);
+  }
+}
+
 __global__ __launch_bounds__(256) void hamming_batch_kernel(const uint8_t* __restrict__ a,
                                                             const uint8_t* __restrict__ b, int n,
                                                             uint32_t* __restrict__ out) {
@@ -753,6 +847,18 @@ int launch_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, cons
       hipLaunchKernelGGL(tri_resolve_kernel<false>, dim3(1), dim3(256), 0, h->stream, A, prop, owner, d_pairs, d_n_out);
     }
   }
+  ORBX_HIP(h, hipGetLastError());
+  return ORBX_OK;
+}
+
+int launch_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* d_positions, const uint8_t* d_mp_desc, int P,
+                       const double* d_kf_pose_cw, const int* d_kf_off, const orbx_keypoint* d_kps, const uint8_t* d_descs,
+                       int T, double radius_scale, unsigned desc_threshold, int* d_out_idx, uint32_t* d_out_dist) {
+  if (P <= 0 || T <= 0) return ORBX_OK;
+  if (T > 65535) return orbx_fail(h, ORBX_ERR_INVALID, "fuse search: more than 65535 target keyframes");
+  ProfScope ps(h, "fuse_search_kernel");
+  hipLaunchKernelGGL(fuse_search_kernel, dim3((P + FUSE_THREADS - 1) / FUSE_THREADS, T), dim3(FUSE_THREADS), 0, h->stream, *cam, d_positions, d_mp_desc, P,
+                     d_kf_pose_cw, d_kf_off, d_kps, d_descs, T, radius_scale, desc_threshold, d_out_idx, d_out_dist);
   ORBX_HIP(h, hipGetLastError());
   return ORBX_OK;
 }

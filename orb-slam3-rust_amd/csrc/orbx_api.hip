@@ -451,6 +451,56 @@ int orbx_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const 
   return ORBX_OK;
 }
 
+int orbx_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* positions, const uint8_t* mp_desc, int P,
+                     const double* kf_poses_wc, const int* kf_feat_offset, const orbx_keypoint* kps, const uint8_t* descs, int T,
+                     double radius_scale, unsigned desc_threshold, int* out_idx, uint32_t* out_dist) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || P < 0 || T < 0 || (P > 0 && (!positions || !mp_desc)) || (T > 0 && (!kf_poses_wc || !kf_feat_offset)) ||
+      (P > 0 && T > 0 && (!out_idx || !out_dist)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_fuse_search: bad argument");
+  if (P == 0 || T == 0) return ORBX_OK;
+  if (kf_feat_offset[0] != 0) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_fuse_search: kf_feat_offset[0] must be 0");
+  for (int t = 0; t < T; ++t)
+    if (kf_feat_offset[t + 1] < kf_feat_offset[t]) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_fuse_search: kf_feat_offset not ascending");
+  const int n = kf_feat_offset[T];
+  if (n > 0 && (!kps || !descs)) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_fuse_search: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  std::vector<double> cw(7 * (size_t)T);                                 // kf.pose.inverse() (se3.rs:56-63)
+  for (int t = 0; t < T; ++t) {
+    const double* p = kf_poses_wc + 7 * (size_t)t;
+    const Quat qi{p[0], -p[1], -p[2], -p[3]};
+    double r[3];
+    quat_rotate(qi, p + 4, r);
+    double* o = cw.data() + 7 * (size_t)t;
+    o[0] = qi.w; o[1] = qi.x; o[2] = qi.y; o[3] = qi.z; o[4] = -r[0]; o[5] = -r[1]; o[6] = -r[2];
+  }
+  const size_t pt = (size_t)P * T;
+  if (int rc = orbx_reserve(h, h->ws_io[0], sizeof(orbx_keypoint) * (size_t)std::max(n, 1))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[1], 32 * ((size_t)std::max(n, 1) + P))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[2], sizeof(double) * (3 * (size_t)P + 7 * (size_t)T) + sizeof(int) * ((size_t)T + 1))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[3], 8 * pt)) return rc;
+  orbx_keypoint* d_kps = (orbx_keypoint*)h->ws_io[0].p;
+  uint8_t* d_descs = (uint8_t*)h->ws_io[1].p; uint8_t* d_mpd = d_descs + 32 * (size_t)std::max(n, 1);
+  double* d_pos = (double*)h->ws_io[2].p; double* d_cw = d_pos + 3 * (size_t)P; int* d_off = (int*)(d_cw + 7 * (size_t)T);
+  int* d_idx = (int*)h->ws_io[3].p; uint32_t* d_dist = (uint32_t*)(d_idx + pt);
+  if (n > 0) {
+    ORBX_HIP(h, hipMemcpyAsync(d_kps, kps, sizeof(orbx_keypoint) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP(h, hipMemcpyAsync(d_descs, descs, 32 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  }
+  ORBX_HIP(h, hipMemcpyAsync(d_mpd, mp_desc, 32 * (size_t)P, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_pos, positions, sizeof(double) * 3 * (size_t)P, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_cw, cw.data(), sizeof(double) * 7 * (size_t)T, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_off, kf_feat_offset, sizeof(int) * ((size_t)T + 1), hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));   // cw is a local; pageable copies are staged but keep it simple
+  orbx_prof_begin_call(h);
+  if (int rc = launch_fuse_search(h, cam, d_pos, d_mpd, P, d_cw, d_off, d_kps, d_descs, T, radius_scale, desc_threshold, d_idx, d_dist))
+    return rc;
+  ORBX_HIP(h, hipMemcpyAsync(out_idx, d_idx, sizeof(int) * pt, hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(out_dist, d_dist, sizeof(uint32_t) * pt, hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  return ORBX_OK;
+}
+
 // ---- extraction + full per-frame path -------------------------------------------------------------------
 
 int orbx_extract_batch_device(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,

@@ -135,6 +135,9 @@ int launch_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, cons
                                     const orbx_keypoint* d_kp1, const uint8_t* d_desc1, const uint8_t* d_mp1,
                                     const uint8_t* d_stereo1, int n1, const orbx_keypoint* d_kp2, const uint8_t* d_desc2,
                                     const uint8_t* d_mp2, int n2, unsigned max_dist, int* d_pairs, int* d_n_out);
+int launch_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* d_positions, const uint8_t* d_mp_desc, int P,
+                       const double* d_kf_pose_cw, const int* d_kf_off, const orbx_keypoint* d_kps, const uint8_t* d_descs,
+                       int T, double radius_scale, unsigned desc_threshold, int* d_out_idx, uint32_t* d_out_dist);
 // extractor (orb_kernels.hip)
 int orb_prepare_geometry(orbx_handle* h, int w, int h_px);
 int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,

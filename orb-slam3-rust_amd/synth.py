@@ -208,3 +208,43 @@ def two_view_features(seed, n_points, keypoint_dtype, n_distractors=300, camera=
     out["stereo1"] = (rng.random(len(out["kp1"])) < 0.5).astype(np.uint8)
     out["pose1_wc"] = pose1; out["pose2_wc"] = pose2; out["camera"] = cam
     return out
+
+
+def fuse_scene(seed, n_points, n_kfs, n_feat, keypoint_dtype, camera=None, far_fraction=0.1):
+    """Map points + target keyframes for the fuse search (search_in_neighbors.rs:273-343): keyframe t sits at
+    (0.2t, 0.03 sin t, 0) m with a small yaw; every keyframe sees ~60 % of the points as features (pixel noise
+    N(0,1.5), ~4 % descriptor bits flipped), the rest of its n_feat features are random.  Some points lie behind
+    the cameras or project outside the image; `far_fraction` of them sit 400-4000 m away so that the depth-scaled
+    radius leaves its lower clamp.  Returns dict(positions, mp_desc, kf_poses_wc, kf_feat_offset, kps, descs, camera)."""
+    cam = dict(EUROC_CAMERA if camera is None else camera)
+    rng = np.random.default_rng([0xF05E, seed])
+    w, h = 2.0 * cam["cx"], 2.0 * cam["cy"]
+    z = rng.uniform(2, 20, n_points)
+    far = rng.random(n_points) < far_fraction
+    z[far] = rng.uniform(400, 4000, far.sum())
+    z[rng.random(n_points) < 0.05] *= -1.0
+    X = np.stack([rng.uniform(-0.9, 1.1, n_points) * z * cam["cx"] / cam["fx"], rng.uniform(-0.9, 1.1, n_points) * z * cam["cy"] / cam["fy"], z], 1)
+    mp_desc = rng.integers(0, 256, (n_points, 32), dtype=np.uint8)
+    poses, kps, descs, off = [], [], [], [0]
+    for t in range(n_kfs):
+        pose = np.concatenate([_quat_from_axis_angle([0.05, 1, 0.02], 0.015 * t), [0.2 * t, 0.03 * np.sin(t), 0.0]])
+        poses.append(pose)
+        qi = pose[:4] * np.array([1, -1, -1, -1.0])
+        pc = _quat_rot(qi, X - pose[4:])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = cam["fx"] * pc[:, 0] / pc[:, 2] + cam["cx"]; v = cam["fy"] * pc[:, 1] / pc[:, 2] + cam["cy"]
+        vis = np.nonzero((pc[:, 2] > 0) & (u >= 0) & (u < w) & (v >= 0) & (v < h) & (rng.random(n_points) < 0.6))[0]
+        vis = vis[:n_feat]
+        m = len(vis)
+        kp = np.zeros(n_feat, keypoint_dtype)
+        kp["x"] = np.concatenate([u[vis] + rng.normal(0, 1.5, m), rng.uniform(0, w, n_feat - m)]).astype(np.float32)
+        kp["y"] = np.concatenate([v[vis] + rng.normal(0, 1.5, m), rng.uniform(0, h, n_feat - m)]).astype(np.float32)
+        kp["octave"] = rng.integers(0, 8, n_feat)
+        flips = rng.random((m, 256)) < 0.04
+        d = np.packbits(np.unpackbits(mp_desc[vis], axis=1, bitorder="little") ^ flips.astype(np.uint8), axis=1, bitorder="little")
+        d = np.concatenate([d, rng.integers(0, 256, (n_feat - m, 32), dtype=np.uint8)])
+        perm = rng.permutation(n_feat)
+        kps.append(kp[perm]); descs.append(d[perm]); off.append(off[-1] + n_feat)
+    return dict(positions=X, mp_desc=mp_desc, kf_poses_wc=np.array(poses), kf_feat_offset=np.array(off, np.int32),
+                kps=np.concatenate(kps) if kps else np.zeros(0, keypoint_dtype),
+                descs=np.concatenate(descs) if descs else np.zeros((0, 32), np.uint8), camera=cam)

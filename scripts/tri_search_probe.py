@@ -20,3 +20,25 @@ for n, dup in ((1200, 0.0), (2500, 0.3), (6000, 0.9)):
     h.set_profiling(False)
     print(f"n1={len(s['kp1'])} dup={dup} matches={len(m)} host_call={dt*1e3:.3f} ms  " +
           "  ".join(f"{k}={v[0]/max(v[1],1)*1e3:.1f}us" for k, v in kt.items()))
+
+# fuse search (search_in_neighbors.rs:273-343): P map points x T keyframes x N features
+import ctypes
+from oracle import oracle as O
+for Pn, T, N in ((2000, 20, 1200), (8000, 30, 2000)):
+    s = P.synth.fuse_scene(1, Pn, T, N, P.KEYPOINT)
+    cam = P.CameraModel(**s["camera"])
+    args = (cam, s["positions"], s["mp_desc"], s["kf_poses_wc"], s["kf_feat_offset"], s["kps"], s["descs"], 10.75, 50)
+    for _ in range(3):
+        idx, _d = h.fuse_search(*args)
+    h.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        idx, _d = h.fuse_search(*args)
+    dt = (time.perf_counter() - t0) / 10
+    kt = h.kernel_times()
+    h.set_profiling(False)
+    t0 = time.perf_counter()
+    O.fuse_search(O.Camera(**s["camera"]), *args[1:])
+    tc = time.perf_counter() - t0
+    print(f"fuse P={Pn} T={T} N={N} found={(idx >= 0).sum()} host_call={dt*1e3:.3f} ms  cpu_oracle={tc*1e3:.1f} ms  " +
+          "  ".join(f"{k}={v[0]/max(v[1],1)*1e3:.1f}us" for k, v in kt.items()))
