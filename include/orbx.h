@@ -266,6 +266,21 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
                          int* iterations, double* initial_error, double* final_error);
 
+/* Replaces solve_global_ba (src/optimizer/global_ba.rs:184-418): the same LM loop over ALL keyframes of the map
+ * with the first one (smallest id, :116-119) fixed, and one difference in the linearisation — an observation whose
+ * point is not in front of its camera (z_c <= 0.001) keeps its 100-px residual but contributes zero Jacobian rows
+ * (:561-563).
+ *   poses_cw [K][7]: T_cw of the K = n_kfs - 1 optimised keyframes in kf_ids order with the fixed one removed
+ *   (:214-220); fixed_pose_cw [7]: T_cw of the fixed keyframe; obs[i].kf_idx < 0 (fixed_idx 0) marks it.
+ *   Tolerances come from cfg (GlobalBAConfig defaults: 10 iterations, 1e-6, 1e-6, sqrt(5.991), :36-45).
+ *   poses_wc_out [K][7]; the fixed keyframe's result is its input pose (:386).
+ * ORBX_ERR_EMPTY where the reference returns None (:194-196, :207-209) and for N = 0, which
+ * collect_global_ba_data never produces (:176-178).  The all-reduce hook applies as in orbx_ba_solve_visual. */
+int orbx_ba_solve_global(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+                         const double* poses_cw, const double* fixed_pose_cw, int M, double* points, int N,
+                         const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user,
+                         double* poses_wc_out, int* iterations, double* initial_error, double* final_error);
+
 /* Per-kernel device time for bench.py's roofline block.  While profiling is on
  * (orbx_set_profiling), every launch is bracketed by HIP events on the handle's stream;
  * orbx_get_kernel_times synchronises, fills up to `cap` entries with the durations summed

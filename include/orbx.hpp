@@ -296,4 +296,108 @@ inline std::optional<VisualBAResultData> solve_visual_ba(Handle& h, const Visual
   return r;
 }
 
+
+// ---- global bundle adjustment (src/optimizer/global_ba.rs) --------------------------------------------------------
+struct GlobalBAConfig {   // global_ba.rs:21-46
+  int max_iterations = 10;
+  double param_tolerance = 1e-6, gradient_tolerance = 1e-6, huber_threshold = std::sqrt(5.991);
+};
+
+struct GlobalBAObservation {   // global_ba.rs:70-80
+  KeyFrameId kf_id;
+  MapPointId mp_id;
+  std::array<double, 2> observed_uv;
+};
+
+struct GlobalBAProblemData {   // global_ba.rs:49-67; poses are T_cw
+  std::unordered_map<KeyFrameId, SE3> kf_poses;
+  std::unordered_map<MapPointId, std::array<double, 3>> mp_positions;
+  std::vector<GlobalBAObservation> observations;
+  std::vector<KeyFrameId> kf_ids;
+  std::vector<MapPointId> mp_ids;
+  KeyFrameId fixed_kf_id = 0;
+};
+
+struct GlobalBAResult {   // global_ba.rs:83-98; optimized_poses are T_wc and include the fixed keyframe
+  std::unordered_map<KeyFrameId, SE3> optimized_poses;
+  std::unordered_map<MapPointId, std::array<double, 3>> optimized_points;
+  size_t iterations = 0;
+  double initial_error = 0, final_error = 0;
+};
+
+inline SE3 se3_inverse(const SE3& p) {   // se3.rs:56-63 with nalgebra's quaternion-vector product
+  const double w = p.rotation[0], x = -p.rotation[1], y = -p.rotation[2], z = -p.rotation[3];
+  const double* v = p.translation.data();
+  const double t[3] = {2.0 * (y * v[2] - z * v[1]), 2.0 * (z * v[0] - x * v[2]), 2.0 * (x * v[1] - y * v[0])};
+  const double c[3] = {y * t[2] - z * t[1], z * t[0] - x * t[2], x * t[1] - y * t[0]};
+  SE3 r;
+  r.rotation = {w, x, y, z};
+  for (int i = 0; i < 3; ++i) r.translation[i] = -(t[i] * w + c[i] + v[i]);
+  return r;
+}
+
+// global_ba.rs:184-418.  The id -> index re-keying is the reference's own (:198-229).  Observations of a map point
+// that is not in mp_ids are rejected (collect_global_ba_data never emits one, :160).
+inline std::optional<GlobalBAResult> solve_global_ba(Handle& h, const GlobalBAProblemData& problem, const CameraModel& camera,
+                                                     const GlobalBAConfig& config, const std::function<bool()>& should_stop) {
+  const size_t n_kfs = problem.kf_ids.size(), n_mps = problem.mp_ids.size();
+  if (n_kfs < 2 || n_mps == 0) return std::nullopt;                      // :194-196
+  size_t fixed_pos = n_kfs;
+  for (size_t i = 0; i < n_kfs; ++i) if (problem.kf_ids[i] == problem.fixed_kf_id) { fixed_pos = i; break; }
+  if (fixed_pos == n_kfs) return std::nullopt;                           // :199-202
+  std::unordered_map<KeyFrameId, int> kf_to_param;
+  std::vector<KeyFrameId> opt_ids;
+  for (size_t i = 0; i < n_kfs; ++i) if (i != fixed_pos) { kf_to_param[problem.kf_ids[i]] = (int)opt_ids.size(); opt_ids.push_back(problem.kf_ids[i]); }
+  std::unordered_map<MapPointId, int> mp_to_param;
+  for (size_t i = 0; i < n_mps; ++i) mp_to_param[problem.mp_ids[i]] = (int)i;
+  auto push7 = [](std::vector<double>& v, const SE3& p) {
+    v.insert(v.end(), p.rotation.begin(), p.rotation.end());
+    v.insert(v.end(), p.translation.begin(), p.translation.end());
+  };
+  std::vector<double> poses, fixed, points;
+  for (KeyFrameId id : opt_ids) { auto it = problem.kf_poses.find(id); push7(poses, it != problem.kf_poses.end() ? it->second : SE3{}); }   // :232-243
+  auto fit = problem.kf_poses.find(problem.fixed_kf_id);
+  const SE3 fixed_pose = fit != problem.kf_poses.end() ? fit->second : SE3{};                                                             // :256-261
+  push7(fixed, fixed_pose);
+  for (MapPointId id : problem.mp_ids) {
+    auto it = problem.mp_positions.find(id);
+    const std::array<double, 3> p = it != problem.mp_positions.end() ? it->second : std::array<double, 3>{0, 0, 0};
+    points.insert(points.end(), p.begin(), p.end());
+  }
+  std::vector<orbx_ba_obs> obs;
+  for (const GlobalBAObservation& o : problem.observations) {
+    auto m = mp_to_param.find(o.mp_id);
+    if (m == mp_to_param.end()) throw Error(ORBX_ERR_INVALID, "solve_global_ba: observation of a map point that is not in mp_ids");
+    orbx_ba_obs b{};
+    b.mp_idx = m->second; b.u = o.observed_uv[0]; b.v = o.observed_uv[1];
+    auto k = kf_to_param.find(o.kf_id);
+    if (o.kf_id == problem.fixed_kf_id) { b.kf_idx = -1; b.fixed_idx = 0; }            // :639-641
+    else if (k != kf_to_param.end()) { b.kf_idx = k->second; b.fixed_idx = -1; }
+    else { b.kf_idx = -1; b.fixed_idx = -1; }                                          // :649 identity
+    obs.push_back(b);
+  }
+  const int K = (int)opt_ids.size(), M = (int)n_mps;
+  std::vector<double> out((size_t)K * 7);
+  int it = 0;
+  double e0 = 0, e1 = 0;
+  const orbx_camera c = camera.c();
+  const orbx_ba_config cfg{config.max_iterations, config.param_tolerance, config.gradient_tolerance, config.huber_threshold, 0};
+  auto tramp = [](void* user) -> int { return (*static_cast<const std::function<bool()>*>(user))() ? 1 : 0; };
+  const int rc = orbx_ba_solve_global(h.get(), &c, &cfg, K, poses.data(), fixed.data(), M, points.data(), (int)obs.size(), obs.data(),
+                                      should_stop ? +tramp : nullptr, const_cast<std::function<bool()>*>(&should_stop), out.data(), &it,
+                                      &e0, &e1);
+  if (rc != ORBX_OK) return std::nullopt;
+  GlobalBAResult r;
+  r.optimized_poses[problem.fixed_kf_id] = se3_inverse(fixed_pose);      // :386
+  for (int i = 0; i < K; ++i) {
+    SE3 p;
+    for (int q = 0; q < 4; ++q) p.rotation[q] = out[7 * (size_t)i + q];
+    for (int q = 0; q < 3; ++q) p.translation[q] = out[7 * (size_t)i + 4 + q];
+    r.optimized_poses[opt_ids[(size_t)i]] = p;
+  }
+  for (int j = 0; j < M; ++j) r.optimized_points[problem.mp_ids[(size_t)j]] = {points[3 * (size_t)j], points[3 * (size_t)j + 1], points[3 * (size_t)j + 2]};
+  r.iterations = (size_t)it; r.initial_error = e0; r.final_error = e1;
+  return r;
+}
+
 }  // namespace orbx

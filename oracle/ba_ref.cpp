@@ -103,8 +103,10 @@ inline Pose se3_inverse(const Pose& T) {
 struct ObsTerms { double e[2], sw, r[2], A[12], B[6]; };
 
 // one observation: error (:192-212), Huber (:291-297, :578-584), Jacobian blocks (:216-288) * sqrt(w)
+// zero_behind: global_ba.rs:561-563 leaves both Jacobian rows of an observation zero when z_c <= 0.001 (the
+// residual keeps its 100-px penalty); the local solver only zeroes them for |z_c| < 1e-6 (:227, :270).
 inline void obs_terms(const orbx_camera& cam, double huber, const Pose& T, const double* X, double u,
-                      double v, ObsTerms& o) {
+                      double v, ObsTerms& o, bool zero_behind = false) {
   double pc[3];
   transform_point(T, X, pc);
   const double x = pc[0], y = pc[1], z = pc[2];
@@ -118,7 +120,7 @@ inline void obs_terms(const orbx_camera& cam, double huber, const Pose& T, const
   const double w = (en <= huber) ? 1.0 : huber / en;
   o.sw = std::sqrt(w);
   o.r[0] = o.e[0] * o.sw; o.r[1] = o.e[1] * o.sw;
-  if (std::fabs(z) < 1e-6) {
+  if (std::fabs(z) < 1e-6 || (zero_behind && z <= 0.001)) {
     memset(o.A, 0, sizeof(o.A));
     memset(o.B, 0, sizeof(o.B));
     return;
@@ -147,6 +149,7 @@ struct Problem {
   int K, F, M, N;
   std::vector<Pose> fixed;
   const orbx_ba_obs* obs;
+  bool global_mode = false;   // solve_global_ba (global_ba.rs:184-418) instead of solve_visual_ba
 };
 
 inline Pose obs_pose(const Problem& P, const std::vector<double>& params, const orbx_ba_obs& o) {
@@ -256,7 +259,7 @@ void build_blocks(const Problem& P, const std::vector<double>& params, std::vect
   for (int i = 0; i < P.N; ++i) {
     const orbx_ba_obs& o = P.obs[i];
     obs_terms(P.cam, P.cfg.huber_threshold, obs_pose(P, params, o),
-              &params[6 * (size_t)P.K + 3 * (size_t)o.mp_idx], o.u, o.v, t);
+              &params[6 * (size_t)P.K + 3 * (size_t)o.mp_idx], o.u, o.v, t, P.global_mode);
     c2 += t.r[0] * t.r[0];
     c2 += t.r[1] * t.r[1];
     double* Vj = &V[9 * (size_t)o.mp_idx];
@@ -394,13 +397,14 @@ void oracle_ba_obs_terms(const orbx_camera* cam, double huber, const double* pos
   memcpy(Jpoint6, t.B, sizeof(t.B));
 }
 
-int oracle_ba_solve_dense(const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+static int ba_solve_dense_impl(bool global_mode, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
                           const double* poses_cw, int F, const double* fixed_poses_cw, int M,
                           double* points, int N, const orbx_ba_obs* obs, int stop_after,
                           double* poses_wc_out, int* iterations, double* initial_error,
                           double* final_error, double* trace) {
   Problem P;
   init_problem(P, cam, cfg, K, F, fixed_poses_cw, M, N, obs);
+  P.global_mode = global_mode;
   std::vector<double> params;
   init_params(P, poses_cw, points, params);
   const int np = (int)params.size();
@@ -412,7 +416,7 @@ int oracle_ba_solve_dense(const orbx_camera* cam, const orbx_ba_config* cfg, int
     ObsTerms t;
     for (int i = 0; i < P.N; ++i) {
       const orbx_ba_obs& o = P.obs[i];
-      obs_terms(P.cam, P.cfg.huber_threshold, obs_pose(P, p, o), &p[6 * (size_t)P.K + 3 * (size_t)o.mp_idx], o.u, o.v, t);
+      obs_terms(P.cam, P.cfg.huber_threshold, obs_pose(P, p, o), &p[6 * (size_t)P.K + 3 * (size_t)o.mp_idx], o.u, o.v, t, P.global_mode);
       r[2 * i] = t.r[0]; r[2 * i + 1] = t.r[1];
       for (int row = 0; row < 2; ++row) {
         double* Jr = &J[(size_t)(2 * i + row) * np];
@@ -458,13 +462,14 @@ int oracle_ba_solve_dense(const orbx_camera* cam, const orbx_ba_config* cfg, int
   return ORBX_OK;
 }
 
-int oracle_ba_solve_schur(const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+static int ba_solve_schur_impl(bool global_mode, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
                           const double* poses_cw, int F, const double* fixed_poses_cw, int M,
                           double* points, int N, const orbx_ba_obs* obs, int stop_after,
                           double* poses_wc_out, int* iterations, double* initial_error,
                           double* final_error, double* trace) {
   Problem P;
   init_problem(P, cam, cfg, K, F, fixed_poses_cw, M, N, obs);
+  P.global_mode = global_mode;
   std::vector<double> params;
   init_params(P, poses_cw, points, params);
   const int n = 6 * K;
@@ -535,6 +540,33 @@ int oracle_ba_reduced_system(const orbx_camera* cam, const orbx_ba_config* cfg, 
   memcpy(Sred, S.data(), sizeof(double) * S.size());
   memcpy(bred, b.data(), sizeof(double) * b.size());
   return ORBX_OK;
+}
+
+// solve_visual_ba (local_ba_lm.rs:912-1098) and solve_global_ba (global_ba.rs:184-418): same LM loop, the global one
+// drops the Jacobian rows of observations behind the camera.
+int oracle_ba_solve_dense(const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                          const double* fixed_poses_cw, int M, double* points, int N, const orbx_ba_obs* obs, int stop_after,
+                          double* poses_wc_out, int* iterations, double* initial_error, double* final_error, double* trace) {
+  return ba_solve_dense_impl(false, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, stop_after, poses_wc_out, iterations,
+                           initial_error, final_error, trace);
+}
+int oracle_ba_solve_schur(const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                          const double* fixed_poses_cw, int M, double* points, int N, const orbx_ba_obs* obs, int stop_after,
+                          double* poses_wc_out, int* iterations, double* initial_error, double* final_error, double* trace) {
+  return ba_solve_schur_impl(false, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, stop_after, poses_wc_out, iterations,
+                           initial_error, final_error, trace);
+}
+int oracle_global_ba_solve_dense(const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                          const double* fixed_poses_cw, int M, double* points, int N, const orbx_ba_obs* obs, int stop_after,
+                          double* poses_wc_out, int* iterations, double* initial_error, double* final_error, double* trace) {
+  return ba_solve_dense_impl(true, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, stop_after, poses_wc_out, iterations,
+                           initial_error, final_error, trace);
+}
+int oracle_global_ba_solve_schur(const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                          const double* fixed_poses_cw, int M, double* points, int N, const orbx_ba_obs* obs, int stop_after,
+                          double* poses_wc_out, int* iterations, double* initial_error, double* final_error, double* trace) {
+  return ba_solve_schur_impl(true, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, stop_after, poses_wc_out, iterations,
+                           initial_error, final_error, trace);
 }
 
 }  // extern "C"

@@ -98,6 +98,15 @@ int oracle_ba_solve_schur(const orbx_camera* cam, const orbx_ba_config* cfg, int
 /* reduced system of one linearisation (for the multi-GPU partition test): S [6K*6K] row-major,
  * bs [6K], chi2; contributions of the given observations only, no damping of U when
  * `add_pose_damping` == 0 (rank partial) */
+/* solve_global_ba (global_ba.rs:184-418): F = 1 (the anchor), Jacobian rows zero where z_c <= 0.001 (:561-563) */
+int oracle_global_ba_solve_dense(const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                                 const double* fixed_poses_cw, int M, double* points, int N, const orbx_ba_obs* obs,
+                                 int stop_after, double* poses_wc_out, int* iterations, double* initial_error,
+                                 double* final_error, double* trace);
+int oracle_global_ba_solve_schur(const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                                 const double* fixed_poses_cw, int M, double* points, int N, const orbx_ba_obs* obs,
+                                 int stop_after, double* poses_wc_out, int* iterations, double* initial_error,
+                                 double* final_error, double* trace);
 int oracle_ba_reduced_system(const orbx_camera* cam, const orbx_ba_config* cfg, double lambda,
                              int K, const double* params_pose /*6K*/, int F,
                              const double* fixed_poses_cw, int M, const double* points, int N,

@@ -276,6 +276,14 @@ def ba_solve_schur(cam, cfg, poses_cw, fixed_cw, points, obs, stop_after=-1):
     return _ba_solve(lib().oracle_ba_solve_schur, cam, cfg, poses_cw, fixed_cw, points, obs, stop_after)
 
 
+def global_ba_solve_dense(cam, cfg, poses_cw, fixed_cw, points, obs, stop_after=-1):
+    return _ba_solve(lib().oracle_global_ba_solve_dense, cam, cfg, poses_cw, fixed_cw, points, obs, stop_after)
+
+
+def global_ba_solve_schur(cam, cfg, poses_cw, fixed_cw, points, obs, stop_after=-1):
+    return _ba_solve(lib().oracle_global_ba_solve_schur, cam, cfg, poses_cw, fixed_cw, points, obs, stop_after)
+
+
 def ba_reduced_system(cam, cfg, lam, params_pose, fixed_cw, points, obs):
     params_pose = np.ascontiguousarray(params_pose, np.float64).reshape(-1)
     K = len(params_pose) // 6

@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "orbx_extract_batch_device", "orbx_check_status", "orbx_stereo_match",
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
-    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual", "orbx_ba_solve_global",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_fuse_search",
     "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
     "orbx_debug_read_candidates",
@@ -167,6 +167,18 @@ class LocalBAConfigLM:
     def _c(self):
         return _BaConfig(self.max_iterations, self.param_tolerance, self.gradient_tolerance,
                          self.huber_threshold, self.max_covisible_keyframes)
+
+
+@dataclass
+class GlobalBAConfig:
+    """global_ba.rs:21-46 (Default impl :36-45)"""
+    max_iterations: int = 10
+    param_tolerance: float = 1e-6
+    gradient_tolerance: float = 1e-6
+    huber_threshold: float = math.sqrt(5.991)
+
+    def _c(self):
+        return _BaConfig(self.max_iterations, self.param_tolerance, self.gradient_tolerance, self.huber_threshold, 0)
 
 
 @dataclass
@@ -488,6 +500,25 @@ class Handle:
         return dict(poses_wc=out_wc[:K], points=pts, iterations=it.value, initial_error=e0.value,
                     final_error=e1.value)
 
+    def ba_solve_global(self, camera, cfg, poses_cw, fixed_pose_cw, points, obs, should_stop=None):
+        """solve_global_ba (global_ba.rs:184-418): every keyframe but the first is optimised."""
+        poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)
+        fixed = np.ascontiguousarray(fixed_pose_cw, np.float64).reshape(7)
+        pts = np.array(points, np.float64, copy=True).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs, BA_OBS)
+        K, M, N = len(poses_cw), len(pts), len(obs)
+        out_wc = np.zeros((max(K, 1), 7))
+        it = C.c_int(); e0 = C.c_double(); e1 = C.c_double()
+        cb = SHOULD_STOP_FN((lambda user: 1 if should_stop() else 0)) if should_stop else C.cast(None, SHOULD_STOP_FN)
+        cam = camera._c(); c = cfg._c()
+        rc = self._L.orbx_ba_solve_global(self._h, C.byref(cam), C.byref(c), C.c_int(K), _vp(poses_cw), _vp(fixed), C.c_int(M),
+                                          _vp(pts), C.c_int(N), _vp(obs), cb, None, _vp(out_wc), C.byref(it), C.byref(e0),
+                                          C.byref(e1))
+        if rc in (ORBX_ERR_EMPTY,):
+            return None                      # reference returns None, global_ba.rs:194-196
+        self._check(rc)
+        return dict(poses_wc=out_wc[:K], points=pts, iterations=it.value, initial_error=e0.value, final_error=e1.value)
+
 
 class StereoProcessor:
     """stereo.rs:31-66.  `new` = the constructor; `process` takes two grayscale u8 images."""
@@ -598,3 +629,85 @@ def solve_visual_ba(problem: VisualBAProblemData, camera: CameraModel, config: L
         {k: r["poses_wc"][i] for i, k in enumerate(problem.optimized_kf_ids)},
         {m: r["points"][i] for i, m in enumerate(problem.mp_ids)},
         r["iterations"], r["initial_error"], r["final_error"])
+
+
+@dataclass
+class GlobalBAObservation:
+    """global_ba.rs:70-80"""
+    kf_id: int
+    mp_id: int
+    observed_uv: tuple
+
+
+@dataclass
+class GlobalBAProblemData:
+    """global_ba.rs:49-67.  Poses are 7-vectors (qw,qx,qy,qz,tx,ty,tz), T_cw."""
+    kf_poses: Dict[int, np.ndarray]
+    mp_positions: Dict[int, np.ndarray]
+    observations: List[GlobalBAObservation]
+    kf_ids: List[int]
+    mp_ids: List[int]
+    fixed_kf_id: int
+
+
+@dataclass
+class GlobalBAResult:
+    """global_ba.rs:83-98.  optimized_poses are T_wc and include the fixed keyframe."""
+    optimized_poses: Dict[int, np.ndarray] = field(default_factory=dict)
+    optimized_points: Dict[int, np.ndarray] = field(default_factory=dict)
+    iterations: int = 0
+    initial_error: float = 0.0
+    final_error: float = 0.0
+
+
+def se3_inverse(pose7):
+    """se3.rs:56-63 with nalgebra's quaternion-vector product (v + w t + q x t, t = 2 q x v)."""
+    p = np.asarray(pose7, np.float64)
+    w, x, y, z = p[0], -p[1], -p[2], -p[3]
+    v = p[4:]
+    t = np.array([2.0 * (y * v[2] - z * v[1]), 2.0 * (z * v[0] - x * v[2]), 2.0 * (x * v[1] - y * v[0])])
+    c = np.array([y * t[2] - z * t[1], z * t[0] - x * t[2], x * t[1] - y * t[0]])
+    return np.concatenate([[w, x, y, z], -(t * w + c + v)])
+
+
+def flatten_global_ba_problem(problem: GlobalBAProblemData):
+    """The id -> index re-keying of global_ba.rs:198-261: the fixed keyframe is removed from the parameter order,
+    a keyframe without a pose starts at the identity, an observation of an unknown keyframe uses the identity pose
+    (:649).  Returns (opt_ids, poses_cw, fixed_pose_cw, points, obs) or None where the reference returns None."""
+    if len(problem.kf_ids) < 2 or len(problem.mp_ids) == 0 or problem.fixed_kf_id not in problem.kf_ids:
+        return None
+    fixed_pos = problem.kf_ids.index(problem.fixed_kf_id)
+    opt_ids = [k for i, k in enumerate(problem.kf_ids) if i != fixed_pos]
+    kf_to_param = {k: i for i, k in enumerate(opt_ids)}
+    mp_to_param = {m: i for i, m in enumerate(problem.mp_ids)}
+    ident = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    poses = np.array([problem.kf_poses.get(k, ident) for k in opt_ids], np.float64).reshape(-1, 7)
+    fixed = np.asarray(problem.kf_poses.get(problem.fixed_kf_id, ident), np.float64)
+    pts = np.array([problem.mp_positions.get(m, np.zeros(3)) for m in problem.mp_ids], np.float64).reshape(-1, 3)
+    rows = []
+    for o in problem.observations:
+        if o.mp_id not in mp_to_param:
+            raise ValueError("solve_global_ba: observation of a map point that is not in mp_ids (never produced by collect_global_ba_data)")
+        if o.kf_id == problem.fixed_kf_id:
+            rows.append((-1, 0, mp_to_param[o.mp_id], 0, o.observed_uv[0], o.observed_uv[1]))
+        elif o.kf_id in kf_to_param:
+            rows.append((kf_to_param[o.kf_id], -1, mp_to_param[o.mp_id], 0, o.observed_uv[0], o.observed_uv[1]))
+        else:
+            rows.append((-1, -1, mp_to_param[o.mp_id], 0, o.observed_uv[0], o.observed_uv[1]))
+    return opt_ids, poses, fixed, pts, np.array(rows, BA_OBS)
+
+
+def solve_global_ba(problem: GlobalBAProblemData, camera: CameraModel, config: GlobalBAConfig,
+                    should_stop: Callable[[], bool], handle: Handle = None) -> Optional[GlobalBAResult]:
+    """global_ba.rs:184-418."""
+    flat = flatten_global_ba_problem(problem)
+    if flat is None:
+        return None
+    opt_ids, poses, fixed, pts, obs = flat
+    r = (handle or _handle()).ba_solve_global(camera, config, poses, fixed, pts, obs, should_stop)
+    if r is None:
+        return None
+    out = {problem.fixed_kf_id: se3_inverse(fixed)}
+    out.update({k: r["poses_wc"][i] for i, k in enumerate(opt_ids)})
+    return GlobalBAResult(out, {m: r["points"][i] for i, m in enumerate(problem.mp_ids)}, r["iterations"], r["initial_error"],
+                          r["final_error"])

@@ -39,7 +39,11 @@ struct BaDims {
   int ntile;    // P/16
 };
 
-struct BaCam { double fx, fy, cx, cy, huber; };
+struct BaCam {
+  double fx, fy, cx, cy, huber;
+  int zero_behind;   // solve_global_ba: Jacobian rows are zero where z_c <= 0.001 (global_ba.rs:561-563)
+  int pad;
+};
 
 // Levenberg-Marquardt state kept on the device (local_ba_lm.rs:1004-1056): the host only polls should_stop and
 // enqueues; accept/reject, lambda, the stop tests and the iteration count are decided by ba_decide_kernel, and
@@ -106,7 +110,7 @@ __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, co
   const double sw = sqrt(w);
   o.r0 = e0 * sw; o.r1 = e1 * sw;
   if (!want_jac) return;
-  if (fabs(z) < 1e-6) {
+  if (fabs(z) < 1e-6 || (cam.zero_behind && z <= 0.001)) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) o.A[i] = 0.0;
 #pragma unroll
@@ -941,7 +945,7 @@ void host_params_to_pose_wc(const double* p6, double* out7) {
 int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
                     const double* poses_cw, int F, const double* fixed_poses_cw, int M, double* points, int N,
                     const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
-                    int* iterations, double* initial_error, double* final_error) {
+                    int* iterations, double* initial_error, double* final_error, bool global_mode) {
   const bool dist = h->allreduce != nullptr;
   *iterations = 0; *initial_error = 0.0; *final_error = 0.0;
   // local_ba_lm.rs:923-925 (with a partition the local N may be 0 while the global problem is not)
@@ -961,7 +965,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   d.rows = ((3 * M + 4 * d.ksplit - 1) / (4 * d.ksplit)) * (4 * d.ksplit);
   if (d.rows == 0) d.rows = 4 * d.ksplit;
   const int n = 6 * K;
-  BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, cfg->huber_threshold};
+  BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, cfg->huber_threshold, global_mode ? 1 : 0, 0};
 
   // ---- host preprocessing: point-major CSR, keyframe CSR over the point-major order
   std::vector<int> pt_start(M + 1, 0), order(N);

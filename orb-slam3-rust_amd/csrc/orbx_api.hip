@@ -709,4 +709,20 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          poses_wc_out, iterations, initial_error, final_error);
 }
 
+int orbx_ba_solve_global(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw,
+                         const double* fixed_pose_cw, int M, double* points, int N, const orbx_ba_obs* obs,
+                         orbx_should_stop_fn should_stop, void* user, double* poses_wc_out, int* iterations,
+                         double* initial_error, double* final_error) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || !cfg || K < 0 || M < 0 || N < 0 || !iterations || !initial_error || !final_error || !fixed_pose_cw ||
+      (K > 0 && (!poses_cw || !poses_wc_out)) || (M > 0 && !points) || (N > 0 && !obs))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_global: bad argument");
+  *iterations = 0; *initial_error = 0.0; *final_error = 0.0;
+  if (K < 1 || M == 0) return orbx_fail(h, ORBX_ERR_EMPTY, "global BA needs two keyframes and a map point");   // global_ba.rs:194-196
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  return ba_solve_visual(h, cam, cfg, K, poses_cw, 1, fixed_pose_cw, M, points, N, obs, should_stop, user, poses_wc_out,
+                         iterations, initial_error, final_error, true);
+}
+
 }  // extern "C"

@@ -147,4 +147,4 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
                     const double* poses_cw, int F, const double* fixed_poses_cw, int M,
                     double* points, int N, const orbx_ba_obs* obs, orbx_should_stop_fn should_stop,
                     void* user, double* poses_wc_out, int* iterations, double* initial_error,
-                    double* final_error);
+                    double* final_error, bool global_mode = false);

@@ -84,3 +84,20 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
     assert ok == 1 and it == o["iterations"] and abs(e1 - o["final_error"]) < 1e-8 * o["final_error"]
     rel = lambda a, b: np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))
     assert rel(poses, o["poses_wc"]) < 1e-6 and rel(pts, o["points"]) < 1e-6
+    # --- solve_global_ba through GlobalBAProblemData keyed by ids (fixed keyframe first in kf_ids)
+    gb = open(os.path.join(tmp, "gba_out.bin"), "rb").read()
+    ok, it = struct.unpack_from("<ii", gb, 0)
+    e0, e1 = struct.unpack_from("<dd", gb, 8)
+    gposes = np.frombuffer(gb, np.float64, 7 * (K + 1), 24).reshape(K + 1, 7)
+    gpts = np.frombuffer(gb, np.float64, 3 * M, 24 + 56 * (K + 1)).reshape(M, 3)
+    keep = (w["obs"]["kf_idx"] >= 0) | (w["obs"]["fixed_idx"] == 0)
+    go = oracle.global_ba_solve_dense(oracle.Camera(**w["camera"]), oracle.BaConfig(10, 1e-9, 1e-9, float(np.sqrt(5.991)), 0),
+                                      w["poses_cw"], w["fixed_cw"][:1], w["points"], w["obs"][keep])
+    go2 = oracle.global_ba_solve_schur(oracle.Camera(**w["camera"]), oracle.BaConfig(10, 1e-9, 1e-9, float(np.sqrt(5.991)), 0),
+                                       w["poses_cw"], w["fixed_cw"][:1], w["points"], w["obs"][keep])
+    # one fixed keyframe leaves the monocular scale free: the answer is only defined up to the spread between the
+    # oracle's own two formulations (same rule as tests/test_fuzz_gpu.py)
+    gtol = max(1e-6, 50.0 * max(rel(go2["poses_wc"], go["poses_wc"]), rel(go2["points"], go["points"])))
+    assert ok == 1 and it == go["iterations"] and abs(e1 - go["final_error"]) < 1e-8 * go["final_error"]
+    assert rel(gposes[1:], go["poses_wc"]) < gtol and rel(gpts, go["points"]) < gtol, gtol
+    assert np.allclose(gposes[0], pkg.se3_inverse(w["fixed_cw"][0]), atol=1e-15)
