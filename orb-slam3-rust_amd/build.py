@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbx_hip.so")
+# ORBX_LIBRARY points at another build of the same library (A/B timing of two builds on one box)
+LIB_PATH = os.environ.get("ORBX_LIBRARY") or os.path.join(_HERE, "liborbx_hip.so")
 
 
 def build(jobs=4, verbose=False):

@@ -82,6 +82,7 @@ struct orbx_handle {
   OrbGeom geom{};
   DevBuf resize_tab;                     // per level l>=1: xtab[w_l], ytab[h_l] packed (ofs<<16 | c1)
   std::vector<unsigned> resize_tab_off;  // element offsets: [2*l] x table, [2*l+1] y table
+  unsigned btile_tab_off = 0, ftile_tab_off = 0;   // tile -> (level, tx, ty) tables of the blur / FAST launches, same buffer
   // grow-only workspaces
   DevBuf ws_pyr, ws_blur, ws_cand, ws_counters, ws_sel, ws_sel2, ws_match, ws_io[12];
   DevBuf ws_ba[24];
