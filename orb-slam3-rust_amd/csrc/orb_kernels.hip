@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void copy_l0_kernel(const uint8_t* __restrict_
 // one unaligned 8-byte window; a tap pair is (window >> 8*o) and the 8.8 horizontal sum is one
 // v_dot4_u32_u8:  cx0*p0 + cx1*p1 = (cx0-1)*p0 + cx1*p1 + p0  (cx0 = 256-cx1 can be 256, cx0-1 fits a byte).
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
+constexpr int RESIZE_ROWS = 2;   // measured: 0.245 ms (1 row) -> 0.196 ms (2 rows) = 4 rows, over the 7 launches of a 128-pair batch
 __device__ __forceinline__ unsigned resize_h(unsigned long long win, int o, unsigned coef) {
   const unsigned pr = (unsigned)(win >> (8 * o));
   return __builtin_amdgcn_udot4(pr, coef, pr & 0xffu, false);
@@ -97,47 +98,65 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
   const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h;
   const int w = g.lv[l].w, h = g.lv[l].h, dp = g.lv[l].pitch;
   uint8_t* dst = s.pyr + (size_t)img * g.slot_bytes + g.lv[l].off;
+  // RESIZE_ROWS output rows per thread (y, y+16, ...): the dependent chain table -> source rows -> arithmetic is
+  // latency-bound, so every row's loads are issued before the first row is computed
   const int x0 = tbx * 64 + (threadIdx.x & 15) * 4;
-  const int y = tby * 16 + (threadIdx.x >> 4);
-  if (y >= h || x0 >= w) return;
-  const unsigned yt = ytab[y];
-  const int y0 = (int)(yt >> 16), y1 = min(y0 + 1, sh - 1);
-  const unsigned cy1 = yt & 0xffffu, cy0 = 256u - cy1;
-  const uint8_t* r0 = src + (size_t)y0 * sp;
-  const uint8_t* r1 = src + (size_t)y1 * sp;
+  const int yb = tby * (16 * RESIZE_ROWS) + (threadIdx.x >> 4);
+  if (yb >= h || x0 >= w) return;
   const uint4 xt4 = *reinterpret_cast<const uint4*>(xtab + x0);      // table padded to a multiple of 4 entries
+  unsigned yt[RESIZE_ROWS];
+#pragma unroll
+  for (int r = 0; r < RESIZE_ROWS; ++r) yt[r] = ytab[min(yb + 16 * r, h - 1)];
   const unsigned xt[4] = {xt4.x, xt4.y, xt4.z, xt4.w};
   const int xb = (int)(xt[0] >> 16);
-  unsigned packed = 0;
-  if (xb + 8 <= sp) {
-    const unsigned long long w0 = (unsigned long long)ld_u32(r0 + xb) | ((unsigned long long)ld_u32(r0 + xb + 4) << 32);
-    const unsigned long long w1 = (unsigned long long)ld_u32(r1 + xb) | ((unsigned long long)ld_u32(r1 + xb + 4) << 32);
+  const bool fastp = xb + 8 <= sp;
+  const uint8_t* r0[RESIZE_ROWS];
+  const uint8_t* r1[RESIZE_ROWS];
+  unsigned long long w0[RESIZE_ROWS], w1[RESIZE_ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (x0 + k < w) {
-        const int o = (int)(xt[k] >> 16) - xb;             // 0..4; tap o+1 <= 5 (weight 0 when clamped at the edge)
-        const unsigned cx1 = xt[k] & 0xffffu;
-        const unsigned coef = (255u - cx1) | (cx1 << 8);   // (cx0 - 1, cx1)
-        const unsigned h0 = resize_h(w0, o, coef), h1 = resize_h(w1, o, coef);   // 8.8
-        const unsigned v = cy0 * h0 + cy1 * h1;                                  // 16.16
-        packed |= ((v + 32768u) >> 16) << (8 * k);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int x = x0 + k;
-      if (x < w) {
-        const int xo = (int)(xt[k] >> 16), x1 = min(xo + 1, sw - 1);
-        const unsigned cx1 = xt[k] & 0xffffu, cx0 = 256u - cx1;
-        const unsigned h0 = cx0 * r0[xo] + cx1 * r0[x1];
-        const unsigned h1 = cx0 * r1[xo] + cx1 * r1[x1];
-        const unsigned v = cy0 * h0 + cy1 * h1;
-        packed |= ((v + 32768u) >> 16) << (8 * k);
-      }
+  for (int r = 0; r < RESIZE_ROWS; ++r) {
+    const int y0 = (int)(yt[r] >> 16), y1 = min(y0 + 1, sh - 1);
+    r0[r] = src + (size_t)y0 * sp;
+    r1[r] = src + (size_t)y1 * sp;
+    if (fastp) {
+      w0[r] = (unsigned long long)ld_u32(r0[r] + xb) | ((unsigned long long)ld_u32(r0[r] + xb + 4) << 32);
+      w1[r] = (unsigned long long)ld_u32(r1[r] + xb) | ((unsigned long long)ld_u32(r1[r] + xb + 4) << 32);
     }
   }
-  *reinterpret_cast<unsigned*>(dst + (size_t)y * dp + x0) = packed;
+#pragma unroll
+  for (int r = 0; r < RESIZE_ROWS; ++r) {
+    const int y = yb + 16 * r;
+    if (y >= h) break;
+    const unsigned cy1 = yt[r] & 0xffffu, cy0 = 256u - cy1;
+    unsigned packed = 0;
+    if (fastp) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (x0 + k < w) {
+          const int o = (int)(xt[k] >> 16) - xb;             // 0..4; tap o+1 <= 5 (weight 0 when clamped at the edge)
+          const unsigned cx1 = xt[k] & 0xffffu;
+          const unsigned coef = (255u - cx1) | (cx1 << 8);   // (cx0 - 1, cx1)
+          const unsigned h0 = resize_h(w0[r], o, coef), h1 = resize_h(w1[r], o, coef);   // 8.8
+          const unsigned v = cy0 * h0 + cy1 * h1;                                        // 16.16
+          packed |= ((v + 32768u) >> 16) << (8 * k);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = x0 + k;
+        if (x < w) {
+          const int xo = (int)(xt[k] >> 16), x1 = min(xo + 1, sw - 1);
+          const unsigned cx1 = xt[k] & 0xffffu, cx0 = 256u - cx1;
+          const unsigned h0 = cx0 * r0[r][xo] + cx1 * r0[r][x1];
+          const unsigned h1 = cx0 * r1[r][xo] + cx1 * r1[r][x1];
+          const unsigned v = cy0 * h0 + cy1 * h1;
+          packed |= ((v + 32768u) >> 16) << (8 * k);
+        }
+      }
+    }
+    *reinterpret_cast<unsigned*>(dst + (size_t)y * dp + x0) = packed;
+  }
 }
 
 // tile -> (level, tile x, tile y) from the table orb_prepare_geometry builds (one scalar load instead of a
@@ -173,10 +192,9 @@ __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2,
   hs[3] = __builtin_amdgcn_udot4(d2, G1, __builtin_amdgcn_udot4(d1, G0, 0u, false), false);
 }
 
-// rp = row base (wave-uniform), xl = this lane's clamped dword column
-__device__ __forceinline__ void blur_row(const uint8_t* __restrict__ rp, int xl, bool slow, const int (&col)[12],
-                                         unsigned (&hs)[4]) {
-  unsigned d1 = *reinterpret_cast<const unsigned*>(rp + xl);
+// rp = row base (wave-uniform); d1 = this lane's dword of the row, loaded two rows ahead by the caller so that the
+// load latency overlaps the arithmetic of the rows in between
+__device__ __forceinline__ void blur_row(const uint8_t* __restrict__ rp, unsigned d1, bool slow, const int (&col)[12], unsigned (&hs)[4]) {
   unsigned d0 = __builtin_amdgcn_update_dpp(0u, d1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
   unsigned d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
   if (slow) {   // window crosses the image edge: gather the 12 bytes from the precomputed reflected columns
@@ -190,6 +208,12 @@ __device__ __forceinline__ void blur_row(const uint8_t* __restrict__ rp, int xl,
   blur_hsum(d0, d1, d2, hs);
 }
 
+// BORDER_REFLECT_101 for an index at most n-1 outside [0, n) (levels are at least 8 px, the kernel reaches 3 px out)
+__device__ __forceinline__ int reflect101_once(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// 7 waves/SIMD (<= 72 VGPRs): measured best — 8 spills the ring, 5-6 leave less latency cover (A/B on one box:
+// 0.32 ms vs 0.34 at 6, 0.36 at 5, 0.62 at 8 with scratch)
+__attribute__((amdgpu_waves_per_eu(7, 7)))
 __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab) {
   int img, tile;
   if (!xcd_decode(xm, n_img, img, tile)) return;
@@ -213,16 +237,28 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
   int col[12];
 #pragma unroll
   for (int t = 0; t < 12; ++t) col[t] = slow ? reflect101(x0 - 4 + t, w) : 0;
+  // input rows q = 0 .. nrows+5 are image rows reflect(ys-3+q); p0/p1 hold this lane's dword of rows q and q+1
+  const int last = nrows + 5;
+  auto rowp = [&](int q) { return src + (size_t)reflect101_once(ys - 3 + min(q, last), h) * pitch; };
+  unsigned p0 = *reinterpret_cast<const unsigned*>(rowp(0) + xl), p1 = *reinterpret_cast<const unsigned*>(rowp(1) + xl);
   unsigned ring[7][4];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) blur_row(src + (size_t)reflect101(ys - 3 + i, h) * pitch, xl, slow, col, ring[i]);
+  for (int i = 0; i < 6; ++i) {
+    const unsigned cur = p0;
+    p0 = p1;
+    p1 = *reinterpret_cast<const unsigned*>(rowp(i + 2) + xl);
+    blur_row(rowp(i), cur, slow, col, ring[i]);
+  }
   for (int y0 = 0; y0 < nrows; y0 += 7) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int y = y0 + i;
       if (y < nrows) {   // wave-uniform
-        // ring slot (i+6)%7 receives input row ys+y+3; slots (i..i+6)%7 hold rows y-3..y+3
-        blur_row(src + (size_t)reflect101(ys + y + 3, h) * pitch, xl, slow, col, ring[(i + 6) % 7]);
+        // ring slot (i+6)%7 receives input row q = y+6 (image row ys+y+3); slots (i..i+6)%7 hold rows y-3..y+3
+        const unsigned cur = p0;
+        p0 = p1;
+        p1 = *reinterpret_cast<const unsigned*>(rowp(y + 8) + xl);
+        blur_row(rowp(y + 6), cur, slow, col, ring[(i + 6) % 7]);
         unsigned packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1037,7 +1073,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     {
       ProfScope ps(h, "resize_kernel");
       for (int l = 1; l < nl; ++l) {
-        const int tx = (g.lv[l].w + 63) / 64, ty = (g.lv[l].h + 15) / 16;
+        const int tx = (g.lv[l].w + 63) / 64, ty = (g.lv[l].h + 16 * RESIZE_ROWS - 1) / (16 * RESIZE_ROWS);
         hipLaunchKernelGGL(resize_kernel, xcd_grid(tx * ty, n), dim3(256), 0, st, s, g, l, n, xcd_map(tx * ty), tx, ty,
                            tab + h->resize_tab_off[2 * l], tab + h->resize_tab_off[2 * l + 1]);
       }
