@@ -21,7 +21,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int SM_THREADS = 256;
-constexpr int SM_LEFT_PER_WAVE = 4;
+constexpr int SM_LEFT_PER_WAVE = 8;   // multiple of 4: four left keypoints share a wave
 constexpr int SM_LEFT_PER_BLOCK = SM_LEFT_PER_WAVE * (SM_THREADS / kWave);
 constexpr unsigned TH_HIGH = 100;  // stereo.rs:10
 
@@ -110,7 +110,9 @@ __device__ __forceinline__ void push_top2(unsigned& b, int& bi, unsigned& s, uns
   else s = min(s, d);
 }
 
-// One wave per left keypoint (SM_LEFT_PER_WAVE in turn), lanes over the right keypoints of its rows.
+// Sixteen lanes per left keypoint, four left keypoints per wave at a time (a left keypoint has ~30 right keypoints
+// in its 7 rows, ~10 of them inside the gates: a whole wave per keypoint left most lanes idle and paid a 6-step
+// reduction); SM_LEFT_PER_WAVE keypoints per wave in turn.
 __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
     const orbx_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
     const int* __restrict__ nkp, int cap, float max_disp, float min_disp,
@@ -122,13 +124,14 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
   const uint8_t* dR = dL + (size_t)cap * 32;
   const int nL = min(nkp[2 * pair], cap), nR = min(nkp[2 * pair + 1], cap);
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int grp = lane >> 4, gl = lane & 15;
   const int* bs = bstart + (size_t)pair * (SB_ROWS + 1);
   const int* si = sidx + (size_t)pair * cap;
   const float2* sx = sxy + (size_t)pair * cap;
 #pragma unroll 1
-  for (int q = 0; q < SM_LEFT_PER_WAVE; ++q) {
-    const int li = blockIdx.x * SM_LEFT_PER_BLOCK + wave * SM_LEFT_PER_WAVE + q;
-    if (li >= nL) return;                                                    // wave-uniform
+  for (int q = 0; q < SM_LEFT_PER_WAVE; q += 4) {
+    const int li = blockIdx.x * SM_LEFT_PER_BLOCK + wave * SM_LEFT_PER_WAVE + q + grp;
+    if (li >= nL) return;                                                    // uniform over the 16-lane group
     const float ul = kpL[li].x, vl = kpL[li].y;
     const float min_u = fmaxf(ul - max_disp, 0.0f);                          // stereo.rs:100
     const float lim = ((float)nR * ul) / (float)nL;                          // stereo.rs:102
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
     const int lo = bs[max(rb - 3, 0)], hi = bs[min(rb + 3, SB_ROWS - 1) + 1];
     unsigned b = TH_HIGH, s = TH_HIGH;
     int bi = 0x7fffffff;
-    for (int t = lo + lane; t < hi; t += kWave) {
+    for (int t = lo + gl; t < hi; t += 16) {
       const float2 r = sx[t];
       if (fabsf(vl - r.y) > 2.0f) continue;                                  // stereo.rs:117
       if (r.x < min_u || r.x > max_u) continue;                              // stereo.rs:122
@@ -148,13 +151,13 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
       if (d < TH_HIGH) push_top2(b, bi, s, d, ri);                           // :135-141 (d >= 100 never enters)
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = 8; off >= 1; off >>= 1) {                                 // xor < 16 stays inside the group
       const unsigned ob = __shfl_xor(b, off);
       const int obi = __shfl_xor(bi, off);
       const unsigned os = __shfl_xor(s, off);
       merge_top2(b, bi, s, ob, obi, os);
     }
-    if (lane == 0) {
+    if (gl == 0) {
       const bool has = bi != 0x7fffffff;
       const bool emit = has && (((float)b < 0.9f * (float)s) || s == TH_HIGH);   // stereo.rs:145-148
       tmp[(size_t)pair * cap + li] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);

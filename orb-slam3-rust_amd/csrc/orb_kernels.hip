@@ -354,7 +354,8 @@ __device__ __forceinline__ int fast_arc_min_pk(int v, const int (&r)[16], bool b
 //      two adjacent compass points (0,4,8,12), so a corner needs two adjacent ones both brighter than
 //      v+t or both darker than v-t; survivors (~10 %) are compacted into an LDS list;
 //   2. full arc score only for the listed positions, written into the LDS score tile;
-//   3. 3x3 NMS + border filter over the list, block-aggregated append to the level's candidates.
+//   3. 3x3 NMS over the corners phase 2 found (second, much shorter list), block-aggregated append to the
+//      level's candidates.
 constexpr int FT_W = 62, FT_H = 30;          // inner tile
 constexpr int FS_W = 64, FS_H = 32;          // score region
 constexpr int FP_PITCH = 72, FP_ROWS = FS_H + 6;
@@ -367,8 +368,9 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   __shared__ __attribute__((aligned(16))) uint8_t sp[FP_ROWS][FP_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t ss[FS_H][FS_W];
   __shared__ unsigned short s_pos[FS_W * FS_H];
+  __shared__ unsigned short s_cor[FS_W * FS_H];
   __shared__ unsigned s_list[512];
-  __shared__ int s_npos, s_cnt;
+  __shared__ int s_npos, s_cnt, s_ncor;
   __shared__ unsigned s_base;
   int img, tile;
   if (!xcd_decode(xm, n_img, img, tile)) return;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   const int w = g.lv[l].w, h = g.lv[l].h;
   const int x0 = EDGE + tx * FT_W, y0 = EDGE + ty * FT_H;   // first inner pixel; score position (i,j) = pixel (x0-1+i, y0-1+j)
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) { s_npos = 0; s_cnt = 0; }
+  if (tid == 0) { s_npos = 0; s_cnt = 0; s_ncor = 0; }
   // pixel tile: LDS row r = image row y0-4+r, byte b = image column x0-5+b
   for (int i = tid; i < FP_ROWS * (FP_PITCH / 4); i += 256) {
     const int r = i / (FP_PITCH / 4), c = i - r * (FP_PITCH / 4);
@@ -463,17 +465,29 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     const bool darker = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0);
     int b = fast_arc_min_pk(v, r, brighter);
     if (brighter && darker) b = max(b, fast_arc_min_pk(v, r, false));   // both passed (rare)
-    ss[j][i] = (uint8_t)(b > t ? b - 1 : 0);
+    const int sc = b > t ? b - 1 : 0;
+    ss[j][i] = (uint8_t)sc;
+    // corners inside the tile and the border-filtered region go on to NMS (a few per cent of the survivors: the
+    // pre-test also passes every straight edge)
+    const bool corner = sc > 0 && i >= 1 && i <= FT_W && j >= 1 && j <= FT_H && x0 + i - 1 < w - EDGE && y0 + j - 1 < h - EDGE;
+    const unsigned long long cm = __ballot(corner);
+    if (cm) {
+      const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&s_ncor, __popcll(cm));
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (corner) s_cor[base + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] = (unsigned short)p;
+    }
   }
   __syncthreads();
   // phase 3: NMS (strictly greater than the 8 neighbours) + runByImageBorder, over the list
-  for (int q = tid; q < npos; q += 256) {
-    const int p = s_pos[q];
+  const int ncor = s_ncor;
+  for (int q = tid; q < ncor; q += 256) {
+    const int p = s_cor[q];
     const int j = p >> 6, i = p & 63;
-    if (i < 1 || i > FT_W || j < 1 || j > FT_H) continue;      // NMS frame position
     const int x = x0 + i - 1, y = y0 + j - 1;
     const int sc = ss[j][i];
-    if (sc > 0 && x < w - EDGE && y < h - EDGE) {
+    {
       const bool keep = sc > ss[j - 1][i - 1] && sc > ss[j - 1][i] && sc > ss[j - 1][i + 1] && sc > ss[j][i - 1] &&
                         sc > ss[j][i + 1] && sc > ss[j + 1][i - 1] && sc > ss[j + 1][i] && sc > ss[j + 1][i + 1];
       if (keep) {
