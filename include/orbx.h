@@ -207,6 +207,42 @@ int orbx_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const 
                                   const double* pose1_wc, const double* pose2_wc, unsigned max_dist,
                                   int* out_pairs, int* n_out);
 
+/* = search_for_triangulation_bow (src/local_mapping/triangulation.rs:541-658): as above, but the candidates of a
+ * feature are the features of keyframe 2 in the same FeatureVector node instead of a grid neighbourhood.
+ *   node1 [n1] / node2 [n2]: the FeatureVector key of each feature (the out_node of orbx_bow_transform), 0xffffffff
+ *   for a feature in no list.  The reference walks feat_vec1 in HashMap order; features of different nodes never
+ *   compete, so the set of pairs does not depend on that order — here they come out in ascending idx1. */
+int orbx_search_for_triangulation_bow(orbx_handle* h, const orbx_camera* cam, const orbx_keypoint* kp1,
+                                      const uint8_t* desc1, const uint8_t* mp1, const uint8_t* stereo1,
+                                      const uint32_t* node1, int n1, const orbx_keypoint* kp2, const uint8_t* desc2,
+                                      const uint8_t* mp2, const uint32_t* node2, int n2, const double* pose1_wc,
+                                      const double* pose2_wc, unsigned max_dist, int* out_pairs, int* n_out);
+
+/* ---- ORB vocabulary (src/vocabulary/mod.rs) ------------------------------------------------------------------
+ * orbx_vocab_load_text = OrbVocabulary::load_from_text (:117-211): DBoW2 text format, "k L scoring weighting" then
+ * one line per node "parent_id is_leaf d0 .. d31 weight"; lines with fewer than 35 fields are skipped, a field that
+ * does not parse fails the load (ORBX_ERR_INVALID + message), node ids are sequential from 1, a node is linked to its
+ * parent only when the parent id is smaller than its own.  orbx_vocab_create takes the same nodes as arrays
+ * (index 0 = root, ignored).  The tables live on the handle's device until orbx_vocab_destroy. */
+typedef struct orbx_vocabulary orbx_vocabulary;
+int orbx_vocab_load_text(orbx_handle* h, const char* path, orbx_vocabulary** out);
+int orbx_vocab_create(orbx_handle* h, int n_nodes, const uint32_t* parent, const uint8_t* is_leaf, const uint8_t* desc,
+                      const double* weight, int k, int l, orbx_vocabulary** out);
+void orbx_vocab_destroy(orbx_vocabulary* v);
+int orbx_vocab_info(const orbx_vocabulary* v, int* k, int* l, int* n_nodes, int* n_words);   /* params/num_nodes/num_words */
+int orbx_vocab_nodes(const orbx_vocabulary* v, uint32_t* parent, uint8_t* is_leaf, uint8_t* desc, double* weight);
+
+/* The per-descriptor part of OrbVocabulary::transform (:296-325): descent to the leaf taking the closest child at
+ * every node (first child on ties, :230-248), then `levels_up` parents up (:262-275).
+ *   out_word [n] word id (0 for a terminal node that is not flagged leaf, :247), out_leaf [n] leaf node id,
+ *   out_node [n] FeatureVector key, out_weight [n] the leaf's weight.  BowVector = sum of out_weight per out_word,
+ *   L1-normalised; FeatureVector = feature indices grouped by out_node — both left to the caller.
+ * _device: descriptors and outputs in device memory, asynchronous on the handle's stream. */
+int orbx_bow_transform(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* desc, int n, int levels_up,
+                       uint32_t* out_word, uint32_t* out_leaf, uint32_t* out_node, double* out_weight);
+int orbx_bow_transform_device(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* d_desc, int n, int levels_up,
+                              uint32_t* d_word, uint32_t* d_leaf, uint32_t* d_node, double* d_weight);
+
 /* = the search of fuse_points_into_keyframes (src/local_mapping/search_in_neighbors.rs:273-343, with
  * KeyFrame::get_features_in_area, src/atlas/map/keyframe.rs:408-443) for every (map point, target keyframe) pair:
  * project the point with the keyframe's inverse pose, skip it behind the camera or outside [0,2cx)x[0,2cy), radius

@@ -17,6 +17,7 @@
 // Errors: the reference propagates `anyhow::Error` with `?` — here orbx::Error is thrown; where the
 // reference returns `None` (solve_visual_ba) std::nullopt is returned.  Everything computes on the GPU.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -296,6 +297,80 @@ inline std::optional<VisualBAResultData> solve_visual_ba(Handle& h, const Visual
   return r;
 }
 
+
+// ---- ORB vocabulary (src/vocabulary/mod.rs) ----------------------------------------------------------------------
+using BowVector = std::unordered_map<uint32_t, double>;                  // mod.rs:31
+using FeatureVector = std::unordered_map<uint32_t, std::vector<size_t>>; // mod.rs:37
+
+class OrbVocabulary {   // mod.rs:83-94; the tree lives in device memory, transform runs on the GPU
+ public:
+  static OrbVocabulary load_from_text(Handle& h, const std::string& path) {   // mod.rs:117-211; throws where the reference returns Err
+    orbx_vocabulary* v = nullptr;
+    h.check(orbx_vocab_load_text(h.get(), path.c_str(), &v));
+    return OrbVocabulary(h, v);
+  }
+  OrbVocabulary(const OrbVocabulary&) = delete;
+  OrbVocabulary& operator=(const OrbVocabulary&) = delete;
+  OrbVocabulary(OrbVocabulary&& o) noexcept : h_(o.h_), v_(o.v_) { o.v_ = nullptr; }
+  ~OrbVocabulary() { if (v_) orbx_vocab_destroy(v_); }
+  std::pair<size_t, size_t> params() const { int k, l; orbx_vocab_info(v_, &k, &l, nullptr, nullptr); return {(size_t)k, (size_t)l}; }
+  size_t num_words() const { int n; orbx_vocab_info(v_, nullptr, nullptr, nullptr, &n); return (size_t)n; }
+  size_t num_nodes() const { int n; orbx_vocab_info(v_, nullptr, nullptr, &n, nullptr); return (size_t)n; }
+  const orbx_vocabulary* get() const { return v_; }
+
+  // mod.rs:296-325.  The L1 normalisation sums in ascending word id (the reference sums in HashMap order).
+  std::pair<BowVector, FeatureVector> transform(const std::vector<uint8_t>& descriptors, size_t levels_up) const {
+    const int n = (int)(descriptors.size() / 32);
+    std::vector<uint32_t> word((size_t)n), leaf((size_t)n), node((size_t)n);
+    std::vector<double> w((size_t)n);
+    h_->check(orbx_bow_transform(h_->get(), v_, descriptors.data(), n, (int)levels_up, word.data(), leaf.data(), node.data(), w.data()));
+    BowVector bow;
+    FeatureVector feat;
+    for (int i = 0; i < n; ++i) { bow[word[(size_t)i]] += w[(size_t)i]; feat[node[(size_t)i]].push_back((size_t)i); }
+    std::vector<uint32_t> keys;
+    for (const auto& kv : bow) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    double sum = 0.0;
+    for (uint32_t k : keys) sum += bow[k];
+    if (sum > 0.0) for (auto& kv : bow) kv.second /= sum;
+    return {std::move(bow), std::move(feat)};
+  }
+  BowVector transform_bow_only(const std::vector<uint8_t>& descriptors) const { return transform(descriptors, 0).first; }   // mod.rs:330-356
+
+  static double score(const BowVector& v1, const BowVector& v2) {          // mod.rs:362-380
+    double diff = 0.0;
+    for (const auto& kv : v1) { auto it = v2.find(kv.first); diff += std::fabs(kv.second - (it != v2.end() ? it->second : 0.0)); }
+    for (const auto& kv : v2) if (!v1.count(kv.first)) diff += std::fabs(kv.second);
+    return 1.0 - 0.5 * diff;
+  }
+
+ private:
+  OrbVocabulary(Handle& h, orbx_vocabulary* v) : h_(&h), v_(v) {}
+  Handle* h_;
+  orbx_vocabulary* v_;
+};
+
+// triangulation.rs:541-658: candidates restricted to the same FeatureVector node.  Pairs in ascending idx1.
+inline std::vector<std::pair<size_t, size_t>> search_for_triangulation_bow(
+    Handle& h, const FeatureVector& feat_vec1, const FeatureVector& feat_vec2, const FeatureSet& f1, const std::vector<uint8_t>& has_map_point1,
+    const std::vector<uint8_t>& has_point_cam1, const FeatureSet& f2, const std::vector<uint8_t>& has_map_point2, const SE3& pose1,
+    const SE3& pose2, const CameraModel& camera, uint32_t max_dist) {
+  const int n1 = (int)f1.keypoints.size(), n2 = (int)f2.keypoints.size();
+  std::vector<uint32_t> node1((size_t)n1, 0xffffffffu), node2((size_t)n2, 0xffffffffu);
+  for (const auto& kv : feat_vec1) for (size_t i : kv.second) if (i < (size_t)n1) node1[i] = kv.first;
+  for (const auto& kv : feat_vec2) for (size_t i : kv.second) if (i < (size_t)n2) node2[i] = kv.first;
+  const double p1[7] = {pose1.rotation[0], pose1.rotation[1], pose1.rotation[2], pose1.rotation[3], pose1.translation[0], pose1.translation[1], pose1.translation[2]};
+  const double p2[7] = {pose2.rotation[0], pose2.rotation[1], pose2.rotation[2], pose2.rotation[3], pose2.translation[0], pose2.translation[1], pose2.translation[2]};
+  std::vector<int> pairs((size_t)std::max(n1, 1) * 2);
+  int n = 0;
+  const orbx_camera cam = camera.c();
+  h.check(orbx_search_for_triangulation_bow(h.get(), &cam, f1.keypoints.data(), f1.descriptors.data(), has_map_point1.data(),
+                                            has_point_cam1.data(), node1.data(), n1, f2.keypoints.data(), f2.descriptors.data(),
+                                            has_map_point2.data(), node2.data(), n2, p1, p2, max_dist, pairs.data(), &n));
+  std::vector<std::pair<size_t, size_t>> out((size_t)n);
+  for (int i = 0; i < n; ++i) out[(size_t)i] = {(size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]};
+  return out;
+}
 
 // ---- global bundle adjustment (src/optimizer/global_ba.rs) --------------------------------------------------------
 struct GlobalBAConfig {   // global_ba.rs:21-46

@@ -360,3 +360,183 @@ void oracle_fuse_search(const orbx_camera* cam, const double* positions, const u
     }
   }
 }
+
+// ---- ORB vocabulary: DBoW2 text format, tree descent, FeatureVector level (src/vocabulary/mod.rs) -----------------
+#include <array>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+namespace {
+struct OVocab {
+  int k = 0, l = 0;
+  std::vector<uint32_t> parent;                      // [n_nodes], root = 0xffffffff (:152)
+  std::vector<std::vector<uint32_t>> children;       // in file order (:196-198)
+  std::vector<std::array<uint8_t, 32>> desc;
+  std::vector<double> weight;
+  std::vector<long long> word_id;                    // -1 = None
+  int n_words = 0;
+};
+void ovocab_push(OVocab& v, uint32_t parent_id, bool is_leaf, const uint8_t* d, double w) {   // :183-200
+  const uint32_t id = (uint32_t)v.parent.size();
+  v.parent.push_back(parent_id);
+  v.children.emplace_back();
+  std::array<uint8_t, 32> a;
+  memcpy(a.data(), d, 32);
+  v.desc.push_back(a);
+  v.weight.push_back(w);
+  v.word_id.push_back(is_leaf ? (long long)v.n_words++ : -1);
+  if ((size_t)parent_id < v.parent.size() - 1) v.children[parent_id].push_back(id);
+}
+void ovocab_root(OVocab& v) {
+  v.parent.push_back(0xffffffffu);
+  v.children.emplace_back();
+  v.desc.push_back(std::array<uint8_t, 32>{});
+  v.weight.push_back(0.0);
+  v.word_id.push_back(-1);
+}
+bool parse_u64(const std::string& s, unsigned long long max, unsigned long long* out) {   // Rust's str::parse::<uN>
+  if (s.empty()) return false;
+  size_t i = s[0] == '+' ? 1 : 0;
+  if (i >= s.size()) return false;
+  unsigned long long v = 0;
+  for (; i < s.size(); ++i) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    v = v * 10 + (unsigned)(s[i] - '0');
+    if (v > max) return false;
+  }
+  *out = v;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+// load_from_text (:117-211).  Returns null where the reference returns Err.
+void* oracle_vocab_load_text(const char* path) {
+  std::ifstream f(path);
+  if (!f) return nullptr;
+  std::string line;
+  if (!std::getline(f, line)) return nullptr;                      // :124-127
+  std::vector<std::string> parts;
+  auto split = [&](const std::string& s) { parts.clear(); std::istringstream is(s); std::string t; while (is >> t) parts.push_back(t); };
+  split(line);
+  if (parts.size() < 2) return nullptr;                            // :130-134
+  unsigned long long k, l;
+  if (!parse_u64(parts[0], ~0ull, &k) || !parse_u64(parts[1], ~0ull, &l)) return nullptr;
+  OVocab* v = new OVocab();
+  v->k = (int)k; v->l = (int)l;
+  ovocab_root(*v);
+  while (std::getline(f, line)) {
+    split(line);
+    if (parts.size() < 35) continue;                               // :155-157
+    unsigned long long pid;
+    if (!parse_u64(parts[0], 0xffffffffull, &pid)) { delete v; return nullptr; }
+    uint8_t d[32];
+    for (int i = 0; i < 32; ++i) {
+      unsigned long long b;
+      if (!parse_u64(parts[2 + i], 255, &b)) { delete v; return nullptr; }
+      d[i] = (uint8_t)b;
+    }
+    char* end = nullptr;
+    const double w = strtod(parts[34].c_str(), &end);
+    if (end == parts[34].c_str() || *end != 0) { delete v; return nullptr; }
+    ovocab_push(*v, (uint32_t)pid, parts[1] == "1", d, w);
+  }
+  return v;
+}
+
+void* oracle_vocab_from_arrays(int n_nodes, const uint32_t* parent, const uint8_t* is_leaf, const uint8_t* desc, const double* weight,
+                               int k, int l) {
+  OVocab* v = new OVocab();
+  v->k = k; v->l = l;
+  ovocab_root(*v);
+  for (int i = 1; i < n_nodes; ++i) ovocab_push(*v, parent[i], is_leaf[i] != 0, desc + 32 * (size_t)i, weight[i]);
+  return v;
+}
+
+void oracle_vocab_free(void* p) { delete (OVocab*)p; }
+
+void oracle_vocab_info(void* p, int* k, int* l, int* n_nodes, int* n_words) {
+  const OVocab* v = (const OVocab*)p;
+  *k = v->k; *l = v->l; *n_nodes = (int)v->parent.size(); *n_words = v->n_words;
+}
+
+void oracle_vocab_arrays(void* p, uint32_t* parent, uint8_t* is_leaf, uint8_t* desc, double* weight) {
+  const OVocab* v = (const OVocab*)p;
+  for (size_t i = 0; i < v->parent.size(); ++i) {
+    parent[i] = v->parent[i]; is_leaf[i] = v->word_id[i] >= 0; memcpy(desc + 32 * i, v->desc[i].data(), 32); weight[i] = v->weight[i];
+  }
+}
+
+// transform (:296-325) without the HashMap accumulation: per descriptor the word id, the leaf node, the node
+// `levels_up` above it (:262-275) and the leaf's weight.
+void oracle_bow_transform(void* p, const uint8_t* desc, int n, int levels_up, uint32_t* word, uint32_t* leaf, uint32_t* node,
+                          double* weight) {
+  const OVocab* v = (const OVocab*)p;
+  for (int i = 0; i < n; ++i) {
+    const uint8_t* d = desc + 32 * (size_t)i;
+    size_t id = 0;
+    while (!v->children[id].empty()) {                               // :231-245
+      uint32_t best = v->children[id][0];
+      uint32_t bd = oracle_hamming256(d, v->desc[best].data());
+      for (size_t c = 1; c < v->children[id].size(); ++c) {
+        const uint32_t ch = v->children[id][c];
+        const uint32_t dd = oracle_hamming256(d, v->desc[ch].data());
+        if (dd < bd) { bd = dd; best = ch; }
+      }
+      id = best;
+    }
+    word[i] = v->word_id[id] >= 0 ? (uint32_t)v->word_id[id] : 0u;   // :247 unwrap_or(0)
+    leaf[i] = (uint32_t)id;
+    weight[i] = v->weight[id];
+    uint32_t nd = (uint32_t)id;
+    for (int s = 0; s < levels_up; ++s) {                            // :265-272
+      const uint32_t pa = v->parent[nd];
+      if (pa == 0xffffffffu) break;
+      nd = pa;
+    }
+    node[i] = nd;
+  }
+}
+
+// search_for_triangulation_bow (src/local_mapping/triangulation.rs:541-658).  node1/node2: the FeatureVector key of each
+// feature (0xffffffff = in no list).  The reference walks feat_vec1 in HashMap order; features in different nodes
+// never compete (a feature of keyframe 2 belongs to one node), so the SET of pairs is order-independent and only
+// the output order is hash-random there.  Here: ascending idx1.
+int oracle_search_for_triangulation_bow(const orbx_camera* cam, const orbx_keypoint* kp1, const uint8_t* desc1, const uint8_t* mp1,
+                                        const uint8_t* stereo1, const uint32_t* node1, int n1, const orbx_keypoint* kp2,
+                                        const uint8_t* desc2, const uint8_t* mp2, const uint32_t* node2, int n2,
+                                        const double* pose1_wc, const double* pose2_wc, unsigned max_dist, int* out_pairs) {
+  double ep[2], F[9];
+  oracle_triangulation_geometry(cam, pose1_wc, pose2_wc, ep, F);
+  std::vector<uint8_t> matched2((size_t)std::max(n2, 1), 0);
+  int n = 0;
+  for (int i1 = 0; i1 < n1; ++i1) {
+    if (node1[i1] == 0xffffffffu || mp1[i1]) continue;               // :583-586
+    const double p0 = (double)kp1[i1].x, p1 = (double)kp1[i1].y;
+    const double l0 = F[0] * p0 + F[1] * p1 + F[2] * 1.0, l1 = F[3] * p0 + F[4] * p1 + F[5] * 1.0, l2 = F[6] * p0 + F[7] * p1 + F[8] * 1.0;
+    const double den = std::sqrt(l0 * l0 + l1 * l1);
+    unsigned best = max_dist;
+    int bi = -1;
+    for (int i2 = 0; i2 < n2; ++i2) {                                // indices2 of the node are ascending (:309 pushes in row order)
+      if (node2[i2] != node1[i1]) continue;
+      if (matched2[i2] || mp2[i2]) continue;                         // :606-608
+      const double x2 = (double)kp2[i2].x, y2 = (double)kp2[i2].y;
+      if (!stereo1[i1]) {                                            // :616-623
+        const double dx = ep[0] - x2, dy = ep[1] - y2;
+        if (dx * dx + dy * dy < 100.0) continue;
+      }
+      if (den < 1e-10) continue;                                     // check_epipolar_constraint (:661-705)
+      const double dl = std::fabs(l0 * x2 + l1 * y2 + l2 * 1.0) / den;
+      if (!(dl * dl < 3.84)) continue;
+      const unsigned d = oracle_hamming256(desc1 + 32 * (size_t)i1, desc2 + 32 * (size_t)i2);
+      if (d < best && d <= max_dist) { best = d; bi = i2; }          // :644-647
+    }
+    if (bi >= 0) { out_pairs[2 * n] = i1; out_pairs[2 * n + 1] = bi; ++n; matched2[bi] = 1; }
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -50,6 +50,21 @@ void oracle_fuse_search(const orbx_camera* cam, const double* positions, const u
                         const uint8_t* descs, int T, double radius_scale, unsigned desc_threshold, int* out_idx,
                         uint32_t* out_dist);
 
+/* vocabulary (src/vocabulary/mod.rs): loader of the DBoW2 text format, per-descriptor tree descent */
+void* oracle_vocab_load_text(const char* path);
+void* oracle_vocab_from_arrays(int n_nodes, const uint32_t* parent, const uint8_t* is_leaf, const uint8_t* desc,
+                               const double* weight, int k, int l);
+void oracle_vocab_free(void* v);
+void oracle_vocab_info(void* v, int* k, int* l, int* n_nodes, int* n_words);
+void oracle_vocab_arrays(void* v, uint32_t* parent, uint8_t* is_leaf, uint8_t* desc, double* weight);
+void oracle_bow_transform(void* v, const uint8_t* desc, int n, int levels_up, uint32_t* word, uint32_t* leaf, uint32_t* node,
+                          double* weight);
+int oracle_search_for_triangulation_bow(const orbx_camera* cam, const orbx_keypoint* kp1, const uint8_t* desc1,
+                                        const uint8_t* mp1, const uint8_t* stereo1, const uint32_t* node1, int n1,
+                                        const orbx_keypoint* kp2, const uint8_t* desc2, const uint8_t* mp2,
+                                        const uint32_t* node2, int n2, const double* pose1_wc, const double* pose2_wc,
+                                        unsigned max_dist, int* out_pairs);
+
 /* ---- ORB extractor (orb_ref.cpp) ---- */
 typedef struct {
   int n_levels;

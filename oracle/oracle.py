@@ -162,6 +162,62 @@ def fuse_search(cam, positions, mp_desc, kf_poses_wc, kf_feat_offset, kps, descs
     return idx, dist
 
 
+class Vocabulary:
+    """OrbVocabulary (src/vocabulary/mod.rs): load_from_text / from arrays, transform."""
+
+    def __init__(self, ptr):
+        if not ptr:
+            raise ValueError("vocabulary could not be loaded")
+        self._p = C.c_void_p(ptr)
+        k, l, nn, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib().oracle_vocab_info(self._p, C.byref(k), C.byref(l), C.byref(nn), C.byref(nw))
+        self.k, self.l, self.n_nodes, self.n_words = k.value, l.value, nn.value, nw.value
+
+    @classmethod
+    def load_from_text(cls, path):
+        lib().oracle_vocab_load_text.restype = C.c_void_p
+        return cls(lib().oracle_vocab_load_text(str(path).encode()))
+
+    @classmethod
+    def from_arrays(cls, parent, is_leaf, desc, weight, k=10, l=6):
+        parent = np.ascontiguousarray(parent, np.uint32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); weight = np.ascontiguousarray(weight, np.float64)
+        lib().oracle_vocab_from_arrays.restype = C.c_void_p
+        return cls(lib().oracle_vocab_from_arrays(C.c_int(len(parent)), _p(parent), _p(is_leaf), _p(desc), _p(weight), C.c_int(k), C.c_int(l)))
+
+    def arrays(self):
+        parent = np.zeros(self.n_nodes, np.uint32); leaf = np.zeros(self.n_nodes, np.uint8)
+        desc = np.zeros((self.n_nodes, 32), np.uint8); weight = np.zeros(self.n_nodes, np.float64)
+        lib().oracle_vocab_arrays(self._p, _p(parent), _p(leaf), _p(desc), _p(weight))
+        return parent, leaf, desc, weight
+
+    def transform(self, desc, levels_up=4):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        word = np.zeros(n, np.uint32); leaf = np.zeros(n, np.uint32); node = np.zeros(n, np.uint32); weight = np.zeros(n, np.float64)
+        lib().oracle_bow_transform(self._p, _p(desc), C.c_int(n), C.c_int(levels_up), _p(word), _p(leaf), _p(node), _p(weight))
+        return word, leaf, node, weight
+
+    def __del__(self):
+        try:
+            lib().oracle_vocab_free(self._p)
+        except Exception:
+            pass
+
+
+def search_for_triangulation_bow(cam, kp1, desc1, mp1, stereo1, node1, kp2, desc2, mp2, node2, pose1_wc, pose2_wc, max_dist=50):
+    kp1 = np.ascontiguousarray(kp1, KEYPOINT); kp2 = np.ascontiguousarray(kp2, KEYPOINT)
+    desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    mp1 = np.ascontiguousarray(mp1, np.uint8); mp2 = np.ascontiguousarray(mp2, np.uint8); stereo1 = np.ascontiguousarray(stereo1, np.uint8)
+    node1 = np.ascontiguousarray(node1, np.uint32); node2 = np.ascontiguousarray(node2, np.uint32)
+    p1 = np.ascontiguousarray(pose1_wc, np.float64); p2 = np.ascontiguousarray(pose2_wc, np.float64)
+    out = np.zeros((max(len(kp1), 1), 2), np.int32)
+    n = lib().oracle_search_for_triangulation_bow(C.byref(cam), _p(kp1), _p(desc1), _p(mp1), _p(stereo1), _p(node1), C.c_int(len(kp1)),
+                                                  _p(kp2), _p(desc2), _p(mp2), _p(node2), C.c_int(len(kp2)), _p(p1), _p(p2),
+                                                  C.c_uint(max_dist), _p(out))
+    return out[:n].copy()
+
+
 def orb_level_table(w, h, params):
     T = OrbLevels()
     rc = lib().oracle_orb_level_table(C.c_int(w), C.c_int(h), C.byref(params), C.byref(T))

@@ -51,7 +51,9 @@ ABI_SYMBOLS = [
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
     "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual", "orbx_ba_solve_global",
-    "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_fuse_search",
+    "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_bow", "orbx_fuse_search",
+    "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
+    "orbx_bow_transform", "orbx_bow_transform_device",
     "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
     "orbx_debug_read_candidates",
 ]
@@ -124,6 +126,12 @@ def load_library():
         L.orbx_stream.restype = C.c_void_p
         L.orbx_stream.argtypes = [C.c_void_p]
         L.orbx_destroy.argtypes = [C.c_void_p]
+        L.orbx_vocab_destroy.argtypes = [C.c_void_p]
+        L.orbx_vocab_destroy.restype = None
+        L.orbx_vocab_info.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orbx_vocab_nodes.argtypes = [C.c_void_p] * 5
+        L.orbx_vocab_load_text.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        L.orbx_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
         L.orbx_destroy.restype = None
         for name in ABI_SYMBOLS:
             getattr(L, name)
@@ -340,6 +348,23 @@ class Handle:
         self._check(self._L.orbx_search_for_triangulation(
             self._h, C.byref(cam), _vp(kp1), _vp(desc1), _vp(mp1), _vp(stereo1), C.c_int(len(kp1)), _vp(kp2), _vp(desc2),
             _vp(mp2), C.c_int(len(kp2)), _vp(p1), _vp(p2), C.c_uint(max_dist), _vp(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def search_for_triangulation_bow(self, camera, kp1, desc1, mp1, stereo1, node1, kp2, desc2, mp2, node2, pose1_wc, pose2_wc,
+                                     max_dist=50):
+        """triangulation.rs:541-658.  node1/node2: FeatureVector key per feature.  int32 [n,2], ascending idx1."""
+        kp1 = np.ascontiguousarray(kp1, KEYPOINT); kp2 = np.ascontiguousarray(kp2, KEYPOINT)
+        desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        mp1 = np.ascontiguousarray(mp1, np.uint8); mp2 = np.ascontiguousarray(mp2, np.uint8)
+        stereo1 = np.ascontiguousarray(stereo1, np.uint8)
+        node1 = np.ascontiguousarray(node1, np.uint32); node2 = np.ascontiguousarray(node2, np.uint32)
+        p1 = np.ascontiguousarray(pose1_wc, np.float64); p2 = np.ascontiguousarray(pose2_wc, np.float64)
+        out = np.zeros((max(len(kp1), 1), 2), np.int32)
+        n = C.c_int()
+        cam = camera._c()
+        self._check(self._L.orbx_search_for_triangulation_bow(
+            self._h, C.byref(cam), _vp(kp1), _vp(desc1), _vp(mp1), _vp(stereo1), _vp(node1), C.c_int(len(kp1)), _vp(kp2), _vp(desc2),
+            _vp(mp2), _vp(node2), C.c_int(len(kp2)), _vp(p1), _vp(p2), C.c_uint(max_dist), _vp(out), C.byref(n)))
         return out[:n.value].copy()
 
     def fuse_search(self, camera, positions, mp_desc, kf_poses_wc, kf_feat_offset, kps, descs, radius_scale, desc_threshold=TH_LOW):
@@ -711,3 +736,92 @@ def solve_global_ba(problem: GlobalBAProblemData, camera: CameraModel, config: G
     out.update({k: r["poses_wc"][i] for i, k in enumerate(opt_ids)})
     return GlobalBAResult(out, {m: r["points"][i] for i, m in enumerate(problem.mp_ids)}, r["iterations"], r["initial_error"],
                           r["final_error"])
+
+
+class OrbVocabulary:
+    """vocabulary/mod.rs:83-94: the tree lives in device memory; transform runs on the GPU."""
+
+    def __init__(self, handle: Handle, ptr):
+        self._handle = handle
+        self._v = ptr
+        L = handle._L
+        k, l, nn, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.orbx_vocab_info(self._v, C.byref(k), C.byref(l), C.byref(nn), C.byref(nw))
+        self.k, self.l, self._n_nodes, self._n_words = k.value, l.value, nn.value, nw.value
+
+    @classmethod
+    def load_from_text(cls, path, handle: Handle = None):
+        """mod.rs:117-211.  Raises OrbxError where the reference returns VocabularyError."""
+        h = handle or _handle()
+        v = C.c_void_p()
+        h._check(h._L.orbx_vocab_load_text(h._h, str(path).encode(), C.byref(v)))
+        return cls(h, v)
+
+    @classmethod
+    def from_nodes(cls, parent, is_leaf, desc, weight, k=10, l=6, handle: Handle = None):
+        h = handle or _handle()
+        parent = np.ascontiguousarray(parent, np.uint32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); weight = np.ascontiguousarray(weight, np.float64)
+        v = C.c_void_p()
+        h._check(h._L.orbx_vocab_create(h._h, C.c_int(len(parent)), _vp(parent), _vp(is_leaf), _vp(desc), _vp(weight), C.c_int(k),
+                                        C.c_int(l), C.byref(v)))
+        return cls(h, v)
+
+    def params(self):
+        return self.k, self.l
+
+    def num_words(self):
+        return self._n_words
+
+    def num_nodes(self):
+        return self._n_nodes
+
+    def nodes(self):
+        parent = np.zeros(self._n_nodes, np.uint32); leaf = np.zeros(self._n_nodes, np.uint8)
+        desc = np.zeros((self._n_nodes, 32), np.uint8); weight = np.zeros(self._n_nodes, np.float64)
+        self._handle._L.orbx_vocab_nodes(self._v, _vp(parent), _vp(leaf), _vp(desc), _vp(weight))
+        return parent, leaf, desc, weight
+
+    def transform_arrays(self, descriptors, levels_up=4):
+        """Per descriptor: (word id, leaf node, FeatureVector key, leaf weight)."""
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word = np.zeros(n, np.uint32); leaf = np.zeros(n, np.uint32); node = np.zeros(n, np.uint32); w = np.zeros(n, np.float64)
+        h = self._handle
+        h._check(h._L.orbx_bow_transform(h._h, self._v, _vp(d), C.c_int(n), C.c_int(levels_up), _vp(word), _vp(leaf), _vp(node), _vp(w)))
+        return word, leaf, node, w
+
+    def transform(self, descriptors, levels_up=4):
+        """mod.rs:296-325 -> (BowVector dict word -> weight, FeatureVector dict node -> [feature indices]).  The L1
+        normalisation sums in ascending word id (the reference sums in HashMap order: same value up to rounding)."""
+        word, _leaf, node, w = self.transform_arrays(descriptors, levels_up)
+        bow, feat = {}, {}
+        for i in range(len(word)):
+            bow[int(word[i])] = bow.get(int(word[i]), 0.0) + float(w[i])
+            feat.setdefault(int(node[i]), []).append(i)
+        total = sum(bow[k] for k in sorted(bow))
+        if total > 0.0:
+            bow = {k: v / total for k, v in bow.items()}
+        return bow, feat
+
+    def transform_bow_only(self, descriptors):
+        """mod.rs:330-356"""
+        return self.transform(descriptors, 0)[0]
+
+    @staticmethod
+    def score(v1, v2):
+        """mod.rs:362-380: 1 - 0.5 * |v1 - v2|_1"""
+        diff = sum(abs(w1 - v2.get(k, 0.0)) for k, w1 in v1.items()) + sum(abs(w2) for k, w2 in v2.items() if k not in v1)
+        return 1.0 - 0.5 * diff
+
+    def close(self):
+        if self._v:
+            self._handle._L.orbx_vocab_destroy(self._v)
+            self._v = None
+
+    def __del__(self):
+        try:
+            if self._handle._h:
+                self.close()
+        except Exception:
+            pass

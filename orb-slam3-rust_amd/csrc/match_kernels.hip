@@ -431,6 +431,9 @@ struct TriArgs {
   const orbx_keypoint* kp2; const uint8_t* desc2;
   const int* cell_start; const int* sorted_idx; const unsigned short* cell_of;
   uint8_t* taken;              // per feature of keyframe 2: has a map point (mp2) or has been matched
+  // FeatureVector mode (search_for_triangulation_bow, :541-658): candidates of feature i1 are sorted_idx[rng_lo[i1] ..
+  // rng_hi[i1]) = the features of keyframe 2 in the same vocabulary node, ascending; no grid (cell_of == nullptr)
+  const int* rng_lo; const int* rng_hi;
 };
 
 __device__ __forceinline__ int f32_as_cell(float v, int last) {          // Rust `f32 as usize` then .min(last)
@@ -478,12 +481,7 @@ __global__ __launch_bounds__(1024) void tri_grid_build_kernel(const orbx_keypoin
 template <typename TakenPtr>
 __device__ __forceinline__ unsigned long long tri_scan(const TriArgs& A, TakenPtr taken, int i1, int t, int stride) {
   const float x = A.kp1[i1].x, y = A.kp1[i1].y;
-  const int c0 = f32_as_cell(fmaxf(floorf((x - 100.0f) / 32.0f), 0.0f), 1 << 30);   // :376-379, radius 100 (:442)
-  const int c1 = min(f32_as_cell(ceilf((x + 100.0f) / 32.0f), 1 << 30), A.cols - 1);
-  const int r0 = f32_as_cell(fmaxf(floorf((y - 100.0f) / 32.0f), 0.0f), 1 << 30);
-  const int r1 = min(f32_as_cell(ceilf((y + 100.0f) / 32.0f), 1 << 30), A.rows - 1);
   unsigned long long best = ~0ull;
-  if (c0 > c1) return best;
   const double p0 = (double)x, p1 = (double)y;
   const double l0 = A.F[0] * p0 + A.F[1] * p1 + A.F[2] * 1.0;           // l2 = F p1 (:685-687)
   const double l1 = A.F[3] * p0 + A.F[4] * p1 + A.F[5] * 1.0;
@@ -492,8 +490,7 @@ __device__ __forceinline__ unsigned long long tri_scan(const TriArgs& A, TakenPt
   if (den < 1e-10) return best;                                          // :694-696
   const bool mono = A.stereo1[i1] == 0;
   const Desc256 d1 = load_desc(A.desc1 + (size_t)i1 * 32);
-  for (int r = r0; r <= r1; ++r) {
-    const int lo = A.cell_start[r * A.cols + c0], hi = A.cell_start[r * A.cols + c1 + 1];
+  auto visit = [&](int lo, int hi) {
     for (int p = lo + t; p < hi; p += stride) {
       const int i2 = A.sorted_idx[p];
       if (taken[i2]) continue;                                           // :479-481
@@ -507,10 +504,21 @@ __device__ __forceinline__ unsigned long long tri_scan(const TriArgs& A, TakenPt
       if (!(dl * dl < 3.84)) continue;                                   // :698-702
       const unsigned d = hamming(d1, load_desc(A.desc2 + (size_t)i2 * 32));
       if (d >= A.max_dist) continue;                                     // :516 with best_dist starting at max_dist
-      const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)A.cell_of[i2] << 32) | (unsigned)i2;
+      const unsigned cell = A.cell_of ? A.cell_of[i2] : 0u;
+      const unsigned long long key = ((unsigned long long)d << 48) | ((unsigned long long)cell << 32) | (unsigned)i2;
       best = key < best ? key : best;
     }
+  };
+  if (A.rng_lo) {                                                        // same vocabulary node (:577-581)
+    visit(A.rng_lo[i1], A.rng_hi[i1]);
+    return best;
   }
+  const int c0 = f32_as_cell(fmaxf(floorf((x - 100.0f) / 32.0f), 0.0f), 1 << 30);   // :376-379, radius 100 (:442)
+  const int c1 = min(f32_as_cell(ceilf((x + 100.0f) / 32.0f), 1 << 30), A.cols - 1);
+  const int r0 = f32_as_cell(fmaxf(floorf((y - 100.0f) / 32.0f), 0.0f), 1 << 30);
+  const int r1 = min(f32_as_cell(ceilf((y + 100.0f) / 32.0f), 1 << 30), A.rows - 1);
+  if (c0 > c1) return best;
+  for (int r = r0; r <= r1; ++r) visit(A.cell_start[r * A.cols + c0], A.cell_start[r * A.cols + c1 + 1]);
   return best;
 }
 
@@ -862,6 +870,48 @@ int launch_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* d_p
   ProfScope ps(h, "fuse_search_kernel");
   hipLaunchKernelGGL(fuse_search_kernel, dim3((P + FUSE_THREADS - 1) / FUSE_THREADS, T), dim3(FUSE_THREADS), 0, h->stream, *cam, d_positions, d_mp_desc, P,
                      d_kf_pose_cw, d_kf_off, d_kps, d_descs, T, radius_scale, desc_threshold, d_out_idx, d_out_dist);
+  ORBX_HIP(h, hipGetLastError());
+  return ORBX_OK;
+}
+
+int launch_search_for_triangulation_bow(orbx_handle* h, const double* F9, const double* epipole, const orbx_keypoint* d_kp1,
+                                        const uint8_t* d_desc1, const uint8_t* d_mp1, const uint8_t* d_stereo1, int n1,
+                                        const orbx_keypoint* d_kp2, const uint8_t* d_desc2, const uint8_t* d_mp2, int n2,
+                                        const int* d_sorted_idx, const int* d_rng_lo, const int* d_rng_hi, unsigned max_dist,
+                                        int* d_pairs, int* d_n_out) {
+  if (n1 <= 0 || n2 <= 0) {
+    ORBX_HIP(h, hipMemsetAsync(d_n_out, 0, sizeof(int), h->stream));
+    return ORBX_OK;
+  }
+  // workspace: prop int[n1] | owner int[n2] | taken u8[n2]
+  const size_t bytes = sizeof(int) * ((size_t)n1 + (size_t)n2) + (size_t)n2 + 64;
+  if (int rc = orbx_reserve(h, h->ws_match, bytes)) return rc;
+  int* prop = (int*)h->ws_match.p;
+  int* owner = prop + n1;
+  uint8_t* taken = (uint8_t*)(owner + n2);
+  ORBX_HIP(h, hipMemcpyAsync(taken, d_mp2, (size_t)n2, hipMemcpyDeviceToDevice, h->stream));   // :606-608
+  TriArgs A{};
+  for (int i = 0; i < 9; ++i) A.F[i] = F9[i];
+  A.epx = epipole[0]; A.epy = epipole[1];
+  A.cols = 0; A.rows = 0; A.max_dist = max_dist; A.n1 = n1; A.n2 = n2;
+  A.kp1 = d_kp1; A.desc1 = d_desc1; A.mp1 = d_mp1; A.stereo1 = d_stereo1; A.kp2 = d_kp2; A.desc2 = d_desc2;
+  A.cell_start = nullptr; A.sorted_idx = d_sorted_idx; A.cell_of = nullptr; A.taken = taken;
+  A.rng_lo = d_rng_lo; A.rng_hi = d_rng_hi;
+  {
+    ProfScope ps(h, "tri_propose_kernel");
+    hipLaunchKernelGGL(tri_propose_kernel, dim3((n1 + 3) / 4), dim3(256), 0, h->stream, A, prop);
+  }
+  {
+    ProfScope ps(h, "tri_resolve_kernel");
+    const size_t lds = 5 * (size_t)n2 + 16;
+    if (lds <= 150 * 1024) {
+      if (lds > 64 * 1024)
+        ORBX_HIP(h, hipFuncSetAttribute((const void*)tri_resolve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      hipLaunchKernelGGL(tri_resolve_kernel<true>, dim3(1), dim3(256), lds, h->stream, A, prop, owner, d_pairs, d_n_out);
+    } else {
+      hipLaunchKernelGGL(tri_resolve_kernel<false>, dim3(1), dim3(256), 0, h->stream, A, prop, owner, d_pairs, d_n_out);
+    }
+  }
   ORBX_HIP(h, hipGetLastError());
   return ORBX_OK;
 }

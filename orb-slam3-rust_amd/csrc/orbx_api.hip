@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <mutex>
 
+#include <algorithm>
+
 #include "orbx_internal.hpp"
 
 static thread_local std::string g_create_error;
@@ -444,6 +446,64 @@ int orbx_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const 
   ORBX_HIP(h, hipMemcpyAsync(d_mp2, mp2, (size_t)n2, hipMemcpyHostToDevice, h->stream));
   orbx_prof_begin_call(h);
   if (int rc = launch_search_for_triangulation(h, cam, F, ep, d_kp1, d_d1, d_mp1, d_st1, n1, d_kp2, d_d2, d_mp2, n2, max_dist, d_pairs, d_n))
+    return rc;
+  ORBX_HIP(h, hipMemcpyAsync(n_out, d_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  if (*n_out > 0) ORBX_HIP(h, hipMemcpy(out_pairs, d_pairs, sizeof(int) * 2 * (size_t)*n_out, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_search_for_triangulation_bow(orbx_handle* h, const orbx_camera* cam, const orbx_keypoint* kp1, const uint8_t* desc1,
+                                      const uint8_t* mp1, const uint8_t* stereo1, const uint32_t* node1, int n1,
+                                      const orbx_keypoint* kp2, const uint8_t* desc2, const uint8_t* mp2, const uint32_t* node2, int n2,
+                                      const double* pose1_wc, const double* pose2_wc, unsigned max_dist, int* out_pairs, int* n_out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || n1 < 0 || n2 < 0 || !pose1_wc || !pose2_wc || !n_out || max_dist > 256 ||
+      (n1 > 0 && (!kp1 || !desc1 || !mp1 || !stereo1 || !node1 || !out_pairs)) || (n2 > 0 && (!kp2 || !desc2 || !mp2 || !node2)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_search_for_triangulation_bow: bad argument");
+  *n_out = 0;
+  if (n1 == 0 || n2 == 0) return ORBX_OK;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  double ep[2], F[9];
+  triangulation_geometry(*cam, pose1_wc, pose2_wc, ep, F);
+  // FeatureVector of keyframe 2 as one sorted array: (node, index) ascending = every node's list in push order (:309)
+  std::vector<int> sorted((size_t)n2), lo((size_t)n1, 0), hi((size_t)n1, 0);
+  for (int i = 0; i < n2; ++i) sorted[(size_t)i] = i;
+  std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b) { return node2[a] < node2[b]; });
+  int m2 = n2;                                                           // features in no list sort last and are cut off
+  while (m2 > 0 && node2[sorted[(size_t)m2 - 1]] == 0xffffffffu) --m2;
+  for (int i = 0; i < n1; ++i) {
+    if (node1[i] == 0xffffffffu) continue;
+    const uint32_t key = node1[i];
+    const auto b = std::lower_bound(sorted.begin(), sorted.begin() + m2, key, [&](int a, uint32_t k) { return node2[a] < k; });
+    const auto e = std::upper_bound(b, sorted.begin() + m2, key, [&](uint32_t k, int a) { return k < node2[a]; });
+    lo[(size_t)i] = (int)(b - sorted.begin()); hi[(size_t)i] = (int)(e - sorted.begin());
+  }
+  const size_t s1 = sizeof(orbx_keypoint) * (size_t)n1, s2 = sizeof(orbx_keypoint) * (size_t)n2;
+  if (int rc = orbx_reserve(h, h->ws_io[0], s1 + s2)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[1], 32 * ((size_t)n1 + n2))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[2], 2 * (size_t)n1 + n2)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[3], sizeof(int) * (2 * (size_t)n1 + 4))) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[4], sizeof(int) * (2 * (size_t)n1 + (size_t)n2))) return rc;
+  orbx_keypoint* d_kp1 = (orbx_keypoint*)h->ws_io[0].p; orbx_keypoint* d_kp2 = d_kp1 + n1;
+  uint8_t* d_d1 = (uint8_t*)h->ws_io[1].p; uint8_t* d_d2 = d_d1 + 32 * (size_t)n1;
+  uint8_t* d_mp1 = (uint8_t*)h->ws_io[2].p; uint8_t* d_st1 = d_mp1 + n1; uint8_t* d_mp2 = d_st1 + n1;
+  int* d_pairs = (int*)h->ws_io[3].p; int* d_n = d_pairs + 2 * (size_t)n1;
+  int* d_lo = (int*)h->ws_io[4].p; int* d_hi = d_lo + n1; int* d_sorted = d_hi + n1;
+  ORBX_HIP(h, hipMemcpyAsync(d_kp1, kp1, s1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_kp2, kp2, s2, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_d1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_d2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_mp1, mp1, (size_t)n1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_st1, stereo1, (size_t)n1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_mp2, mp2, (size_t)n2, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * (size_t)n1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_hi, hi.data(), sizeof(int) * (size_t)n1, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipMemcpyAsync(d_sorted, sorted.data(), sizeof(int) * (size_t)n2, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));   // lo/hi/sorted are locals
+  orbx_prof_begin_call(h);
+  if (int rc = launch_search_for_triangulation_bow(h, F, ep, d_kp1, d_d1, d_mp1, d_st1, n1, d_kp2, d_d2, d_mp2, n2, d_sorted, d_lo, d_hi,
+                                                   max_dist, d_pairs, d_n))
     return rc;
   ORBX_HIP(h, hipMemcpyAsync(n_out, d_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   ORBX_HIP(h, hipStreamSynchronize(h->stream));

@@ -136,6 +136,11 @@ int launch_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, cons
                                     const orbx_keypoint* d_kp1, const uint8_t* d_desc1, const uint8_t* d_mp1,
                                     const uint8_t* d_stereo1, int n1, const orbx_keypoint* d_kp2, const uint8_t* d_desc2,
                                     const uint8_t* d_mp2, int n2, unsigned max_dist, int* d_pairs, int* d_n_out);
+int launch_search_for_triangulation_bow(orbx_handle* h, const double* F9, const double* epipole, const orbx_keypoint* d_kp1,
+                                        const uint8_t* d_desc1, const uint8_t* d_mp1, const uint8_t* d_stereo1, int n1,
+                                        const orbx_keypoint* d_kp2, const uint8_t* d_desc2, const uint8_t* d_mp2, int n2,
+                                        const int* d_sorted_idx, const int* d_rng_lo, const int* d_rng_hi, unsigned max_dist,
+                                        int* d_pairs, int* d_n_out);
 int launch_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* d_positions, const uint8_t* d_mp_desc, int P,
                        const double* d_kf_pose_cw, const int* d_kf_off, const orbx_keypoint* d_kps, const uint8_t* d_descs,
                        int T, double radius_scale, unsigned desc_threshold, int* d_out_idx, uint32_t* d_out_dist);

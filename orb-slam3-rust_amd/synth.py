@@ -248,3 +248,44 @@ def fuse_scene(seed, n_points, n_kfs, n_feat, keypoint_dtype, camera=None, far_f
     return dict(positions=X, mp_desc=mp_desc, kf_poses_wc=np.array(poses), kf_feat_offset=np.array(off, np.int32),
                 kps=np.concatenate(kps) if kps else np.zeros(0, keypoint_dtype),
                 descs=np.concatenate(descs) if descs else np.zeros((0, 32), np.uint8), camera=cam)
+
+
+def vocabulary(seed, k=10, depth=3, ragged=False):
+    """A synthetic DBoW2-style vocabulary tree (the real ORBvoc.txt is not in the build): node 0 is the root; every
+    inner node has k children whose descriptors are the parent's with ~12 % of the bits flipped (so that descents are
+    meaningful), leaves carry an IDF-like weight.  Nodes are numbered in the order a DBoW2 text file lists them
+    (depth-first, children contiguous).  `ragged`: child counts vary from 1 to 2k (more than the 16 lanes a
+    descriptor gets), some branches stop early, a few nodes name a parent that comes later (never linked).
+    Returns (parent u32 [n], is_leaf u8 [n], desc u8 [n,32], weight f64 [n])."""
+    rng = np.random.default_rng([0xB0, seed])
+    parent, leaf, desc, weight = [0], [0], [np.zeros(32, np.uint8)], [0.0]
+
+    def grow(pid, pdesc, level):
+        nc = int(rng.integers(1, 2 * k + 1)) if ragged else k
+        for _ in range(nc):
+            flips = rng.random(256) < 0.12
+            d = np.packbits(np.unpackbits(pdesc, bitorder="little") ^ flips.astype(np.uint8), bitorder="little")
+            nid = len(parent)
+            stop = level + 1 >= depth or (ragged and level >= 1 and rng.random() < 0.2)
+            parent.append(pid); leaf.append(1 if stop else 0); desc.append(d)
+            weight.append(float(rng.uniform(0.5, 12.0)) if stop else 0.0)
+            if not stop:
+                grow(nid, d, level + 1)
+
+    grow(0, rng.integers(0, 256, 32, dtype=np.uint8), 0)
+    parent = np.array(parent, np.uint32); leaf = np.array(leaf, np.uint8)
+    if ragged:   # forward references: load_from_text never links these (mod.rs:196-198)
+        for nid in rng.permutation(np.arange(1, len(parent) - 5))[:5]:
+            parent[nid] = nid + 3
+    return parent, leaf, np.array(desc, np.uint8), np.array(weight, np.float64)
+
+
+def write_vocabulary_text(path, parent, is_leaf, desc, weight, k=10, depth=3, junk_lines=True):
+    """DBoW2 text format as load_from_text reads it (mod.rs:101-116): header 'k L scoring weighting', then
+    'parent_id is_leaf d0..d31 weight' per node (root excluded).  junk_lines adds short lines that the loader skips."""
+    with open(path, "w") as f:
+        f.write("%d %d 0 0\n" % (k, depth))
+        for i in range(1, len(parent)):
+            if junk_lines and i % 97 == 0:
+                f.write("# %d short line\n\n" % i)
+            f.write("%d %d %s %r \n" % (parent[i], is_leaf[i], " ".join(str(int(b)) for b in desc[i]), float(weight[i])))

@@ -42,3 +42,25 @@ for Pn, T, N in ((2000, 20, 1200), (8000, 30, 2000)):
     tc = time.perf_counter() - t0
     print(f"fuse P={Pn} T={T} N={N} found={(idx >= 0).sum()} host_call={dt*1e3:.3f} ms  cpu_oracle={tc*1e3:.1f} ms  " +
           "  ".join(f"{k}={v[0]/max(v[1],1)*1e3:.1f}us" for k, v in kt.items()))
+
+# BoW transform (vocabulary/mod.rs:296-325): k=10, depth 5 synthetic tree (111 111 nodes, the size class of ORBvoc.txt's upper 5 levels)
+voc = P.synth.vocabulary(1, k=10, depth=5)
+gv = P.OrbVocabulary.from_nodes(*voc, 10, 5, handle=h)
+ov = O.Vocabulary.from_arrays(*voc, 10, 5)
+rng = np.random.default_rng(0)
+for n in (2000, 256000):
+    q = voc[2][rng.integers(1, len(voc[2]), n)] ^ rng.integers(0, 2, (n, 32), dtype=np.uint8)
+    for _ in range(2):
+        gv.transform_arrays(q, 4)
+    h.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g = gv.transform_arrays(q, 4)
+    dt = (time.perf_counter() - t0) / 5
+    kt = h.kernel_times()
+    h.set_profiling(False)
+    t0 = time.perf_counter()
+    o = ov.transform(q, 4)
+    tc = time.perf_counter() - t0
+    print(f"bow n={n} nodes={gv.num_nodes()} equal={all(np.array_equal(a, b) for a, b in zip(g, o))} host_call={dt*1e3:.3f} ms cpu_oracle={tc*1e3:.1f} ms  " +
+          "  ".join(f"{k}={v[0]/max(v[1],1)*1e3:.1f}us" for k, v in kt.items()))

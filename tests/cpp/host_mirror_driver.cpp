@@ -70,6 +70,33 @@ int main(int argc, char** argv) {
       fclose(fo);
     }
 
+    // OrbVocabulary::load_from_text + transform + search_for_triangulation_bow (vocabulary/mod.rs, triangulation.rs:541-658)
+    {
+      FILE* ft = fopen((in + "/voc.txt").c_str(), "rb");
+      if (ft) {
+        fclose(ft);
+        orbx::OrbVocabulary voc = orbx::OrbVocabulary::load_from_text(sp.handle(), in + "/voc.txt");
+        auto t1 = voc.transform(f.left_features.descriptors, 1);
+        auto t2 = voc.transform(f.right_features.descriptors, 1);
+        const size_t n1 = f.left_features.keypoints.size(), n2 = f.right_features.keypoints.size();
+        std::vector<uint8_t> mp1(n1), st1(n1), mp2(n2);
+        for (size_t i = 0; i < n1; ++i) { mp1[i] = i % 3 == 0; st1[i] = f.points_cam[i].has_value(); }
+        for (size_t i = 0; i < n2; ++i) mp2[i] = i % 4 == 0;
+        orbx::SE3 p1, p2;
+        p2.rotation = {0.9998000066665778, 0.0, 0.01999866669333308, 0.0};
+        p2.translation = {0.11007, 0.01, 0.02};
+        auto pairs = orbx::search_for_triangulation_bow(sp.handle(), t1.second, t2.second, f.left_features, mp1, st1, f.right_features, mp2, p1, p2, cam, 50);
+        fo = fopen((out + "/bow_out.bin").c_str(), "wb");
+        const int hdr[4] = {(int)voc.num_nodes(), (int)voc.num_words(), (int)t1.first.size(), (int)pairs.size()};
+        put(fo, hdr, 4);
+        double bsum = 0.0;
+        for (const auto& kv : t1.first) bsum += kv.second;
+        put(fo, &bsum, 1);
+        for (auto& pr : pairs) { const int v[2] = {(int)pr.first, (int)pr.second}; put(fo, v, 2); }
+        fclose(fo);
+      }
+    }
+
     // ---- solve_visual_ba (local_ba_lm.rs:912-1098) through VisualBAProblemData keyed by ids -----------------
     std::vector<uint8_t> b = slurp(in + "/ba.bin");
     const int* hd = (const int*)b.data();

@@ -1,0 +1,168 @@
+"""ORB vocabulary + BoW transform + FeatureVector-guided triangulation search (reference src/vocabulary/mod.rs:117-325,
+src/local_mapping/triangulation.rs:541-658).  ORBvoc.txt is not in the build: the trees
+are synthetic, in the same text format.  CPU: oracle vs numpy restatements + the reference's own unit-test values.
+GPU: HIP path vs oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import orb_slam3_rust_amd as P
+from oracle import oracle as O
+
+POP = np.unpackbits(np.arange(256, dtype=np.uint8)[:, None], axis=1).sum(1)
+
+
+def _numpy_transform(parent, leaf, desc, weight, q, levels_up):
+    n = len(parent)
+    children = [[] for _ in range(n)]
+    for i in range(1, n):
+        if parent[i] < i:
+            children[parent[i]].append(i)
+    word_of = np.cumsum(leaf) - 1
+    out = []
+    for d in q:
+        node = 0
+        while children[node]:
+            dist = [int(POP[d ^ desc[c]].sum()) for c in children[node]]
+            node = children[node][int(np.argmin(dist))]          # argmin = first minimum
+        nd = node
+        for _ in range(levels_up):
+            if nd == 0:
+                break
+            nd = int(parent[nd]) if nd != 0 else 0
+        out.append((int(word_of[node]) if leaf[node] else 0, node, nd, weight[node]))
+    return out
+
+
+def _queries(seed, desc, n):
+    rng = np.random.default_rng(seed)
+    src = desc[rng.integers(1, len(desc), n)]
+    flips = rng.random((n, 256)) < 0.05
+    return np.packbits(np.unpackbits(src, axis=1, bitorder="little") ^ flips.astype(np.uint8), axis=1, bitorder="little")
+
+
+def test_reference_unit_values():
+    """vocabulary/mod.rs tests: test_hamming_distance (:429-441), test_bow_score (:443-462)."""
+    a = np.zeros(32, np.uint8); c = a.copy(); c[0] = 0xFF
+    assert O.hamming_batch(a, c)[0] == 8
+    c[1] = 0x0F
+    assert O.hamming_batch(a, c)[0] == 12
+    v1 = {0: 0.5, 1: 0.5}
+    assert abs(P.OrbVocabulary.score(v1, dict(v1)) - 1.0) < 1e-10
+    assert P.OrbVocabulary.score(v1, {2: 0.5, 3: 0.5}) < 0.01
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_oracle_transform_matches_numpy(ragged):
+    parent, leaf, desc, weight = P.synth.vocabulary(1, k=6, depth=3, ragged=ragged)
+    v = O.Vocabulary.from_arrays(parent, leaf, desc, weight, 6, 3)
+    assert v.n_nodes == len(parent) and v.n_words == int(leaf.sum())
+    q = _queries(2, desc, 300)
+    for lu in (0, 1, 2, 7):
+        word, lf, node, w = v.transform(q, lu)
+        want = _numpy_transform(parent, leaf, desc, weight, q, lu)
+        assert [(int(a), int(b), int(c), float(d)) for a, b, c, d in zip(word, lf, node, w)] == want
+
+
+def test_oracle_text_loader(tmp_path):
+    parent, leaf, desc, weight = P.synth.vocabulary(3, k=5, depth=3, ragged=True)
+    path = tmp_path / "voc.txt"
+    P.synth.write_vocabulary_text(path, parent, leaf, desc, weight, 5, 3)
+    v = O.Vocabulary.load_from_text(path)
+    p2, l2, d2, w2 = v.arrays()
+    assert (v.k, v.l) == (5, 3)
+    assert np.array_equal(p2[1:], parent[1:]) and np.array_equal(l2[1:], leaf[1:]) and np.array_equal(d2[1:], desc[1:])
+    assert np.array_equal(w2, weight)                      # repr() round-trips f64 exactly
+    q = _queries(4, desc, 100)
+    a = v.transform(q, 2); b = O.Vocabulary.from_arrays(parent, leaf, desc, weight, 5, 3).transform(q, 2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # a field that does not parse fails the load (mod.rs:160-181); an empty file too (:124-127)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("10 6 0 0\n0 1 " + " ".join(["300"] * 32) + " 1.0\n")
+    with pytest.raises(ValueError):
+        O.Vocabulary.load_from_text(bad)
+    (tmp_path / "empty.txt").write_text("")
+    with pytest.raises(ValueError):
+        O.Vocabulary.load_from_text(tmp_path / "empty.txt")
+
+
+def _bow_scene(seed, n, voc):
+    s = P.synth.two_view_features(seed, n, O.KEYPOINT, dup=0.3)
+    parent, leaf, desc, weight = voc
+    v = O.Vocabulary.from_arrays(parent, leaf, desc, weight)
+    s["node1"] = v.transform(s["desc1"], 1)[2]
+    s["node2"] = v.transform(s["desc2"], 1)[2]
+    return s
+
+
+def test_oracle_bow_search_semantics():
+    voc = P.synth.vocabulary(5, k=4, depth=2)
+    s = _bow_scene(6, 1500, voc)
+    cam = O.Camera(**s["camera"])
+    m = O.search_for_triangulation_bow(cam, s["kp1"], s["desc1"], s["mp1"], s["stereo1"], s["node1"], s["kp2"], s["desc2"], s["mp2"],
+                                       s["node2"], s["pose1_wc"], s["pose2_wc"])
+    assert len(m) > 100 and len(set(m[:, 1].tolist())) == len(m) and np.all(np.diff(m[:, 0]) > 0)
+    assert np.array_equal(s["node1"][m[:, 0]], s["node2"][m[:, 1]])            # only within a vocabulary node
+    assert not s["mp1"][m[:, 0]].any() and not s["mp2"][m[:, 1]].any()
+    # one node for everything = no grouping: a superset of the grid search's candidates -> at least as many pairs
+    one = np.zeros_like(s["node1"]); one2 = np.zeros_like(s["node2"])
+    m_all = O.search_for_triangulation_bow(cam, s["kp1"], s["desc1"], s["mp1"], s["stereo1"], one, s["kp2"], s["desc2"], s["mp2"], one2,
+                                           s["pose1_wc"], s["pose2_wc"])
+    assert len(m_all) >= len(m)
+    absent = np.full_like(s["node1"], 0xFFFFFFFF)
+    assert len(O.search_for_triangulation_bow(cam, s["kp1"], s["desc1"], s["mp1"], s["stereo1"], absent, s["kp2"], s["desc2"], s["mp2"],
+                                              s["node2"], s["pose1_wc"], s["pose2_wc"])) == 0
+
+
+# ---- GPU -----------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,depth,ragged,n", [(10, 4, False, 6000), (10, 3, True, 3000), (3, 6, False, 1000), (20, 2, True, 500)])
+def test_gpu_transform_matches_oracle(gpu_handle, k, depth, ragged, n):
+    parent, leaf, desc, weight = P.synth.vocabulary(7, k=k, depth=depth, ragged=ragged)
+    ov = O.Vocabulary.from_arrays(parent, leaf, desc, weight, k, depth)
+    gv = P.OrbVocabulary.from_nodes(parent, leaf, desc, weight, k, depth, handle=gpu_handle)
+    assert (gv.num_nodes(), gv.num_words(), gv.params()) == (ov.n_nodes, ov.n_words, (k, depth))
+    q = np.concatenate([_queries(8, desc, n), np.random.default_rng(9).integers(0, 256, (200, 32), dtype=np.uint8)])
+    for lu in (0, 1, 4):
+        got = gv.transform_arrays(q, lu); want = ov.transform(q, lu)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    bow, feat = gv.transform(q, 1)
+    assert abs(sum(bow.values()) - 1.0) < 1e-12 and sorted(i for v in feat.values() for i in v) == list(range(len(q)))
+    assert gv.transform_arrays(q[:0], 1)[0].shape == (0,)
+    gv.close()
+
+
+@pytest.mark.gpu
+def test_gpu_text_loader_matches_oracle(gpu_handle, tmp_path):
+    parent, leaf, desc, weight = P.synth.vocabulary(11, k=8, depth=3, ragged=True)
+    path = tmp_path / "voc.txt"
+    P.synth.write_vocabulary_text(path, parent, leaf, desc, weight, 8, 3)
+    gv = P.OrbVocabulary.load_from_text(path, handle=gpu_handle)
+    ov = O.Vocabulary.load_from_text(path)
+    assert (gv.num_nodes(), gv.num_words(), gv.params()) == (ov.n_nodes, ov.n_words, (8, 3))
+    gp, gl, gd, gw = gv.nodes(); op, ol, od, ow = ov.arrays()
+    assert np.array_equal(gp[1:], op[1:]) and np.array_equal(gl, ol) and np.array_equal(gd, od) and np.array_equal(gw, ow)
+    q = _queries(12, desc, 2000)
+    assert all(np.array_equal(a, b) for a, b in zip(gv.transform_arrays(q, 2), ov.transform(q, 2)))
+    bad = tmp_path / "bad.txt"
+    bad.write_text("10 6 0 0\n0 1 " + " ".join(["12"] * 31) + " x 1.0\n")
+    with pytest.raises(P.OrbxError):
+        P.OrbVocabulary.load_from_text(bad, handle=gpu_handle)
+    with pytest.raises(P.OrbxError):
+        P.OrbVocabulary.load_from_text(tmp_path / "missing.txt", handle=gpu_handle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,k,depth", [(1, 1500, 4, 2), (2, 4000, 10, 3), (3, 3000, 2, 1)])
+def test_gpu_bow_search_matches_oracle(gpu_handle, seed, n, k, depth):
+    voc = P.synth.vocabulary(20 + seed, k=k, depth=depth)
+    s = _bow_scene(seed, n, voc)
+    args = (s["kp1"], s["desc1"], s["mp1"], s["stereo1"], s["node1"], s["kp2"], s["desc2"], s["mp2"], s["node2"], s["pose1_wc"], s["pose2_wc"])
+    want = O.search_for_triangulation_bow(O.Camera(**s["camera"]), *args)
+    got = gpu_handle.search_for_triangulation_bow(P.CameraModel(**s["camera"]), *args)
+    assert np.array_equal(got, want) and len(want) > 50
+    # a few features in no list
+    n1 = s["node1"].copy(); n1[::7] = 0xFFFFFFFF
+    n2 = s["node2"].copy(); n2[::5] = 0xFFFFFFFF
+    args = (s["kp1"], s["desc1"], s["mp1"], s["stereo1"], n1, s["kp2"], s["desc2"], s["mp2"], n2, s["pose1_wc"], s["pose2_wc"])
+    assert np.array_equal(gpu_handle.search_for_triangulation_bow(P.CameraModel(**s["camera"]), *args, 80),
+                          O.search_for_triangulation_bow(O.Camera(**s["camera"]), *args, 80))

@@ -42,6 +42,8 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
         f.write(struct.pack("<iiiiiiii", K, F, M, N, -1, 0, 0, 0))
         for a in (w["poses_cw"], w["fixed_cw"], w["points"], ob):
             f.write(np.ascontiguousarray(a, np.float64).tobytes())
+    voc = pkg.synth.vocabulary(31, k=5, depth=2)
+    pkg.synth.write_vocabulary_text(os.path.join(tmp, "voc.txt"), *voc, 5, 2)
     env = dict(os.environ); env.pop("LD_PRELOAD", None)
     r = subprocess.run([exe, tmp, tmp], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "HOST_MIRROR_OK" in r.stdout, (r.stdout, r.stderr)
@@ -74,6 +76,17 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
                                            np.array([1.0, 0, 0, 0, 0, 0, 0]),
                                            np.array([0.9998000066665778, 0.0, 0.01999866669333308, 0.0, 0.11007, 0.01, 0.02]), 50)
     assert np.array_equal(np.frombuffer(tb, np.int32, 2 * npairs, 4).reshape(-1, 2), want)
+    # --- OrbVocabulary::load_from_text + transform + search_for_triangulation_bow
+    bb = open(os.path.join(tmp, "bow_out.bin"), "rb").read()
+    nn, nw, nbow, npairs = struct.unpack_from("<iiii", bb, 0)
+    (bsum,) = struct.unpack_from("<d", bb, 16)
+    ov = oracle.Vocabulary.load_from_text(os.path.join(tmp, "voc.txt"))
+    w1, _l1, n1, _ = ov.transform(odl, 1); _w2, _l2, n2, _ = ov.transform(odr, 1)
+    assert (nn, nw) == (ov.n_nodes, ov.n_words) and nbow == len(set(w1.tolist())) and abs(bsum - 1.0) < 1e-12
+    want = oracle.search_for_triangulation_bow(oracle.Camera(**pkg.synth.EUROC_CAMERA), okl, odl, mp1, h0.astype(np.uint8), n1, okr, odr, mp2, n2,
+                                               np.array([1.0, 0, 0, 0, 0, 0, 0]),
+                                               np.array([0.9998000066665778, 0.0, 0.01999866669333308, 0.0, 0.11007, 0.01, 0.02]), 50)
+    assert np.array_equal(np.frombuffer(bb, np.int32, 2 * npairs, 24).reshape(-1, 2), want)
     # --- solve_visual_ba through VisualBAProblemData keyed by ids
     bb = open(os.path.join(tmp, "ba_out.bin"), "rb").read()
     ok, it = struct.unpack_from("<ii", bb, 0)
