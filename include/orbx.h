@@ -257,6 +257,27 @@ int orbx_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* posit
                      const double* kf_poses_wc, const int* kf_feat_offset, const orbx_keypoint* kps, const uint8_t* descs,
                      int T, double radius_scale, unsigned desc_threshold, int* out_idx, uint32_t* out_dist);
 
+/* ---- input side (src/io/euroc.rs) ------------------------------------------------------------------------------
+ * Host code: the EuRoC `mav0` reader of EurocDataset::new / len / frame_timestamp / stereo_pair (:64-132,
+ * load_image_list :189-211, the camera part of load_stereo_calibration :325-360) and the PNG decode that
+ * cv::imread(IMREAD_GRAYSCALE) does there.  No GPU involved; outputs feed orbx_process_stereo[_batch].
+ *   orbx_png_decode_gray8: non-interlaced greyscale PNG (8 or 16 bit, optional alpha) -> 8-bit rows; out == NULL
+ *     returns only the size.  Anything else (palette, RGB, interlaced, damaged) is ORBX_ERR_INVALID.
+ *   orbx_euroc_open: ORBX_ERR_INVALID + message in err where the reference returns Err (missing file, a timestamp
+ *     that does not parse, records of different lengths, cam0/cam1 of different lengths, bad yaml).
+ *   orbx_euroc_calibration: left = {fx, fy, cx, cy of cam0, baseline = |t(T_cam1_body * T_cam0_body^-1)|}.
+ *   orbx_euroc_read_pairs: frames [first, first+count) decoded by `threads` host threads into out[pair][2][h][w],
+ *     the layout orbx_process_stereo_batch takes (use orbx_host_alloc memory to overlap the upload). */
+typedef struct orbx_euroc orbx_euroc;
+int orbx_png_decode_gray8(const uint8_t* file, size_t n, uint8_t* out, size_t stride, int* w, int* h);
+int orbx_euroc_open(const char* mav0_dir, orbx_euroc** out, char* err, size_t err_cap);
+void orbx_euroc_close(orbx_euroc* d);
+int orbx_euroc_len(const orbx_euroc* d);
+const char* orbx_euroc_last_error(const orbx_euroc* d);
+int orbx_euroc_frame_timestamp(const orbx_euroc* d, int idx, uint64_t* timestamp_ns);
+int orbx_euroc_calibration(const orbx_euroc* d, orbx_camera* left, double* k_right4, int* w, int* h);
+int orbx_euroc_read_pairs(orbx_euroc* d, int first, int count, uint8_t* out, int threads);
+
 /* ---- local bundle adjustment ------------------------------------------------------ */
 
 /* = LocalBAConfigLM, src/optimizer/local_ba_lm.rs:96-119 */

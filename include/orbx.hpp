@@ -298,6 +298,58 @@ inline std::optional<VisualBAResultData> solve_visual_ba(Handle& h, const Visual
 }
 
 
+// ---- input side (src/io/euroc.rs) -------------------------------------------------------------------------------
+struct StereoImagePair {   // euroc.rs:21-26 (Mat -> row-major u8)
+  std::vector<uint8_t> left, right;
+  int width = 0, height = 0;
+  uint64_t timestamp_ns = 0;
+};
+
+class EurocDataset {   // euroc.rs:54-132, the image side
+ public:
+  explicit EurocDataset(const std::string& mav0_dir) {   // EurocDataset::new (:64-90)
+    char err[512] = {0};
+    const int rc = orbx_euroc_open(mav0_dir.c_str(), &d_, err, sizeof(err));
+    if (rc != ORBX_OK) throw Error(rc, err);
+    orbx_camera c;
+    orbx_euroc_calibration(d_, &c, nullptr, &w_, &h_);
+    camera_ = CameraModel{c.fx, c.fy, c.cx, c.cy, c.baseline};
+  }
+  EurocDataset(const EurocDataset&) = delete;
+  EurocDataset& operator=(const EurocDataset&) = delete;
+  ~EurocDataset() { orbx_euroc_close(d_); }
+  size_t len() const { return (size_t)orbx_euroc_len(d_); }
+  std::optional<uint64_t> frame_timestamp(size_t idx) const {
+    uint64_t ts;
+    if (orbx_euroc_frame_timestamp(d_, (int)idx, &ts) != ORBX_OK) return std::nullopt;
+    return ts;
+  }
+  const CameraModel& camera() const { return camera_; }
+  int width() const { return w_; }
+  int height() const { return h_; }
+  StereoImagePair stereo_pair(size_t idx) const {        // :100-132
+    StereoImagePair p;
+    p.width = w_; p.height = h_;
+    std::vector<uint8_t> both(2 * (size_t)w_ * h_);
+    const int rc = orbx_euroc_read_pairs(d_, (int)idx, 1, both.data(), 2);
+    if (rc != ORBX_OK) throw Error(rc, orbx_euroc_last_error(d_));
+    p.left.assign(both.begin(), both.begin() + (size_t)w_ * h_);
+    p.right.assign(both.begin() + (size_t)w_ * h_, both.end());
+    p.timestamp_ns = *frame_timestamp(idx);
+    return p;
+  }
+  // `count` pairs from `first` into out[pair][2][h][w] (e.g. orbx_host_alloc memory), decoded by `threads` host threads
+  void read_pairs(size_t first, size_t count, uint8_t* out, int threads) const {
+    const int rc = orbx_euroc_read_pairs(d_, (int)first, (int)count, out, threads);
+    if (rc != ORBX_OK) throw Error(rc, orbx_euroc_last_error(d_));
+  }
+
+ private:
+  orbx_euroc* d_ = nullptr;
+  CameraModel camera_{};
+  int w_ = 0, h_ = 0;
+};
+
 // ---- ORB vocabulary (src/vocabulary/mod.rs) ----------------------------------------------------------------------
 using BowVector = std::unordered_map<uint32_t, double>;                  // mod.rs:31
 using FeatureVector = std::unordered_map<uint32_t, std::vector<size_t>>; // mod.rs:37

@@ -54,6 +54,8 @@ ABI_SYMBOLS = [
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_bow", "orbx_fuse_search",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
     "orbx_bow_transform", "orbx_bow_transform_device",
+    "orbx_png_decode_gray8", "orbx_euroc_open", "orbx_euroc_close", "orbx_euroc_len", "orbx_euroc_last_error",
+    "orbx_euroc_frame_timestamp", "orbx_euroc_calibration", "orbx_euroc_read_pairs",
     "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
     "orbx_debug_read_candidates",
 ]
@@ -126,6 +128,16 @@ def load_library():
         L.orbx_stream.restype = C.c_void_p
         L.orbx_stream.argtypes = [C.c_void_p]
         L.orbx_destroy.argtypes = [C.c_void_p]
+        L.orbx_euroc_close.argtypes = [C.c_void_p]
+        L.orbx_euroc_close.restype = None
+        L.orbx_euroc_len.argtypes = [C.c_void_p]
+        L.orbx_euroc_last_error.argtypes = [C.c_void_p]
+        L.orbx_euroc_last_error.restype = C.c_char_p
+        L.orbx_euroc_open.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.orbx_euroc_frame_timestamp.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orbx_euroc_calibration.argtypes = [C.c_void_p] * 5
+        L.orbx_euroc_read_pairs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orbx_png_decode_gray8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orbx_vocab_destroy.argtypes = [C.c_void_p]
         L.orbx_vocab_destroy.restype = None
         L.orbx_vocab_info.argtypes = [C.c_void_p] + [C.c_void_p] * 4
@@ -823,5 +835,78 @@ class OrbVocabulary:
         try:
             if self._handle._h:
                 self.close()
+        except Exception:
+            pass
+
+
+def png_decode_gray8(data: bytes):
+    """cv::imread(IMREAD_GRAYSCALE) for the PNG subset EuRoC uses (host code in the library, no GPU)."""
+    L = load_library()
+    buf = np.frombuffer(data, np.uint8)
+    w, h = C.c_int(), C.c_int()
+    rc = L.orbx_png_decode_gray8(_vp(buf), C.c_size_t(len(buf)), None, C.c_size_t(0), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise OrbxError(rc, "not a supported greyscale PNG")
+    out = np.empty((h.value, w.value), np.uint8)
+    rc = L.orbx_png_decode_gray8(_vp(buf), C.c_size_t(len(buf)), _vp(out), C.c_size_t(w.value), None, None)
+    if rc != 0:
+        raise OrbxError(rc, "damaged PNG")
+    return out
+
+
+class EurocDataset:
+    """io/euroc.rs:54-132, the image side: cam0/cam1 lists, calibration, stereo pairs (host code, no GPU)."""
+
+    def __init__(self, root):
+        L = load_library()
+        self._L = L
+        self._d = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.orbx_euroc_open(str(root).encode(), C.byref(self._d), err, C.c_size_t(512))
+        if rc != 0:
+            self._d = None
+            raise OrbxError(rc, err.value.decode())
+        cam = _Camera(); kr = (C.c_double * 4)(); w, h = C.c_int(), C.c_int()
+        L.orbx_euroc_calibration(self._d, C.byref(cam), kr, C.byref(w), C.byref(h))
+        self.camera = CameraModel(cam.fx, cam.fy, cam.cx, cam.cy, cam.baseline)
+        self.k_right = tuple(kr)
+        self.width, self.height = w.value, h.value
+
+    @classmethod
+    def new(cls, root):
+        return cls(root)
+
+    def __len__(self):
+        return self._L.orbx_euroc_len(self._d)
+
+    def len(self):
+        return len(self)
+
+    def frame_timestamp(self, idx):
+        ts = C.c_uint64()
+        return ts.value if self._L.orbx_euroc_frame_timestamp(self._d, C.c_int(idx), C.byref(ts)) == 0 else None
+
+    def read_pairs(self, first, count, out=None, threads=8):
+        """[count, 2, h, w] u8, decoded by `threads` host threads; `out` may be a pinned buffer of that shape."""
+        if out is None:
+            out = np.empty((count, 2, self.height, self.width), np.uint8)
+        rc = self._L.orbx_euroc_read_pairs(self._d, C.c_int(first), C.c_int(count), _vp(out), C.c_int(threads))
+        if rc != 0:
+            raise OrbxError(rc, self._L.orbx_euroc_last_error(self._d).decode())
+        return out
+
+    def stereo_pair(self, idx):
+        """euroc.rs:100-132 -> (left, right, timestamp_ns)"""
+        p = self.read_pairs(idx, 1, threads=2)
+        return p[0, 0], p[0, 1], self.frame_timestamp(idx)
+
+    def close(self):
+        if self._d:
+            self._L.orbx_euroc_close(self._d)
+            self._d = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass

@@ -289,3 +289,89 @@ def write_vocabulary_text(path, parent, is_leaf, desc, weight, k=10, depth=3, ju
             if junk_lines and i % 97 == 0:
                 f.write("# %d short line\n\n" % i)
             f.write("%d %d %s %r \n" % (parent[i], is_leaf[i], " ".join(str(int(b)) for b in desc[i]), float(weight[i])))
+
+
+def png_encode(img, filters="cycle", bit_depth=8, alpha=False, level=6):
+    """A PNG file (bytes) of a greyscale image, written with zlib only: `filters` = 'cycle' (row y uses filter type
+    y % 5, exercising None/Sub/Up/Average/Paeth), 'none', or an int 0..4; bit_depth 8 or 16 (16: value*257, so the
+    high byte is the 8-bit value); alpha adds an opaque alpha channel (colour type 4)."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    px = img.astype(np.uint16)
+    chans = [px * 257 if bit_depth == 16 else px]
+    if alpha:
+        chans.append(np.full_like(px, 65535 if bit_depth == 16 else 255))
+    inter = np.stack(chans, -1)                                            # [h, w, c]
+    raw = inter.astype(">u2").view(np.uint8).reshape(h, -1) if bit_depth == 16 else inter.astype(np.uint8).reshape(h, -1)
+    bpp = len(chans) * (bit_depth // 8)
+    rows = []
+    prev = np.zeros(raw.shape[1], np.int32)
+    for y in range(h):
+        cur = raw[y].astype(np.int32)
+        ft = y % 5 if filters == "cycle" else (0 if filters == "none" else int(filters))
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if ft == 0:
+            f = cur
+        elif ft == 1:
+            f = cur - a
+        elif ft == 2:
+            f = cur - prev
+        elif ft == 3:
+            f = cur - ((a + prev) >> 1)
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            f = cur - pred
+        rows.append(bytes([ft]) + (f & 255).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    ihdr = struct.pack(">IIBBBBB", w, h, bit_depth, 4 if alpha else 0, 0, 0, 0)
+    z = zlib.compress(b"".join(rows), level)
+    half = len(z) // 2                                                     # two IDAT chunks: the stream may be split anywhere
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"tEXt", b"Comment\x00synthetic") + chunk(b"IDAT", z[:half]) + \
+        chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+
+
+def write_euroc_mav0(root, n_frames, seed=0, w=752, h=480, camera=None):
+    """A synthetic EuRoC `mav0` directory (cam0/cam1 data.csv + data/*.png + sensor.yaml in the dataset's own layout)
+    holding stereo_pair(seed, i) for i < n_frames.  Returns the list of (left, right) arrays written."""
+    import os
+    cam = dict(EUROC_CAMERA if camera is None else camera)
+    pairs = []
+    t0 = 1403636579763555584
+    # T_BS of the two cameras: cam1 displaced by the baseline along cam0's x axis, both slightly rotated vs. the body
+    R = _quat_rot(_quat_from_axis_angle([0.2, -0.1, 1.0], 1.57), np.eye(3)).T
+    t_b_c0 = np.array([-0.0216, -0.0647, 0.0098])
+    t_b_c1 = t_b_c0 + R @ np.array([cam["baseline"], 0.0, 0.0])
+    for c, t in ((0, t_b_c0), (1, t_b_c1)):
+        d = os.path.join(root, "cam%d" % c, "data")
+        os.makedirs(d, exist_ok=True)
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+        with open(os.path.join(root, "cam%d" % c, "sensor.yaml"), "w") as f:
+            f.write("# General sensor definitions.\nsensor_type: camera\ncomment: VI-Sensor cam%d (MT9M034)\n\n" % c)
+            f.write("# Sensor extrinsics wrt. the body-frame.\nT_BS:\n  cols: 4\n  rows: 4\n  data: [")
+            f.write(",\n         ".join(", ".join(repr(float(v)) for v in T[r]) for r in range(4)))
+            f.write("]\n\n# Camera specific definitions.\nrate_hz: 20\nresolution: [%d, %d]\ncamera_model: pinhole\n" % (w, h))
+            f.write("intrinsics: [%r, %r, %r, %r] #fu, fv, cu, cv\n" % (cam["fx"], cam["fy"], cam["cx"], cam["cy"]))
+            f.write("distortion_model: radial-tangential\ndistortion_coefficients: [0.0, 0.0, 0.0, 0.0]\n")
+    rows = []
+    for i in range(n_frames):
+        L, Rr = stereo_pair(seed, i, w, h)
+        pairs.append((L, Rr))
+        ts = t0 + 50000000 * i
+        name = "%d.png" % ts
+        rows.append("%d,%s" % (ts, name))
+        for c, img in ((0, L), (1, Rr)):
+            with open(os.path.join(root, "cam%d" % c, "data", name), "wb") as f:
+                f.write(png_encode(img, filters="cycle" if i % 2 == 0 else (i % 5)))
+    for c in (0, 1):
+        with open(os.path.join(root, "cam%d" % c, "data.csv"), "w") as f:
+            f.write("#timestamp [ns],filename\n" + "\r\n".join(rows) + "\n")
+    return pairs

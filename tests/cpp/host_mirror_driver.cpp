@@ -3,6 +3,7 @@
 // results back for comparison with the oracle.  usage: driver <in_dir> <out_dir>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "orbx.hpp"
@@ -68,6 +69,27 @@ int main(int argc, char** argv) {
       put(fo, &np, 1);
       for (auto& pr : pairs) { const int v[2] = {(int)pr.first, (int)pr.second}; put(fo, v, 2); }
       fclose(fo);
+    }
+
+    // EurocDataset (io/euroc.rs): when the test wrote a mav0 directory, frame 1 read through the mirror must process to the
+    // same StereoFrame sizes as the raw images of stereo.bin (the test stores the same pair as frame 1)
+    {
+      FILE* fc = fopen((in + "/mav0/cam0/data.csv").c_str(), "rb");
+      if (fc) {
+        fclose(fc);
+        orbx::EurocDataset ds(in + "/mav0");
+        orbx::StereoImagePair pr = ds.stereo_pair(1);
+        if (pr.width != w || pr.height != h || memcmp(pr.left.data(), left, (size_t)w * h) != 0 || memcmp(pr.right.data(), right, (size_t)w * h) != 0) {
+          fprintf(stderr, "EurocDataset::stereo_pair differs from the raw images\n");
+          return 5;
+        }
+        fo = fopen((out + "/euroc_out.bin").c_str(), "wb");
+        const uint64_t meta[3] = {(uint64_t)ds.len(), *ds.frame_timestamp(1), pr.timestamp_ns};
+        put(fo, meta, 3);
+        const double cal[5] = {ds.camera().fx, ds.camera().fy, ds.camera().cx, ds.camera().cy, ds.camera().baseline};
+        put(fo, cal, 5);
+        fclose(fo);
+      }
     }
 
     // OrbVocabulary::load_from_text + transform + search_for_triangulation_bow (vocabulary/mod.rs, triangulation.rs:541-658)

@@ -42,6 +42,14 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
         f.write(struct.pack("<iiiiiiii", K, F, M, N, -1, 0, 0, 0))
         for a in (w["poses_cw"], w["fixed_cw"], w["points"], ob):
             f.write(np.ascontiguousarray(a, np.float64).tobytes())
+    # a two-frame mav0 directory whose frame 1 is the pair of stereo.bin
+    import struct as _st
+    mav0 = os.path.join(tmp, "mav0")
+    pkg.synth.write_euroc_mav0(mav0, 2, seed=17)
+    ts1 = 1403636579763555584 + 50000000
+    for c, img in ((0, L), (1, R)):
+        with open(os.path.join(mav0, "cam%d" % c, "data", "%d.png" % ts1), "wb") as f:
+            f.write(pkg.synth.png_encode(img, filters=3))
     voc = pkg.synth.vocabulary(31, k=5, depth=2)
     pkg.synth.write_vocabulary_text(os.path.join(tmp, "voc.txt"), *voc, 5, 2)
     env = dict(os.environ); env.pop("LD_PRELOAD", None)
@@ -76,6 +84,12 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
                                            np.array([1.0, 0, 0, 0, 0, 0, 0]),
                                            np.array([0.9998000066665778, 0.0, 0.01999866669333308, 0.0, 0.11007, 0.01, 0.02]), 50)
     assert np.array_equal(np.frombuffer(tb, np.int32, 2 * npairs, 4).reshape(-1, 2), want)
+    # --- EurocDataset mirror (the driver itself compared the decoded pair with the raw images)
+    eb = open(os.path.join(tmp, "euroc_out.bin"), "rb").read()
+    n_frames, t1a, t1b = struct.unpack_from("<QQQ", eb, 0)
+    cal = struct.unpack_from("<5d", eb, 24)
+    ec = pkg.synth.EUROC_CAMERA
+    assert (n_frames, t1a, t1b) == (2, ts1, ts1) and cal[:4] == (ec["fx"], ec["fy"], ec["cx"], ec["cy"]) and abs(cal[4] - ec["baseline"]) < 1e-12
     # --- OrbVocabulary::load_from_text + transform + search_for_triangulation_bow
     bb = open(os.path.join(tmp, "bow_out.bin"), "rb").read()
     nn, nw, nbow, npairs = struct.unpack_from("<iiii", bb, 0)
