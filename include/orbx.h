@@ -290,7 +290,7 @@ typedef struct {
 /* One VisualObservation (local_ba_lm.rs:68-78) after the id -> index re-keying the
  * reference does at :928-961.  kf_idx >= 0: optimised keyframe (is_kf_optimized);
  * kf_idx < 0: fixed keyframe `fixed_idx` (fixed_idx < 0 = unknown id -> identity pose,
- * local_ba_lm.rs:569). */
+ * local_ba_lm.rs:569).  _pad: 0 for the visual solvers; bit 0 = is_stereo for orbx_ba_solve_inertial. */
 typedef struct {
   int32_t kf_idx, fixed_idx, mp_idx, _pad;
   double u, v;
@@ -337,6 +337,36 @@ int orbx_ba_solve_global(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          const double* poses_cw, const double* fixed_pose_cw, int M, double* points, int N,
                          const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user,
                          double* poses_wc_out, int* iterations, double* initial_error, double* final_error);
+
+/* LocalInertialBAConfig (src/optimizer/local_inertial_ba.rs:109-141); orbx_default_inertial_ba_config = its Default:
+ * 10 iterations, window 10, sqrt(5.991), sqrt(7.815), lambda 1e-2, gyro random-walk information 1e6, accel 1e4. */
+typedef struct {
+  int max_iterations;
+  int window_size;               /* used by the caller when it collects the temporal window (:366-384) */
+  double huber_threshold_mono, huber_threshold_stereo;
+  double initial_lambda;
+  double gyro_rw_info, accel_rw_info;
+} orbx_inertial_ba_config;
+void orbx_default_inertial_ba_config(orbx_inertial_ba_config* cfg);
+
+/* Replaces solve_inertial_ba (src/optimizer/local_inertial_ba.rs:1074-1275): visual-inertial local BA over the K
+ * keyframes of the temporal window, 15 parameters each (T_wc pose as axis-angle + translation, velocity, gyro bias,
+ * accel bias), plus M map points.  Residuals: reprojection (Huber, threshold per observation mono/stereo,
+ * obs[i]._pad bit 0 = is_stereo; 100-px penalty and no Jacobian where z_c <= 0.001), the 9-d preintegration
+ * residual of imu_factors.rs:66-103 per IMU edge with forward-difference Jacobians (eps 1e-6, :806-861), and the
+ * 6-d bias random walk per edge (:676-698).  LM as :1198-1243: initial lambda from cfg, stop on |gradient| < 1e-8
+ * or a singular system, no step-size test; errors are |r| (not RMS).
+ *   poses_wc [K][7], velocities [K][3], biases [K][6] (gyro xyz, accel xyz); fixed_poses_cw [F][7] (T_cw);
+ *   obs: kf_idx = index into the window or -1 (+ fixed_idx); edge_kf [E][2] window indices (i earlier, j later);
+ *   preint [E][11] = delta_rot (qw,qx,qy,qz), delta_vel, delta_pos, dt of PreintegratedState (preintegration.rs:85-98).
+ *   Outputs for ALL K keyframes (the reference's result maps skip index 0, :1250 — the caller's business).
+ * ORBX_ERR_EMPTY where the reference returns None (K < 2, :1080-1082). */
+int orbx_ba_solve_inertial(orbx_handle* h, const orbx_camera* cam, const orbx_inertial_ba_config* cfg, int K,
+                           const double* poses_wc, const double* velocities, const double* biases, int F,
+                           const double* fixed_poses_cw, int M, double* points, int N, const orbx_ba_obs* obs, int E,
+                           const int* edge_kf, const double* preint, orbx_should_stop_fn should_stop, void* user,
+                           double* poses_wc_out, double* vel_out, double* bias_out, int* iterations,
+                           double* initial_error, double* final_error);
 
 /* Per-kernel device time for bench.py's roofline block.  While profiling is on
  * (orbx_set_profiling), every launch is bracketed by HIP events on the handle's stream;

@@ -527,4 +527,134 @@ inline std::optional<GlobalBAResult> solve_global_ba(Handle& h, const GlobalBAPr
   return r;
 }
 
+
+// ---- local inertial bundle adjustment (src/optimizer/local_inertial_ba.rs) -----------------------------------------
+struct ImuBias { std::array<double, 3> gyro{0, 0, 0}, accel{0, 0, 0}; };   // imu/types.rs
+
+struct PreintegratedState {   // imu/preintegration.rs:85-98, the fields the residual reads (imu_factors.rs:66-103)
+  std::array<double, 4> delta_rot{1, 0, 0, 0};
+  std::array<double, 3> delta_vel{0, 0, 0}, delta_pos{0, 0, 0};
+  double dt = 0.0;
+};
+
+struct LocalInertialBAConfig {   // local_inertial_ba.rs:109-141
+  int max_iterations = 10, window_size = 10;
+  double huber_threshold_mono = std::sqrt(5.991), huber_threshold_stereo = std::sqrt(7.815), initial_lambda = 1e-2;
+  double gyro_rw_info = 1e6, accel_rw_info = 1e4;
+};
+
+struct InertialVisualObs {   // :64-77
+  KeyFrameId kf_id;
+  MapPointId mp_id;
+  std::array<double, 2> observed_uv;
+  bool is_stereo, is_kf_in_window;
+};
+
+struct ImuEdgeData {   // :79-88
+  KeyFrameId kf_i_id, kf_j_id;
+  PreintegratedState preint;
+};
+
+struct InertialBAProblemData {   // :40-62; kf_poses T_wc, fixed_kf_poses T_cw
+  std::unordered_map<KeyFrameId, SE3> kf_poses;
+  std::unordered_map<KeyFrameId, std::array<double, 3>> kf_velocities;
+  std::unordered_map<KeyFrameId, ImuBias> kf_biases;
+  std::unordered_map<MapPointId, std::array<double, 3>> mp_positions;
+  std::unordered_map<KeyFrameId, SE3> fixed_kf_poses;
+  std::vector<InertialVisualObs> visual_observations;
+  std::vector<ImuEdgeData> imu_edges;
+  std::vector<KeyFrameId> opt_kf_ids;
+  std::vector<MapPointId> mp_ids;
+};
+
+struct InertialBAResultData {   // :90-106; the first keyframe of the window is not reported (:1250)
+  std::unordered_map<KeyFrameId, SE3> optimized_poses;
+  std::unordered_map<KeyFrameId, std::array<double, 3>> optimized_velocities;
+  std::unordered_map<KeyFrameId, ImuBias> optimized_biases;
+  std::unordered_map<MapPointId, std::array<double, 3>> optimized_points;
+  size_t iterations = 0;
+  double initial_error = 0, final_error = 0;
+};
+
+// local_inertial_ba.rs:1074-1275.  The id -> index re-keying is the reference's own (:1084-1185).
+inline std::optional<InertialBAResultData> solve_inertial_ba(Handle& h, const InertialBAProblemData& problem, const CameraModel& camera,
+                                                             const LocalInertialBAConfig& config, const std::function<bool()>& should_stop) {
+  const int K = (int)problem.opt_kf_ids.size(), M = (int)problem.mp_ids.size();
+  if (K < 2) return std::nullopt;                                         // :1080-1082
+  std::unordered_map<KeyFrameId, int> kf_idx, fixed_idx;
+  std::unordered_map<MapPointId, int> mp_idx;
+  for (int i = 0; i < K; ++i) kf_idx[problem.opt_kf_ids[(size_t)i]] = i;
+  for (int i = 0; i < M; ++i) mp_idx[problem.mp_ids[(size_t)i]] = i;
+  std::vector<double> poses, vel, bias, fixed, points, preint;
+  auto push7 = [](std::vector<double>& v, const SE3& p) {
+    v.insert(v.end(), p.rotation.begin(), p.rotation.end());
+    v.insert(v.end(), p.translation.begin(), p.translation.end());
+  };
+  for (KeyFrameId id : problem.opt_kf_ids) {                               // :1140-1174, missing entries stay zero
+    auto p = problem.kf_poses.find(id);
+    push7(poses, p != problem.kf_poses.end() ? p->second : SE3{});
+    auto v = problem.kf_velocities.find(id);
+    const std::array<double, 3> vv = v != problem.kf_velocities.end() ? v->second : std::array<double, 3>{0, 0, 0};
+    vel.insert(vel.end(), vv.begin(), vv.end());
+    auto b = problem.kf_biases.find(id);
+    const ImuBias bb = b != problem.kf_biases.end() ? b->second : ImuBias{};
+    bias.insert(bias.end(), bb.gyro.begin(), bb.gyro.end());
+    bias.insert(bias.end(), bb.accel.begin(), bb.accel.end());
+  }
+  for (const auto& kv : problem.fixed_kf_poses) { fixed_idx[kv.first] = (int)fixed_idx.size(); push7(fixed, kv.second); }
+  for (MapPointId id : problem.mp_ids) {
+    auto it = problem.mp_positions.find(id);
+    const std::array<double, 3> p = it != problem.mp_positions.end() ? it->second : std::array<double, 3>{0, 0, 0};
+    points.insert(points.end(), p.begin(), p.end());
+  }
+  std::vector<orbx_ba_obs> obs;
+  for (const InertialVisualObs& o : problem.visual_observations) {         // :1101-1120
+    auto m = mp_idx.find(o.mp_id);
+    if (m == mp_idx.end()) continue;
+    orbx_ba_obs b{};
+    b.mp_idx = m->second; b.u = o.observed_uv[0]; b.v = o.observed_uv[1]; b._pad = o.is_stereo ? 1 : 0;
+    auto k = o.is_kf_in_window ? kf_idx.find(o.kf_id) : kf_idx.end();
+    if (k != kf_idx.end()) { b.kf_idx = k->second; b.fixed_idx = -1; }
+    else { auto f = fixed_idx.find(o.kf_id); b.kf_idx = -1; b.fixed_idx = f != fixed_idx.end() ? f->second : -1; }
+    obs.push_back(b);
+  }
+  std::vector<int> edges;
+  for (const ImuEdgeData& e : problem.imu_edges) {                         // :1123-1137
+    auto i = kf_idx.find(e.kf_i_id), j = kf_idx.find(e.kf_j_id);
+    if (i == kf_idx.end() || j == kf_idx.end()) continue;
+    edges.push_back(i->second); edges.push_back(j->second);
+    preint.insert(preint.end(), e.preint.delta_rot.begin(), e.preint.delta_rot.end());
+    preint.insert(preint.end(), e.preint.delta_vel.begin(), e.preint.delta_vel.end());
+    preint.insert(preint.end(), e.preint.delta_pos.begin(), e.preint.delta_pos.end());
+    preint.push_back(e.preint.dt);
+  }
+  std::vector<double> po((size_t)K * 7), vo((size_t)K * 3), bo((size_t)K * 6);
+  int it = 0;
+  double e0 = 0, e1 = 0;
+  const orbx_camera c = camera.c();
+  const orbx_inertial_ba_config cfg{config.max_iterations, config.window_size, config.huber_threshold_mono, config.huber_threshold_stereo,
+                                    config.initial_lambda, config.gyro_rw_info, config.accel_rw_info};
+  auto tramp = [](void* user) -> int { return (*static_cast<const std::function<bool()>*>(user))() ? 1 : 0; };
+  const int rc = orbx_ba_solve_inertial(h.get(), &c, &cfg, K, poses.data(), vel.data(), bias.data(), (int)fixed_idx.size(), fixed.data(), M,
+                                        points.data(), (int)obs.size(), obs.data(), (int)(edges.size() / 2), edges.data(), preint.data(),
+                                        should_stop ? +tramp : nullptr, const_cast<std::function<bool()>*>(&should_stop), po.data(), vo.data(),
+                                        bo.data(), &it, &e0, &e1);
+  if (rc != ORBX_OK) return std::nullopt;
+  InertialBAResultData r;
+  for (int i = 1; i < K; ++i) {                                            // skip(1), :1250
+    const KeyFrameId id = problem.opt_kf_ids[(size_t)i];
+    SE3 p;
+    for (int q = 0; q < 4; ++q) p.rotation[q] = po[7 * (size_t)i + q];
+    for (int q = 0; q < 3; ++q) p.translation[q] = po[7 * (size_t)i + 4 + q];
+    r.optimized_poses[id] = p;
+    r.optimized_velocities[id] = {vo[3 * (size_t)i], vo[3 * (size_t)i + 1], vo[3 * (size_t)i + 2]};
+    ImuBias b;
+    for (int q = 0; q < 3; ++q) { b.gyro[q] = bo[6 * (size_t)i + q]; b.accel[q] = bo[6 * (size_t)i + 3 + q]; }
+    r.optimized_biases[id] = b;
+  }
+  for (int j = 0; j < M; ++j) r.optimized_points[problem.mp_ids[(size_t)j]] = {points[3 * (size_t)j], points[3 * (size_t)j + 1], points[3 * (size_t)j + 2]};
+  r.iterations = (size_t)it; r.initial_error = e0; r.final_error = e1;
+  return r;
+}
+
 }  // namespace orbx

@@ -122,6 +122,13 @@ int oracle_global_ba_solve_schur(const orbx_camera* cam, const orbx_ba_config* c
                                  const double* fixed_poses_cw, int M, double* points, int N, const orbx_ba_obs* obs,
                                  int stop_after, double* poses_wc_out, int* iterations, double* initial_error,
                                  double* final_error, double* trace);
+/* solve_inertial_ba (local_inertial_ba.rs:1074-1275), inertial_ba_ref.cpp */
+void oracle_inertial_imu_residual(const double* state_i9, const double* state_j9, const double* preint11, double* r9);
+int oracle_inertial_ba_solve(const orbx_camera* cam, const orbx_inertial_ba_config* cfg, int K, const double* poses_wc,
+                             const double* velocities, const double* biases, int F, const double* fixed_poses_cw, int M,
+                             double* points, int N, const orbx_ba_obs* obs, int E, const int* edge_kf, const double* preint,
+                             int stop_after, double* poses_wc_out, double* vel_out, double* bias_out, int* iterations,
+                             double* initial_error, double* final_error, double* trace);
 int oracle_ba_reduced_system(const orbx_camera* cam, const orbx_ba_config* cfg, double lambda,
                              int K, const double* params_pose /*6K*/, int F,
                              const double* fixed_poses_cw, int M, const double* points, int N,

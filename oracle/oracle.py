@@ -36,6 +36,17 @@ class BaConfig(C.Structure):
                 ("max_covisible_keyframes", C.c_int)]
 
 
+class InertialBaConfig(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("window_size", C.c_int), ("huber_threshold_mono", C.c_double),
+                ("huber_threshold_stereo", C.c_double), ("initial_lambda", C.c_double), ("gyro_rw_info", C.c_double),
+                ("accel_rw_info", C.c_double)]
+
+
+def inertial_ba_config():
+    """LocalInertialBAConfig::default, local_inertial_ba.rs:126-141"""
+    return InertialBaConfig(10, 10, float(np.sqrt(5.991)), float(np.sqrt(7.815)), 1e-2, 1e6, 1e4)
+
+
 class OrbLevels(C.Structure):
     _fields_ = [("n_levels", C.c_int), ("w", C.c_int * 8), ("h", C.c_int * 8),
                 ("scale", C.c_float * 8), ("quota", C.c_int * 8)]
@@ -338,6 +349,33 @@ def global_ba_solve_dense(cam, cfg, poses_cw, fixed_cw, points, obs, stop_after=
 
 def global_ba_solve_schur(cam, cfg, poses_cw, fixed_cw, points, obs, stop_after=-1):
     return _ba_solve(lib().oracle_global_ba_solve_schur, cam, cfg, poses_cw, fixed_cw, points, obs, stop_after)
+
+
+def inertial_imu_residual(state_i9, state_j9, preint11):
+    a = np.ascontiguousarray(state_i9, np.float64); b = np.ascontiguousarray(state_j9, np.float64)
+    pr = np.ascontiguousarray(preint11, np.float64); r = np.zeros(9)
+    lib().oracle_inertial_imu_residual(_p(a), _p(b), _p(pr), _p(r))
+    return r
+
+
+def inertial_ba_solve(cam, cfg, poses_wc, velocities, biases, fixed_cw, points, obs, edge_kf, preint, stop_after=-1):
+    poses_wc = np.ascontiguousarray(poses_wc, np.float64).reshape(-1, 7)
+    vel = np.ascontiguousarray(velocities, np.float64).reshape(-1, 3); bias = np.ascontiguousarray(biases, np.float64).reshape(-1, 6)
+    fixed_cw = np.ascontiguousarray(fixed_cw, np.float64).reshape(-1, 7)
+    pts = np.array(points, np.float64, copy=True).reshape(-1, 3)
+    obs = np.ascontiguousarray(obs, BA_OBS)
+    ek = np.ascontiguousarray(edge_kf, np.int32).reshape(-1, 2); pre = np.ascontiguousarray(preint, np.float64).reshape(-1, 11)
+    K, F, M, N, E = len(poses_wc), len(fixed_cw), len(pts), len(obs), len(ek)
+    out_p = np.zeros((max(K, 1), 7)); out_v = np.zeros((max(K, 1), 3)); out_b = np.zeros((max(K, 1), 6))
+    it = C.c_int(); e0 = C.c_double(); e1 = C.c_double()
+    trace = np.zeros((max(cfg.max_iterations, 1), 4))
+    rc = lib().oracle_inertial_ba_solve(C.byref(cam), C.byref(cfg), C.c_int(K), _p(poses_wc), _p(vel), _p(bias), C.c_int(F), _p(fixed_cw),
+                                        C.c_int(M), _p(pts), C.c_int(N), _p(obs), C.c_int(E), _p(ek), _p(pre), C.c_int(stop_after),
+                                        _p(out_p), _p(out_v), _p(out_b), C.byref(it), C.byref(e0), C.byref(e1), _p(trace))
+    if rc != 0:
+        return None
+    return dict(poses_wc=out_p[:K], velocities=out_v[:K], biases=out_b[:K], points=pts, iterations=it.value,
+                initial_error=e0.value, final_error=e1.value, trace=trace[:it.value])
 
 
 def ba_reduced_system(cam, cfg, lam, params_pose, fixed_cw, points, obs):

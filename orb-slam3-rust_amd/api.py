@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "orbx_extract_batch_device", "orbx_check_status", "orbx_stereo_match",
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
-    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual", "orbx_ba_solve_global",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_bow", "orbx_fuse_search",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
     "orbx_bow_transform", "orbx_bow_transform_device",
@@ -81,6 +81,12 @@ class _BaConfig(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("param_tolerance", C.c_double),
                 ("gradient_tolerance", C.c_double), ("huber_threshold", C.c_double),
                 ("max_covisible_keyframes", C.c_int)]
+
+
+class _InertialBaConfig(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("window_size", C.c_int), ("huber_threshold_mono", C.c_double),
+                ("huber_threshold_stereo", C.c_double), ("initial_lambda", C.c_double), ("gyro_rw_info", C.c_double),
+                ("accel_rw_info", C.c_double)]
 
 
 class _KernelTime(C.Structure):
@@ -199,6 +205,22 @@ class GlobalBAConfig:
 
     def _c(self):
         return _BaConfig(self.max_iterations, self.param_tolerance, self.gradient_tolerance, self.huber_threshold, 0)
+
+
+@dataclass
+class LocalInertialBAConfig:
+    """local_inertial_ba.rs:109-141 (Default impl :126-141)"""
+    max_iterations: int = 10
+    window_size: int = 10
+    huber_threshold_mono: float = math.sqrt(5.991)
+    huber_threshold_stereo: float = math.sqrt(7.815)
+    initial_lambda: float = 1e-2
+    gyro_rw_info: float = 1e6
+    accel_rw_info: float = 1e4
+
+    def _c(self):
+        return _InertialBaConfig(self.max_iterations, self.window_size, self.huber_threshold_mono, self.huber_threshold_stereo,
+                                 self.initial_lambda, self.gyro_rw_info, self.accel_rw_info)
 
 
 @dataclass
@@ -536,6 +558,30 @@ class Handle:
         self._check(rc)
         return dict(poses_wc=out_wc[:K], points=pts, iterations=it.value, initial_error=e0.value,
                     final_error=e1.value)
+
+    def ba_solve_inertial(self, camera, cfg, poses_wc, velocities, biases, fixed_cw, points, obs, edge_kf, preint, should_stop=None):
+        """solve_inertial_ba (local_inertial_ba.rs:1074-1275) on flat arrays; every keyframe of the window is returned."""
+        poses_wc = np.ascontiguousarray(poses_wc, np.float64).reshape(-1, 7)
+        vel = np.ascontiguousarray(velocities, np.float64).reshape(-1, 3); bias = np.ascontiguousarray(biases, np.float64).reshape(-1, 6)
+        fixed_cw = np.ascontiguousarray(fixed_cw, np.float64).reshape(-1, 7)
+        pts = np.array(points, np.float64, copy=True).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs, BA_OBS)
+        ek = np.ascontiguousarray(edge_kf, np.int32).reshape(-1, 2); pre = np.ascontiguousarray(preint, np.float64).reshape(-1, 11)
+        K, F, M, N, E = len(poses_wc), len(fixed_cw), len(pts), len(obs), len(ek)
+        if len(vel) != K or len(bias) != K or len(pre) != E:
+            raise ValueError("ba_solve_inertial: inconsistent array lengths")
+        out_p = np.zeros((max(K, 1), 7)); out_v = np.zeros((max(K, 1), 3)); out_b = np.zeros((max(K, 1), 6))
+        it = C.c_int(); e0 = C.c_double(); e1 = C.c_double()
+        cb = SHOULD_STOP_FN((lambda user: 1 if should_stop() else 0)) if should_stop else C.cast(None, SHOULD_STOP_FN)
+        cam = camera._c(); c = cfg._c()
+        rc = self._L.orbx_ba_solve_inertial(self._h, C.byref(cam), C.byref(c), C.c_int(K), _vp(poses_wc), _vp(vel), _vp(bias), C.c_int(F),
+                                            _vp(fixed_cw), C.c_int(M), _vp(pts), C.c_int(N), _vp(obs), C.c_int(E), _vp(ek), _vp(pre), cb,
+                                            None, _vp(out_p), _vp(out_v), _vp(out_b), C.byref(it), C.byref(e0), C.byref(e1))
+        if rc in (ORBX_ERR_EMPTY,):
+            return None                      # reference returns None, local_inertial_ba.rs:1080-1082
+        self._check(rc)
+        return dict(poses_wc=out_p[:K], velocities=out_v[:K], biases=out_b[:K], points=pts, iterations=it.value,
+                    initial_error=e0.value, final_error=e1.value)
 
     def ba_solve_global(self, camera, cfg, poses_cw, fixed_pose_cw, points, obs, should_stop=None):
         """solve_global_ba (global_ba.rs:184-418): every keyframe but the first is optimised."""
@@ -910,3 +956,90 @@ class EurocDataset:
             self.close()
         except Exception:
             pass
+
+
+@dataclass
+class InertialVisualObs:
+    """local_inertial_ba.rs:64-77"""
+    kf_id: int
+    mp_id: int
+    observed_uv: tuple
+    is_stereo: bool
+    is_kf_in_window: bool
+
+
+@dataclass
+class ImuEdgeData:
+    """local_inertial_ba.rs:79-88; preint = (delta_rot qw,qx,qy,qz, delta_vel, delta_pos, dt) of PreintegratedState"""
+    kf_i_id: int
+    kf_j_id: int
+    preint: np.ndarray
+
+
+@dataclass
+class InertialBAProblemData:
+    """local_inertial_ba.rs:40-62.  kf_poses are T_wc, fixed_kf_poses T_cw (7-vectors); biases 6-vectors (gyro, accel)."""
+    kf_poses: Dict[int, np.ndarray]
+    kf_velocities: Dict[int, np.ndarray]
+    kf_biases: Dict[int, np.ndarray]
+    mp_positions: Dict[int, np.ndarray]
+    fixed_kf_poses: Dict[int, np.ndarray]
+    visual_observations: List[InertialVisualObs]
+    imu_edges: List[ImuEdgeData]
+    opt_kf_ids: List[int]
+    mp_ids: List[int]
+
+
+@dataclass
+class InertialBAResultData:
+    """local_inertial_ba.rs:90-106: the first keyframe of the window is not reported (:1250)."""
+    optimized_poses: Dict[int, np.ndarray] = field(default_factory=dict)
+    optimized_velocities: Dict[int, np.ndarray] = field(default_factory=dict)
+    optimized_biases: Dict[int, np.ndarray] = field(default_factory=dict)
+    optimized_points: Dict[int, np.ndarray] = field(default_factory=dict)
+    iterations: int = 0
+    initial_error: float = 0.0
+    final_error: float = 0.0
+
+
+def flatten_inertial_ba_problem(problem: InertialBAProblemData):
+    """The id -> index re-keying of local_inertial_ba.rs:1084-1185: observations of unknown map points and IMU edges
+    with a keyframe outside the window are dropped (:1107, :1129-1130); an in-window flag whose keyframe is not in
+    opt_kf_ids, or a fixed keyframe without a pose, falls back to the identity pose (:637); missing states start at 0."""
+    kf_idx = {k: i for i, k in enumerate(problem.opt_kf_ids)}
+    mp_idx = {m: i for i, m in enumerate(problem.mp_ids)}
+    fixed_ids = list(problem.fixed_kf_poses.keys())
+    fixed_idx = {k: i for i, k in enumerate(fixed_ids)}
+    ident = np.array([1.0, 0, 0, 0, 0, 0, 0])
+    poses = np.array([problem.kf_poses.get(k, ident) for k in problem.opt_kf_ids], np.float64).reshape(-1, 7)
+    vel = np.array([problem.kf_velocities.get(k, np.zeros(3)) for k in problem.opt_kf_ids], np.float64).reshape(-1, 3)
+    bias = np.array([problem.kf_biases.get(k, np.zeros(6)) for k in problem.opt_kf_ids], np.float64).reshape(-1, 6)
+    fixed = np.array([problem.fixed_kf_poses[k] for k in fixed_ids], np.float64).reshape(-1, 7)
+    pts = np.array([problem.mp_positions.get(m, np.zeros(3)) for m in problem.mp_ids], np.float64).reshape(-1, 3)
+    rows = []
+    for o in problem.visual_observations:
+        if o.mp_id not in mp_idx:
+            continue
+        if o.is_kf_in_window and o.kf_id in kf_idx:
+            rows.append((kf_idx[o.kf_id], -1, mp_idx[o.mp_id], int(o.is_stereo), o.observed_uv[0], o.observed_uv[1]))
+        else:
+            rows.append((-1, fixed_idx.get(o.kf_id, -1), mp_idx[o.mp_id], int(o.is_stereo), o.observed_uv[0], o.observed_uv[1]))
+    edges = [(kf_idx[e.kf_i_id], kf_idx[e.kf_j_id], e.preint) for e in problem.imu_edges if e.kf_i_id in kf_idx and e.kf_j_id in kf_idx]
+    ek = np.array([(a, b) for a, b, _ in edges], np.int32).reshape(-1, 2)
+    pre = np.array([p for _, _, p in edges], np.float64).reshape(-1, 11)
+    return poses, vel, bias, fixed, pts, np.array(rows, BA_OBS), ek, pre
+
+
+def solve_inertial_ba(problem: InertialBAProblemData, camera: CameraModel, config: LocalInertialBAConfig,
+                      should_stop: Callable[[], bool], handle: Handle = None) -> Optional[InertialBAResultData]:
+    """local_inertial_ba.rs:1074-1275."""
+    if len(problem.opt_kf_ids) < 2:
+        return None
+    poses, vel, bias, fixed, pts, obs, ek, pre = flatten_inertial_ba_problem(problem)
+    r = (handle or _handle()).ba_solve_inertial(camera, config, poses, vel, bias, fixed, pts, obs, ek, pre, should_stop)
+    if r is None:
+        return None
+    ids = problem.opt_kf_ids
+    return InertialBAResultData({k: r["poses_wc"][i] for i, k in enumerate(ids) if i > 0}, {k: r["velocities"][i] for i, k in enumerate(ids) if i > 0},
+                                {k: r["biases"][i] for i, k in enumerate(ids) if i > 0}, {m: r["points"][i] for i, m in enumerate(problem.mp_ids)},
+                                r["iterations"], r["initial_error"], r["final_error"])

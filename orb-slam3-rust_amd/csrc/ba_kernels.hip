@@ -42,7 +42,10 @@ struct BaDims {
 struct BaCam {
   double fx, fy, cx, cy, huber;
   int zero_behind;   // solve_global_ba: Jacobian rows are zero where z_c <= 0.001 (global_ba.rs:561-563)
-  int pad;
+  int inertial;      // solve_inertial_ba: T_wc pose parameters, the Jacobian forms of local_inertial_ba.rs:735-804,
+                     // no Huber on the 100-px penalty, Huber threshold per observation (o_flag bit 0 = stereo)
+  double huber_stereo;
+  const int* o_flag;
 };
 
 // Levenberg-Marquardt state kept on the device (local_ba_lm.rs:1004-1056): the host only polls should_stop and
@@ -68,14 +71,45 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
 }
 
 // local_ba_lm.rs:648-662 then R|t (12 doubles)
+// nalgebra UnitQuaternion::from_scaled_axis = exp of the pure quaternion r/2 (identity when |r/2|^2 <= eps^2)
+__device__ __forceinline__ void dev_q_from_scaled_axis(const double* r, double* q) {
+  const double v0 = r[0] / 2.0, v1 = r[1] / 2.0, v2 = r[2] / 2.0;
+  const double nn = v0 * v0 + v1 * v1 + v2 * v2;
+  const double eps = 2.220446049250313e-16;
+  if (nn <= eps * eps) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; return; }
+  const double n = sqrt(nn), s = 1.0 * sin(n) / n;
+  q[0] = 1.0 * cos(n); q[1] = v0 * s; q[2] = v1 * s; q[3] = v2 * s;
+}
+__device__ __forceinline__ void dev_q_rot(const double* q, const double* v, double* o) {   // UnitQuaternion * Vector3
+  const double t0 = 2.0 * (q[2] * v[2] - q[3] * v[1]), t1 = 2.0 * (q[3] * v[0] - q[1] * v[2]), t2 = 2.0 * (q[1] * v[1] - q[2] * v[0]);
+  const double c0 = q[2] * t2 - q[3] * t1, c1 = q[3] * t0 - q[1] * t2, c2 = q[1] * t1 - q[2] * t0;
+  o[0] = t0 * q[0] + c0 + v[0]; o[1] = t1 * q[0] + c1 + v[1]; o[2] = t2 * q[0] + c2 + v[2];
+}
+__device__ __forceinline__ void dev_q_mul(const double* a, const double* b, double* o) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
 __global__ void ba_pose_kernel(BaState* S, double* P0, double* P1, int which /*0 cur, 1 trial*/, int iter, int K,
-                               double* __restrict__ Rt) {
+                               double* __restrict__ Rt, int inertial) {
   if (S->done) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k == 0 && which == 0 && iter >= 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
   if (k >= K) return;
   const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
   const double* p = params + 6 * (size_t)k;
+  if (inertial) {   // extract_pose(..).inverse() (local_inertial_ba.rs:584-591, :634; se3.rs:56-63)
+    double qwc[4], rt[3];
+    dev_q_from_scaled_axis(p, qwc);
+    const double qcw[4] = {qwc[0], -qwc[1], -qwc[2], -qwc[3]};
+    dev_q_rot(qcw, p + 3, rt);
+    double* o = Rt + 12 * (size_t)k;
+    quat_to_R(qcw, o);
+    o[9] = -rt[0]; o[10] = -rt[1]; o[11] = -rt[2];
+    return;
+  }
   double q[4];
   const double angle = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
   if (angle > 1e-10) {
@@ -96,12 +130,43 @@ struct ObsOut { double r0, r1, A[12], B[6]; };
 
 // error (:192-212), Huber (:291-297), J_pose (:239-254), J_point (:281-287), both * sqrt(w)
 __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, const double* X, double u, double v,
-                                          bool want_jac, ObsOut& o) {
+                                          bool want_jac, ObsOut& o, int flag = 0) {
   // X_c = R X + t.  (The reference rotates with the quaternion form v + w t + q x t; R X is the same
   // rotation — agreement is to rounding, well inside the stated tolerance.)
   const double x = Rt[0] * X[0] + Rt[1] * X[1] + Rt[2] * X[2] + Rt[9];
   const double y = Rt[3] * X[0] + Rt[4] * X[1] + Rt[5] * X[2] + Rt[10];
   const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+  if (cam.inertial) {   // local_inertial_ba.rs:633-659 (residual), :735-804 (Jacobian rows)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o.A[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o.B[i] = 0.0;
+    if (!(z > 0.001)) { o.r0 = 100.0; o.r1 = 100.0; return; }
+    const double thr = (flag & 1) ? cam.huber_stereo : cam.huber, fx = cam.fx, fy = cam.fy;
+    {
+      const double e0 = u - (fx * x / z + cam.cx), e1 = v - (fy * y / z + cam.cy);
+      const double en = sqrt(e0 * e0 + e1 * e1);
+      const double sw = sqrt(en <= thr ? 1.0 : thr / en);
+      o.r0 = e0 * sw; o.r1 = e1 * sw;
+    }
+    if (!want_jac) return;
+    const double zi = 1.0 / z, zi2 = zi * zi;
+    const double e0 = u - (fx * x * zi + cam.cx), e1 = v - (fy * y * zi + cam.cy);   // :743-745 (x * z_inv, not x / z)
+    const double en = sqrt(e0 * e0 + e1 * e1);
+    const double sw = en <= thr ? 1.0 : sqrt(thr / en);
+    const double du0 = fx * zi, du2 = -fx * x * zi2, dv1 = fy * zi, dv2 = -fy * y * zi2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                      // -(R_cw^T d(u,v)/dp_cam) (:760-771)
+      o.B[c] = -(Rt[c] * du0 + Rt[3 + c] * 0.0 + Rt[6 + c] * du2) * sw;
+      o.B[3 + c] = -(Rt[c] * 0.0 + Rt[3 + c] * dv1 + Rt[6 + c] * dv2) * sw;
+    }
+    const double xy = x * y, xs = x * x, ys = y * y;    // :774-803 (the caller drops A for a fixed keyframe)
+    o.A[0] = -fx * xy * zi2 * sw; o.A[1] = fx * (1.0 + xs * zi2) * sw; o.A[2] = -fx * y * zi * sw;
+    o.A[3] = fx * zi * sw; o.A[4] = 0.0; o.A[5] = -fx * x * zi2 * sw;
+    o.A[6] = -fy * (1.0 + ys * zi2) * sw; o.A[7] = fy * xy * zi2 * sw; o.A[8] = fy * x * zi * sw;
+    o.A[9] = 0.0; o.A[10] = fy * zi * sw; o.A[11] = -fy * y * zi2 * sw;
+    return;
+  }
   double e0, e1;
   if (z <= 0.001) { e0 = 100.0; e1 = 100.0; }
   else { e0 = u - (cam.fx * x / z + cam.cx); e1 = v - (cam.fy * y / z + cam.cy); }
@@ -159,7 +224,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, cons
     const int k = o_kf[i];
     const double* Rt = k >= 0 ? Rt_opt + 12 * (size_t)k : Rt_fix + 12 * (size_t)o_fix[i];
     ObsOut o;
-    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o);
+    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
     chi += o.r0 * o.r0 + o.r1 * o.r1;
     V[0] += o.B[0] * o.B[0] + o.B[3] * o.B[3];
     V[1] += o.B[0] * o.B[1] + o.B[3] * o.B[4];
@@ -202,7 +267,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, cons
     if (k < 0) continue;
     const double* Rt = Rt_opt + 12 * (size_t)k;
     ObsOut o;
-    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o);
+    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
     double yg[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -852,7 +917,7 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const
     const int k = o_kf[i];
     const double* Rt = k >= 0 ? Rt_opt + 12 * (size_t)k : Rt_fix + 12 * (size_t)o_fix[i];
     ObsOut o;
-    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o);
+    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
     chi += o.r0 * o.r0 + o.r1 * o.r1;
   }
   pt_chi2[j] = chi;
@@ -893,6 +958,206 @@ __global__ void ba_decide_kernel(BaState* S, const double* __restrict__ res) {
     S->lambda = fmax(S->lambda * 0.1, 1e-10);
   } else {
     S->lambda = fmin(S->lambda * 10.0, 1e10);
+  }
+}
+
+// ---- inertial terms (src/optimizer/local_inertial_ba.rs:661-698, :806-880; src/optimizer/imu_factors.rs:66-103) --------------------
+// Device parameter layout in inertial mode: [6K T_wc pose | 3M points | 9K velocity, gyro bias, accel bias].
+struct BaInertialDev {
+  int K, M, E;
+  double gw, aw;                 // sqrt of the random-walk informations
+  const int* edge_kf;            // [E][2]
+  const double* preint;          // [E][11]
+};
+constexpr int IMU_REC = 18 * 18 + 18 + 2;   // per edge: H (18x18) | g (18) | chi2(imu + random walk) | spare
+
+__device__ __forceinline__ void dev_scaled_axis(const double* q, double* o) {   // nalgebra UnitQuaternion::scaled_axis
+  double v0 = q[1], v1 = q[2], v2 = q[3];
+  if (!(q[0] >= 0.0)) { v0 = -v0; v1 = -v1; v2 = -v2; }
+  const double n = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+  if (n > 0.0) {
+    const double ang = atan2(n, fabs(q[0])) * 2.0;
+    o[0] = v0 / n * ang; o[1] = v1 / n * ang; o[2] = v2 / n * ang;
+  } else { o[0] = o[1] = o[2] = 0.0; }
+}
+
+// si / sj: pose (6) + velocity (3) of the two keyframes
+__device__ __forceinline__ void imu_residual_dev(const double* si, const double* sj, const double* pre, double* r9) {
+  const double dt = pre[10];
+  double ri[4], rj[4];
+  dev_q_from_scaled_axis(si, ri);
+  dev_q_from_scaled_axis(sj, rj);
+  const double ric[4] = {ri[0], -ri[1], -ri[2], -ri[3]}, drc[4] = {pre[0], -pre[1], -pre[2], -pre[3]};
+  double t[4], err[4];
+  dev_q_mul(drc, ric, t);
+  dev_q_mul(t, rj, err);                                                  // imu_factors.rs:85
+  dev_scaled_axis(err, r9);
+  const double g[3] = {0.0, 0.0, -9.81};                                  // imu/sample.rs:6
+  double a[3], b[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) a[i] = sj[6 + i] - si[6 + i] - g[i] * dt;   // :89
+  dev_q_rot(ric, a, b);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r9[3 + i] = b[i] - pre[4 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) a[i] = sj[3 + i] - si[3 + i] - si[6 + i] * dt - 0.5 * g[i] * dt * dt;   // :93-94
+  dev_q_rot(ric, a, b);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r9[6 + i] = b[i] - pre[7 + i];
+}
+
+// One block (64 threads) per IMU edge.  full: residual, forward-difference Jacobian (eps 1e-6, 18 columns = pose and
+// velocity of both keyframes), J^T J, J^T r; always: chi2 of the IMU and bias-random-walk residuals of the edge.
+__global__ __launch_bounds__(64) void ba_imu_kernel(const BaState* S, double* P0, double* P1, int which, int full, BaInertialDev in,
+                                                    double* __restrict__ imu_buf) {
+  __shared__ double st[2][9];
+  __shared__ double r[19][9];
+  __shared__ double J[9][18];
+  if (S->done) return;
+  const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const int ki = in.edge_kf[2 * e], kj = in.edge_kf[2 * e + 1];
+  const double* ex = params + 6 * (size_t)in.K + 3 * (size_t)in.M;
+  if (tid < 18) {
+    const int s = tid / 9, j = tid % 9, k = s ? kj : ki;
+    st[s][j] = j < 6 ? params[6 * (size_t)k + j] : ex[9 * (size_t)k + (j - 6)];
+  }
+  __syncthreads();
+  const double* pre = in.preint + 11 * (size_t)e;
+  if (tid < (full ? 19 : 1)) {
+    double a[9], b[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { a[j] = st[0][j]; b[j] = st[1][j]; }
+    if (tid > 0) {                                                        // params_plus[col] += eps (:822-824)
+      const int c = tid - 1;
+      if (c < 9) a[c] += 1e-6; else b[c - 9] += 1e-6;
+      if (ki == kj) { if (c < 9) b[c] += 1e-6; else a[c - 9] += 1e-6; }  // one parameter vector: both views move
+    }
+    double rr[9];
+    imu_residual_dev(a, b, pre, rr);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[tid][k] = rr[k];
+  }
+  __syncthreads();
+  double* out = imu_buf + (size_t)e * IMU_REC;
+  if (tid == 0) {
+    double chi = 0.0;
+    for (int k = 0; k < 9; ++k) chi += r[0][k] * r[0][k];
+    for (int k = 0; k < 6; ++k) {                                         // :676-698
+      const double w = k < 3 ? in.gw : in.aw;
+      const double d = (ex[9 * (size_t)kj + 3 + k] - ex[9 * (size_t)ki + 3 + k]) * w;
+      chi += d * d;
+    }
+    out[18 * 18 + 18] = chi;
+  }
+  if (!full) return;
+  for (int t = tid; t < 9 * 18; t += 64) { const int k = t / 18, c = t % 18; J[k][c] = (r[c + 1][k] - r[0][k]) / 1e-6; }   // :833-836
+  __syncthreads();
+  for (int t = tid; t < 18 * 18; t += 64) {
+    const int a = t / 18, b = t % 18;
+    double h = 0.0;
+    for (int k = 0; k < 9; ++k) h += J[k][a] * J[k][b];
+    out[t] = h;
+  }
+  if (tid < 18) {
+    double g = 0.0;
+    for (int k = 0; k < 9; ++k) g += J[k][tid] * r[0][k];
+    out[18 * 18 + tid] = g;
+  }
+}
+
+// res[slot] += sum over the edges of their chi2 (fixed order)
+__global__ void ba_imu_addchi_kernel(const BaState* S, int E, const double* __restrict__ imu_buf, double* __restrict__ res, int slot) {
+  if (S->done) return;
+  double c = 0.0;
+  for (int e = 0; e < E; ++e) c += imu_buf[(size_t)e * IMU_REC + 18 * 18 + 18];
+  res[slot] += c;
+}
+
+// The damped normal equations of the 15K keyframe states after the points are eliminated (one block):
+//   H = scatter(U - W V*^-1 W^T) + sum_e J_e^T J_e + random-walk blocks,  H_ii += lambda * max(JtJ_ii, 1e-6) with the
+//   FULL J^T J diagonal (visual U_ii + IMU + random walk, local_inertial_ba.rs:1217-1221),  rhs = -(g - W V*^-1 g_l).
+// rb: the visual reduce buffer [Sred n6^2 | U 36K | gp n6 | bred n6 | chi2 | glsq].  State order inside a keyframe as
+// the reference: pose 0..5, velocity 6..8, gyro bias 9..11, accel bias 12..14.
+__global__ __launch_bounds__(256) void ba_inertial_assemble_kernel(const BaState* St, double* P0, double* P1, BaInertialDev in,
+                                                                   const double* __restrict__ rb, const double* __restrict__ imu_buf,
+                                                                   double* __restrict__ Sg, double* __restrict__ bvec,
+                                                                   double* __restrict__ gfull, double* __restrict__ res) {
+  __shared__ double red[256];
+  if (St->done) return;
+  const double lambda = St->lambda;
+  const double* params = ba_cur(St, P0, P1);
+  const int K = in.K, n6 = 6 * K, n = 15 * K, tid = threadIdx.x;
+  const double* U = rb + (size_t)n6 * n6;
+  const double* gp = U + 36 * (size_t)K;
+  const double* bred = gp + n6;
+  const double* ex = params + 6 * (size_t)K + 3 * (size_t)in.M;
+  for (size_t idx = tid; idx < (size_t)n * n; idx += 256) Sg[idx] = 0.0;
+  for (int i = tid; i < n; i += 256) { bvec[i] = 0.0; gfull[i] = 0.0; }
+  __syncthreads();
+  // J^T J of the IMU and random-walk rows, edge after edge (fixed order, no atomics)
+  for (int e = 0; e < in.E; ++e) {
+    const int kk[2] = {in.edge_kf[2 * e], in.edge_kf[2 * e + 1]};
+    const double* rec = imu_buf + (size_t)e * IMU_REC;
+    for (int t = tid; t < 18 * 18; t += 256) {
+      const int a = t / 18, b = t % 18;
+      Sg[(size_t)(15 * kk[a / 9] + a % 9) * n + 15 * kk[b / 9] + b % 9] += rec[t];
+    }
+    if (tid < 18) gfull[15 * kk[tid / 9] + tid % 9] += rec[18 * 18 + tid];
+    if (tid >= 32 && tid < 38) {                                          // :863-880
+      const int k = tid - 32;
+      const double w = k < 3 ? in.gw : in.aw;
+      const int ii = 15 * kk[0] + 9 + k, jj = 15 * kk[1] + 9 + k;
+      const double r = (ex[9 * (size_t)kk[1] + 3 + k] - ex[9 * (size_t)kk[0] + 3 + k]) * w;
+      Sg[(size_t)ii * n + ii] += w * w; Sg[(size_t)jj * n + jj] += w * w;
+      Sg[(size_t)ii * n + jj] -= w * w; Sg[(size_t)jj * n + ii] -= w * w;
+      gfull[ii] += -w * r; gfull[jj] += w * r;
+    }
+    __syncthreads();
+  }
+  // visual part: U on the keyframe diagonal blocks, the gradient, damping with the full diagonal, then the Schur term
+  for (int t = tid; t < 36 * K; t += 256) {
+    const int k = t / 36, a = (t % 36) / 6, b = t % 6;
+    Sg[(size_t)(15 * k + a) * n + 15 * k + b] += U[t];
+  }
+  for (int t = tid; t < n6; t += 256) gfull[15 * (t / 6) + t % 6] += gp[t];
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) Sg[(size_t)i * n + i] += lambda * fmax(Sg[(size_t)i * n + i], 1e-6);
+  __syncthreads();
+  for (size_t idx = tid; idx < (size_t)n6 * n6; idx += 256) {
+    const int i = (int)(idx / n6), j = (int)(idx - (size_t)i * n6);
+    Sg[(size_t)(15 * (i / 6) + i % 6) * n + 15 * (j / 6) + j % 6] -= rb[idx];
+  }
+  for (int i = tid; i < n; i += 256) {
+    double b = -gfull[i];
+    if (i % 15 < 6) b += bred[6 * (i / 15) + i % 15];
+    bvec[i] = b;
+  }
+  double gs = 0.0;
+  for (int i = tid; i < n; i += 256) gs += gfull[i] * gfull[i];
+  red[tid] = gs;
+  __syncthreads();
+  for (int s2 = 128; s2 >= 1; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+  if (tid == 0) {
+    double chi = bred[n6];                                                // visual chi2 (gather kernel)
+    for (int e = 0; e < in.E; ++e) chi += imu_buf[(size_t)e * IMU_REC + 18 * 18 + 18];
+    res[0] = chi;
+    res[1] = sqrt(red[0] + bred[n6 + 1]);                                 // |gradient| over keyframe states and points (:1213)
+    res[2] = 1.0;
+  }
+}
+
+// after the solve: dp15 -> the 6-d pose steps the point back-substitution reads, and the trial velocity / bias block
+__global__ void ba_inertial_scatter_kernel(const BaState* S, double* P0, double* P1, int K, int M, const double* __restrict__ dp15,
+                                           double* __restrict__ dp6) {
+  if (S->done) return;
+  const double* params = ba_cur(S, P0, P1);
+  double* trial = ba_trial(S, P0, P1);
+  const size_t off = 6 * (size_t)K + 3 * (size_t)M;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 15 * K; i += gridDim.x * blockDim.x) {
+    const int k = i / 15, a = i % 15;
+    if (a < 6) dp6[6 * k + a] = dp15[i];
+    else trial[off + 9 * (size_t)k + (a - 6)] = params[off + 9 * (size_t)k + (a - 6)] + dp15[i];
   }
 }
 
@@ -945,11 +1210,15 @@ void host_params_to_pose_wc(const double* p6, double* out7) {
 int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
                     const double* poses_cw, int F, const double* fixed_poses_cw, int M, double* points, int N,
                     const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
-                    int* iterations, double* initial_error, double* final_error, bool global_mode) {
-  const bool dist = h->allreduce != nullptr;
+                    int* iterations, double* initial_error, double* final_error, bool global_mode, const BaInertialHost* inr) {
+  // inr != nullptr: solve_inertial_ba (local_inertial_ba.rs:1074-1275).  `poses_cw` then holds the T_wc poses of the window
+  // and cfg carries max_iterations only; the point elimination, the per-keyframe 6x6 blocks and the Schur product are the
+  // visual solver's kernels, the 15-d keyframe states are assembled and solved on top of them.
+  const bool inertial = inr != nullptr;
+  const bool dist = h->allreduce != nullptr && !inertial;
   *iterations = 0; *initial_error = 0.0; *final_error = 0.0;
   // local_ba_lm.rs:923-925 (with a partition the local N may be 0 while the global problem is not)
-  if ((6 * (size_t)K + 3 * (size_t)M == 0) || (N == 0 && !dist)) return orbx_fail(h, ORBX_ERR_EMPTY, "no parameters or no residuals");
+  if ((6 * (size_t)K + 3 * (size_t)M == 0) || (N == 0 && !dist && !inertial)) return orbx_fail(h, ORBX_ERR_EMPTY, "no parameters or no residuals");
   // ---- validate indices on the host before any kernel dereferences them
   for (int i = 0; i < N; ++i) {
     const orbx_ba_obs& o = obs[i];
@@ -965,7 +1234,8 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   d.rows = ((3 * M + 4 * d.ksplit - 1) / (4 * d.ksplit)) * (4 * d.ksplit);
   if (d.rows == 0) d.rows = 4 * d.ksplit;
   const int n = 6 * K;
-  BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, cfg->huber_threshold, global_mode ? 1 : 0, 0};
+  BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, inertial ? inr->cfg->huber_threshold_mono : cfg->huber_threshold, global_mode ? 1 : 0,
+           inertial ? 1 : 0, inertial ? inr->cfg->huber_threshold_stereo : 0.0, nullptr};
 
   // ---- host preprocessing: point-major CSR, keyframe CSR over the point-major order
   std::vector<int> pt_start(M + 1, 0), order(N);
@@ -975,10 +1245,11 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
     for (int i = 0; i < N; ++i) order[fill[obs[i].mp_idx]++] = i;   // stable: input order within a point
   }
-  std::vector<int> o_kf(N), o_fix(N), kf_start(K + 1, 0), kf_obs;
+  std::vector<int> o_kf(N), o_fix(N), kf_start(K + 1, 0), kf_obs, o_flag(inertial ? N : 0);
   std::vector<double> o_uv(2 * (size_t)N);
   for (int t = 0; t < N; ++t) {
     const orbx_ba_obs& o = obs[order[t]];
+    if (inertial) o_flag[t] = o._pad;
     o_kf[t] = o.kf_idx >= 0 ? o.kf_idx : -1;
     o_fix[t] = o.kf_idx >= 0 ? 0 : (o.fixed_idx >= 0 ? o.fixed_idx : F);   // slot F = identity (:569)
     o_uv[2 * (size_t)t] = o.u; o_uv[2 * (size_t)t + 1] = o.v;
@@ -990,9 +1261,15 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     std::vector<int> fill(kf_start.begin(), kf_start.end() - 1);
     for (int t = 0; t < N; ++t) if (o_kf[t] >= 0) kf_obs[fill[o_kf[t]]++] = t;
   }
-  std::vector<double> params(6 * (size_t)K + 3 * (size_t)M), Rt_fix(12 * (size_t)(F + 1));
-  for (int k = 0; k < K; ++k) host_se3_to_params(poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);
+  std::vector<double> params(6 * (size_t)K + 3 * (size_t)M + (inertial ? 9 * (size_t)K : 0)), Rt_fix(12 * (size_t)(F + 1));
+  for (int k = 0; k < K; ++k) host_se3_to_params(poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);   // scaled axis + translation
   for (int j = 0; j < 3 * M; ++j) params[6 * (size_t)K + j] = points[j];
+  if (inertial)                                                          // :1154-1173
+    for (int k = 0; k < K; ++k) {
+      double* ex = &params[6 * (size_t)K + 3 * (size_t)M + 9 * (size_t)k];
+      for (int i = 0; i < 3; ++i) ex[i] = inr->velocities[3 * (size_t)k + i];
+      for (int i = 0; i < 6; ++i) ex[3 + i] = inr->biases[6 * (size_t)k + i];
+    }
   for (int f = 0; f <= F; ++f) {
     const double ident[7] = {1, 0, 0, 0, 0, 0, 0};
     const double* p = f < F ? fixed_poses_cw + 7 * (size_t)f : ident;
@@ -1002,7 +1279,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
 
   // ---- device buffers
   enum { B_PARAMS, B_TRIAL, B_RTOPT, B_RTFIX, B_PTSTART, B_OKF, B_OFIX, B_OUV, B_KFSTART, B_KFOBS, B_OA, B_OR, B_OYG,
-         B_VINV, B_GL, B_PT, B_WT, B_YT, B_PART, B_UG, B_RB, B_SOLVE, B_RES };
+         B_VINV, B_GL, B_PT, B_WT, B_YT, B_PART, B_UG, B_RB, B_SOLVE, B_RES, B_STATE_, B_OFLAG, B_IMU, B_S15 };
   const size_t np = params.size();
   const size_t n_upper = (size_t)d.ntile * (d.ntile + 1) / 2;
   const size_t rb_len = (size_t)n * n + 36 * (size_t)K + 2 * (size_t)n + 2;
@@ -1013,7 +1290,12 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
       {B_OA, 96 * (size_t)std::max(N, 1)}, {B_OR, 16 * (size_t)std::max(N, 1)}, {B_OYG, 48 * (size_t)std::max(N, 1)},
       {B_VINV, 72 * (size_t)std::max(M, 1)}, {B_GL, 24 * (size_t)std::max(M, 1)}, {B_PT, 8 * 4 * (size_t)std::max(M, 1)},
       {B_WT, 8 * (size_t)d.rows * d.P}, {B_YT, 8 * (size_t)d.rows * d.P}, {B_PART, 8 * n_upper * d.ksplit * 256},
-      {B_UG, 8 * (size_t)(33 * BA_KFSPLIT * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 4 * (size_t)n + 64 + BA_SOLVE_THREADS)}, {B_RES, 8 * 16}};
+      {B_UG, 8 * (size_t)(33 * BA_KFSPLIT * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 4 * (size_t)n + 64 + BA_SOLVE_THREADS)}, {B_RES, 8 * 16},
+      {B_OFLAG, 4 * (size_t)std::max(N, 1)},
+      // inertial: edges (int [E][2]) | preint [E][11] | per-edge J^T J records
+      {B_IMU, inertial ? 8 * ((size_t)inr->E * (1 + 11 + IMU_REC) + 8) : 8},
+      // inertial: dp15 [n15 pad 16] | S [n15^2] | b [n15] | 1/L_jj [n15] | gradient [n15]
+      {B_S15, inertial ? 8 * ((size_t)(15 * K) * (15 * K) + 4 * (size_t)(15 * K) + 64) : 8}};
   for (auto& nd : need) if (int rc = orbx_reserve(h, h->ws_ba[nd.id], nd.bytes)) return rc;
   auto D = [&](int id) { return (double*)h->ws_ba[id].p; };
   auto I = [&](int id) { return (int*)h->ws_ba[id].p; };
@@ -1028,6 +1310,27 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     ORBX_HIP(h, hipMemcpyAsync(D(B_OUV), o_uv.data(), 16 * (size_t)N, hipMemcpyHostToDevice, st));
   }
   if (!kf_obs.empty()) ORBX_HIP(h, hipMemcpyAsync(I(B_KFOBS), kf_obs.data(), 4 * kf_obs.size(), hipMemcpyHostToDevice, st));
+  BaInertialDev ind{};
+  const int n15 = 15 * K;
+  double* imu_buf = nullptr;
+  if (inertial) {
+    if (n15 > BA_MAX_N) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d keyframes per inertial window", BA_MAX_N / 15);
+    for (int e = 0; e < inr->E; ++e)
+      if (inr->edge_kf[2 * e] < 0 || inr->edge_kf[2 * e] >= K || inr->edge_kf[2 * e + 1] < 0 || inr->edge_kf[2 * e + 1] >= K)
+        return orbx_fail(h, ORBX_ERR_INVALID, "IMU edge %d: keyframe index out of range", e);
+    if (N > 0) ORBX_HIP(h, hipMemcpyAsync(I(B_OFLAG), o_flag.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
+    bc.o_flag = I(B_OFLAG);
+    int* d_edges = I(B_IMU);
+    double* d_pre = D(B_IMU) + inr->E;                                   // 2 ints per edge = 1 double slot per edge
+    imu_buf = d_pre + 11 * (size_t)inr->E;
+    if (inr->E > 0) {
+      ORBX_HIP(h, hipMemcpyAsync(d_edges, inr->edge_kf, 8 * (size_t)inr->E, hipMemcpyHostToDevice, st));
+      ORBX_HIP(h, hipMemcpyAsync(d_pre, inr->preint, 88 * (size_t)inr->E, hipMemcpyHostToDevice, st));
+    }
+    ind.K = K; ind.M = M; ind.E = inr->E;
+    ind.gw = std::sqrt(inr->cfg->gyro_rw_info); ind.aw = std::sqrt(inr->cfg->accel_rw_info);
+    ind.edge_kf = d_edges; ind.preint = d_pre;
+  }
   // the sparsity pattern of WT/YT is the same every iteration: zero once
   ORBX_HIP(h, hipMemsetAsync(D(B_WT), 0, 8 * (size_t)d.rows * d.P, st));
   ORBX_HIP(h, hipMemsetAsync(D(B_YT), 0, 8 * (size_t)d.rows * d.P, st));
@@ -1048,8 +1351,9 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   BaState* S = (BaState*)h->ws_ba[23].p;
   {
     BaState s0{};
-    s0.lambda = 1e-3;                                                  // :1006-1010
-    s0.gtol = cfg->gradient_tolerance; s0.ptol = cfg->param_tolerance;
+    s0.lambda = inertial ? inr->cfg->initial_lambda : 1e-3;            // :1006-1010 / local_inertial_ba.rs:1195
+    s0.gtol = inertial ? 1e-8 : cfg->gradient_tolerance;              // local_inertial_ba.rs:1213
+    s0.ptol = inertial ? 0.0 : cfg->param_tolerance;                  // the inertial loop has no step-size test
     ORBX_HIP(h, hipMemcpyAsync(S, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
     ORBX_HIP(h, hipStreamSynchronize(st));                             // s0 is a stack object
   }
@@ -1061,10 +1365,14 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     return ORBX_OK;
   };
   auto chi2_of = [&](int which, int iter, double* out_sum3, const double* b2, const double* c2) {
-    if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, which, iter, K, D(B_RTOPT));
+    if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, which, iter, K, D(B_RTOPT), inertial ? 1 : 0);
     if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTOPT), D(B_RTFIX),
                                   I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
     hipLaunchKernelGGL(ba_sum3_kernel, dim3(1), dim3(256), 0, st, S, M, pt_chi2, b2, c2, out_sum3);
+    if (inertial && inr->E > 0) {                                        // + IMU and bias-random-walk residuals (:661-698)
+      hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, S, P0, P1, which, 0, ind, imu_buf);
+      hipLaunchKernelGGL(ba_imu_addchi_kernel, dim3(1), dim3(1), 0, st, S, inr->E, imu_buf, out_sum3, 0);
+    }
   };
   // total residual count over all ranks (for the RMS error): all-reduce one double when partitioned
   double n_res = 2.0 * (double)N;
@@ -1089,8 +1397,8 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     if (should_stop && should_stop(user)) break;                     // :1013
     {
       ProfScope ps(h, "ba_pose_kernel");
-      if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, 0, iter, K, D(B_RTOPT));
-      else hipLaunchKernelGGL(ba_pose_kernel, dim3(1), dim3(64), 0, st, S, P0, P1, 0, iter, 0, D(B_RTOPT));   // iteration counter
+      if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, 0, iter, K, D(B_RTOPT), inertial ? 1 : 0);
+      else hipLaunchKernelGGL(ba_pose_kernel, dim3(1), dim3(64), 0, st, S, P0, P1, 0, iter, 0, D(B_RTOPT), 0);   // iteration counter
     }
     {
       ProfScope ps(h, "ba_build_kernel");
@@ -1113,7 +1421,26 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
       hipLaunchKernelGGL(ba_gather_kernel, dim3(blocks), dim3(256), 0, st, d, S, D(B_PART), kfpart, pt_chi2, pt_glsq, D(B_RB));
     }
     if (int rc = allreduce(D(B_RB), rb_len)) return rc;
-    {
+    if (inertial) {
+      ProfScope ps(h, "ba_inertial_solve");
+      double* dp15 = D(B_S15);
+      double* Sg = dp15 + ((n15 + 15) & ~15);
+      double* bvec = Sg + (size_t)n15 * n15;
+      double* ginv = bvec + n15;
+      double* gfull = ginv + n15;
+      if (inr->E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, S, P0, P1, 0, 1, ind, imu_buf);
+      hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, S, P0, P1, ind, D(B_RB), imu_buf, Sg, bvec, gfull, res);
+      for (int c0 = 0; c0 < n15; c0 += BB_NB) {
+        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(1), dim3(256), 0, st, n15, c0, S, Sg, ginv, res);
+        const int m = n15 - c0 - BB_NB;
+        if (m > 0) {
+          const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2;
+          hipLaunchKernelGGL(ba_big_update_kernel, dim3((units + 3) / 4), dim3(256), 0, st, n15, c0, S, Sg, res);
+        }
+      }
+      hipLaunchKernelGGL(ba_big_subst_kernel, dim3(1), dim3(256), 0, st, n15, S, P0, P1, Sg, ginv, bvec, dp15, res);
+      hipLaunchKernelGGL(ba_inertial_scatter_kernel, dim3(1), dim3(256), 0, st, S, P0, P1, K, M, dp15, D(B_SOLVE));
+    } else {
       ProfScope ps(h, "ba_solve_kernel");
       if (use_lds) {
         hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_THREADS), lds_need, st, n, S, P0, P1, D(B_RB), K, D(B_SOLVE), res);
@@ -1157,10 +1484,15 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   ORBX_HIP(h, hipMemcpyAsync(&sh, S, sizeof(sh), hipMemcpyDeviceToHost, st));
   ORBX_HIP(h, hipStreamSynchronize(st));
   ORBX_HIP(h, hipGetLastError());
-  *initial_error = std::sqrt(hres[12]) / std::sqrt(n_res);
   *iterations = sh.iters;
   const double final_sq = sh.iters > 0 ? sh.final_sq : hres[12];
-  *final_error = std::sqrt(final_sq) / std::sqrt(n_res);            // :1059-1060
+  if (inertial) {                                                      // |r|, not RMS (local_inertial_ba.rs:1191, :1244)
+    *initial_error = std::sqrt(hres[12]);
+    *final_error = std::sqrt(final_sq);
+  } else {
+    *initial_error = std::sqrt(hres[12]) / std::sqrt(n_res);
+    *final_error = std::sqrt(final_sq) / std::sqrt(n_res);            // :1059-1060
+  }
   double* cur = sh.sel ? P1 : P0;
   std::vector<double> init_pts;
   if (dist && M > 0) {
@@ -1179,7 +1511,22 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     ORBX_HIP(h, hipMemcpyAsync(params.data(), cur, 8 * np, hipMemcpyDeviceToHost, st));
     ORBX_HIP(h, hipStreamSynchronize(st));
   }
-  for (int k = 0; k < K; ++k) host_params_to_pose_wc(&params[6 * (size_t)k], poses_wc_out + 7 * (size_t)k);
+  if (inertial) {                                                      // extract_pose / velocity / bias (:584-608, :1250-1254)
+    for (int k = 0; k < K; ++k) {
+      const double* p6 = &params[6 * (size_t)k];
+      double* o = poses_wc_out + 7 * (size_t)k;
+      const double v[3] = {p6[0] / 2.0, p6[1] / 2.0, p6[2] / 2.0};
+      const double nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], eps = 2.220446049250313e-16;
+      if (nn <= eps * eps) { o[0] = 1.0; o[1] = o[2] = o[3] = 0.0; }
+      else { const double nv = std::sqrt(nn), sn = 1.0 * std::sin(nv) / nv; o[0] = 1.0 * std::cos(nv); o[1] = v[0] * sn; o[2] = v[1] * sn; o[3] = v[2] * sn; }
+      o[4] = p6[3]; o[5] = p6[4]; o[6] = p6[5];
+      const double* ex = &params[6 * (size_t)K + 3 * (size_t)M + 9 * (size_t)k];
+      for (int i = 0; i < 3; ++i) inr->vel_out[3 * (size_t)k + i] = ex[i];
+      for (int i = 0; i < 6; ++i) inr->bias_out[6 * (size_t)k + i] = ex[3 + i];
+    }
+  } else {
+    for (int k = 0; k < K; ++k) host_params_to_pose_wc(&params[6 * (size_t)k], poses_wc_out + 7 * (size_t)k);
+  }
   for (int j = 0; j < 3 * M; ++j) points[j] = params[6 * (size_t)K + j];
   return ORBX_OK;
 }

@@ -769,6 +769,33 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          poses_wc_out, iterations, initial_error, final_error);
 }
 
+void orbx_default_inertial_ba_config(orbx_inertial_ba_config* c) {       // local_inertial_ba.rs:126-141
+  if (!c) return;
+  c->max_iterations = 10; c->window_size = 10;
+  c->huber_threshold_mono = std::sqrt(5.991); c->huber_threshold_stereo = std::sqrt(7.815);
+  c->initial_lambda = 1e-2; c->gyro_rw_info = 1e6; c->accel_rw_info = 1e4;
+}
+
+int orbx_ba_solve_inertial(orbx_handle* h, const orbx_camera* cam, const orbx_inertial_ba_config* cfg, int K, const double* poses_wc,
+                           const double* velocities, const double* biases, int F, const double* fixed_poses_cw, int M, double* points,
+                           int N, const orbx_ba_obs* obs, int E, const int* edge_kf, const double* preint,
+                           orbx_should_stop_fn should_stop, void* user, double* poses_wc_out, double* vel_out, double* bias_out,
+                           int* iterations, double* initial_error, double* final_error) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || !cfg || K < 0 || F < 0 || M < 0 || N < 0 || E < 0 || !iterations || !initial_error || !final_error ||
+      (K > 0 && (!poses_wc || !velocities || !biases || !poses_wc_out || !vel_out || !bias_out)) || (F > 0 && !fixed_poses_cw) ||
+      (M > 0 && !points) || (N > 0 && !obs) || (E > 0 && (!edge_kf || !preint)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_inertial: bad argument");
+  *iterations = 0; *initial_error = 0.0; *final_error = 0.0;
+  if (K < 2) return orbx_fail(h, ORBX_ERR_EMPTY, "inertial BA needs two keyframes in the window");   // local_inertial_ba.rs:1080-1082
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  orbx_ba_config vc{cfg->max_iterations, 0.0, 1e-8, cfg->huber_threshold_mono, 0};
+  BaInertialHost in{cfg, velocities, biases, E, edge_kf, preint, vel_out, bias_out};
+  return ba_solve_visual(h, cam, &vc, K, poses_wc, F, fixed_poses_cw, M, points, N, obs, should_stop, user, poses_wc_out, iterations,
+                         initial_error, final_error, false, &in);
+}
+
 int orbx_ba_solve_global(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw,
                          const double* fixed_pose_cw, int M, double* points, int N, const orbx_ba_obs* obs,
                          orbx_should_stop_fn should_stop, void* user, double* poses_wc_out, int* iterations,

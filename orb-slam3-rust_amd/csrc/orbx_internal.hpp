@@ -85,7 +85,7 @@ struct orbx_handle {
   unsigned btile_tab_off = 0, ftile_tab_off = 0;   // tile -> (level, tx, ty) tables of the blur / FAST launches, same buffer
   // grow-only workspaces
   DevBuf ws_pyr, ws_blur, ws_cand, ws_counters, ws_sel, ws_sel2, ws_match, ws_io[12];
-  DevBuf ws_ba[24];
+  DevBuf ws_ba[28];
   // pipelined host-batch path: copy streams, events, double-buffered staging
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
@@ -153,4 +153,15 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
                     const double* poses_cw, int F, const double* fixed_poses_cw, int M,
                     double* points, int N, const orbx_ba_obs* obs, orbx_should_stop_fn should_stop,
                     void* user, double* poses_wc_out, int* iterations, double* initial_error,
-                    double* final_error, bool global_mode = false);
+                    double* final_error, bool global_mode = false, const struct BaInertialHost* inr = nullptr);
+// the extra inputs / outputs of solve_inertial_ba (local_inertial_ba.rs:1074-1275) for ba_solve_visual's inertial mode
+struct BaInertialHost {
+  const orbx_inertial_ba_config* cfg;
+  const double* velocities;   // [K][3]
+  const double* biases;       // [K][6]
+  int E;
+  const int* edge_kf;         // [E][2]
+  const double* preint;       // [E][11]
+  double* vel_out;            // [K][3]
+  double* bias_out;           // [K][6]
+};

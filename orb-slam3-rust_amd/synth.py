@@ -375,3 +375,65 @@ def write_euroc_mav0(root, n_frames, seed=0, w=752, h=480, camera=None):
         with open(os.path.join(root, "cam%d" % c, "data.csv"), "w") as f:
             f.write("#timestamp [ns],filename\n" + "\r\n".join(rows) + "\n")
     return pairs
+
+
+def inertial_window(seed, K, M, obs_dtype, n_fixed=2, dt=0.25, w=752, h=480, camera=None, noise_px=1.0, stereo_fraction=0.5):
+    """A local inertial-BA window (local_inertial_ba.rs): K consecutive keyframes dt apart on a smooth accelerating
+    trajectory (T_wc poses, world velocities, per-keyframe biases), `n_fixed` older keyframes that only observe (T_cw),
+    M points.  The preintegrated deltas of edge (k, k+1) are the exact ones of the ground-truth states
+    (dR = Ri^T Rj, dv = Ri^T (vj - vi - g dt), dp = Ri^T (pj - pi - vi dt - g dt^2 / 2), imu_factors.rs:66-103) plus a
+    little noise; initial states are perturbed.  obs[i]["_pad"] bit 0 marks stereo observations.
+    Returns dict(poses_wc, velocities, biases, fixed_cw, points, obs, edge_kf, preint, camera, gt_*)."""
+    cam = dict(EUROC_CAMERA if camera is None else camera)
+    rng = np.random.default_rng([0x1BA, seed])
+    g = np.array([0.0, 0.0, -9.81])
+    tt = (np.arange(-n_fixed, K)) * dt
+
+    def pos(t):
+        return np.array([0.6 * t + 0.05 * t * t, 0.08 * np.sin(1.3 * t), 0.03 * np.cos(0.9 * t)])
+
+    def velo(t):
+        return np.array([0.6 + 0.1 * t, 0.08 * 1.3 * np.cos(1.3 * t), -0.03 * 0.9 * np.sin(0.9 * t)])
+
+    q_wc = [_quat_mul(_quat_from_axis_angle([0, 1, 0], 0.04 * t), _quat_from_axis_angle([1, 0, 0], 0.02 * np.sin(t))) for t in tt]
+    p_wc = [pos(t) for t in tt]
+    v_w = [velo(t) for t in tt]
+    pts = np.stack([rng.uniform(-5, 7, M), rng.uniform(-3, 3, M), rng.uniform(3, 14, M)], 1)
+    obs = []
+    for idx in range(len(tt)):
+        qi = q_wc[idx] * np.array([1, -1, -1, -1.0])
+        pc = _quat_rot(qi, pts - p_wc[idx])
+        u = cam["fx"] * pc[:, 0] / pc[:, 2] + cam["cx"]; v = cam["fy"] * pc[:, 1] / pc[:, 2] + cam["cy"]
+        vis = (pc[:, 2] > 0.1) & (u >= 0) & (u < w) & (v >= 0) & (v < h)
+        nz = rng.normal(0, noise_px, (M, 2)) if noise_px > 0 else np.zeros((M, 2))
+        st = rng.random(M) < stereo_fraction
+        for j in np.nonzero(vis)[0]:
+            k = idx - n_fixed
+            obs.append((k if k >= 0 else -1, idx if k < 0 else -1, j, int(st[j]), u[j] + nz[j, 0], v[j] + nz[j, 1]))
+    obs = np.array(obs, dtype=obs_dtype)
+    fixed_cw = []
+    for idx in range(n_fixed):
+        qi = q_wc[idx] * np.array([1, -1, -1, -1.0])
+        fixed_cw.append(np.concatenate([qi, -_quat_rot(qi, p_wc[idx])]))
+    gt_poses = np.array([np.concatenate([q_wc[n_fixed + k], p_wc[n_fixed + k]]) for k in range(K)])
+    gt_vel = np.array(v_w[n_fixed:])
+    edge_kf, preint = [], []
+    for k in range(K - 1):
+        qi, qj = gt_poses[k, :4], gt_poses[k + 1, :4]
+        qic = qi * np.array([1, -1, -1, -1.0])
+        dR = _quat_mul(qic, qj)
+        dv = _quat_rot(qic, gt_vel[k + 1] - gt_vel[k] - g * dt)
+        dp = _quat_rot(qic, gt_poses[k + 1, 4:] - gt_poses[k, 4:] - gt_vel[k] * dt - 0.5 * g * dt * dt)
+        dR = _quat_mul(dR, _quat_from_axis_angle(rng.normal(0, 1, 3), rng.normal(0, 2e-3)))
+        edge_kf.append((k, k + 1))
+        preint.append(np.concatenate([dR / np.linalg.norm(dR), dv + rng.normal(0, 5e-3, 3), dp + rng.normal(0, 2e-3, 3), [dt]]))
+    poses = gt_poses.copy()
+    for k in range(K):
+        dq = _quat_from_axis_angle(rng.normal(0, 1, 3), np.deg2rad(rng.normal(0, 0.4)))
+        poses[k, :4] = _quat_mul(dq, poses[k, :4])
+        poses[k, 4:] += rng.normal(0, 0.02, 3)
+    vel = gt_vel + rng.normal(0, 0.05, (K, 3))
+    bias = np.concatenate([rng.normal(0, 2e-3, (K, 3)), rng.normal(0, 2e-2, (K, 3))], 1)
+    return dict(poses_wc=poses, velocities=vel, biases=bias, fixed_cw=np.array(fixed_cw).reshape(-1, 7), points=pts + rng.normal(0, 0.03, (M, 3)),
+                obs=obs, edge_kf=np.array(edge_kf, np.int32).reshape(-1, 2), preint=np.array(preint).reshape(-1, 11), camera=cam,
+                gt_poses_wc=gt_poses, gt_velocities=gt_vel, gt_points=pts)

@@ -23,3 +23,28 @@ tot = 0
 for k, (ms, n) in sorted(kt.items(), key=lambda kv: -kv[1][0]):
     print("  %-22s %8.3f ms  %3d scopes  %7.1f us each" % (k, ms, n, ms / n * 1e3)); tot += ms
 print("sum of kernel scopes: %.3f ms" % tot)
+
+# local inertial BA (local_inertial_ba.rs:1074-1275): window of 10 keyframes, 2000 points
+from oracle import oracle as O
+iw = P.synth.inertial_window(42, 10, 2000, P.BA_OBS)
+icfg = P.LocalInertialBAConfig()
+args = (cam, icfg, iw["poses_wc"], iw["velocities"], iw["biases"], iw["fixed_cw"], iw["points"], iw["obs"], iw["edge_kf"], iw["preint"])
+for _ in range(2):
+    r = h.ba_solve_inertial(*args)
+t0 = time.perf_counter()
+for _ in range(5):
+    r = h.ba_solve_inertial(*args)
+gpu_ms = (time.perf_counter() - t0) * 200
+print("inertial BA K=10 M=2000 obs=%d: %.3f ms/solve (%d iterations)" % (len(iw["obs"]), gpu_ms, r["iterations"]))
+# the literal dense formulation (LU of 15K+3M unknowns per iteration) is O(n^3): timed on a small window only
+sw = P.synth.inertial_window(42, 5, 300, P.BA_OBS)
+t0 = time.perf_counter()
+o = O.inertial_ba_solve(O.Camera(**sw["camera"]), O.inertial_ba_config(), sw["poses_wc"], sw["velocities"], sw["biases"], sw["fixed_cw"],
+                        sw["points"], sw["obs"], sw["edge_kf"], sw["preint"])
+cpu_ms = (time.perf_counter() - t0) * 1e3
+sargs = (cam, icfg, sw["poses_wc"], sw["velocities"], sw["biases"], sw["fixed_cw"], sw["points"], sw["obs"], sw["edge_kf"], sw["preint"])
+h.ba_solve_inertial(*sargs)
+t0 = time.perf_counter()
+r2 = h.ba_solve_inertial(*sargs)
+print("inertial BA K=5 M=300: GPU %.3f ms, CPU oracle (dense, %d unknowns) %.0f ms, iterations %d / %d" %
+      ((time.perf_counter() - t0) * 1e3, 15 * 5 + 900, cpu_ms, r2["iterations"], o["iterations"]))

@@ -190,6 +190,65 @@ int main(int argc, char** argv) {
       one.kf_ids = {1}; one.mp_ids = {2}; one.fixed_kf_id = 1;
       if (orbx::solve_global_ba(sp.handle(), one, cam, orbx::GlobalBAConfig{}, nullptr).has_value()) return 4;
     }
+    // ---- solve_inertial_ba (local_inertial_ba.rs:1074-1275) through InertialBAProblemData keyed by ids
+    {
+      FILE* fi = fopen((in + "/iba.bin").c_str(), "rb");
+      if (fi) {
+        fclose(fi);
+        std::vector<uint8_t> ib = slurp(in + "/iba.bin");
+        const int* ih = (const int*)ib.data();
+        const int iK = ih[0], iF = ih[1], iM = ih[2], iN = ih[3], iE = ih[4];
+        const double* q = (const double*)(ib.data() + 32);
+        const double* ipose = q; const double* ivel = ipose + 7 * (size_t)iK; const double* ibias = ivel + 3 * (size_t)iK;
+        const double* ifix = ibias + 6 * (size_t)iK; const double* ipts = ifix + 7 * (size_t)iF; const double* iobs = ipts + 3 * (size_t)iM;
+        const double* iedge = iobs + 6 * (size_t)iN; const double* ipre = iedge + 2 * (size_t)iE;
+        orbx::InertialBAProblemData ip;
+        for (int k = 0; k < iK; ++k) {
+          const orbx::KeyFrameId id = 700 + 13 * (uint64_t)k;
+          ip.opt_kf_ids.push_back(id);
+          ip.kf_poses[id] = se3(ipose + 7 * (size_t)k);
+          ip.kf_velocities[id] = {ivel[3 * (size_t)k], ivel[3 * (size_t)k + 1], ivel[3 * (size_t)k + 2]};
+          orbx::ImuBias b;
+          for (int a = 0; a < 3; ++a) { b.gyro[a] = ibias[6 * (size_t)k + a]; b.accel[a] = ibias[6 * (size_t)k + 3 + a]; }
+          ip.kf_biases[id] = b;
+        }
+        for (int f2 = 0; f2 < iF; ++f2) ip.fixed_kf_poses[20 + (uint64_t)f2] = se3(ifix + 7 * (size_t)f2);
+        for (int j = 0; j < iM; ++j) { const orbx::MapPointId id = 8000 + 5 * (uint64_t)j; ip.mp_ids.push_back(id); ip.mp_positions[id] = {ipts[3 * (size_t)j], ipts[3 * (size_t)j + 1], ipts[3 * (size_t)j + 2]}; }
+        for (int i = 0; i < iN; ++i) {
+          const double* o = iobs + 6 * (size_t)i;
+          const int kf = (int)o[0], fx = (int)o[1];
+          ip.visual_observations.push_back({kf >= 0 ? 700 + 13 * (uint64_t)kf : 20 + (uint64_t)fx, 8000 + 5 * (uint64_t)(int)o[2], {o[4], o[5]}, o[3] != 0.0, kf >= 0});
+        }
+        for (int e = 0; e < iE; ++e) {
+          orbx::ImuEdgeData ed;
+          ed.kf_i_id = 700 + 13 * (uint64_t)(int)iedge[2 * (size_t)e]; ed.kf_j_id = 700 + 13 * (uint64_t)(int)iedge[2 * (size_t)e + 1];
+          const double* pr = ipre + 11 * (size_t)e;
+          for (int a = 0; a < 4; ++a) ed.preint.delta_rot[a] = pr[a];
+          for (int a = 0; a < 3; ++a) { ed.preint.delta_vel[a] = pr[4 + a]; ed.preint.delta_pos[a] = pr[7 + a]; }
+          ed.preint.dt = pr[10];
+          ip.imu_edges.push_back(ed);
+        }
+        auto ir = orbx::solve_inertial_ba(sp.handle(), ip, cam, orbx::LocalInertialBAConfig{}, nullptr);
+        fo = fopen((out + "/iba_out.bin").c_str(), "wb");
+        const int iok = ir.has_value();
+        put(fo, &iok, 1);
+        if (iok) {
+          const int it = (int)ir->iterations, nrep = (int)ir->optimized_poses.size();
+          put(fo, &it, 1); put(fo, &nrep, 1);
+          const int padi = 0; put(fo, &padi, 1);
+          put(fo, &ir->initial_error, 1); put(fo, &ir->final_error, 1);
+          for (int k = 1; k < iK; ++k) {
+            const orbx::KeyFrameId id = ip.opt_kf_ids[(size_t)k];
+            const orbx::SE3& p = ir->optimized_poses.at(id);
+            put(fo, p.rotation.data(), 4); put(fo, p.translation.data(), 3);
+            put(fo, ir->optimized_velocities.at(id).data(), 3);
+            put(fo, ir->optimized_biases.at(id).gyro.data(), 3); put(fo, ir->optimized_biases.at(id).accel.data(), 3);
+          }
+          for (orbx::MapPointId id : ip.mp_ids) put(fo, ir->optimized_points.at(id).data(), 3);
+        }
+        fclose(fo);
+      }
+    }
     // an empty problem is None, as local_ba_lm.rs:923-925
     orbx::VisualBAProblemData empty;
     if (orbx::solve_visual_ba(sp.handle(), empty, cam, orbx::LocalBAConfigLM{}, nullptr).has_value()) return 3;

@@ -50,6 +50,12 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
     for c, img in ((0, L), (1, R)):
         with open(os.path.join(mav0, "cam%d" % c, "data", "%d.png" % ts1), "wb") as f:
             f.write(pkg.synth.png_encode(img, filters=3))
+    iw = pkg.synth.inertial_window(21, 4, 100, pkg.BA_OBS, n_fixed=2)
+    iob = np.stack([iw["obs"]["kf_idx"], iw["obs"]["fixed_idx"], iw["obs"]["mp_idx"], iw["obs"]["_pad"], iw["obs"]["u"], iw["obs"]["v"]], 1).astype(np.float64)
+    with open(os.path.join(tmp, "iba.bin"), "wb") as f:
+        f.write(struct.pack("<iiiiiiii", 4, 2, len(iw["points"]), len(iob), len(iw["edge_kf"]), 0, 0, 0))
+        for a in (iw["poses_wc"], iw["velocities"], iw["biases"], iw["fixed_cw"], iw["points"], iob, iw["edge_kf"].astype(np.float64), iw["preint"]):
+            f.write(np.ascontiguousarray(a, np.float64).tobytes())
     voc = pkg.synth.vocabulary(31, k=5, depth=2)
     pkg.synth.write_vocabulary_text(os.path.join(tmp, "voc.txt"), *voc, 5, 2)
     env = dict(os.environ); env.pop("LD_PRELOAD", None)
@@ -128,3 +134,14 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
     assert ok == 1 and it == go["iterations"] and abs(e1 - go["final_error"]) < 1e-8 * go["final_error"]
     assert rel(gposes[1:], go["poses_wc"]) < gtol and rel(gpts, go["points"]) < gtol, gtol
     assert np.allclose(gposes[0], pkg.se3_inverse(w["fixed_cw"][0]), atol=1e-15)
+    # --- solve_inertial_ba through InertialBAProblemData keyed by ids (first keyframe of the window not reported)
+    ib = open(os.path.join(tmp, "iba_out.bin"), "rb").read()
+    iok, iit, nrep, _ = struct.unpack_from("<iiii", ib, 0)
+    ie0, ie1 = struct.unpack_from("<dd", ib, 16)
+    st = np.frombuffer(ib, np.float64, 16 * 3, 32).reshape(3, 16)
+    ipts = np.frombuffer(ib, np.float64, 3 * len(iw["points"]), 32 + 8 * 48).reshape(-1, 3)
+    io = oracle.inertial_ba_solve(oracle.Camera(**iw["camera"]), oracle.inertial_ba_config(), iw["poses_wc"], iw["velocities"], iw["biases"],
+                                  iw["fixed_cw"], iw["points"], iw["obs"], iw["edge_kf"], iw["preint"])
+    assert iok == 1 and nrep == 3 and iit == io["iterations"] and abs(ie1 - io["final_error"]) < 1e-7 * io["final_error"]
+    assert rel(st[:, :7], io["poses_wc"][1:]) < 1e-6 and rel(st[:, 7:10], io["velocities"][1:]) < 1e-6 and rel(st[:, 10:], io["biases"][1:]) < 1e-6
+    assert rel(ipts, io["points"]) < 1e-6
