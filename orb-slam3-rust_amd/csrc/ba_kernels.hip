@@ -428,6 +428,17 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
+// sum over the block in a fixed order: shuffle tree inside each wave, then thread 0 adds the wave totals in wave order
+// (two barriers instead of the ten of a shared-memory tree over 1024 threads)
+__device__ __forceinline__ double block_sum_fixed(double v, double* s_w /* [blockDim/64] */) {
+  v = wave_sum(v);
+  __syncthreads();                                        // s_w may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_w[w];
+  return t;                                               // same value in every thread
+}
 
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps y <- y + y*(1 - x y^2)/2 (full f64 accuracy)
 __device__ __forceinline__ double rsqrt_nr(double x) {
@@ -478,14 +489,16 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     }
   double gs = 0.0;
   for (int i = tid; i < n; i += nth) { sb[i] = -gp[i] + bred[i]; gs += gp[i] * gp[i]; }
-  s_red[tid] = gs;
-  __syncthreads();
-  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_red[tid] += s_red[tid + s2]; __syncthreads(); }
-  if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(s_red[0] + bred[n + 1]); }
+  gs = block_sum_fixed(gs, s_red);
+  if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(gs + bred[n + 1]); }
+  __shared__ int s_ok;
+  if (tid == 0) s_ok = 1;
   int ok = 1;
-  for (int c0 = 0; c0 < n && ok; c0 += BA_NB) {
+  for (int c0 = 0; c0 < n; c0 += BA_NB) {
     const int nb = min(BA_NB, n - c0);
     __syncthreads();
+    ok = s_ok;                                            // written by thread 0 in step (b) of the previous panel
+    if (!ok) break;
     // (a) panel update with everything to the left of the panel
     if (c0 > 0) {
       for (int idx = tid; idx < (n - c0) * BA_NB; idx += nth) {
@@ -506,58 +519,68 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       }
       __syncthreads();
     }
-    // (b) diagonal block (redundantly per thread) + this thread's row of the panel
+    // (b) diagonal block (redundantly per thread) + this thread's row of the panel.  Only the waves that own rows of
+    // the panel take part: the redundant 8x8 factorisation is ~300 dependent f64 instructions, and with all 16 waves
+    // doing it (4 per SIMD) it was the bulk of the solve (n = 114: rows live in 2 waves)
     const int r = c0 + tid;
+    const bool act = c0 + (tid & ~63) < n;                 // wave-uniform
     double L[BA_NB][BA_NB], rinv[BA_NB];
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < BA_NB; ++i)
+      for (int i = 0; i < BA_NB; ++i)
 #pragma unroll
-      for (int j = 0; j <= i; ++j) L[i][j] = (i < nb) ? S[(size_t)(c0 + i) * n + c0 + j] : (i == j ? 1.0 : 0.0);
-    __syncthreads();   // every wave has read the block before the block's own rows overwrite it with the factor
-#pragma unroll
-    for (int j = 0; j < BA_NB; ++j) {
-      double d = L[j][j];
-#pragma unroll
-      for (int i = 0; i < j; ++i) d = fma(-L[j][i], L[j][i], d);
-      if (j < nb && !(d > 0.0)) ok = 0;                 // same value in every thread
-      const double ri = rsqrt_nr(ok ? d : 1.0);
-      rinv[j] = ri;
-      L[j][j] = d * ri;                                  // sqrt(d)
-#pragma unroll
-      for (int i = j + 1; i < BA_NB; ++i) {
-        double v = L[i][j];
-#pragma unroll
-        for (int t = 0; t < j; ++t) v = fma(-L[i][t], L[j][t], v);
-        L[i][j] = v * ri;
-      }
+        for (int j = 0; j <= i; ++j) L[i][j] = (i < nb) ? S[(size_t)(c0 + i) * n + c0 + j] : (i == j ? 1.0 : 0.0);
     }
-    if (ok && r < n) {
-      if (tid < nb) {
-        // a row of the diagonal block: write the factor
+    __syncthreads();   // every wave has read the block before the block's own rows overwrite it with the factor
+    if (act) {
 #pragma unroll
-        for (int i = 0; i < BA_NB; ++i)
-          if (i == tid) {
+      for (int j = 0; j < BA_NB; ++j) {
+        double d = L[j][j];
 #pragma unroll
-            for (int j = 0; j <= i; ++j) S[(size_t)r * n + c0 + j] = L[i][j];
-            srinv[r] = rinv[i];
-          }
-      } else {
-        // a row below the block: x = a L11^-T
-        double x[BA_NB];
+        for (int i = 0; i < j; ++i) d = fma(-L[j][i], L[j][i], d);
+        if (j < nb && !(d > 0.0)) ok = 0;                 // same value in every participating thread
+        const double ri = rsqrt_nr(ok ? d : 1.0);
+        rinv[j] = ri;
+        L[j][j] = d * ri;                                  // sqrt(d)
 #pragma unroll
-        for (int j = 0; j < BA_NB; ++j) x[j] = (j < nb) ? S[(size_t)r * n + c0 + j] : 0.0;
+        for (int i = j + 1; i < BA_NB; ++i) {
+          double v = L[i][j];
 #pragma unroll
-        for (int j = 0; j < BA_NB; ++j) {
-          double v = x[j];
-#pragma unroll
-          for (int t = 0; t < j; ++t) v = fma(-x[t], L[j][t], v);
-          x[j] = v * rinv[j];
+          for (int t = 0; t < j; ++t) v = fma(-L[i][t], L[j][t], v);
+          L[i][j] = v * ri;
         }
+      }
+      if (tid == 0 && !ok) s_ok = 0;
+      if (ok && r < n) {
+        if (tid < nb) {
+          // a row of the diagonal block: write the factor
 #pragma unroll
-        for (int j = 0; j < BA_NB; ++j) if (j < nb) S[(size_t)r * n + c0 + j] = x[j];
+          for (int i = 0; i < BA_NB; ++i)
+            if (i == tid) {
+#pragma unroll
+              for (int j = 0; j <= i; ++j) S[(size_t)r * n + c0 + j] = L[i][j];
+              srinv[r] = rinv[i];
+            }
+        } else {
+          // a row below the block: x = a L11^-T
+          double x[BA_NB];
+#pragma unroll
+          for (int j = 0; j < BA_NB; ++j) x[j] = (j < nb) ? S[(size_t)r * n + c0 + j] : 0.0;
+#pragma unroll
+          for (int j = 0; j < BA_NB; ++j) {
+            double v = x[j];
+#pragma unroll
+            for (int t = 0; t < j; ++t) v = fma(-x[t], L[j][t], v);
+            x[j] = v * rinv[j];
+          }
+#pragma unroll
+          for (int j = 0; j < BA_NB; ++j) if (j < nb) S[(size_t)r * n + c0 + j] = x[j];
+        }
       }
     }
   }
+  __syncthreads();
+  ok = s_ok;
   __syncthreads();
   if (ok && tid < 64 && n <= 128) {
     // forward L y = b then backward L^T x = y, column oriented: lane holds rows `lane` and `lane+64` of the
@@ -635,15 +658,9 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     dsq += v * v;
     psq += params[i] * params[i];
   }
-  s_red[tid] = dsq;
-  __syncthreads();
-  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_red[tid] += s_red[tid + s2]; __syncthreads(); }
-  if (tid == 0) { res[2] = (double)ok; res[3] = s_red[0]; }
-  __syncthreads();
-  s_red[tid] = psq;
-  __syncthreads();
-  for (int s2 = nth >> 1; s2 >= 1; s2 >>= 1) { if (tid < s2) s_red[tid] += s_red[tid + s2]; __syncthreads(); }
-  if (tid == 0) res[4] = s_red[0];
+  dsq = block_sum_fixed(dsq, s_red);
+  psq = block_sum_fixed(psq, s_red);
+  if (tid == 0) { res[2] = (double)ok; res[3] = dsq; res[4] = psq; }
 }
 
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(int n, const BaState* St, double* P0, double* P1,
@@ -908,19 +925,22 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const
                                                       double* __restrict__ pt_chi2) {
   if (S->done) return;
   const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= d.M) return;
+  // one 32-lane group per point (as ba_build_kernel): 2000 points alone would fill 8 blocks
+  const int lane32 = threadIdx.x & 31;
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  if (j >= d.M) return;   // whole 32-lane group leaves together
   const double X[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1],
                        params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   double chi = 0.0;
-  for (int i = pt_start[j]; i < pt_start[j + 1]; ++i) {
+  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) {
     const int k = o_kf[i];
     const double* Rt = k >= 0 ? Rt_opt + 12 * (size_t)k : Rt_fix + 12 * (size_t)o_fix[i];
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
     chi += o.r0 * o.r0 + o.r1 * o.r1;
   }
-  pt_chi2[j] = chi;
+  chi = group_sum32(chi);
+  if (lane32 == 0) pt_chi2[j] = chi;
 }
 
 // out[0..2] = sums over points of up to three per-point arrays, one block, fixed tree
@@ -1366,7 +1386,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   };
   auto chi2_of = [&](int which, int iter, double* out_sum3, const double* b2, const double* c2) {
     if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, which, iter, K, D(B_RTOPT), inertial ? 1 : 0);
-    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTOPT), D(B_RTFIX),
+    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTOPT), D(B_RTFIX),
                                   I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
     hipLaunchKernelGGL(ba_sum3_kernel, dim3(1), dim3(256), 0, st, S, M, pt_chi2, b2, c2, out_sum3);
     if (inertial && inr->E > 0) {                                        // + IMU and bias-random-walk residuals (:661-698)
