@@ -29,7 +29,29 @@ w = synth.ba_window(1, 5, 60, O.BA_OBS, n_fixed_extra=1)
 a = O.ba_solve_dense(O.Camera(**w["camera"]), O.ba_config(), w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
 b = O.ba_solve_schur(O.Camera(**w["camera"]), O.ba_config(), w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
 assert a["iterations"] == b["iterations"]
-print("SANITIZED_OK", len(kl), len(m), a["iterations"])
+# the §8f restatements: triangulation searches (grid / FeatureVector), fuse search, vocabulary, global + inertial BA
+L.oracle_vocab_load_text.restype = C.c_void_p
+L.oracle_vocab_from_arrays.restype = C.c_void_p
+tv = synth.two_view_features(3, 600, O.KEYPOINT, dup=0.4)
+O.search_for_triangulation(O.Camera(**tv["camera"]), tv["kp1"], tv["desc1"], tv["mp1"], tv["stereo1"], tv["kp2"], tv["desc2"], tv["mp2"],
+                           tv["pose1_wc"], tv["pose2_wc"])
+voc = synth.vocabulary(2, k=4, depth=3, ragged=True)
+v = O.Vocabulary.from_arrays(*voc, 4, 3)
+n1 = v.transform(tv["desc1"], 1)[2]; n2 = v.transform(tv["desc2"], 9)[2]
+O.search_for_triangulation_bow(O.Camera(**tv["camera"]), tv["kp1"], tv["desc1"], tv["mp1"], tv["stereo1"], n1, tv["kp2"], tv["desc2"],
+                               tv["mp2"], n2, tv["pose1_wc"], tv["pose2_wc"])
+import tempfile
+with tempfile.TemporaryDirectory() as td:
+    synth.write_vocabulary_text(os.path.join(td, "v.txt"), *voc, 4, 3)
+    assert O.Vocabulary.load_from_text(os.path.join(td, "v.txt")).n_nodes == v.n_nodes
+fs = synth.fuse_scene(1, 200, 3, 150, O.KEYPOINT)
+O.fuse_search(O.Camera(**fs["camera"]), fs["positions"], fs["mp_desc"], fs["kf_poses_wc"], fs["kf_feat_offset"], fs["kps"], fs["descs"], 10.75)
+gw = synth.ba_window(2, 4, 50, O.BA_OBS)
+O.global_ba_solve_dense(O.Camera(**gw["camera"]), O.ba_config(), gw["poses_cw"], gw["fixed_cw"], gw["points"], gw["obs"])
+iw = synth.inertial_window(1, 3, 40, O.BA_OBS)
+ir = O.inertial_ba_solve(O.Camera(**iw["camera"]), O.inertial_ba_config(), iw["poses_wc"], iw["velocities"], iw["biases"], iw["fixed_cw"],
+                         iw["points"], iw["obs"], iw["edge_kf"], iw["preint"])
+print("SANITIZED_OK", len(kl), len(m), a["iterations"], ir["iterations"])
 '''
 
 
