@@ -40,12 +40,13 @@ int orbx_reserve(orbx_handle* h, DevBuf& b, size_t bytes) {
 static hipEvent_t prof_event(orbx_handle* h) {
   if (h->event_next == h->event_pool.size()) {
     hipEvent_t e;
-    hipEventCreate(&e);
+    // timing only: no system-scope release (cache write-back) at every kernel boundary
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) hipEventCreate(&e);
     h->event_pool.push_back(e);
   }
   return h->event_pool[h->event_next++];
 }
-ProfScope::ProfScope(orbx_handle* h_, const char* name) : h(h_), idx(-1) {
+ProfScope::ProfScope(orbx_handle* h_, const char* name, hipStream_t stream_) : h(h_), idx(-1), stream(stream_ ? stream_ : h_->stream) {
   if (!h->profiling) return;
   for (size_t i = 0; i < h->timers.size(); ++i)
     if (h->timers[i].name == name) { idx = (int)i; break; }
@@ -56,13 +57,13 @@ ProfScope::ProfScope(orbx_handle* h_, const char* name) : h(h_), idx(-1) {
     idx = (int)h->timers.size() - 1;
   }
   hipEvent_t e = prof_event(h);
-  hipEventRecord(e, h->stream);
+  hipEventRecord(e, stream);
   h->timers[idx].ev.push_back(e);
 }
 ProfScope::~ProfScope() {
   if (idx < 0) return;
   hipEvent_t e = prof_event(h);
-  hipEventRecord(e, h->stream);
+  hipEventRecord(e, stream);
   h->timers[idx].ev.push_back(e);
 }
 void orbx_prof_begin_call(orbx_handle* h) { (void)h; }   // events accumulate until they are read
@@ -138,6 +139,9 @@ void orbx_destroy(orbx_handle* h) {
   for (DevBuf& b : h->ws_ba) if (b.p) hipFree(b.p);
   for (auto& set : h->ws_pipe) for (DevBuf& b : set) if (b.p) hipFree(b.p);
   for (int i = 0; i < 2; ++i) { if (h->ev_in[i]) hipEventDestroy(h->ev_in[i]); if (h->ev_comp[i]) hipEventDestroy(h->ev_comp[i]); if (h->ev_out[i]) hipEventDestroy(h->ev_out[i]); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
+  if (h->s_aux) hipStreamDestroy(h->s_aux);
   if (h->s_in) hipStreamDestroy(h->s_in);
   if (h->s_out) hipStreamDestroy(h->s_out);
   for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
@@ -183,6 +187,7 @@ int orbx_get_kernel_times(orbx_handle* h, orbx_kernel_time* out, int cap) {
   if (!h) return ORBX_ERR_INVALID;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
+  if (h->s_aux) hipStreamSynchronize(h->s_aux);
   int n = 0;
   for (auto& t : h->timers) {
     if (t.ev.empty()) continue;

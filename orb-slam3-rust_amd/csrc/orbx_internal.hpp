@@ -90,6 +90,9 @@ struct orbx_handle {
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   DevBuf ws_pipe[2][8];
+  // second stream of the extractor: the blur runs beside the FAST -> Harris -> ordering chain (launch_orb_extract)
+  hipStream_t s_aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // BA
   orbx_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -115,7 +118,8 @@ int orbx_reserve(orbx_handle* h, DevBuf& b, size_t bytes);
 struct ProfScope {
   orbx_handle* h;
   int idx;
-  ProfScope(orbx_handle* h, const char* name);
+  hipStream_t stream;   // the stream the bracketed launches go to (default: the handle's)
+  ProfScope(orbx_handle* h, const char* name, hipStream_t stream = nullptr);
   ~ProfScope();
 };
 void orbx_prof_begin_call(orbx_handle* h);
