@@ -195,30 +195,45 @@ int orbx_png_decode_gray8(const uint8_t* file, size_t n, uint8_t* out, size_t st
   std::vector<uint8_t> raw((row + 1) * (size_t)h);
   uLongf got = (uLongf)raw.size();
   if (uncompress(raw.data(), &got, z.data(), (uLong)z.size()) != Z_OK || got != raw.size()) return ORBX_ERR_INVALID;
-  std::vector<uint8_t> prev(row, 0), cur(row);
+  // reconstruction (PNG spec 9.2).  8-bit grey without alpha is rebuilt straight in the caller's rows (the previous
+  // output row is the `prior` line); other layouts go through two scratch lines and keep the grey / high byte.
+  std::vector<uint8_t> zero(row, 0), line[2];
+  if (bpp != 1) { line[0].assign(row, 0); line[1].assign(row, 0); }
+  const uint8_t* prev = zero.data();
   for (uint32_t y = 0; y < h; ++y) {
     const uint8_t* src = raw.data() + (row + 1) * (size_t)y;
-    const int ft = src[0];
-    ++src;
+    const int ft = *src++;
+    uint8_t* cur = bpp == 1 ? out + stride * (size_t)y : line[y & 1].data();
+    const size_t B = (size_t)bpp;
     switch (ft) {
-      case 0: memcpy(cur.data(), src, row); break;
-      case 1: for (size_t i = 0; i < row; ++i) cur[i] = (uint8_t)(src[i] + (i >= (size_t)bpp ? cur[i - bpp] : 0)); break;
+      case 0: memcpy(cur, src, row); break;
+      case 1:
+        for (size_t i = 0; i < B; ++i) cur[i] = src[i];
+        for (size_t i = B; i < row; ++i) cur[i] = (uint8_t)(src[i] + cur[i - B]);
+        break;
       case 2: for (size_t i = 0; i < row; ++i) cur[i] = (uint8_t)(src[i] + prev[i]); break;
-      case 3: for (size_t i = 0; i < row; ++i) cur[i] = (uint8_t)(src[i] + (((i >= (size_t)bpp ? cur[i - bpp] : 0) + prev[i]) >> 1)); break;
-      case 4:
-        for (size_t i = 0; i < row; ++i) {
-          const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
-          const int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+      case 3:
+        for (size_t i = 0; i < B; ++i) cur[i] = (uint8_t)(src[i] + (prev[i] >> 1));
+        for (size_t i = B; i < row; ++i) cur[i] = (uint8_t)(src[i] + ((cur[i - B] + prev[i]) >> 1));
+        break;
+      case 4: {
+        for (size_t i = 0; i < B; ++i) cur[i] = (uint8_t)(src[i] + prev[i]);      // a = c = 0 -> predictor b
+        for (size_t i = B; i < row; ++i) {
+          const int a = cur[i - B], b = prev[i], c = prev[i - B];
+          const int pb0 = a - c, pa0 = b - c;                                      // p - b, p - a
+          const int pa = pa0 < 0 ? -pa0 : pa0, pb = pb0 < 0 ? -pb0 : pb0, pc0 = pa0 + pb0, pc = pc0 < 0 ? -pc0 : pc0;
           const int pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
           cur[i] = (uint8_t)(src[i] + pr);
         }
         break;
+      }
       default: return ORBX_ERR_INVALID;
     }
-    uint8_t* o = out + stride * (size_t)y;
-    if (bpp == 1) memcpy(o, cur.data(), w);
-    else for (uint32_t x = 0; x < w; ++x) o[x] = cur[(size_t)x * bpp];   // grey (high byte of 16 bit), alpha dropped
-    prev.swap(cur);
+    if (bpp != 1) {
+      uint8_t* o = out + stride * (size_t)y;
+      for (uint32_t x = 0; x < w; ++x) o[x] = cur[(size_t)x * bpp];   // grey (high byte of 16 bit), alpha dropped
+    }
+    prev = cur;
   }
   return ORBX_OK;
 }
