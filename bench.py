@@ -317,11 +317,37 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
     dt = time.perf_counter() - t0
     if world > 1:
         dt = P.dist.allreduce_max_seconds(dt, dev)
-    return dict(workload="synth_ba(seed=42, K=20, M=2000), %d observations%s" % (
-                    len(win["obs"]), ", points partitioned over %d ranks + RCCL all-reduce" % world if world > 1 else ""),
-                lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3),
-                iterations=r["iterations"], initial_error_px=round(r["initial_error"], 4),
-                final_error_px=round(r["final_error"], 4))
+    out = dict(workload="synth_ba(seed=42, K=20, M=2000), %d observations%s" % (
+                   len(win["obs"]), ", points partitioned over %d ranks + RCCL all-reduce" % world if world > 1 else ""),
+               lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3),
+               iterations=r["iterations"], initial_error_px=round(r["initial_error"], 4),
+               final_error_px=round(r["final_error"], 4))
+    if world == 1:
+        # SURVEY §8e "many BA windows, independent units": a single window is latency-bound (short dependent launches), so
+        # several windows solved at once — one handle (= one HIP stream + workspaces) per host thread — share the GPU
+        import threading
+        nwin = 8
+        hs = [P.Handle(cam, 100, device=dev.index if dev is not None else 0) for _ in range(nwin)]
+        wins = [P.synth.ba_window(100 + i, 20, 2000, P.BA_OBS) for i in range(nwin)]
+        counts = [0] * nwin
+
+        def work(i):
+            for _ in range(reps):
+                counts[i] += hs[i].ba_solve_visual(cam, cfg, wins[i]["poses_cw"], wins[i]["fixed_cw"], wins[i]["points"], wins[i]["obs"])["iterations"]
+
+        for i in range(nwin):
+            hs[i].ba_solve_visual(cam, cfg, wins[i]["poses_cw"], wins[i]["fixed_cw"], wins[i]["points"], wins[i]["obs"])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nwin)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dtc = time.perf_counter() - t0
+        for x in hs:
+            x.close()
+        out["concurrent_windows"] = dict(windows=nwin, lm_iters_per_s=round(sum(counts) / dtc, 2), note="8 independent windows, one handle and host thread each")
+    return out
 
 
 if __name__ == "__main__":

@@ -207,6 +207,14 @@ int orbx_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const 
                                   const double* pose1_wc, const double* pose2_wc, unsigned max_dist,
                                   int* out_pairs, int* n_out);
 
+/* Device-resident form: every array in device memory (keypoints and descriptors as the extractor left them), poses on the
+ * host; asynchronous on the handle's stream.  d_pairs [n1][2], d_n_out [1]. */
+int orbx_search_for_triangulation_device(orbx_handle* h, const orbx_camera* cam, const orbx_keypoint* d_kp1,
+                                         const uint8_t* d_desc1, const uint8_t* d_mp1, const uint8_t* d_stereo1, int n1,
+                                         const orbx_keypoint* d_kp2, const uint8_t* d_desc2, const uint8_t* d_mp2, int n2,
+                                         const double* pose1_wc, const double* pose2_wc, unsigned max_dist,
+                                         int* d_pairs, int* d_n_out);
+
 /* = search_for_triangulation_bow (src/local_mapping/triangulation.rs:541-658): as above, but the candidates of a
  * feature are the features of keyframe 2 in the same FeatureVector node instead of a grid neighbourhood.
  *   node1 [n1] / node2 [n2]: the FeatureVector key of each feature (the out_node of orbx_bow_transform), 0xffffffff
@@ -256,6 +264,13 @@ int orbx_bow_transform_device(orbx_handle* h, const orbx_vocabulary* v, const ui
 int orbx_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* positions, const uint8_t* mp_desc, int P,
                      const double* kf_poses_wc, const int* kf_feat_offset, const orbx_keypoint* kps, const uint8_t* descs,
                      int T, double radius_scale, unsigned desc_threshold, int* out_idx, uint32_t* out_dist);
+
+/* Device-resident form of orbx_fuse_search: positions, descriptors, keypoints, offsets and outputs in device memory, the
+ * keyframe poses on the host (they are inverted there); asynchronous on the handle's stream. */
+int orbx_fuse_search_device(orbx_handle* h, const orbx_camera* cam, const double* d_positions, const uint8_t* d_mp_desc, int P,
+                            const double* kf_poses_wc, const int* d_kf_feat_offset, const orbx_keypoint* d_kps,
+                            const uint8_t* d_descs, int T, double radius_scale, unsigned desc_threshold, int* d_out_idx,
+                            uint32_t* d_out_dist);
 
 /* ---- input side (src/io/euroc.rs) ------------------------------------------------------------------------------
  * Host code: the EuRoC `mav0` reader of EurocDataset::new / len / frame_timestamp / stereo_pair (:64-132,

@@ -51,7 +51,8 @@ ABI_SYMBOLS = [
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
     "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
-    "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_bow", "orbx_fuse_search",
+    "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
+    "orbx_fuse_search", "orbx_fuse_search_device",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
     "orbx_bow_transform", "orbx_bow_transform_device",
     "orbx_png_decode_gray8", "orbx_euroc_open", "orbx_euroc_close", "orbx_euroc_len", "orbx_euroc_last_error",
@@ -383,6 +384,35 @@ class Handle:
             self._h, C.byref(cam), _vp(kp1), _vp(desc1), _vp(mp1), _vp(stereo1), C.c_int(len(kp1)), _vp(kp2), _vp(desc2),
             _vp(mp2), C.c_int(len(kp2)), _vp(p1), _vp(p2), C.c_uint(max_dist), _vp(out), C.byref(n)))
         return out[:n.value].copy()
+
+    def search_for_triangulation_device(self, camera, kp1, desc1, mp1, stereo1, kp2, desc2, mp2, pose1_wc, pose2_wc, max_dist=50):
+        """Device-resident form: torch CUDA tensors (kp [n,7] f32 as the extractor writes them, desc [n,32] u8, flags [n] u8).
+        Returns (pairs [n1,2] int32 tensor, count [1] int32 tensor); asynchronous."""
+        import torch
+        n1, n2 = kp1.shape[0], kp2.shape[0]
+        pairs = torch.empty((max(n1, 1), 2), dtype=torch.int32, device=kp1.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=kp1.device)
+        p1 = np.ascontiguousarray(pose1_wc, np.float64); p2 = np.ascontiguousarray(pose2_wc, np.float64)
+        cam = camera._c()
+        self._after_torch(kp1, desc1, mp1, stereo1, kp2, desc2, mp2, pairs, cnt)
+        self._check(self._L.orbx_search_for_triangulation_device(
+            self._h, C.byref(cam), _vp(kp1), _vp(desc1), _vp(mp1), _vp(stereo1), C.c_int(n1), _vp(kp2), _vp(desc2), _vp(mp2), C.c_int(n2),
+            _vp(p1), _vp(p2), C.c_uint(max_dist), _vp(pairs), _vp(cnt)))
+        return pairs, cnt
+
+    def fuse_search_device(self, camera, positions, mp_desc, kf_poses_wc, kf_feat_offset, kps, descs, radius_scale, desc_threshold=TH_LOW):
+        """Device-resident form of fuse_search: torch CUDA tensors except the poses.  Returns (idx [P,T] int32, dist [P,T] int32 view of u32)."""
+        import torch
+        P_, T = positions.shape[0], len(kf_poses_wc)
+        idx = torch.empty((P_, T), dtype=torch.int32, device=positions.device)
+        dist = torch.empty((P_, T), dtype=torch.int32, device=positions.device)
+        poses = np.ascontiguousarray(kf_poses_wc, np.float64).reshape(-1, 7)
+        cam = camera._c()
+        self._after_torch(positions, mp_desc, kf_feat_offset, kps, descs, idx, dist)
+        self._check(self._L.orbx_fuse_search_device(self._h, C.byref(cam), _vp(positions), _vp(mp_desc), C.c_int(P_), _vp(poses),
+                                                    _vp(kf_feat_offset), _vp(kps), _vp(descs), C.c_int(T), C.c_double(radius_scale),
+                                                    C.c_uint(desc_threshold), _vp(idx), _vp(dist)))
+        return idx, dist
 
     def search_for_triangulation_bow(self, camera, kp1, desc1, mp1, stereo1, node1, kp2, desc2, mp2, node2, pose1_wc, pose2_wc,
                                      max_dist=50):

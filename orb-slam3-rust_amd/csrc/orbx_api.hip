@@ -458,6 +458,22 @@ int orbx_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const 
   return ORBX_OK;
 }
 
+int orbx_search_for_triangulation_device(orbx_handle* h, const orbx_camera* cam, const orbx_keypoint* d_kp1, const uint8_t* d_desc1,
+                                         const uint8_t* d_mp1, const uint8_t* d_stereo1, int n1, const orbx_keypoint* d_kp2,
+                                         const uint8_t* d_desc2, const uint8_t* d_mp2, int n2, const double* pose1_wc,
+                                         const double* pose2_wc, unsigned max_dist, int* d_pairs, int* d_n_out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || n1 < 0 || n2 < 0 || n2 > 65535 * 64 || !pose1_wc || !pose2_wc || !d_n_out || max_dist > 256 ||
+      (n1 > 0 && (!d_kp1 || !d_desc1 || !d_mp1 || !d_stereo1 || !d_pairs)) || (n2 > 0 && (!d_kp2 || !d_desc2 || !d_mp2)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_search_for_triangulation_device: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  double ep[2], F[9];
+  triangulation_geometry(*cam, pose1_wc, pose2_wc, ep, F);
+  orbx_prof_begin_call(h);
+  return launch_search_for_triangulation(h, cam, F, ep, d_kp1, d_desc1, d_mp1, d_stereo1, n1, d_kp2, d_desc2, d_mp2, n2, max_dist, d_pairs,
+                                         d_n_out);
+}
+
 int orbx_search_for_triangulation_bow(orbx_handle* h, const orbx_camera* cam, const orbx_keypoint* kp1, const uint8_t* desc1,
                                       const uint8_t* mp1, const uint8_t* stereo1, const uint32_t* node1, int n1,
                                       const orbx_keypoint* kp2, const uint8_t* desc2, const uint8_t* mp2, const uint32_t* node2, int n2,
@@ -514,6 +530,32 @@ int orbx_search_for_triangulation_bow(orbx_handle* h, const orbx_camera* cam, co
   ORBX_HIP(h, hipStreamSynchronize(h->stream));
   if (*n_out > 0) ORBX_HIP(h, hipMemcpy(out_pairs, d_pairs, sizeof(int) * 2 * (size_t)*n_out, hipMemcpyDeviceToHost));
   return ORBX_OK;
+}
+
+int orbx_fuse_search_device(orbx_handle* h, const orbx_camera* cam, const double* d_positions, const uint8_t* d_mp_desc, int P,
+                            const double* kf_poses_wc, const int* d_kf_feat_offset, const orbx_keypoint* d_kps, const uint8_t* d_descs, int T,
+                            double radius_scale, unsigned desc_threshold, int* d_out_idx, uint32_t* d_out_dist) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || P < 0 || T < 0 || (P > 0 && (!d_positions || !d_mp_desc)) || (T > 0 && (!kf_poses_wc || !d_kf_feat_offset)) ||
+      (P > 0 && T > 0 && (!d_out_idx || !d_out_dist || !d_kps || !d_descs)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_fuse_search_device: bad argument");
+  if (P == 0 || T == 0) return ORBX_OK;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  std::vector<double> cw(7 * (size_t)T);                                 // kf.pose.inverse() (se3.rs:56-63)
+  for (int t = 0; t < T; ++t) {
+    const double* p = kf_poses_wc + 7 * (size_t)t;
+    const Quat qi{p[0], -p[1], -p[2], -p[3]};
+    double r[3];
+    quat_rotate(qi, p + 4, r);
+    double* o = cw.data() + 7 * (size_t)t;
+    o[0] = qi.w; o[1] = qi.x; o[2] = qi.y; o[3] = qi.z; o[4] = -r[0]; o[5] = -r[1]; o[6] = -r[2];
+  }
+  if (int rc = orbx_reserve(h, h->ws_io[5], sizeof(double) * 7 * (size_t)T)) return rc;
+  ORBX_HIP(h, hipMemcpyAsync(h->ws_io[5].p, cw.data(), sizeof(double) * 7 * (size_t)T, hipMemcpyHostToDevice, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));   // cw is a local
+  orbx_prof_begin_call(h);
+  return launch_fuse_search(h, cam, d_positions, d_mp_desc, P, (const double*)h->ws_io[5].p, d_kf_feat_offset, d_kps, d_descs, T, radius_scale,
+                            desc_threshold, d_out_idx, d_out_dist);
 }
 
 int orbx_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* positions, const uint8_t* mp_desc, int P,

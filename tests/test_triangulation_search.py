@@ -186,3 +186,25 @@ def test_gpu_degenerate(handle):
     assert len(want) > 50
     with pytest.raises(P.OrbxError):
         _gpu(handle, s, max_dist=300)
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_forms(handle):
+    """orbx_search_for_triangulation_device / orbx_fuse_search_device: inputs and outputs stay in device memory."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = _scene(11, 2500, dup=0.4)
+    kpt = lambda kp: torch.from_numpy(kp.view(np.float32).reshape(-1, 7).copy()).to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    pairs, cnt = handle.search_for_triangulation_device(P.CameraModel(**s["camera"]), kpt(s["kp1"]), t(s["desc1"]), t(s["mp1"]), t(s["stereo1"]),
+                                                        kpt(s["kp2"]), t(s["desc2"]), t(s["mp2"]), s["pose1_wc"], s["pose2_wc"])
+    handle.synchronize()
+    n = int(cnt.item())
+    assert np.array_equal(pairs[:n].cpu().numpy(), _oracle(s))
+    f = P.synth.fuse_scene(12, 1500, 8, 900, O.KEYPOINT)
+    scale = 3.0 * (1.2 * (1.2 * 1.2) * ((1.2 * 1.2) * (1.2 * 1.2)))
+    idx, dist = handle.fuse_search_device(P.CameraModel(**f["camera"]), t(f["positions"]), t(f["mp_desc"]), f["kf_poses_wc"], t(f["kf_feat_offset"]),
+                                          kpt(f["kps"]), t(f["descs"]), scale)
+    handle.synchronize()
+    i0, d0 = O.fuse_search(O.Camera(**f["camera"]), f["positions"], f["mp_desc"], f["kf_poses_wc"], f["kf_feat_offset"], f["kps"], f["descs"], scale)
+    assert np.array_equal(idx.cpu().numpy(), i0) and np.array_equal(dist.cpu().numpy().view(np.uint32), d0)
