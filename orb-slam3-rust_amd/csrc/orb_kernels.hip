@@ -382,11 +382,20 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   const int x0 = EDGE + tx * FT_W, y0 = EDGE + ty * FT_H;   // first inner pixel; score position (i,j) = pixel (x0-1+i, y0-1+j)
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) { s_npos = 0; s_cnt = 0; s_ncor = 0; }
-  // pixel tile: LDS row r = image row y0-4+r, byte b = image column x0-5+b
-  for (int i = tid; i < FP_ROWS * (FP_PITCH / 4); i += 256) {
-    const int r = i / (FP_PITCH / 4), c = i - r * (FP_PITCH / 4);
-    const int gy = min(y0 - 4 + r, h - 1), gx = min(x0 - 5 + 4 * c, pitch - 4);
-    reinterpret_cast<unsigned*>(&sp[r][0])[c] = ld_u32(src + (size_t)gy * pitch + gx);
+  // pixel tile: LDS row r = image row y0-4+r, byte b = image column x0-5+b.  9 lanes x 8 bytes per 72-byte row, 28 rows
+  // per pass (the division by 9 is of tid, once)
+  {
+    const int r0 = tid / 9, c = tid - 9 * r0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int r = r0 + 28 * k;
+      if (r0 < 28 && r < FP_ROWS) {
+        const int gy = min(y0 - 4 + r, h - 1), gx = min(x0 - 5 + 8 * c, pitch - 8);
+        unsigned long long v;
+        __builtin_memcpy(&v, src + (size_t)gy * pitch + gx, 8);
+        *reinterpret_cast<unsigned long long*>(&sp[r][8 * c]) = v;
+      }
+    }
   }
   for (int i = tid; i < FS_W * FS_H / 4; i += 256) reinterpret_cast<unsigned*>(&ss[0][0])[i] = 0u;
   __syncthreads();
