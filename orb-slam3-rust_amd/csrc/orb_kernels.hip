@@ -175,7 +175,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // No LDS: a wave owns a 256-px-wide column strip (lane = 4 consecutive pixels = one dword) and walks
 // down BLUR_STRIP rows.  Per input row: one coalesced 256-B dword load per wave, neighbour dwords by
 // DPP wave shifts (+2 edge lanes loading), horizontal taps with v_alignbyte + v_dot4_u32_u8 (8.8 sums),
-// a 7-row ring of those sums in registers, vertical taps as 32-bit mads (16.16), one dword store.
+// a ring of row PAIRS of those sums in registers, vertical taps by v_dot2_u32_u16 (16.16), one dword store.
 // Lanes whose 10-px window crosses the image edge rebuild their three dwords bytewise with
 // BORDER_REFLECT_101 (a few lanes per row).
 constexpr int BLUR_W = 248, BLUR_STRIP = 64, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo
@@ -241,29 +241,46 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
   const int last = nrows + 5;
   auto rowp = [&](int q) { return src + (size_t)reflect101_once(ys - 3 + min(q, last), h) * pitch; };
   unsigned p0 = *reinterpret_cast<const unsigned*>(rowp(0) + xl), p1 = *reinterpret_cast<const unsigned*>(rowp(1) + xl);
-  unsigned ring[7][4];
+  // Vertical taps on PAIRS of rows: the 8.8 horizontal sums fit 16 bits, so two consecutive rows of one pixel share a
+  // register and v_dot2_u32_u16 applies two taps at once: out(y) = (w0,w1).(18,34) + (w2,w3).(48,56) + (w4,w5).(48,34)
+  // + 18 w6 — three dot2 and one mad instead of three adds and four multiplies.  pr[q % 6] = rows (q, q+1).
+  typedef unsigned short blur_us2 __attribute__((ext_vector_type(2)));
+  unsigned pr[6][4], hprev[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const unsigned cur = p0;
     p0 = p1;
     p1 = *reinterpret_cast<const unsigned*>(rowp(i + 2) + xl);
-    blur_row(rowp(i), cur, slow, col, ring[i]);
-  }
-  for (int y0 = 0; y0 < nrows; y0 += 7) {
+    unsigned hs[4];
+    blur_row(rowp(i), cur, slow, col, hs);
+    if (i > 0) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+      for (int k = 0; k < 4; ++k) pr[i - 1][k] = hprev[k] | (hs[k] << 16);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hprev[k] = hs[k];
+  }
+  const blur_us2 T0 = {18, 34}, T1 = {48, 56}, T2 = {48, 34};
+  for (int y0 = 0; y0 < nrows; y0 += 6) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
       const int y = y0 + i;
       if (y < nrows) {   // wave-uniform
-        // ring slot (i+6)%7 receives input row q = y+6 (image row ys+y+3); slots (i..i+6)%7 hold rows y-3..y+3
+        // input row q = y+6 (image row ys+y+3) arrives; window rows are q = y .. y+6
         const unsigned cur = p0;
         p0 = p1;
         p1 = *reinterpret_cast<const unsigned*>(rowp(y + 8) + xl);
-        blur_row(rowp(y + 6), cur, slow, col, ring[(i + 6) % 7]);
+        unsigned hs[4];
+        blur_row(rowp(y + 6), cur, slow, col, hs);
         unsigned packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const unsigned v = 18u * (ring[i % 7][k] + ring[(i + 6) % 7][k]) + 34u * (ring[(i + 1) % 7][k] + ring[(i + 5) % 7][k]) +
-                             48u * (ring[(i + 2) % 7][k] + ring[(i + 4) % 7][k]) + 56u * ring[(i + 3) % 7][k];
+          pr[(i + 5) % 6][k] = hprev[k] | (hs[k] << 16);      // rows (y+5, y+6)
+          hprev[k] = hs[k];
+          unsigned v = 18u * hs[k];
+          v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[i % 6][k]), T0, v, false);
+          v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 2) % 6][k]), T1, v, false);
+          v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 4) % 6][k]), T2, v, false);
           packed |= ((v + 32768u) >> 16) << (8 * k);
         }
         if (active) *reinterpret_cast<unsigned*>(dst + (size_t)(ys + y) * dpitch + x0) = packed;
