@@ -147,8 +147,7 @@ def main():
     acc = {k: [v[0], v[1]] for k, v in h.kernel_times().items()}   # durations over the timed region
     h.set_profiling(False)
     h.check_status()
-    # the same K steps once more without the per-kernel HIP events (the library then also runs the blur beside the
-    # FAST chain on a second stream): reported as value_unprofiled, never as value
+    # the same K steps once more without the per-kernel HIP events: reported as value_unprofiled, never as value
     barrier(); torch.cuda.synchronize(); h.synchronize()
     t1 = time.perf_counter()
     for i in range(args.steps):

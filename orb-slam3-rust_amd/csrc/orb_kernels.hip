@@ -1128,10 +1128,11 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
       }
     }
     // blur (latency-bound, ~50 % VALU-busy) and the FAST -> Harris -> ordering chain (issue-bound) both depend only on the
-    // pyramid and meet again at describe: the blur runs beside the chain on a second stream (+2-3 % frames/s).  Not while
-    // per-kernel profiling is on: two kernels sharing the chip stretch each other's duration, which would make the
-    // per-kernel times (and the roofline figure bench.py derives from them) describe the overlap instead of the kernel.
-    const bool fork = n >= 16 && !h->profiling && !getenv("ORBX_NO_FORK");
+    // pyramid and meet again at describe: with ORBX_FORK_BLUR=1 in the environment the blur runs beside the chain on a
+    // second stream (+2-3 % frames/s).  Off by default and never while per-kernel profiling is on: two kernels sharing the
+    // chip stretch each other's duration, so per-kernel times (HIP events, rocprof) would describe the overlap instead of
+    // the kernels and no longer agree between runs.
+    const bool fork = n >= 16 && !h->profiling && getenv("ORBX_FORK_BLUR") != nullptr;
     if (fork && !h->s_aux) {
       ORBX_HIP(h, hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
       ORBX_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
