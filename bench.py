@@ -83,13 +83,14 @@ def cpu_baseline(P, frames_mt, frames_1t, w, h, n_features):
     except Exception:
         pass
     t0 = time.perf_counter()
+    passes = 3                                 # ~15 s of CPU work in total at 752x480 (bounded sample)
     with ThreadPoolExecutor(cores) as ex:      # ctypes releases the GIL inside the oracle
-        list(ex.map(one, range(frames_mt)))
+        list(ex.map(one, [b % frames_mt for b in range(passes * frames_mt)]))
     tm = time.perf_counter() - t0
-    return dict(value=round(frames_mt / tm, 3), unit="stereo frames/s", cores=cores, kind="port",
-                sample="%d synthetic %dx%d stereo frames, N=%d, oracle extract+match+triangulate (g++ %s), %d threads "
+    return dict(value=round(passes * frames_mt / tm, 3), unit="stereo frames/s", cores=cores, kind="port",
+                sample="%d synthetic %dx%d stereo frames x %d passes, N=%d, oracle extract+match+triangulate (g++ %s), %d threads "
                        "(frame-level parallelism); 1 thread: %.3f frames/s on %d frames"
-                       % (frames_mt, w, h, n_features, flags, cores, frames_1t / t1, frames_1t),
+                       % (frames_mt, w, h, passes, n_features, flags, cores, frames_1t / t1, frames_1t),
                 value_1thread=round(frames_1t / t1, 3))
 
 
@@ -221,7 +222,7 @@ def main():
             res["from_png_files"] = dict(error=repr(e))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         big = W * H > 752 * 480
-        res["cpu_baseline"] = cpu_baseline(P, 16 if big else 48, 2 if big else 6, W, H, args.features)
+        res["cpu_baseline"] = cpu_baseline(P, 16 if big else 48, 2 if big else 12, W, H, args.features)
     elif rank == 0:
         res["cpu_baseline"] = None
     if rank == 0:
