@@ -92,20 +92,14 @@ __device__ __forceinline__ void dev_q_mul(const double* a, const double* b, doub
   o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
 }
 
-__global__ void ba_pose_kernel(BaState* S, double* P0, double* P1, int which /*0 cur, 1 trial*/, int iter, int K,
-                               double* __restrict__ Rt, int inertial) {
-  if (S->done) return;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k == 0 && which == 0 && iter >= 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
-  if (k >= K) return;
-  const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
-  const double* p = params + 6 * (size_t)k;
-  if (inertial) {   // extract_pose(..).inverse() (local_inertial_ba.rs:584-591, :634; se3.rs:56-63)
+// pose parameters -> R|t of T_cw (12 doubles).  Visual solvers: se3_from_params (local_ba_lm.rs:648-662) of T_cw parameters;
+// inertial: extract_pose(..).inverse() of T_wc parameters (local_inertial_ba.rs:584-591, :634; se3.rs:56-63)
+__device__ __forceinline__ void pose_to_Rt(const double* p, int inertial, double* o) {
+  if (inertial) {
     double qwc[4], rt[3];
     dev_q_from_scaled_axis(p, qwc);
     const double qcw[4] = {qwc[0], -qwc[1], -qwc[2], -qwc[3]};
     dev_q_rot(qcw, p + 3, rt);
-    double* o = Rt + 12 * (size_t)k;
     quat_to_R(qcw, o);
     o[9] = -rt[0]; o[10] = -rt[1]; o[11] = -rt[2];
     return;
@@ -121,9 +115,23 @@ __global__ void ba_pose_kernel(BaState* S, double* P0, double* P1, int which /*0
   } else {
     q[0] = 1; q[1] = q[2] = q[3] = 0;
   }
-  double* o = Rt + 12 * (size_t)k;
   quat_to_R(q, o);
   o[9] = p[3]; o[10] = p[4]; o[11] = p[5];
+}
+constexpr int BA_MAX_K = 128;   // keyframes whose R|t a block keeps in LDS (= BA_MAX_N / 6)
+
+// Every block of the build / chi2 kernels derives the K rotations it needs itself (K <= 128 sin/cos pairs, a few
+// hundred instructions) instead of reading them from a separate pose kernel: one launch less on a loop whose
+// iterations are a chain of ~6 us launches.
+__device__ __forceinline__ void block_poses(const double* params, int K, int inertial, double* sRt) {
+  for (int k = threadIdx.x; k < K; k += blockDim.x) pose_to_Rt(params + 6 * (size_t)k, inertial, sRt + 12 * k);
+  __syncthreads();
+}
+
+// iteration counter only (windows without points never launch the build kernel)
+__global__ void ba_iter_kernel(BaState* S, int iter) {
+  if (S->done) return;
+  S->iters = iter + 1;                                                  // local_ba_lm.rs:1017
 }
 
 struct ObsOut { double r0, r1, A[12], B[6]; };
@@ -202,16 +210,19 @@ __device__ __forceinline__ double group_sum32(double v) {
 }
 
 // One 32-lane group per point (2 points per wave).  Observations are stored point-major (CSR).
-__global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, const BaState* S, double* P0, double* P1,
-    const double* __restrict__ Rt_opt, const double* __restrict__ Rt_fix,
+__global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, BaState* S, double* P0, double* P1, int iter,
+    const double* __restrict__ Rt_fix,
     const int* __restrict__ pt_start, const int* __restrict__ o_kf, const int* __restrict__ o_fix,
     const double* __restrict__ o_uv, double* __restrict__ oA /*N*12*/, double* __restrict__ oR /*N*2*/,
     double* __restrict__ oYg /*N*6*/, double* __restrict__ Vinv /*M*9*/, double* __restrict__ gl /*M*3*/,
     double* __restrict__ pt_chi2 /*M*/, double* __restrict__ pt_glsq /*M*/, double* __restrict__ WT,
     double* __restrict__ YT) {
+  __shared__ double sRt[12 * BA_MAX_K];
   if (S->done) return;
   const double lambda = S->lambda;
   const double* params = ba_cur(S, P0, P1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
+  block_poses(params, d.K, cam.inertial, sRt);
   const int lane32 = threadIdx.x & 31;
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   if (j >= d.M) return;   // whole 32-lane group leaves together
@@ -222,7 +233,14 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, cons
   // pass 1: residual + Jacobian, accumulate V, g_l (lane-strided, then a fixed shuffle tree)
   for (int i = s + lane32; i < e; i += 32) {
     const int k = o_kf[i];
-    const double* Rt = k >= 0 ? Rt_opt + 12 * (size_t)k : Rt_fix + 12 * (size_t)o_fix[i];
+    double Rt[12];
+    if (k >= 0) {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Rt[a] = sRt[12 * k + a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
+    }
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
     chi += o.r0 * o.r0 + o.r1 * o.r1;
@@ -265,7 +283,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, cons
   for (int i = s + lane32; i < e; i += 32) {
     const int k = o_kf[i];
     if (k < 0) continue;
-    const double* Rt = Rt_opt + 12 * (size_t)k;
+    const double* Rt = sRt + 12 * k;
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
     double yg[6];
@@ -949,12 +967,14 @@ __global__ void ba_diff_kernel(size_t n, const double* __restrict__ a, const dou
 
 // chi2 of a parameter vector: per-point partial sums (fixed order)
 __global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const BaState* S, double* P0, double* P1, int which,
-                                                      const double* __restrict__ Rt_opt, const double* __restrict__ Rt_fix,
+                                                      const double* __restrict__ Rt_fix,
                                                       const int* __restrict__ pt_start, const int* __restrict__ o_kf,
                                                       const int* __restrict__ o_fix, const double* __restrict__ o_uv,
                                                       double* __restrict__ pt_chi2) {
+  __shared__ double sRt[12 * BA_MAX_K];
   if (S->done) return;
   const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
+  block_poses(params, d.K, cam.inertial, sRt);
   // one 32-lane group per point (as ba_build_kernel): 2000 points alone would fill 8 blocks
   const int lane32 = threadIdx.x & 31;
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -964,7 +984,14 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const
   double chi = 0.0;
   for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) {
     const int k = o_kf[i];
-    const double* Rt = k >= 0 ? Rt_opt + 12 * (size_t)k : Rt_fix + 12 * (size_t)o_fix[i];
+    double Rt[12];
+    if (k >= 0) {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Rt[a] = sRt[12 * k + a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
+    }
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
     chi += o.r0 * o.r0 + o.r1 * o.r1;
@@ -1390,7 +1417,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   double* res = D(B_RES);
   double hres[16];
 
-  if (n > BA_MAX_N) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d optimised keyframes per window", BA_MAX_N / 6);
+  if (n > BA_MAX_N || K > BA_MAX_K) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d optimised keyframes per window", BA_MAX_N / 6);
   const size_t lds_need = 8 * ((size_t)n * n + BA_SOLVE_THREADS);
   const bool use_lds = lds_need + 8 * (2 * BA_MAX_N + BA_SOLVE_THREADS) + 64 <= 160 * 1024;
   if (use_lds && n > 0)
@@ -1415,8 +1442,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     return ORBX_OK;
   };
   auto chi2_of = [&](int which, int iter, double* out_sum3, const double* b2, const double* c2) {
-    if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, which, iter, K, D(B_RTOPT), inertial ? 1 : 0);
-    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTOPT), D(B_RTFIX),
+    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTFIX),
                                   I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
     hipLaunchKernelGGL(ba_sum3_kernel, dim3(1), dim3(256), 0, st, S, M, pt_chi2, b2, c2, out_sum3);
     if (inertial && inr->E > 0) {                                        // + IMU and bias-random-walk residuals (:661-698)
@@ -1446,15 +1472,11 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   for (int iter = 0; iter < cfg->max_iterations; ++iter) {           // :1012
     if (should_stop && should_stop(user)) break;                     // :1013
     {
-      ProfScope ps(h, "ba_pose_kernel");
-      if (K > 0) hipLaunchKernelGGL(ba_pose_kernel, dim3((K + 63) / 64), dim3(64), 0, st, S, P0, P1, 0, iter, K, D(B_RTOPT), inertial ? 1 : 0);
-      else hipLaunchKernelGGL(ba_pose_kernel, dim3(1), dim3(64), 0, st, S, P0, P1, 0, iter, 0, D(B_RTOPT), 0);   // iteration counter
-    }
-    {
       ProfScope ps(h, "ba_build_kernel");
-      if (M > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, D(B_RTOPT),
+      if (M > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, iter,
                                     D(B_RTFIX), I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), D(B_OA), D(B_OR), D(B_OYG),
                                     D(B_VINV), D(B_GL), pt_chi2, pt_glsq, D(B_WT), D(B_YT));
+      else hipLaunchKernelGGL(ba_iter_kernel, dim3(1), dim3(1), 0, st, S, iter);
     }
     {
       ProfScope ps(h, "ba_kf_kernel");
