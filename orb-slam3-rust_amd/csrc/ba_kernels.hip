@@ -308,12 +308,11 @@ __global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, BaSt
 constexpr int BA_KFSPLIT = 8;
 // BA_KFSPLIT blocks per optimised keyframe: partial U_k (21 unique), g_p (6), b_red (6) over a slice of its
 // observations; the gather kernel adds the partials in a fixed order.
-__global__ __launch_bounds__(256) void ba_kf_kernel(BaDims d, const BaState* S, const int* __restrict__ kf_start, const int* __restrict__ kf_obs,
-                                                    const double* __restrict__ oA, const double* __restrict__ oR,
-                                                    const double* __restrict__ oYg, double* __restrict__ kfpart /*[K][BA_KFSPLIT][33]*/) {
+__device__ __forceinline__ void ba_kf_body(int bx, const BaDims& d, const int* __restrict__ kf_start, const int* __restrict__ kf_obs,
+                                           const double* __restrict__ oA, const double* __restrict__ oR,
+                                           const double* __restrict__ oYg, double* __restrict__ kfpart /*[K][BA_KFSPLIT][33]*/) {
   __shared__ double red[4][33];
-  if (S->done) return;
-  const int k = blockIdx.x / BA_KFSPLIT, sp = blockIdx.x % BA_KFSPLIT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = bx / BA_KFSPLIT, sp = bx % BA_KFSPLIT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s0 = kf_start[k], len = kf_start[k + 1] - s0;
   const int s = s0 + (int)((long long)len * sp / BA_KFSPLIT), e = s0 + (int)((long long)len * (sp + 1) / BA_KFSPLIT);
   double acc[33];   // 21 unique U entries, 6 g_p, 6 b_red
@@ -348,11 +347,10 @@ __global__ __launch_bounds__(256) void ba_kf_kernel(BaDims d, const BaState* S, 
 
 // S_red partials: one wave per (upper tile, k-split).  A[i][k] = YT[k][i0+i], B[k][j] = WT[k][j0+j].
 // v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4], B[l>>4][l&15]; D[(l>>4)+4r][l&15], r = 0..3.
-__global__ __launch_bounds__(256) void ba_schur_kernel(BaDims d, const BaState* S, const double* __restrict__ YT,
-                                                       const double* __restrict__ WT, double* __restrict__ part) {
-  if (S->done) return;
+__device__ __forceinline__ void ba_schur_body(int bx, const BaDims& d, const double* __restrict__ YT, const double* __restrict__ WT,
+                                              double* __restrict__ part) {
   const int lane = threadIdx.x & 63;
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int unit = bx * 4 + (threadIdx.x >> 6);
   const int n_upper = d.ntile * (d.ntile + 1) / 2;
   if (unit >= n_upper * d.ksplit) return;
   const int tile = unit / d.ksplit, ks = unit - tile * d.ksplit;
@@ -383,6 +381,18 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(BaDims d, const BaState* 
   double* o = part + ((size_t)tile * d.ksplit + ks) * 256;
 #pragma unroll
   for (int r = 0; r < 4; ++r) o[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+}
+
+// Both consume the build kernel's output and feed the gather kernel, neither fills the chip (K*8 blocks, and one wave
+// per tile x k-split): one launch, the first nkf blocks take the keyframe partials, the rest the Schur tiles.
+__global__ __launch_bounds__(256) void ba_kf_schur_kernel(BaDims d, const BaState* S, int nkf, const int* __restrict__ kf_start,
+                                                          const int* __restrict__ kf_obs, const double* __restrict__ oA,
+                                                          const double* __restrict__ oR, const double* __restrict__ oYg,
+                                                          double* __restrict__ kfpart, const double* __restrict__ YT,
+                                                          const double* __restrict__ WT, double* __restrict__ part) {
+  if (S->done) return;
+  if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, d, kf_start, kf_obs, oA, oR, oYg, kfpart);
+  else ba_schur_body((int)blockIdx.x - nkf, d, YT, WT, part);
 }
 
 // reduce-buffer layout (doubles): [Sred n*n | U 36K | gp n | bred n | chi2 | glsq], n = 6K
@@ -912,17 +922,28 @@ __global__ __launch_bounds__(256) void ba_big_subst_kernel(int n, const BaState*
 
 // delta_l = V*^-1 (-g_l - sum_k W_kj^T delta_p_k); trial = params + delta; per-point |delta_l|^2, |p_l|^2.
 // One 32-lane group per point: lanes take the point's observations, fixed shuffle tree for the three sums.
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims d, const BaState* S, double* P0, double* P1, const double* __restrict__ dp,
-                                                         const int* __restrict__ pt_start, const int* __restrict__ o_kf,
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims d, BaCam cam, const BaState* S, double* P0, double* P1,
+                                                         const double* __restrict__ dp, const int* __restrict__ pt_start,
+                                                         const int* __restrict__ o_kf, const int* __restrict__ o_fix,
+                                                         const double* __restrict__ o_uv, const double* __restrict__ Rt_fix,
                                                          const double* __restrict__ WT, const double* __restrict__ Vinv,
-                                                         const double* __restrict__ gl,
-                                                         double* __restrict__ pt_dsq, double* __restrict__ pt_psq,
-                                                         int owned_only) {
+                                                         const double* __restrict__ gl, double* __restrict__ pt_dsq,
+                                                         double* __restrict__ pt_psq, double* __restrict__ pt_chi2, int owned_only) {
+  // + the trial residuals of the point (local_ba_lm.rs:1047-1048): the group that back-substitutes a point already holds
+  // its trial position, and the trial rotations follow from the pose step alone, so chi2(trial) needs no launch of its own
+  __shared__ double sRt[12 * BA_MAX_K];
   if (S->done) return;
   const double* params = ba_cur(S, P0, P1);
   double* trial = ba_trial(S, P0, P1);
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gtid < 6 * d.K) trial[gtid] = params[gtid] + dp[gtid];
+  for (int k = threadIdx.x; k < d.K; k += blockDim.x) {
+    double p6[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) p6[a] = params[6 * (size_t)k + a] + dp[6 * (size_t)k + a];   // = the trial pose written above
+    pose_to_Rt(p6, cam.inertial, sRt + 12 * k);
+  }
+  __syncthreads();
   const int lane32 = threadIdx.x & 31;
   const int j = gtid >> 5;
   if (j >= d.M) return;     // whole 32-lane group
@@ -944,20 +965,39 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims d, const BaState
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) acc[c] = group_sum32(acc[c]);
-  if (lane32 != 0) return;
+  // every lane of the group forms the trial position (same arithmetic, same value); lane 0 stores it
   const double rhs[3] = {-gl[3 * (size_t)j] - acc[0], -gl[3 * (size_t)j + 1] - acc[1], -gl[3 * (size_t)j + 2] - acc[2]};
   const double* I = Vinv + 9 * (size_t)j;
-  double dsq = 0.0, psq = 0.0;
+  double X[3], dsq = 0.0, psq = 0.0;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const double dl = I[a * 3] * rhs[0] + I[a * 3 + 1] * rhs[1] + I[a * 3 + 2] * rhs[2];
     const double p = params[6 * (size_t)d.K + 3 * (size_t)j + a];
-    trial[6 * (size_t)d.K + 3 * (size_t)j + a] = p + dl;
+    X[a] = p + dl;
     dsq += dl * dl; psq += p * p;
   }
+  double chi = 0.0;
+  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) {
+    const int k = o_kf[i];
+    double Rt[12];
+    if (k >= 0) {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Rt[a] = sRt[12 * k + a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
+    }
+    ObsOut o;
+    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
+    chi += o.r0 * o.r0 + o.r1 * o.r1;
+  }
+  chi = group_sum32(chi);
+  if (lane32 != 0) return;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) trial[6 * (size_t)d.K + 3 * (size_t)j + a] = X[a];
   // partitioned over ranks: a point's |p|^2 is counted by the rank that holds its observations
   if (owned_only && pt_start[j + 1] == pt_start[j]) psq = 0.0;
-  pt_dsq[j] = dsq; pt_psq[j] = psq;
+  pt_dsq[j] = dsq; pt_psq[j] = psq; pt_chi2[j] = chi;
 }
 
 // out[i] = a[i] - b[i]  /  a[i] += b[i]   (merging point updates across ranks)
@@ -1020,8 +1060,35 @@ __global__ __launch_bounds__(256) void ba_sum3_kernel(const BaState* S, int M, c
 
 // The tail of one LM iteration, local_ba_lm.rs:1022-1055, on the device.  res: [0] chi2(cur) [1] |g| [2] chol ok
 // [3] |dp|^2 [4] |p_pose|^2 [5] chi2(trial) [6] |dl|^2 [7] |p_points|^2.
-__global__ void ba_decide_kernel(BaState* S, const double* __restrict__ res) {
+// With M >= 0 the kernel first forms res[5..7] itself — the fixed-order sums of the per-point chi2(trial), |delta_l|^2 and
+// |p_l|^2 the back-substitution left (what ba_sum3_kernel does), plus the IMU / random-walk chi2 of the trial state — so
+// that the single-GPU loop ends in one launch; M < 0: res[5..7] were reduced (and all-reduced) by the caller.
+__global__ __launch_bounds__(256) void ba_decide_kernel(BaState* S, double* __restrict__ res, int M, const double* __restrict__ pt_chi2,
+                                                        const double* __restrict__ pt_dsq, const double* __restrict__ pt_psq,
+                                                        const double* __restrict__ imu_buf, int E) {
+  __shared__ double sh[3][256];
   if (S->done) return;
+  const int tid = threadIdx.x;
+  if (M >= 0) {
+    double x = 0.0, y = 0.0, z = 0.0;
+    for (int j = tid; j < M; j += 256) { x += pt_chi2[j]; y += pt_dsq[j]; z += pt_psq[j]; }
+    sh[0][tid] = x; sh[1][tid] = y; sh[2][tid] = z;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+      if (tid < s2) { sh[0][tid] += sh[0][tid + s2]; sh[1][tid] += sh[1][tid + s2]; sh[2][tid] += sh[2][tid + s2]; }
+      __syncthreads();
+    }
+  }
+  if (tid != 0) return;
+  if (M >= 0) {
+    double c = sh[0][0];
+    if (E > 0) {
+      double ci = 0.0;
+      for (int e = 0; e < E; ++e) ci += imu_buf[(size_t)e * (18 * 18 + 18 + 2) + 18 * 18 + 18];
+      c += ci;
+    }
+    res[5] = c; res[6] = sh[1][0]; res[7] = sh[2][0];
+  }
   const double cur_sq = res[0];
   S->cur_sq = cur_sq;
   S->final_sq = cur_sq;
@@ -1441,14 +1508,17 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     if (h->allreduce(h->allreduce_user, dptr, cnt, (void*)st) != 0) return orbx_fail(h, ORBX_ERR_HIP, "all-reduce hook failed");
     return ORBX_OK;
   };
-  auto chi2_of = [&](int which, int iter, double* out_sum3, const double* b2, const double* c2) {
-    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTFIX),
-                                  I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
+  auto chi2_sum = [&](int which, double* out_sum3, const double* b2, const double* c2) {
     hipLaunchKernelGGL(ba_sum3_kernel, dim3(1), dim3(256), 0, st, S, M, pt_chi2, b2, c2, out_sum3);
     if (inertial && inr->E > 0) {                                        // + IMU and bias-random-walk residuals (:661-698)
       hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, S, P0, P1, which, 0, ind, imu_buf);
       hipLaunchKernelGGL(ba_imu_addchi_kernel, dim3(1), dim3(1), 0, st, S, inr->E, imu_buf, out_sum3, 0);
     }
+  };
+  auto chi2_of = [&](int which, double* out_sum3, const double* b2, const double* c2) {
+    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTFIX),
+                                  I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
+    chi2_sum(which, out_sum3, b2, c2);
   };
   // total residual count over all ranks (for the RMS error): all-reduce one double when partitioned
   double n_res = 2.0 * (double)N;
@@ -1464,7 +1534,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
   // initial error (:1000-1001) -> res[12]
   {
     ProfScope ps(h, "ba_chi2");
-    chi2_of(0, -1, res + 12, nullptr, nullptr);
+    chi2_of(0, res + 12, nullptr, nullptr);
   }
   if (int rc = allreduce(res + 12, 1)) return rc;
 
@@ -1478,14 +1548,11 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
                                     D(B_VINV), D(B_GL), pt_chi2, pt_glsq, D(B_WT), D(B_YT));
       else hipLaunchKernelGGL(ba_iter_kernel, dim3(1), dim3(1), 0, st, S, iter);
     }
-    {
-      ProfScope ps(h, "ba_kf_kernel");
-      if (K > 0) hipLaunchKernelGGL(ba_kf_kernel, dim3(K * BA_KFSPLIT), dim3(256), 0, st, d, S, I(B_KFSTART), I(B_KFOBS), D(B_OA), D(B_OR), D(B_OYG), kfpart);
-    }
     if (K > 0) {
-      ProfScope ps(h, "ba_schur_kernel");
-      const int units = (int)n_upper * d.ksplit;
-      hipLaunchKernelGGL(ba_schur_kernel, dim3((units + 3) / 4), dim3(256), 0, st, d, S, D(B_YT), D(B_WT), D(B_PART));
+      ProfScope ps(h, "ba_kf_schur_kernel");
+      const int units = (int)n_upper * d.ksplit, nkf = K * BA_KFSPLIT;
+      hipLaunchKernelGGL(ba_kf_schur_kernel, dim3(nkf + (units + 3) / 4), dim3(256), 0, st, d, S, nkf, I(B_KFSTART), I(B_KFOBS), D(B_OA),
+                         D(B_OR), D(B_OYG), kfpart, D(B_YT), D(B_WT), D(B_PART));
     }
     {
       ProfScope ps(h, "ba_gather_kernel");
@@ -1537,18 +1604,25 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     {
       ProfScope ps(h, "ba_backsub_kernel");
       const int cnt = std::max(32 * M, n);
-      hipLaunchKernelGGL(ba_backsub_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, d, S, P0, P1, D(B_SOLVE), I(B_PTSTART), I(B_OKF), D(B_WT),
-                         D(B_VINV), D(B_GL), pt_dsq, pt_psq, dist ? 1 : 0);
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, D(B_SOLVE), I(B_PTSTART), I(B_OKF),
+                         I(B_OFIX), D(B_OUV), D(B_RTFIX), D(B_WT), D(B_VINV), D(B_GL), pt_dsq, pt_psq, pt_chi2, dist ? 1 : 0);
     }
-    {
-      ProfScope ps(h, "ba_chi2");
-      // trial residuals (:1047-1048): res[5] = chi2(trial), res[6] = |delta_l|^2, res[7] = |p_l|^2
-      chi2_of(1, -1, res + 5, pt_dsq, pt_psq);
-    }
-    if (int rc = allreduce(res + 5, 3)) return rc;
-    {
+    // trial residuals (:1047-1048): res[5] = chi2(trial), res[6] = |delta_l|^2, res[7] = |p_l|^2 from the per-point parts the
+    // back-substitution kernel left; then the accept / reject / stop decision (:1041-1055)
+    if (dist) {
+      {
+        ProfScope ps(h, "ba_chi2");
+        chi2_sum(1, res + 5, pt_dsq, pt_psq);
+      }
+      if (int rc = allreduce(res + 5, 3)) return rc;
       ProfScope ps(h, "ba_decide_kernel");
-      hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(1), 0, st, S, res);
+      hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(256), 0, st, S, res, -1, (const double*)nullptr, (const double*)nullptr,
+                         (const double*)nullptr, (const double*)nullptr, 0);
+    } else {
+      ProfScope ps(h, "ba_decide_kernel");
+      const int E = inertial ? inr->E : 0;
+      if (E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(E), dim3(64), 0, st, S, P0, P1, 1, 0, ind, imu_buf);
+      hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(256), 0, st, S, res, M, pt_chi2, pt_dsq, pt_psq, imu_buf, E);
     }
   }
   BaState sh{};
