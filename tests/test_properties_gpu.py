@@ -40,6 +40,27 @@ def test_rerun_is_bitwise_identical(full_batch):
             assert torch.equal(out["matches"][b, :nm[b]], snap["matches"][b, :nm[b]])
 
 
+def test_optional_blur_fork_gives_identical_results(full_batch):
+    """ORBX_FORK_BLUR=1 runs the blur on a second stream beside the FAST chain (read at launch time): same bytes out."""
+    import os
+    import torch
+    h, imgs, out, snap, B, cap = full_batch
+    os.environ["ORBX_FORK_BLUR"] = "1"
+    try:
+        for _ in range(3):
+            h.process_stereo_batch_device(imgs, out)
+        h.check_status()
+    finally:
+        del os.environ["ORBX_FORK_BLUR"]
+    nk = snap["nkp"].cpu().numpy(); nm = snap["nmatches"].cpu().numpy()
+    assert torch.equal(out["nkp"], snap["nkp"]) and torch.equal(out["nmatches"], snap["nmatches"])
+    for b in range(0, B, 9):
+        for s in range(2):
+            assert torch.equal(out["kp"][b, s, :nk[b, s]].view(torch.int32), snap["kp"][b, s, :nk[b, s]].view(torch.int32))
+            assert torch.equal(out["desc"][b, s, :nk[b, s]], snap["desc"][b, s, :nk[b, s]])
+        assert torch.equal(out["matches"][b, :nm[b]], snap["matches"][b, :nm[b]])
+
+
 def test_pair_result_independent_of_batch_position(full_batch, pkg):
     """reversing the batch order permutes the results and nothing else (no cross-talk through shared workspaces,
     the XCD-aware block mapping or the atomically appended candidate lists)"""
