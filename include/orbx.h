@@ -24,7 +24,13 @@
  *     until the work has run; the others take
  *     host pointers, copy in/out, and return when the results are in the buffers.
  *   - there is NO CPU fallback: every entry point fails with ORBX_ERR_NO_DEVICE
- *     when no gfx950 device can be opened.
+ *     when no gfx950 device can be opened (the host-only orbx_euroc_* / orbx_png_*
+ *     input functions need no device).
+ *   - two environment switches, both read at call time and both without effect on results:
+ *     ORBX_NO_GRAPH=1 keeps orbx_process_stereo on eager launches instead of a captured hipGraph;
+ *     ORBX_FORK_BLUR=1 lets batches of >= 16 images run the blur on a second stream beside the
+ *     FAST -> Harris -> ordering chain (a few per cent faster; off by default because it makes
+ *     per-kernel timings describe the overlap rather than the kernels).
  */
 #ifndef ORBX_H
 #define ORBX_H
