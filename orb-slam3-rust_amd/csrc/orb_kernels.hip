@@ -632,24 +632,51 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
   const uint8_t* src = level_ptr(s, g, img, l, pitch);
   const unsigned* cl = cand + (size_t)img * g.cand_total + g.lv[l].cand_off;
   unsigned long long* out = sel + (size_t)img * g.cand_total + g.lv[l].cand_off;
-  // one atomic per wave (ballot-aggregated): the 8 chunk blocks of a level all append to one counter
-  for (unsigned base = chunk * 256; base < count; base += HARRIS_CHUNKS * 256) {   // block-uniform bound
-    const unsigned i = base + tid;
-    const unsigned c = i < count ? cl[i] : 0u;
-    const bool pass = i < count && (c >> 24) >= thr;
-    unsigned long long key = 0;
-    if (pass) {
-      const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
-      const float r = harris_response(src, pitch, x, y);
-      key = ((unsigned long long)(~orderable(r)) << 32) | ((unsigned)y << 16) | (unsigned)x;
+  // Two steps per round of 1024 candidates: (1) the ones at or above the threshold (typically a third) are compacted into
+  // an LDS list, (2) the list is worked off densely — the 9x9 response costs ~750 instructions, so a wave should not
+  // carry lanes that failed the threshold.  Appends to the level's survivor list take one atomic per wave.
+  __shared__ unsigned s_pass[1024];
+  __shared__ unsigned s_np;
+  const int lane = tid & 63;
+  const unsigned per = (count + HARRIS_CHUNKS - 1) / HARRIS_CHUNKS;                    // this block's contiguous share
+  const unsigned lim = min(count, (chunk + 1) * per);
+  for (unsigned base = chunk * per; base < lim; base += 1024u) {                       // block-uniform bounds
+    if (tid == 0) s_np = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned i = base + k * 256 + tid;
+      const unsigned c = i < lim ? cl[i] : 0u;
+      const bool pass = i < lim && (c >> 24) >= thr;
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        unsigned p0 = 0;
+        if (lane == 0) p0 = atomicAdd(&s_np, (unsigned)__popcll(m));
+        p0 = __builtin_amdgcn_readfirstlane(p0);
+        if (pass) s_pass[p0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = c;
+      }
     }
-    const unsigned long long m = __ballot(pass);
-    if (m) {
-      unsigned pos0 = 0;
-      if ((tid & 63) == 0) pos0 = atomicAdd(&sel_count[il], (unsigned)__popcll(m));
-      pos0 = __builtin_amdgcn_readfirstlane(pos0);
-      if (pass) out[pos0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = key;
+    __syncthreads();
+    const unsigned np = s_np;
+    for (unsigned q0 = 0; q0 < np; q0 += 256) {                                        // block-uniform bound
+      const unsigned q = q0 + tid;
+      const bool act = q < np;
+      unsigned long long key = 0;
+      if (act) {
+        const unsigned c = s_pass[q];
+        const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
+        const float r = harris_response(src, pitch, x, y);
+        key = ((unsigned long long)(~orderable(r)) << 32) | ((unsigned)y << 16) | (unsigned)x;
+      }
+      const unsigned long long m = __ballot(act);
+      if (m) {
+        unsigned pos0 = 0;
+        if (lane == 0) pos0 = atomicAdd(&sel_count[il], (unsigned)__popcll(m));
+        pos0 = __builtin_amdgcn_readfirstlane(pos0);
+        if (act) out[pos0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = key;
+      }
     }
+    __syncthreads();
   }
 }
 
