@@ -71,6 +71,28 @@ int main(int argc, char** argv) {
       fclose(fo);
     }
 
+    // fuse_search (search_in_neighbors.rs:273-343): a few synthetic map points in front of two keyframes = the two feature sets
+    {
+      std::vector<std::array<double, 3>> pos;
+      std::vector<uint8_t> mpd;
+      for (int i = 0; i < 200; ++i) {
+        const orbx::KeyPoint& k = f.left_features.keypoints[(size_t)i * 3 % f.left_features.keypoints.size()];
+        const double z = 4.0 + 0.05 * i;
+        pos.push_back({(k.x - cam.cx) * z / cam.fx, (k.y - cam.cy) * z / cam.fy, z});
+        const uint8_t* d = f.left_features.descriptors.data() + 32 * ((size_t)i * 3 % f.left_features.keypoints.size());
+        mpd.insert(mpd.end(), d, d + 32);
+      }
+      orbx::SE3 p0, p1;
+      p1.translation = {0.11007, 0.0, 0.0};
+      auto idx = orbx::fuse_search(sp.handle(), pos, mpd, {{p0, &f.left_features}, {p1, &f.right_features}}, cam);
+      fo = fopen((out + "/fuse_out.bin").c_str(), "wb");
+      const int np = (int)idx.size();
+      put(fo, &np, 1);
+      put(fo, idx.data(), idx.size());
+      for (auto& q : pos) put(fo, q.data(), 3);
+      fclose(fo);
+    }
+
     // EurocDataset (io/euroc.rs): when the test wrote a mav0 directory, frame 1 read through the mirror must process to the
     // same StereoFrame sizes as the raw images of stereo.bin (the test stores the same pair as frame 1)
     {

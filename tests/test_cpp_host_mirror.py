@@ -90,6 +90,16 @@ def test_cpp_mirror_matches_oracle(pkg, oracle, tmp_path):
                                            np.array([1.0, 0, 0, 0, 0, 0, 0]),
                                            np.array([0.9998000066665778, 0.0, 0.01999866669333308, 0.0, 0.11007, 0.01, 0.02]), 50)
     assert np.array_equal(np.frombuffer(tb, np.int32, 2 * npairs, 4).reshape(-1, 2), want)
+    # --- fuse_search mirror: 200 points on the rays of left keypoints, two keyframes
+    fb = open(os.path.join(tmp, "fuse_out.bin"), "rb").read()
+    (nfp,) = struct.unpack_from("<i", fb, 0)
+    fidx = np.frombuffer(fb, np.int32, nfp, 4).reshape(200, 2)
+    fpos = np.frombuffer(fb, np.float64, 600, 4 + 4 * nfp).reshape(200, 3)
+    sel = (np.arange(200) * 3) % len(okl)
+    s7 = (1.2 * (1.2 * 1.2)) * ((1.2 * 1.2) * (1.2 * 1.2))
+    fi, _fd = oracle.fuse_search(oracle.Camera(**pkg.synth.EUROC_CAMERA), fpos, odl[sel], np.array([[1.0, 0, 0, 0, 0, 0, 0], [1.0, 0, 0, 0, 0.11007, 0, 0]]),
+                                 np.array([0, len(okl), len(okl) + len(okr)], np.int32), np.concatenate([okl, okr]), np.concatenate([odl, odr]), 3.0 * s7, 50)
+    assert np.array_equal(fidx, fi) and (fidx[:, 0] >= 0).sum() > 150
     # --- EurocDataset mirror (the driver itself compared the decoded pair with the raw images)
     eb = open(os.path.join(tmp, "euroc_out.bin"), "rb").read()
     n_frames, t1a, t1b = struct.unpack_from("<QQQ", eb, 0)
