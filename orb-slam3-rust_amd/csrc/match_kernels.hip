@@ -736,13 +736,13 @@ int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, co
     hipLaunchKernelGGL(stereo_bucket_kernel, dim3(batch), dim3(SB_THREADS), 0, h->stream, d_kp, d_nkp, cap_kp, bstart, sidx, sxy);
   }
   {
-    ProfScope ps(h, "stereo_match_kernel");
+    ProfScope ps(h, "stereo_match_kernel", nullptr, true);
     dim3 grid((cap_kp + SM_LEFT_PER_BLOCK - 1) / SM_LEFT_PER_BLOCK, batch);
     hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(SM_THREADS), 0, h->stream, d_kp, d_desc, d_nkp,
                        cap_kp, max_disp, min_disp, bstart, sidx, sxy, tmp);
   }
   {
-    ProfScope ps(h, "stereo_compact_kernel");
+    ProfScope ps(h, "stereo_compact_kernel", nullptr, true);
     hipLaunchKernelGGL(stereo_compact_kernel, dim3(batch), dim3(256), 0, h->stream, d_kp, d_nkp, cap_kp,
                        (const int2*)tmp, h->cam, d_matches, d_nmatches, d_points, d_has_point);
   }

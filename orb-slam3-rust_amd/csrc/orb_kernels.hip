@@ -1170,29 +1170,29 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
       ORBX_HIP(h, hipStreamWaitEvent(h->s_aux, h->ev_fork, 0));
     }
     {
-      ProfScope ps(h, "blur_kernel", fork ? h->s_aux : st);
+      ProfScope ps(h, "blur_kernel", fork ? h->s_aux : st, true);
       hipLaunchKernelGGL(blur_kernel, xcd_grid(g.btiles_total, n), dim3(256), 0, fork ? h->s_aux : st, s, g, n, xcd_map(g.btiles_total),
                          tab + h->btile_tab_off);
     }
     if (fork) ORBX_HIP(h, hipEventRecord(h->ev_join, h->s_aux));
     if (g.ftiles_total > 0) {
-      ProfScope ps(h, "fast_kernel");
+      ProfScope ps(h, "fast_kernel", nullptr, true);
       hipLaunchKernelGGL(fast_kernel, xcd_grid(g.ftiles_total, n), dim3(256), 0, st, s, g, n, xcd_map(g.ftiles_total),
                          tab + h->ftile_tab_off, cand, cc, hs);
     }
     {
-      ProfScope ps(h, "harris_select_kernel");
+      ProfScope ps(h, "harris_select_kernel", nullptr, true);
       hipLaunchKernelGGL(harris_select_kernel, xcd_grid(nl * HARRIS_CHUNKS, n), dim3(256), 0, st, s, g, n, xcd_map(nl * HARRIS_CHUNKS),
                          (const unsigned*)cand, cc, hs, sel, sc);
     }
     {
-      ProfScope ps(h, "rank_select_kernel");
+      ProfScope ps(h, "rank_select_kernel", nullptr, true);
       hipLaunchKernelGGL(rank_select_kernel, xcd_grid(nl, n), dim3(1024), 0, st, g, n, xcd_map(nl), (const unsigned long long*)sel, sc,
                          sel2, kp);
     }
     if (fork) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
     {
-      ProfScope ps(h, "describe_kernel");
+      ProfScope ps(h, "describe_kernel", nullptr, true);
       const int blocks_x = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block
       hipLaunchKernelGGL(describe_kernel, xcd_grid(blocks_x, n), dim3(256), 0, st, s, g, n, xcd_map(blocks_x), blocks_x,
                          (const unsigned long long*)sel2, kp, d_kp + (size_t)img0 * cap_kp, d_desc + (size_t)img0 * cap_kp * 32,

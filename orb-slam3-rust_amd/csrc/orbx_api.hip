@@ -46,7 +46,8 @@ static hipEvent_t prof_event(orbx_handle* h) {
   }
   return h->event_pool[h->event_next++];
 }
-ProfScope::ProfScope(orbx_handle* h_, const char* name, hipStream_t stream_) : h(h_), idx(-1), stream(stream_ ? stream_ : h_->stream) {
+ProfScope::ProfScope(orbx_handle* h_, const char* name, hipStream_t stream_, bool chained)
+    : h(h_), idx(-1), stream(stream_ ? stream_ : h_->stream) {
   if (!h->profiling) return;
   for (size_t i = 0; i < h->timers.size(); ++i)
     if (h->timers[i].name == name) { idx = (int)i; break; }
@@ -55,6 +56,12 @@ ProfScope::ProfScope(orbx_handle* h_, const char* name, hipStream_t stream_) : h
     t.name = name;
     h->timers.push_back(t);
     idx = (int)h->timers.size() - 1;
+  }
+  // chained: nothing was enqueued on this stream since the previous scope ended, so that scope's end event is this
+  // one's start (half the events in a back-to-back kernel sequence: every event costs the stream ~1 us)
+  if (chained && h->prof_tail && h->prof_tail_stream == stream) {
+    h->timers[idx].ev.push_back(h->prof_tail);
+    return;
   }
   hipEvent_t e = prof_event(h);
   hipEventRecord(e, stream);
@@ -65,6 +72,8 @@ ProfScope::~ProfScope() {
   hipEvent_t e = prof_event(h);
   hipEventRecord(e, stream);
   h->timers[idx].ev.push_back(e);
+  h->prof_tail = e;
+  h->prof_tail_stream = stream;
 }
 void orbx_prof_begin_call(orbx_handle* h) { (void)h; }   // events accumulate until they are read
 void orbx_prof_end_call(orbx_handle* h) { (void)h; }
@@ -179,6 +188,7 @@ int orbx_set_profiling(orbx_handle* h, int on) {
   if (!h) return ORBX_ERR_INVALID;
   h->profiling = on != 0;
   h->event_next = 0;
+  h->prof_tail = nullptr;
   for (auto& t : h->timers) t.ev.clear();
   return ORBX_OK;
 }
@@ -208,6 +218,7 @@ int orbx_get_kernel_times(orbx_handle* h, orbx_kernel_time* out, int cap) {
   }
   // reading resets: the next call starts a new accumulation window
   h->event_next = 0;
+  h->prof_tail = nullptr;
   for (auto& t : h->timers) t.ev.clear();
   return n;
 }

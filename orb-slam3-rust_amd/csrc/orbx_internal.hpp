@@ -101,6 +101,8 @@ struct orbx_handle {
   std::vector<KernelTimer> timers;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;
+  hipEvent_t prof_tail = nullptr;          // end event of the last profiling scope (may start the next one)
+  hipStream_t prof_tail_stream = nullptr;
 };
 
 int orbx_fail(orbx_handle* h, int code, const char* fmt, ...);
@@ -119,7 +121,7 @@ struct ProfScope {
   orbx_handle* h;
   int idx;
   hipStream_t stream;   // the stream the bracketed launches go to (default: the handle's)
-  ProfScope(orbx_handle* h, const char* name, hipStream_t stream = nullptr);
+  ProfScope(orbx_handle* h, const char* name, hipStream_t stream = nullptr, bool chained = false);
   ~ProfScope();
 };
 void orbx_prof_begin_call(orbx_handle* h);
