@@ -116,9 +116,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ORBX_DIST_REHEARSE=1: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share the
+    # cards, gloo instead of RCCL, which refuses two ranks on one device).  Never set by the driver; the line it
+    # prints says so in config.parallelism.
+    rehearse = world > 1 and os.environ.get("ORBX_DIST_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -206,7 +215,7 @@ def main():
                config=dict(workload="Synthetic %dx%d stereo, %d ORB/frame, extract+match+triangulate (BASELINE configs[%d])"
                                     % (W, H, args.features, 1 if (W, H, args.features) == (752, 480, 2000) else 4),
                            image=[W, H], n_features=args.features, batch_pairs_per_gpu=args.batch,
-                           distinct_batches=args.n_batches, parallelism="frames sharded, %d rank(s), no collective" % world,
+                           distinct_batches=args.n_batches, parallelism="frames sharded, %d rank(s), no collective%s" % (world, " (REHEARSAL: ranks share GPUs, gloo)" if rehearse else ""),
                            mean_keypoints_per_image=round(n_kp, 1), mean_matches_per_frame=round(n_matches, 1)),
                roofline=roofline, value_unprofiled=round(args.batch * args.steps * world / elapsed_np, 2))
 

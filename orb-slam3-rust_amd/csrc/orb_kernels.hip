@@ -342,26 +342,31 @@ __device__ __forceinline__ int fast_score16_pk(int v, const int (&r)[16], int t)
 // One polarity only: max over the 16 arcs of min over the arc of s*(centre - ring), s = +1 (ring darker) or -1 (ring
 // brighter), on packed 16-bit pairs.  A polarity whose compass pre-test fails cannot exceed the threshold (every
 // 9-arc holds two adjacent compass points), so phase 2 evaluates only the polarity (rarely both) that passes.
+// Packing: X[j] = (d[j], d[j+8]) — a register and its half-swap hold all 16 ring positions, so "position + k" is
+// another register, half-swapped when it wraps past 8; the swap is the op_sel modifier of v_pk_min_i16 (free).
+__device__ __forceinline__ fast_s2 pk_min_swapped(fast_s2 a, fast_s2 b) {   // min(a, (b.hi, b.lo))
+  fast_s2 d;
+  asm("v_pk_min_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ int fast_arc_min_pk(int v, const int (&r)[16], bool brighter) {
-  fast_s2 X[8], Q[8], A[8], B[8];
-  const unsigned vv = (unsigned)v | ((unsigned)v << 16);
-  const fast_s2 sg = brighter ? (fast_s2){-1, -1} : (fast_s2){1, 1};
+  fast_s2 X[8], A[8], B[8];
+  const short sv = (short)(brighter ? -v : v), sm = (short)(brighter ? 1 : -1);
+  const fast_s2 c = {sv, sv}, m = {sm, sm};
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const unsigned rp = (unsigned)r[2 * j] | ((unsigned)r[2 * j + 1] << 16);
-    X[j] = (__builtin_bit_cast(fast_s2, vv) - __builtin_bit_cast(fast_s2, rp)) * sg;
+    const unsigned rp = (unsigned)r[j] | ((unsigned)r[j + 8] << 16);
+    X[j] = __builtin_bit_cast(fast_s2, rp) * m + c;                      // s*(centre - ring): one v_pk_mad_i16
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) Q[j] = __builtin_shufflevector(X[j], X[(j + 1) & 7], 1, 2);
+  for (int j = 0; j < 8; ++j) A[j] = j + 1 < 8 ? __builtin_elementwise_min(X[j], X[j + 1]) : pk_min_swapped(X[j], X[j - 7]);   // window 2
 #pragma unroll
-  for (int j = 0; j < 8; ++j) A[j] = __builtin_elementwise_min(X[j], Q[j]);                 // window 2
+  for (int j = 0; j < 8; ++j) B[j] = j + 2 < 8 ? __builtin_elementwise_min(A[j], A[j + 2]) : pk_min_swapped(A[j], A[j - 6]);   // 4
 #pragma unroll
-  for (int j = 0; j < 8; ++j) B[j] = __builtin_elementwise_min(A[j], A[(j + 1) & 7]);       // 4
+  for (int j = 0; j < 8; ++j) A[j] = j + 4 < 8 ? __builtin_elementwise_min(B[j], B[j + 4]) : pk_min_swapped(B[j], B[j - 4]);   // 8
+  fast_s2 best = pk_min_swapped(A[0], X[0]);                                                                                   // 9
 #pragma unroll
-  for (int j = 0; j < 8; ++j) A[j] = __builtin_elementwise_min(B[j], B[(j + 2) & 7]);       // 8
-  fast_s2 best = {-256, -256};
-#pragma unroll
-  for (int j = 0; j < 8; ++j) best = __builtin_elementwise_max(best, __builtin_elementwise_min(A[j], X[(j + 4) & 7]));   // 9
+  for (int j = 1; j < 8; ++j) best = __builtin_elementwise_max(best, pk_min_swapped(A[j], X[j]));
   return max((int)best[0], (int)best[1]);
 }
 
@@ -399,6 +404,12 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   const int x0 = EDGE + tx * FT_W, y0 = EDGE + ty * FT_H;   // first inner pixel; score position (i,j) = pixel (x0-1+i, y0-1+j)
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) { s_npos = 0; s_cnt = 0; s_ncor = 0; }
+  // score positions this tile needs (inner part that lies inside the border-filtered region + the NMS frame): tiles on
+  // the right / bottom edge of a level are partial — 28 % of all tile area at 752x480 — and only pay for what they hold
+  const int aw = min(FT_W, w - EDGE - x0) + 2, ah = min(FT_H, h - EDGE - y0) + 2;
+  const int qpr = (aw + 3) >> 2;                                   // 4-position tasks per row, 1..16
+  const int ntask = qpr * ah;
+  const unsigned inv = (unsigned)(65536.f / (float)qpr) + 1u;      // task / qpr = (task * inv) >> 16, exact for task < 512
   // pixel tile: LDS row r = image row y0-4+r, byte b = image column x0-5+b.  9 lanes x 8 bytes per 72-byte row, 28 rows
   // per pass (the division by 9 is of tid, once)
   {
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int r = r0 + 28 * k;
-      if (r0 < 28 && r < FP_ROWS) {
+      if (r0 < 28 && r < ah + 6) {
         const int gy = min(y0 - 4 + r, h - 1), gx = min(x0 - 5 + 8 * c, pitch - 8);
         unsigned long long v;
         __builtin_memcpy(&v, src + (size_t)gy * pitch + gx, 8);
@@ -418,37 +429,32 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   __syncthreads();
   const int t = g.fast_threshold;
   // phase 1: compass pre-test, 4 positions per task
-#pragma unroll
-  for (int rep = 0; rep < (FS_W / 4) * FS_H / 256; ++rep) {
-    const int task = rep * 256 + tid;
-    const int j = task >> 4, tq = task & 15;
+  for (int task = tid; task < ntask; task += 256) {
+    const int j = (int)(((unsigned)task * inv) >> 16), tq = task - j * qpr;
     const unsigned* rowc = reinterpret_cast<const unsigned*>(&sp[j + 3][0]) + tq;
     const unsigned c0 = rowc[0], c1 = rowc[1], c2 = rowc[2];
     const unsigned up = reinterpret_cast<const unsigned*>(&sp[j][0])[tq + 1];       // y-3
     const unsigned dn = reinterpret_cast<const unsigned*>(&sp[j + 6][0])[tq + 1];   // y+3
-    // the 4 positions as two packed i16 pairs (v_perm_b32 widens bytes, v_pk_sub/min/max_i16 test two positions
-    // per instruction): with d = ring - centre, two adjacent compass points both brighter  <=>  max over the four
-    // adjacent pairs of min(d_a, d_b) > t; both darker  <=>  min over the pairs of max(d_a, d_b) < -t
+    // the 4 positions as two packed i16 pairs (v_perm_b32 widens bytes, v_pk_min/max/sub_i16 test two positions
+    // per instruction)
     const unsigned xm3 = __builtin_amdgcn_alignbyte(c1, c0, 1);   // x-3 of the 4 positions: bytes 4tq+1 .. 4tq+4
     const unsigned xp3 = __builtin_amdgcn_alignbyte(c2, c1, 3);   // x+3: bytes 4tq+7 .. 4tq+10
-    const fast_s2 tt = {(short)(t + 1), (short)(t + 1)}, zero2 = {0, 0};
+    const fast_s2 tt = {(short)t, (short)t};
     unsigned pass[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const unsigned sel = hf ? 0x0c030c02u : 0x0c010c00u;
       const fast_s2 v2 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, c1, sel));
-      const fast_s2 d0 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, dn, sel)) - v2;
-      const fast_s2 d4 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, xp3, sel)) - v2;
-      const fast_s2 d8 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, up, sel)) - v2;
-      const fast_s2 d12 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, xm3, sel)) - v2;
-      const fast_s2 m = __builtin_elementwise_max(
-          __builtin_elementwise_max(__builtin_elementwise_min(d0, d4), __builtin_elementwise_min(d4, d8)),
-          __builtin_elementwise_max(__builtin_elementwise_min(d8, d12), __builtin_elementwise_min(d12, d0)));
-      const fast_s2 M = __builtin_elementwise_min(
-          __builtin_elementwise_min(__builtin_elementwise_max(d0, d4), __builtin_elementwise_max(d4, d8)),
-          __builtin_elementwise_min(__builtin_elementwise_max(d8, d12), __builtin_elementwise_max(d12, d0)));
-      const fast_s2 e = __builtin_elementwise_max(m, zero2 - M) - tt;   // >= 0 exactly where the pre-test passes
-      pass[hf] = ~__builtin_bit_cast(unsigned, e) & 0x80008000u;
+      const fast_s2 r0 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, dn, sel));
+      const fast_s2 r4 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, xp3, sel));
+      const fast_s2 r8 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, up, sel));
+      const fast_s2 r12 = __builtin_bit_cast(fast_s2, __builtin_amdgcn_perm(0u, xm3, sel));
+      // every adjacent compass pair takes one point of {0, 8} and one of {4, 12}, and every such pair is adjacent:
+      // "two adjacent ones brighter than v+t"  <=>  max(r0,r8) > v+t and max(r4,r12) > v+t; darker likewise with min
+      const fast_s2 B = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
+      const fast_s2 D = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
+      const fast_s2 eb = (v2 + tt) - B, ed = D - (v2 - tt);   // negative exactly where brighter / darker passes
+      pass[hf] = (__builtin_bit_cast(unsigned, eb) | __builtin_bit_cast(unsigned, ed)) & 0x80008000u;
     }
     // wave-level compaction by ballots (list order is free: phases 2/3 only need the set)
     const bool pk0 = pass[0] & 0x8000u, pk1 = pass[0] & 0x80000000u, pk2 = pass[1] & 0x8000u, pk3 = pass[1] & 0x80000000u;
@@ -485,10 +491,8 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     r[15] = sp[cy + 3][cx - 1];
     // which polarity passed the compass pre-test (the other one cannot exceed the threshold)
     const int hi = v + t, lo = v - t;
-    const bool b0 = r[0] > hi, b4 = r[4] > hi, b8 = r[8] > hi, b12 = r[12] > hi;
-    const bool k0 = r[0] < lo, k4 = r[4] < lo, k8 = r[8] < lo, k12 = r[12] < lo;
-    const bool brighter = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
-    const bool darker = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0);
+    const bool brighter = min(max(r[0], r[8]), max(r[4], r[12])) > hi;
+    const bool darker = max(min(r[0], r[8]), min(r[4], r[12])) < lo;
     int b = fast_arc_min_pk(v, r, brighter);
     if (brighter && darker) b = max(b, fast_arc_min_pk(v, r, false));   // both passed (rare)
     const int sc = b > t ? b - 1 : 0;
