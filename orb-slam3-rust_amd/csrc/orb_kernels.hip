@@ -176,8 +176,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // down BLUR_STRIP rows.  Per input row: one coalesced 256-B dword load per wave, neighbour dwords by
 // DPP wave shifts (+2 edge lanes loading), horizontal taps with v_alignbyte + v_dot4_u32_u8 (8.8 sums),
 // a ring of row PAIRS of those sums in registers, vertical taps by v_dot2_u32_u16 (16.16), one dword store.
-// Lanes whose 10-px window crosses the image edge rebuild their three dwords bytewise with
-// BORDER_REFLECT_101 (a few lanes per row).
+// Lanes whose 10-px window crosses the image edge rebuild their three dwords with BORDER_REFLECT_101 from the
+// same registers (v_perm_b32, no loads).
 constexpr int BLUR_W = 248, BLUR_STRIP = 64, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo
 
 __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2, unsigned (&hs)[4]) {
@@ -192,18 +192,48 @@ __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2,
   hs[3] = __builtin_amdgcn_udot4(d2, G1, __builtin_amdgcn_udot4(d1, G0, 0u, false), false);
 }
 
-// rp = row base (wave-uniform); d1 = this lane's dword of the row, loaded two rows ahead by the caller so that the
-// load latency overlaps the arithmetic of the rows in between
-__device__ __forceinline__ void blur_row(const uint8_t* __restrict__ rp, unsigned d1, bool slow, const int (&col)[12], unsigned (&hs)[4]) {
+// BORDER_REFLECT_101 at the left / right image edge without touching memory: every byte an edge lane needs lies in
+// the three dwords the wave already holds (its own and its two neighbours'), so the reflected window is three
+// v_perm_b32 with per-lane selectors computed once (levels are at least 8 px wide, so a lane has at most one edge).
+struct BlurEdge {
+  unsigned s1, s2;      // selectors of d1' = perm(d1, d0, s1) and d2' = perm(hi ? d2 : d1, hi ? d1 : d0, s2)
+  bool left, hi;        // left: d0' = (px4, px3, px2, px1) = perm(d2, d1, 0x01020304)
+};
+__device__ __forceinline__ BlurEdge blur_edge_setup(int x0, int w, bool active) {
+  BlurEdge e;
+  e.s1 = 0x07060504u; e.s2 = 0x07060504u; e.hi = true;
+  e.left = active && x0 == 0;
+  const int rem = w - x0;                       // pixels of the image at and right of x0
+  if (active && rem <= 6) {                     // the window reaches x0+6
+    unsigned s1 = 0, s2 = 0;
+    if (rem >= 4) {                             // d1 whole; d2 byte j = px x0+4+j, reflected px = x0 + (2 rem - 6 - j)
+      s1 = 0x07060504u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s2 |= (unsigned)(j < rem - 4 ? 4 + j : 2 * rem - 6 - j) << (8 * j);   // over (d2, d1)
+    } else {                                    // d1 byte j >= rem reflects to x0 + (2 rem - 2 - j); d2 to x0 + (2 rem - 6 - j)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1 |= (unsigned)(j < rem ? 4 + j : 4 + 2 * rem - 2 - j) << (8 * j);                             // over (d1, d0)
+        const int o = 2 * rem - 6 - j;          // below -4: only feeds pixels past the edge, any byte will do
+        s2 |= (unsigned)(o >= -4 ? 4 + o : 0) << (8 * j);
+      }
+      e.hi = false;
+    }
+    e.s1 = s1; e.s2 = s2;
+  }
+  return e;
+}
+
+// d1 = this lane's dword of the row, loaded two rows ahead by the caller so that the load latency overlaps the
+// arithmetic of the rows in between; edge = some lane of this wave sits on the image edge (wave-uniform)
+__device__ __forceinline__ void blur_row(unsigned d1, bool edge, const BlurEdge& e, unsigned (&hs)[4]) {
   unsigned d0 = __builtin_amdgcn_update_dpp(0u, d1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
   unsigned d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-  if (slow) {   // window crosses the image edge: gather the 12 bytes from the precomputed reflected columns
-    unsigned b[12];
-#pragma unroll
-    for (int t = 0; t < 12; ++t) b[t] = rp[col[t]];
-    d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-    d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-    d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+  if (edge) {
+    const unsigned n0 = e.left ? __builtin_amdgcn_perm(d2, d1, 0x01020304u) : d0;
+    const unsigned n2 = __builtin_amdgcn_perm(e.hi ? d2 : d1, e.hi ? d1 : d0, e.s2);
+    d1 = __builtin_amdgcn_perm(d1, d0, e.s1);
+    d0 = n0; d2 = n2;
   }
   blur_hsum(d0, d1, d2, hs);
 }
@@ -211,9 +241,10 @@ __device__ __forceinline__ void blur_row(const uint8_t* __restrict__ rp, unsigne
 // BORDER_REFLECT_101 for an index at most n-1 outside [0, n) (levels are at least 8 px, the kernel reaches 3 px out)
 __device__ __forceinline__ int reflect101_once(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
-// 7 waves/SIMD (<= 72 VGPRs): measured best — 8 spills the ring, 5-6 leave less latency cover (A/B on one box:
-// 0.32 ms vs 0.34 at 6, 0.36 at 5, 0.62 at 8 with scratch)
-__attribute__((amdgpu_waves_per_eu(7, 7)))
+// 8 waves/SIMD (<= 64 VGPRs, no scratch since the edge lanes stopped gathering bytes from memory — that gather, 12
+// dependent byte loads per row in every wave holding an edge lane, was the latency the kernel waited on: 0.308 ->
+// 0.198 ms; 7 waves: 0.198, 8 waves: 0.195)
+__attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab) {
   int img, tile;
   if (!xcd_decode(xm, n_img, img, tile)) return;
@@ -228,15 +259,12 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
   if (ys >= h) return;
   const int x0 = tx * BLUR_W + (lane - 1) * 4;
   const bool active = lane >= 1 && lane <= 62 && x0 < w;
-  const bool slow = active && (x0 < 4 || x0 + 7 > w);
+  const BlurEdge be = blur_edge_setup(x0, w, active);
+  const bool edge = __ballot(be.left || !be.hi || be.s2 != 0x07060504u) != 0ull;
   const int xl = max(0, min(x0, pitch - 4));
   const int nrows = min(BLUR_STRIP, h - ys);
   uint8_t* dst = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
   const int dpitch = g.lv[l].pitch;
-  // BORDER_REFLECT_101 source columns of this lane's 12-byte window (same for every row)
-  int col[12];
-#pragma unroll
-  for (int t = 0; t < 12; ++t) col[t] = slow ? reflect101(x0 - 4 + t, w) : 0;
   // input rows q = 0 .. nrows+5 are image rows reflect(ys-3+q); p0/p1 hold this lane's dword of rows q and q+1
   const int last = nrows + 5;
   auto rowp = [&](int q) { return src + (size_t)reflect101_once(ys - 3 + min(q, last), h) * pitch; };
@@ -252,7 +280,7 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
     p0 = p1;
     p1 = *reinterpret_cast<const unsigned*>(rowp(i + 2) + xl);
     unsigned hs[4];
-    blur_row(rowp(i), cur, slow, col, hs);
+    blur_row(cur, edge, be, hs);
     if (i > 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) pr[i - 1][k] = hprev[k] | (hs[k] << 16);
@@ -271,7 +299,7 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
         p0 = p1;
         p1 = *reinterpret_cast<const unsigned*>(rowp(y + 8) + xl);
         unsigned hs[4];
-        blur_row(rowp(y + 6), cur, slow, col, hs);
+        blur_row(cur, edge, be, hs);
         unsigned packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
