@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
   const int tby = tb / tiles_x, tbx = tb - tby * tiles_x;
   int sp;
   const uint8_t* src = level_ptr(s, g, img, l - 1, sp);
-  const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h;
+  const int sh = g.lv[l - 1].h;
   const int w = g.lv[l].w, h = g.lv[l].h, dp = g.lv[l].pitch;
   uint8_t* dst = s.pyr + (size_t)img * g.slot_bytes + g.lv[l].off;
   // RESIZE_ROWS output rows per thread (y, y+16, ...): the dependent chain table -> source rows -> arithmetic is
@@ -108,20 +108,15 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
 #pragma unroll
   for (int r = 0; r < RESIZE_ROWS; ++r) yt[r] = ytab[min(yb + 16 * r, h - 1)];
   const unsigned xt[4] = {xt4.x, xt4.y, xt4.z, xt4.w};
-  const int xb = (int)(xt[0] >> 16);
-  const bool fastp = xb + 8 <= sp;
-  const uint8_t* r0[RESIZE_ROWS];
-  const uint8_t* r1[RESIZE_ROWS];
+  // window start, pulled back at the right edge so that the 8 bytes stay inside the row (offsets then reach 7; the
+  // second tap of a pixel clamped at the edge has weight 0, so the zero shifted in for it is never used)
+  const int xb = min((int)(xt[0] >> 16), sp - 8);
   unsigned long long w0[RESIZE_ROWS], w1[RESIZE_ROWS];
 #pragma unroll
   for (int r = 0; r < RESIZE_ROWS; ++r) {
     const int y0 = (int)(yt[r] >> 16), y1 = min(y0 + 1, sh - 1);
-    r0[r] = src + (size_t)y0 * sp;
-    r1[r] = src + (size_t)y1 * sp;
-    if (fastp) {
-      w0[r] = (unsigned long long)ld_u32(r0[r] + xb) | ((unsigned long long)ld_u32(r0[r] + xb + 4) << 32);
-      w1[r] = (unsigned long long)ld_u32(r1[r] + xb) | ((unsigned long long)ld_u32(r1[r] + xb + 4) << 32);
-    }
+    __builtin_memcpy(&w0[r], src + (size_t)y0 * sp + xb, 8);     // one unaligned global_load_dwordx2 per source row
+    __builtin_memcpy(&w1[r], src + (size_t)y1 * sp + xb, 8);
   }
 #pragma unroll
   for (int r = 0; r < RESIZE_ROWS; ++r) {
@@ -129,30 +124,15 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
     if (y >= h) break;
     const unsigned cy1 = yt[r] & 0xffffu, cy0 = 256u - cy1;
     unsigned packed = 0;
-    if (fastp) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (x0 + k < w) {
-          const int o = (int)(xt[k] >> 16) - xb;             // 0..4; tap o+1 <= 5 (weight 0 when clamped at the edge)
-          const unsigned cx1 = xt[k] & 0xffffu;
-          const unsigned coef = (255u - cx1) | (cx1 << 8);   // (cx0 - 1, cx1)
-          const unsigned h0 = resize_h(w0[r], o, coef), h1 = resize_h(w1[r], o, coef);   // 8.8
-          const unsigned v = cy0 * h0 + cy1 * h1;                                        // 16.16
-          packed |= ((v + 32768u) >> 16) << (8 * k);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int x = x0 + k;
-        if (x < w) {
-          const int xo = (int)(xt[k] >> 16), x1 = min(xo + 1, sw - 1);
-          const unsigned cx1 = xt[k] & 0xffffu, cx0 = 256u - cx1;
-          const unsigned h0 = cx0 * r0[r][xo] + cx1 * r0[r][x1];
-          const unsigned h1 = cx0 * r1[r][xo] + cx1 * r1[r][x1];
-          const unsigned v = cy0 * h0 + cy1 * h1;
-          packed |= ((v + 32768u) >> 16) << (8 * k);
-        }
+    for (int k = 0; k < 4; ++k) {
+      if (x0 + k < w) {
+        const int o = (int)(xt[k] >> 16) - xb;             // 0..7
+        const unsigned cx1 = xt[k] & 0xffffu;
+        const unsigned coef = (255u - cx1) | (cx1 << 8);   // (cx0 - 1, cx1)
+        const unsigned h0 = resize_h(w0[r], o, coef), h1 = resize_h(w1[r], o, coef);   // 8.8
+        const unsigned v = cy0 * h0 + cy1 * h1;                                        // 16.16
+        packed |= ((v + 32768u) >> 16) << (8 * k);
       }
     }
     *reinterpret_cast<unsigned*>(dst + (size_t)y * dp + x0) = packed;
@@ -241,32 +221,26 @@ __device__ __forceinline__ void blur_row(unsigned d1, bool edge, const BlurEdge&
 // BORDER_REFLECT_101 for an index at most n-1 outside [0, n) (levels are at least 8 px, the kernel reaches 3 px out)
 __device__ __forceinline__ int reflect101_once(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
-// 8 waves/SIMD (<= 64 VGPRs, no scratch since the edge lanes stopped gathering bytes from memory — that gather, 12
-// dependent byte loads per row in every wave holding an edge lane, was the latency the kernel waited on: 0.308 ->
-// 0.198 ms; 7 waves: 0.198, 8 waves: 0.195)
-__attribute__((amdgpu_waves_per_eu(8, 8)))
-__global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab) {
-  int img, tile;
-  if (!xcd_decode(xm, n_img, img, tile)) return;
-  int l, tx, ty;
-  decode_tile(tile_tab, tile, l, tx, ty);
-  int pitch;
-  const uint8_t* src = level_ptr(s, g, img, l, pitch);
-  const int w = g.lv[l].w, h = g.lv[l].h;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row arithmetic stays on the SALU
-  const int ys = ty * BLUR_H + wave * BLUR_STRIP;
-  if (ys >= h) return;
-  const int x0 = tx * BLUR_W + (lane - 1) * 4;
-  const bool active = lane >= 1 && lane <= 62 && x0 < w;
+// One wave = M row groups of 64/M lanes: group k walks rows [ys + k*64/M, ys + (k+1)*64/M) of a strip (64/M - 2)*4 px
+// wide (first and last lane of a group are halo lanes).  M = 1 is the full 248-px strip; M = 2 (120 px) and M = 4
+// (56 px) take the narrow remainder at the right of a level in 38 resp. 22 row steps instead of 70, so a remainder of
+// 8 px (752 = 3*248 + 8) no longer costs a whole strip.  For M > 1 the row index is per lane (VALU), for M = 1 scalar.
+template <int M>
+__device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int pitch, int w, int h, uint8_t* __restrict__ dst,
+                                           int dpitch, int xbase, int ys_wave, int lane) {
+  constexpr int GL = 64 / M, R = BLUR_STRIP / M;
+  const int gl = lane & (GL - 1);
+  int ys = ys_wave + (lane / GL) * R;
+  const int nrows = min(R, h - ys_wave);          // wave-uniform: group 0 has the most rows
+  int nrows_l = min(R, h - ys);                    // this lane's group (M > 1: can be <= 0 below the image)
+  if (M > 1 && nrows_l <= 0) { ys = ys_wave; nrows_l = 0; }   // idle group: walk group 0's rows, store nothing
+  const int x0 = xbase + (gl - 1) * 4;
+  const bool active = gl >= 1 && gl <= GL - 2 && x0 < w && nrows_l > 0;
   const BlurEdge be = blur_edge_setup(x0, w, active);
   const bool edge = __ballot(be.left || !be.hi || be.s2 != 0x07060504u) != 0ull;
   const int xl = max(0, min(x0, pitch - 4));
-  const int nrows = min(BLUR_STRIP, h - ys);
-  uint8_t* dst = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
-  const int dpitch = g.lv[l].pitch;
   // input rows q = 0 .. nrows+5 are image rows reflect(ys-3+q); p0/p1 hold this lane's dword of rows q and q+1
-  const int last = nrows + 5;
+  const int last = (M > 1 ? max(nrows_l, 1) : nrows) + 5;
   auto rowp = [&](int q) { return src + (size_t)reflect101_once(ys - 3 + min(q, last), h) * pitch; };
   unsigned p0 = *reinterpret_cast<const unsigned*>(rowp(0) + xl), p1 = *reinterpret_cast<const unsigned*>(rowp(1) + xl);
   // Vertical taps on PAIRS of rows: the 8.8 horizontal sums fit 16 bits, so two consecutive rows of one pixel share a
@@ -311,10 +285,34 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
           v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 4) % 6][k]), T2, v, false);
           packed |= ((v + 32768u) >> 16) << (8 * k);
         }
-        if (active) *reinterpret_cast<unsigned*>(dst + (size_t)(ys + y) * dpitch + x0) = packed;
+        if (active && (M == 1 || y < nrows_l)) *reinterpret_cast<unsigned*>(dst + (size_t)(ys + y) * dpitch + x0) = packed;
       }
     }
   }
+}
+
+// 8 waves/SIMD (<= 64 VGPRs, no scratch since the edge lanes stopped gathering bytes from memory — that gather, 12
+// dependent byte loads per row in every wave holding an edge lane, was the latency the kernel waited on: 0.308 ->
+// 0.198 ms; 7 waves: 0.198, 8 waves: 0.195)
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab) {
+  int img, tile;
+  if (!xcd_decode(xm, n_img, img, tile)) return;
+  // strip table of orb_prepare_geometry: level | mode << 3 | (x / 4) << 5 | tile row << 18
+  const unsigned e = tile_tab[tile];
+  const int l = (int)(e & 7u), mode = (int)((e >> 3) & 3u), xbase = (int)((e >> 5) & 0x1fffu) * 4, ty = (int)(e >> 18);
+  int pitch;
+  const uint8_t* src = level_ptr(s, g, img, l, pitch);
+  const int w = g.lv[l].w, h = g.lv[l].h;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row arithmetic stays on the SALU
+  const int ys = ty * BLUR_H + wave * BLUR_STRIP;
+  if (ys >= h) return;
+  uint8_t* dst = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
+  const int dpitch = g.lv[l].pitch;
+  if (mode == 0) blur_strip<1>(src, pitch, w, h, dst, dpitch, xbase, ys, lane);
+  else if (mode == 1) blur_strip<2>(src, pitch, w, h, dst, dpitch, xbase, ys, lane);
+  else blur_strip<4>(src, pitch, w, h, dst, dpitch, xbase, ys, lane);
 }
 
 // ---- A.5 FAST-9/16 ------------------------------------------------------------------------------------------
@@ -1030,6 +1028,28 @@ void build_resize_tab(int src, int dst, std::vector<unsigned>& out) {
   while (out.size() % 4) out.push_back(out.back());   // uint4 loads of the x table
 }
 
+// Column strips of one level for blur_kernel: (first column, mode).  Full 248-px strips while they fit; the remainder
+// goes to the cheapest cover by narrower strips (cost = row steps of a wave: 70 full, 38 half, 22 quarter).
+std::vector<std::pair<int, int>> blur_strips(int w) {
+  std::vector<std::pair<int, int>> out;
+  int x = 0;
+  while (w - x >= BLUR_W) { out.push_back({x, 0}); x += BLUR_W; }
+  const int rem = w - x;
+  if (rem <= 0) return out;
+  const int wid[3] = {BLUR_W, 120, 56}, cost[3] = {70, 38, 22};
+  int best_cost = 1 << 30, best[3] = {1, 0, 0};
+  for (int a = 0; a <= 1; ++a)
+    for (int b = 0; b <= 2; ++b)
+      for (int c = 0; c <= 4; ++c) {
+        if (a * wid[0] + b * wid[1] + c * wid[2] < rem) continue;
+        const int cst = a * cost[0] + b * cost[1] + c * cost[2];
+        if (cst < best_cost) { best_cost = cst; best[0] = a; best[1] = b; best[2] = c; }
+      }
+  for (int m = 0; m < 3; ++m)
+    for (int k = 0; k < best[m] && x < w; ++k) { out.push_back({x, m}); x += wid[m]; }
+  return out;
+}
+
 }  // namespace
 
 int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
@@ -1066,9 +1086,7 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
     L.cand_off = coff;
     L.cand_cap = (iw > 0 && ih > 0) ? (unsigned)(((iw + 1) / 2) * ((ih + 1) / 2)) : 0u;
     coff += (L.cand_cap + 63u) & ~63u;
-    L.btiles_x = (L.w + BLUR_W - 1) / BLUR_W;
-    L.btile_start = bt;
-    bt += L.btiles_x * ((L.h + BLUR_H - 1) / BLUR_H);
+    bt += (int)blur_strips(L.w).size() * ((L.h + BLUR_H - 1) / BLUR_H);
     L.ftiles_x = iw > 0 ? (iw + FT_W - 1) / FT_W : 0;
     L.ftile_start = ft;
     ft += (iw > 0 && ih > 0) ? L.ftiles_x * ((ih + FT_H - 1) / FT_H) : 0;
@@ -1087,23 +1105,24 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
     h->resize_tab_off[2 * l + 1] = (unsigned)tab.size();
     build_resize_tab(g.lv[l - 1].h, g.lv[l].h, tab);
   }
-  // tile -> (level, tx, ty) tables of the blur and FAST launches, behind the resize tables
-  auto push_tiles = [&](bool fast) {
-    for (int l = 0; l < p.n_levels; ++l) {
-      const OrbLevelGeom& L = g.lv[l];
-      const int iw = L.w - 2 * EDGE, ih = L.h - 2 * EDGE;
-      const int nx = fast ? L.ftiles_x : L.btiles_x;
-      const int ny = fast ? ((iw > 0 && ih > 0) ? (ih + FT_H - 1) / FT_H : 0) : (L.h + BLUR_H - 1) / BLUR_H;
-      for (int ty = 0; ty < ny; ++ty)
-        for (int tx = 0; tx < nx; ++tx) tab.push_back((unsigned)l | ((unsigned)tx << 3) | ((unsigned)ty << 17));
-    }
-  };
-  if (g.lv[0].w > 16383 * 62 || g.lv[0].h > 32767 * 16) return orbx_fail(h, ORBX_ERR_INVALID, "image too large for the tile tables");
+  // tile tables of the blur (strips, see blur_kernel) and FAST (level, tx, ty) launches, behind the resize tables
+  if (g.lv[0].w > 8191 * 4 || g.lv[0].h > 16383 * 16) return orbx_fail(h, ORBX_ERR_INVALID, "image too large for the tile tables");
   h->btile_tab_off = (unsigned)tab.size();
-  push_tiles(false);
+  for (int l = 0; l < p.n_levels; ++l) {
+    const std::vector<std::pair<int, int>> strips = blur_strips(g.lv[l].w);
+    for (int ty = 0; ty < (g.lv[l].h + BLUR_H - 1) / BLUR_H; ++ty)
+      for (const auto& st : strips)
+        tab.push_back((unsigned)l | ((unsigned)st.second << 3) | ((unsigned)(st.first / 4) << 5) | ((unsigned)ty << 18));
+  }
   if ((int)(tab.size() - h->btile_tab_off) != bt) return orbx_fail(h, ORBX_ERR_INVALID, "internal: blur tile table size mismatch");
   h->ftile_tab_off = (unsigned)tab.size();
-  push_tiles(true);
+  for (int l = 0; l < p.n_levels; ++l) {
+    const OrbLevelGeom& L = g.lv[l];
+    const int iw = L.w - 2 * EDGE, ih = L.h - 2 * EDGE;
+    const int ny = (iw > 0 && ih > 0) ? (ih + FT_H - 1) / FT_H : 0;
+    for (int ty = 0; ty < ny; ++ty)
+      for (int tx = 0; tx < L.ftiles_x; ++tx) tab.push_back((unsigned)l | ((unsigned)tx << 3) | ((unsigned)ty << 17));
+  }
   if ((int)(tab.size() - h->ftile_tab_off) != ft) return orbx_fail(h, ORBX_ERR_INVALID, "internal: FAST tile table size mismatch");
   if (int rc = orbx_reserve(h, h->resize_tab, sizeof(unsigned) * (tab.size() + 1))) return rc;
   ORBX_HIP(h, hipMemcpy(h->resize_tab.p, tab.data(), sizeof(unsigned) * tab.size(), hipMemcpyHostToDevice));
