@@ -874,11 +874,23 @@ constexpr int PB_ROWS = 37, PB_PITCH = 11;   // blurred 37x37 patch: 10 dwords p
 __constant__ unsigned c_ic_ones[256];
 __constant__ unsigned c_ic_col[256];
 
+// What binds this kernel (PMC, 128-pair batch): the texture addresser — TA busy 86 %, VALU 50 %, LDS 28 % — i.e. the
+// scattered row segments of the two patches, not arithmetic or latency.  Measured and dropped: all pixel loads hoisted
+// in front of their first use (7 -> 2 dependent round trips: +-0), 6 waves/SIMD by a VGPR cap (slower), 16-byte lane
+// loads (unaligned wide accesses split: 0.31 -> 0.36 ms), the test pattern as floats in LDS (ds_read_b128: slower).
 // Four keypoints per wave, 16 lanes each: the per-keypoint work that every lane would otherwise repeat (slot and
 // key decode, the three centroid reductions, fastAtan2, the f64 sin/cos) is shared by 4 keypoints per instruction.
 // Lane li of a group owns centroid tasks t = it*16 + li and descriptor bits r*16 + li (it, r = 0..15); a ballot
 // delivers 16 bits of each of the four descriptors at once.
 constexpr int DG_PER_WAVE = 4, DG_PER_BLOCK = 16;   // 16 lanes per keypoint
+typedef float desc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int row16_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x124 /* row_ror:4 */, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x122 /* row_ror:2 */, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x121 /* row_ror:1 */, 0xf, 0xf, false);
+  return v;
+}
 
 __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, int blocks_per_img,
                                                        const unsigned long long* __restrict__ sel2,
@@ -958,12 +970,8 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
         sC += (r - 15) * (int)sI;
       }
     }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-      sA += __shfl_xor(sA, off);
-      sB += __shfl_xor(sB, off);
-      sC += __shfl_xor(sC, off);
-    }
+    // sums over the 16 lanes of the group = one DPP row: four rotate-and-add steps, no LDS crossbar
+    sA = row16_sum(sA); sB = row16_sum(sB); sC = row16_sum(sC);
     const int m10 = sA - 15 * sB, m01 = sC;
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     float ca, sa;
@@ -974,17 +982,23 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
     // keypoints.  Fully unrolled so that the word / shift a round's bits go to are compile-time constants (with a
     // partial unroll the four 64-bit words were updated through selects: ~16 extra VALU instructions per round).
     unsigned long long word[4] = {0ull, 0ull, 0ull, 0ull};
+    const desc_f2 ca2 = {ca, ca}, sa2 = {sa, sa}, magic2 = {12582912.f, 12582912.f};
+    // byte (row + 18) * pitch + col + 18 of the patch from the raw float bits: the 24-bit multiply sees 0x400000 + row, the
+    // column term carries the whole 0x4B400000 + col
+    constexpr unsigned kBias = 0x400000u * (PB_PITCH * 4) + 0x4B400000u - (18u * (PB_PITCH * 4) + 18u);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      // rotated test points, both ends of the pair per packed-f32 instruction (each product and sum rounded on its own,
+      // as the reference's scalar code); rint by the 1.5*2^23 trick: the low 24 bits of (x + magic) are 0x400000 + rint(x)
       const int pr = s_pat[r * 16 + li];
-      const float px0 = (float)(signed char)(pr & 0xff), py0 = (float)(signed char)((pr >> 8) & 0xff);
-      const float px1 = (float)(signed char)((pr >> 16) & 0xff), py1 = (float)(signed char)((pr >> 24) & 0xff);
-      const int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, ca), __fmul_rn(py0, sa)));
-      const int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, sa), __fmul_rn(py0, ca)));
-      const int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, ca), __fmul_rn(py1, sa)));
-      const int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, sa), __fmul_rn(py1, ca)));
-      const int t0 = pbb[(iy0 + 18) * (PB_PITCH * 4) + ix0 + 18];
-      const int t1 = pbb[(iy1 + 18) * (PB_PITCH * 4) + ix1 + 18];
+      const desc_f2 X = {(float)(signed char)(pr & 0xff), (float)(signed char)((pr >> 16) & 0xff)};
+      const desc_f2 Y = {(float)(signed char)((pr >> 8) & 0xff), (float)(signed char)((pr >> 24) & 0xff)};
+      const desc_f2 fx = X * ca2 - Y * sa2 + magic2;
+      const desc_f2 fy = X * sa2 + Y * ca2 + magic2;
+      const unsigned a0 = __umul24(__float_as_uint(fy[0]), PB_PITCH * 4) + __float_as_uint(fx[0]) - kBias;
+      const unsigned a1 = __umul24(__float_as_uint(fy[1]), PB_PITCH * 4) + __float_as_uint(fx[1]) - kBias;
+      const int t0 = pbb[a0];
+      const int t1 = pbb[a1];
       const unsigned long long bal = __ballot(t0 < t1);
       const unsigned chunk = (unsigned)(bal >> (16 * grp)) & 0xffffu;        // this keypoint's bits 16r .. 16r+15
       word[r >> 2] |= (unsigned long long)chunk << (16 * (r & 3));

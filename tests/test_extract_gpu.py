@@ -51,6 +51,32 @@ def test_blur_levels_bit_exact(h2000, oracle, frame0):
         assert np.array_equal(got, want), "blur level %d: %d pixels differ" % (l, (got != want).sum())
 
 
+@pytest.mark.parametrize("w,h", [(101, 77), (249, 131), (250, 300), (333, 258), (501, 97), (641, 481), (753, 261), (997, 64), (1241, 376)])
+def test_pyramid_and_blur_levels_odd_sizes(pkg, oracle, w, h):
+    """Whole levels (not only the patches keypoints sample) at widths whose last dword holds 1, 2, 3 or 4 pixels and whose
+    remainder after the 248-px blur strips exercises the full, half and quarter strip modes; heights below, at and above
+    one 256-row block: BORDER_REFLECT_101 at all four edges, resize windows clamped at the right edge."""
+    rng = np.random.default_rng(w * 1000 + h)
+    L = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    R = np.ascontiguousarray(L[:, ::-1])
+    hd = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 500, device=0, max_w=w, max_h=h, max_batch=1)
+    try:
+        hd.process_stereo(L, R)
+        p = oracle.orb_params(500)
+        for img_i, img in enumerate((L, R)):
+            for l in range(8):
+                if l > 0:
+                    want = oracle.orb_pyramid_level(img, p, l)
+                    got = hd.debug_level(img_i, l)
+                    assert np.array_equal(got, want), "%dx%d level %d image %d: %d pixels differ" % (w, h, l, img_i, (got != want).sum())
+                want = oracle.orb_blur_level(img, p, l)
+                got = hd.debug_level(img_i, l, blurred=True)
+                bad = np.argwhere(got != want)
+                assert len(bad) == 0, "%dx%d blur level %d image %d: %d pixels differ, first (y,x)=%s" % (w, h, l, img_i, len(bad), bad[:1])
+    finally:
+        hd.close()
+
+
 def test_fast_candidates_bit_exact(h2000, oracle, frame0):
     L, R, _ = frame0
     p = oracle.orb_params(2000)
