@@ -877,7 +877,9 @@ __constant__ unsigned c_ic_col[256];
 // What binds this kernel (PMC, 128-pair batch): the texture addresser — TA busy 86 %, VALU 50 %, LDS 28 % — i.e. the
 // scattered row segments of the two patches, not arithmetic or latency.  Measured and dropped: all pixel loads hoisted
 // in front of their first use (7 -> 2 dependent round trips: +-0), 6 waves/SIMD by a VGPR cap (slower), 16-byte lane
-// loads (unaligned wide accesses split: 0.31 -> 0.36 ms), the test pattern as floats in LDS (ds_read_b128: slower).
+// loads (unaligned wide accesses split: 0.31 -> 0.36 ms), the test pattern as floats in LDS (ds_read_b128: slower),
+// 8-byte loads at aligned addresses with the misalignment undone in the arithmetic (24 loads instead of 29, bit-exact,
+// 0.31 -> 0.32 ms; per-lane task constants must then be kept from being hoisted out of the keypoint loop, ~50 VGPRs).
 // Four keypoints per wave, 16 lanes each: the per-keypoint work that every lane would otherwise repeat (slot and
 // key decode, the three centroid reductions, fastAtan2, the f64 sin/cos) is shared by 4 keypoints per instruction.
 // Lane li of a group owns centroid tasks t = it*16 + li and descriptor bits r*16 + li (it, r = 0..15); a ballot
