@@ -6,12 +6,12 @@ TAG=${1:-rXX}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-python bench.py > $O/bench_b128.json 2> $O/bench_b128.err
+python bench.py > $O/bench_b256.json 2> $O/bench_b256.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-files > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files > /dev/null 2> $O/pmc_write.err
 cd $R
-python scripts/pmc_summary.py $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) 128 2000 $O/pmc_traffic.json > $O/pmc_hbm_traffic_b128.txt
-cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/bench_b128_kernel_stats.csv
-tail -1 $O/bench_b128.json | cut -c1-600
+python scripts/pmc_summary.py $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) 256 2000 $O/pmc_traffic.json > $O/pmc_hbm_traffic_b256.txt
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/bench_b256_kernel_stats.csv
+tail -1 $O/bench_b256.json | cut -c1-600
