@@ -194,14 +194,23 @@ def main():
     # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run
     # separately: scripts/pmc_summary.py -> profiles/*_pmc_traffic.json); counters cannot be read live here
     traffic = None
+    valu = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if pmc.get("batch") == args.batch and pmc.get("n_features") == args.features:
-            traffic = pmc["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+            kd = pmc["kernels"].get(dom_name, {})
+            traffic = kd.get("hbm_bytes_per_launch")
+            # what actually binds these byte/integer kernels: VALU issue.  Wave-instructions per launch from the SQ pass
+            # (same file), priced with the launch time measured live: a SIMD issues one wave64 VALU instruction per 4
+            # cycles, 1024 SIMDs at 2.4 GHz = 614.4 G wave-instructions/s.
+            if kd.get("valu_wave_instr_per_launch") and dom_ms > 0:
+                rate = kd["valu_wave_instr_per_launch"] / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9
+                valu = dict(wave_instr_per_launch=kd["valu_wave_instr_per_launch"], achieved=round(rate, 1), peak=614.4,
+                            unit="G wave-instr/s", frac=round(rate / 614.4, 4))
     except Exception:
         traffic = None
     roofline = dict(bound="hbm", kernel=dom_name, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
+                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, valu_issue=valu,
                     algorithmic_bytes_per_launch=int(per_launch.get(dom_name, 0)),
                     avg_launch_us=round(dom_ms / max(dom_launches, 1) * 1e3, 2),
                     kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in sorted(acc.items())},
