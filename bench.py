@@ -374,6 +374,23 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         for x in hs:
             x.close()
         out["concurrent_windows"] = dict(windows=nwin, lm_iters_per_s=round(sum(counts) / dtc, 2), note="8 independent windows, one handle and host thread each")
+    else:
+        # the other natural sharding: every stream has its own map, so rank r solves ITS OWN window — no
+        # collective in the data path; aggregate LM iterations/s over the ranks
+        import torch
+        import torch.distributed as dist
+        own = P.synth.ba_window(100 + rank, 20, 2000, P.BA_OBS)
+        h.ba_solve_visual(cam, cfg, own["poses_cw"], own["fixed_cw"], own["points"], own["obs"])
+        dist.barrier()
+        t0 = time.perf_counter()
+        n_it = 0
+        for _ in range(reps):
+            n_it += h.ba_solve_visual(cam, cfg, own["poses_cw"], own["fixed_cw"], own["points"], own["obs"])["iterations"]
+        dto = P.dist.allreduce_max_seconds(time.perf_counter() - t0, dev)
+        tot = torch.tensor([float(n_it)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        out["independent_windows"] = dict(windows=world, lm_iters_per_s=round(float(tot.item()) / dto, 2),
+                                          note="one window per rank (its own map), no collective")
     return out
 
 
