@@ -82,6 +82,11 @@ __global__ __launch_bounds__(256) void copy_l0_kernel(const uint8_t* __restrict_
 // v_dot4_u32_u8:  cx0*p0 + cx1*p1 = (cx0-1)*p0 + cx1*p1 + p0  (cx0 = 256-cx1 can be 256, cx0-1 fits a byte).
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
 constexpr int RESIZE_ROWS = 2;   // measured: 0.245 ms (1 row) -> 0.196 ms (2 rows) = 4 rows, over the 7 launches of a 128-pair batch
+// byte 2 of four dwords as one dword: three v_perm_b32 / or instead of four shifts and three shift-ors
+__device__ __forceinline__ unsigned pack_byte2(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return __builtin_amdgcn_perm(b, a, 0x0c0c0602u) | __builtin_amdgcn_perm(d, c, 0x06020c0cu);
+}
+
 __device__ __forceinline__ unsigned resize_h(unsigned long long win, int o, unsigned coef) {
   const unsigned pr = (unsigned)(win >> (8 * o));
   return __builtin_amdgcn_udot4(pr, coef, pr & 0xffu, false);
@@ -123,18 +128,16 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
     const int y = yb + 16 * r;
     if (y >= h) break;
     const unsigned cy1 = yt[r] & 0xffffu, cy0 = 256u - cy1;
-    unsigned packed = 0;
+    unsigned vv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (x0 + k < w) {
-        const int o = (int)(xt[k] >> 16) - xb;             // 0..7
-        const unsigned cx1 = xt[k] & 0xffffu;
-        const unsigned coef = (255u - cx1) | (cx1 << 8);   // (cx0 - 1, cx1)
-        const unsigned h0 = resize_h(w0[r], o, coef), h1 = resize_h(w1[r], o, coef);   // 8.8
-        const unsigned v = cy0 * h0 + cy1 * h1;                                        // 16.16
-        packed |= ((v + 32768u) >> 16) << (8 * k);
-      }
+    for (int k = 0; k < 4; ++k) {                           // (pixels past the row end compute garbage into the row padding)
+      const int o = (int)(xt[k] >> 16) - xb;               // 0..7
+      const unsigned cx1 = xt[k] & 0xffffu;
+      const unsigned coef = (255u - cx1) | (cx1 << 8);     // (cx0 - 1, cx1)
+      const unsigned h0 = resize_h(w0[r], o, coef), h1 = resize_h(w1[r], o, coef);   // 8.8
+      vv[k] = cy0 * h0 + cy1 * h1 + 32768u;                                          // 16.16, rounded
     }
+    const unsigned packed = pack_byte2(vv[0], vv[1], vv[2], vv[3]);
     *reinterpret_cast<unsigned*>(dst + (size_t)y * dp + x0) = packed;
   }
 }
@@ -274,17 +277,17 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
         p1 = *reinterpret_cast<const unsigned*>(rowp(y + 8) + xl);
         unsigned hs[4];
         blur_row(cur, edge, be, hs);
-        unsigned packed = 0;
+        unsigned vv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           pr[(i + 5) % 6][k] = hprev[k] | (hs[k] << 16);      // rows (y+5, y+6)
           hprev[k] = hs[k];
-          unsigned v = 18u * hs[k];
+          unsigned v = 18u * hs[k] + 32768u;                   // rounding constant rides on the first multiply-add
           v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[i % 6][k]), T0, v, false);
           v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 2) % 6][k]), T1, v, false);
-          v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 4) % 6][k]), T2, v, false);
-          packed |= ((v + 32768u) >> 16) << (8 * k);
+          vv[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 4) % 6][k]), T2, v, false);
         }
+        const unsigned packed = pack_byte2(vv[0], vv[1], vv[2], vv[3]);   // (v >> 16) of the four 16.16 sums
         if (active && (M == 1 || y < nrows_l)) *reinterpret_cast<unsigned*>(dst + (size_t)(ys + y) * dpitch + x0) = packed;
       }
     }
