@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
 #pragma unroll
   for (int r = 0; r < RESIZE_ROWS; ++r) {
     const int y0 = (int)(yt[r] >> 16), y1 = min(y0 + 1, sh - 1);
-    __builtin_memcpy(&w0[r], src + (size_t)y0 * sp + xb, 8);     // one unaligned global_load_dwordx2 per source row
-    __builtin_memcpy(&w1[r], src + (size_t)y1 * sp + xb, 8);
+    __builtin_memcpy(&w0[r], src + (unsigned)(__umul24((unsigned)y0, (unsigned)sp) + (unsigned)xb), 8);   // one unaligned global_load_dwordx2
+    __builtin_memcpy(&w1[r], src + (unsigned)(__umul24((unsigned)y1, (unsigned)sp) + (unsigned)xb), 8);   // per source row, 32-bit offset
   }
 #pragma unroll
   for (int r = 0; r < RESIZE_ROWS; ++r) {
@@ -135,10 +135,10 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
       const unsigned cx1 = xt[k] & 0xffffu;
       const unsigned coef = (255u - cx1) | (cx1 << 8);     // (cx0 - 1, cx1)
       const unsigned h0 = resize_h(w0[r], o, coef), h1 = resize_h(w1[r], o, coef);   // 8.8
-      vv[k] = cy0 * h0 + cy1 * h1 + 32768u;                                          // 16.16, rounded
+      vv[k] = __umul24(cy0, h0) + __umul24(cy1, h1) + 32768u;                                        // 16.16, rounded
     }
     const unsigned packed = pack_byte2(vv[0], vv[1], vv[2], vv[3]);
-    *reinterpret_cast<unsigned*>(dst + (size_t)y * dp + x0) = packed;
+    *reinterpret_cast<unsigned*>(dst + (unsigned)(__umul24((unsigned)y, (unsigned)dp) + (unsigned)x0)) = packed;
   }
 }
 
@@ -244,8 +244,10 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
   const int xl = max(0, min(x0, pitch - 4));
   // input rows q = 0 .. nrows+5 are image rows reflect(ys-3+q); p0/p1 hold this lane's dword of rows q and q+1
   const int last = (M > 1 ? max(nrows_l, 1) : nrows) + 5;
-  auto rowp = [&](int q) { return src + (size_t)reflect101_once(ys - 3 + min(q, last), h) * pitch; };
-  unsigned p0 = *reinterpret_cast<const unsigned*>(rowp(0) + xl), p1 = *reinterpret_cast<const unsigned*>(rowp(1) + xl);
+  // 32-bit byte offsets from the (wave-uniform) level base: scalar base + one VGPR offset per access instead of 64-bit
+  // per-lane pointer arithmetic (v_mad_u64_u32 is a quarter-rate instruction: four of them per row were a fifth of the row)
+  auto rowp = [&](int q) { return src + (unsigned)(__umul24((unsigned)reflect101_once(ys - 3 + min(q, last), h), (unsigned)pitch) + (unsigned)xl); };
+  unsigned p0 = *reinterpret_cast<const unsigned*>(rowp(0)), p1 = *reinterpret_cast<const unsigned*>(rowp(1));
   // Vertical taps on PAIRS of rows: the 8.8 horizontal sums fit 16 bits, so two consecutive rows of one pixel share a
   // register and v_dot2_u32_u16 applies two taps at once: out(y) = (w0,w1).(18,34) + (w2,w3).(48,56) + (w4,w5).(48,34)
   // + 18 w6 — three dot2 and one mad instead of three adds and four multiplies.  pr[q % 6] = rows (q, q+1).
@@ -255,7 +257,7 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
   for (int i = 0; i < 6; ++i) {
     const unsigned cur = p0;
     p0 = p1;
-    p1 = *reinterpret_cast<const unsigned*>(rowp(i + 2) + xl);
+    p1 = *reinterpret_cast<const unsigned*>(rowp(i + 2));
     unsigned hs[4];
     blur_row(cur, edge, be, hs);
     if (i > 0) {
@@ -274,7 +276,7 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
         // input row q = y+6 (image row ys+y+3) arrives; window rows are q = y .. y+6
         const unsigned cur = p0;
         p0 = p1;
-        p1 = *reinterpret_cast<const unsigned*>(rowp(y + 8) + xl);
+        p1 = *reinterpret_cast<const unsigned*>(rowp(y + 8));
         unsigned hs[4];
         blur_row(cur, edge, be, hs);
         unsigned vv[4];
@@ -282,13 +284,13 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
         for (int k = 0; k < 4; ++k) {
           pr[(i + 5) % 6][k] = hprev[k] | (hs[k] << 16);      // rows (y+5, y+6)
           hprev[k] = hs[k];
-          unsigned v = 18u * hs[k] + 32768u;                   // rounding constant rides on the first multiply-add
+          unsigned v = __umul24(18u, hs[k]) + 32768u;          // (hs < 2^16) rounding constant rides on the first multiply-add
           v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[i % 6][k]), T0, v, false);
           v = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 2) % 6][k]), T1, v, false);
           vv[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 4) % 6][k]), T2, v, false);
         }
         const unsigned packed = pack_byte2(vv[0], vv[1], vv[2], vv[3]);   // (v >> 16) of the four 16.16 sums
-        if (active && (M == 1 || y < nrows_l)) *reinterpret_cast<unsigned*>(dst + (size_t)(ys + y) * dpitch + x0) = packed;
+        if (active && (M == 1 || y < nrows_l)) *reinterpret_cast<unsigned*>(dst + (unsigned)(__umul24((unsigned)(ys + y), (unsigned)dpitch) + (unsigned)x0)) = packed;
       }
     }
   }
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   const int t = g.fast_threshold;
   // phase 1: compass pre-test, 4 positions per task
   for (int task = tid; task < ntask; task += 256) {
-    const int j = (int)(((unsigned)task * inv) >> 16), tq = task - j * qpr;
+    const int j = (int)(__umul24((unsigned)task, inv) >> 16), tq = task - (int)__umul24((unsigned)j, (unsigned)qpr);   // (v_mul_lo_u32 is quarter rate)
     const unsigned* rowc = reinterpret_cast<const unsigned*>(&sp[j + 3][0]) + tq;
     const unsigned c0 = rowc[0], c1 = rowc[1], c2 = rowc[2];
     const unsigned up = reinterpret_cast<const unsigned*>(&sp[j][0])[tq + 1];       // y-3
@@ -947,14 +949,16 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
     // stage the blurred 37x37 patch (rows of 40 bytes starting at kx-18) into this group's LDS patch: 5 lanes x 8 bytes
     // per row, 3 rows per step (no division, half the loads of a dword-per-lane loop)
     {
-      const uint8_t* b0 = blr + (size_t)(ky - 18) * bpitch + (kx - 18);
       const int sub = li / 5, c2 = li - 5 * sub;           // li = 15 idles
+      // (row pointers by 32-bit steps: a 64-bit multiply-add per load is a quarter-rate instruction)
+      const uint8_t* b0 = blr + (unsigned)(__umul24((unsigned)(ky - 18 + sub), (unsigned)bpitch) + (unsigned)(kx - 18 + 8 * c2));
+      const unsigned bstep = 3u * (unsigned)bpitch;
 #pragma unroll
       for (int it = 0; it < 13; ++it) {
         const int r = 3 * it + sub;
         if (sub < 3 && r < PB_ROWS) {
           unsigned long long v;
-          __builtin_memcpy(&v, b0 + (size_t)r * bpitch + 8 * c2, 8);
+          __builtin_memcpy(&v, b0 + (unsigned)it * bstep, 8);
           myp[r * PB_PITCH + 2 * c2] = (unsigned)v;
           myp[r * PB_PITCH + 2 * c2 + 1] = (unsigned)(v >> 32);
         }
@@ -963,12 +967,14 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
     // intensity centroid over the 749-pixel disc straight from the level image (integer, order independent)
     int sA = 0, sB = 0, sC = 0;
     {
-      const uint8_t* a0 = src + (size_t)(ky - 15) * pitch + (kx - 15);
+      // task t = it*16 + li: row 2 it + (li >> 3), dword li & 7 (row 31 does not exist: zero weights, re-reads row 30)
+      const uint8_t* a0 = src + (unsigned)(__umul24((unsigned)(ky - 15 + (li >> 3)), (unsigned)pitch) + (unsigned)(kx - 15 + 4 * (li & 7)));
+      const unsigned astep = 2u * (unsigned)pitch;
 #pragma unroll 4
       for (int it = 0; it < 16; ++it) {
         const int t = it * 16 + li;
-        const int r = min(t >> 3, 30), c = t & 7;
-        const unsigned px = ld_u32(a0 + (size_t)r * pitch + 4 * c);
+        const int r = min(t >> 3, 30);
+        const unsigned px = ld_u32(a0 + ((unsigned)it * astep - (t >> 3 > 30 ? (unsigned)pitch : 0u)));
         const unsigned sI = __builtin_amdgcn_udot4(px, s_ones[t], 0u, false);
         sA += (int)__builtin_amdgcn_udot4(px, s_col[t], 0u, false);
         sB += (int)sI;
