@@ -752,11 +752,17 @@ __device__ __forceinline__ void rank_pass(const unsigned long long* __restrict__
   }
 }
 
-__global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img, XcdMap xm, const unsigned long long* __restrict__ sel,
+// Besides the canonical list (sel2, the order of the output slots) the kernel leaves the kept keypoints of the level a
+// second time in `sel` — which it has consumed by then — in SPATIAL order: by 128-pixel column band, then by row, each
+// entry x | y << 16 | slot-in-level << 32.  describe_kernel walks that list, so the 16 keypoints of a block are
+// neighbours in one band and share the cache lines of their patch rows (results go to the keypoint's slot: the order
+// of processing is free).
+__global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img, XcdMap xm, unsigned long long* __restrict__ sel,
                                                            const unsigned* __restrict__ sel_count,
                                                            unsigned long long* __restrict__ sel2,
                                                            unsigned* __restrict__ kept) {
   __shared__ unsigned long long chunk[2048];
+  __shared__ unsigned skey[2048];
   __shared__ unsigned s_thr, s_keep;
   int img, l;
   if (!xcd_decode(xm, n_img, img, l)) return;
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
   const int tid = threadIdx.x;
   const unsigned M = sel_count[il];
   const int quota = g.lv[l].quota;
-  const unsigned long long* in = sel + (size_t)img * g.cand_total + g.lv[l].cand_off;
+  unsigned long long* in = sel + (size_t)img * g.cand_total + g.lv[l].cand_off;
   unsigned long long* out = sel2 + (size_t)img * g.cand_total + g.lv[l].cand_off;
   if (tid == 0) { s_thr = 0xffffffffu; s_keep = 0; }
   __syncthreads();
@@ -793,21 +799,77 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
     }
     __syncthreads();
     for (unsigned i = tid; i < M; i += 1024) out[i] = chunk[i];
-    if (M <= (unsigned)quota) { if (tid == 0) kept[il] = M; return; }
-    const unsigned thr = (unsigned)(chunk[quota - 1] >> 32);   // ~orderable(response of the n-th best); ties with it are kept
-    for (unsigned i = tid; i < M; i += 1024)
-      if ((unsigned)(chunk[i] >> 32) <= thr && (i + 1 >= M || (unsigned)(chunk[i + 1] >> 32) > thr)) kept[il] = i + 1;
+    if (M <= (unsigned)quota) {
+      if (tid == 0) { kept[il] = M; s_keep = M; }
+    } else {
+      const unsigned thr = (unsigned)(chunk[quota - 1] >> 32);   // ~orderable(response of the n-th best); ties with it are kept
+      for (unsigned i = tid; i < M; i += 1024)
+        if ((unsigned)(chunk[i] >> 32) <= thr && (i + 1 >= M || (unsigned)(chunk[i + 1] >> 32) > thr)) { kept[il] = i + 1; s_keep = i + 1; }
+    }
+    __syncthreads();
+    // spatial order of the kept keypoints: counting sort by cell = (128-px column band, block of rows) — a walk down
+    // each band; the order inside a cell is whatever the atomics give (processing order only, results are unaffected)
+    const unsigned K = s_keep;
+    int rsh = 4;                                                   // 16-row blocks, coarser if the level is huge
+    while ((unsigned)(((g.lv[l].w + 127) >> 7) * ((g.lv[l].h >> rsh) + 1)) > 1024u) ++rsh;
+    const unsigned nrb = (unsigned)(g.lv[l].h >> rsh) + 1u;
+    skey[tid] = 0u;                                                // histogram in skey[0..1024), positions in skey[1024..)
+    __syncthreads();
+    unsigned mycell[2], mypos[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned i = tid + 1024u * e;
+      if (i < K) {
+        const unsigned xy = (unsigned)chunk[i];
+        mycell[e] = ((xy & 0xffffu) >> 7) * nrb + ((xy >> 16) >> rsh);
+        mypos[e] = atomicAdd(&skey[mycell[e]], 1u);
+      }
+    }
+    __syncthreads();
+    // exclusive prefix over the 1024 counters: scan inside each wave, then add the totals of the waves before
+    {
+      const unsigned v = skey[tid];
+      unsigned inc = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(inc, off);
+        if ((tid & 63) >= off) inc += t;
+      }
+      if ((tid & 63) == 63) skey[1024 + (tid >> 6)] = inc;
+      __syncthreads();
+      unsigned before = 0;
+      for (int w = 0; w < (tid >> 6); ++w) before += skey[1024 + w];
+      __syncthreads();
+      skey[tid] = before + inc - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned i = tid + 1024u * e;
+      if (i < K) in[skey[mycell[e]] + mypos[e]] = (chunk[i] & 0xffffffffull) | ((unsigned long long)i << 32);
+    }
     return;
   }
   for (unsigned g0 = 0; g0 < M; g0 += 4096) rank_pass<4>(in, out, M, g0, chunk, quota, &s_thr);
   __syncthreads();
-  if (M <= (unsigned)quota) { if (tid == 0) kept[il] = M; return; }
+  if (M <= (unsigned)quota) {
+    if (tid == 0) kept[il] = M;
+    __threadfence();
+    __syncthreads();
+    for (unsigned i = tid; i < M; i += 1024) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
+    return;
+  }
   const unsigned thr = s_thr;   // ~orderable(response of the n-th best); keep hi <= thr
   unsigned cnt = 0;
   for (unsigned i = tid; i < M; i += 1024) cnt += ((unsigned)(in[i] >> 32) <= thr) ? 1u : 0u;
   atomicAdd(&s_keep, cnt);
   __syncthreads();
   if (tid == 0) kept[il] = s_keep;
+  // (more than 2048 candidates on one level: no spatial sort, the list is the canonical order)
+  __threadfence();
+  __syncthreads();
+  const unsigned K = min(s_keep, M);
+  for (unsigned i = tid; i < K; i += 1024) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
 }
 
 // ---- A.7 orientation + A.8 descriptor: one wave per keypoint ---------------------------------------------
@@ -901,6 +963,7 @@ __device__ __forceinline__ int row16_sum(int v) {
 
 __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, int blocks_per_img,
                                                        const unsigned long long* __restrict__ sel2,
+                                                       const unsigned long long* __restrict__ spatial,
                                                        const unsigned* __restrict__ kept,
                                                        orbx_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
                                                        int* __restrict__ nkp, int cap_kp, float patch_size,
@@ -930,18 +993,23 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
   }
   unsigned* myp = pb[wave * DG_PER_WAVE + grp];
   const uint8_t* pbb = reinterpret_cast<const uint8_t*>(myp);
-  for (unsigned base = (bx * 4 + wave) * DG_PER_WAVE; base < limit; base += blocks_per_img * DG_PER_BLOCK) {
-    const unsigned slot_raw = base + grp;
-    const bool active = slot_raw < limit;
-    const unsigned slot = active ? slot_raw : base;        // idle groups shadow the wave's first keypoint
+  for (unsigned base = (bx * 4 + wave) * DG_PER_WAVE; base < total; base += blocks_per_img * DG_PER_BLOCK) {
+    // position `pos` of the image's spatially ordered walk (levels one after the other) -> level, entry of the level's
+    // spatial list -> the keypoint and its output slot
+    const unsigned pos_raw = base + grp;
+    const unsigned pos = pos_raw < total ? pos_raw : base;  // idle groups shadow the wave's first keypoint
     int l = 0;
     unsigned lbase = 0;
 #pragma unroll
-    for (int i = 1; i < ORBX_MAX_LEVELS; ++i) if (slot >= start[i]) { l = i; lbase = start[i]; }
-    // (levels beyond n_levels have start == total > slot, so l < n_levels)
-    const unsigned long long key = sel2[(size_t)img * g.cand_total + g.lv[l].cand_off + (slot - lbase)];
-    const int kx = (int)(key & 0xffffu), ky = (int)((key >> 16) & 0xffffu);
-    const float resp = from_orderable(~(unsigned)(key >> 32));
+    for (int i = 1; i < ORBX_MAX_LEVELS; ++i) if (pos >= start[i]) { l = i; lbase = start[i]; }
+    // (levels beyond n_levels have start == total > pos, so l < n_levels)
+    const size_t lofs = (size_t)img * g.cand_total + g.lv[l].cand_off;
+    const unsigned long long ent = spatial[lofs + (pos - lbase)];
+    const int kx = (int)(ent & 0xffffu), ky = (int)((ent >> 16) & 0xffffu);
+    const unsigned j2 = (unsigned)(ent >> 32) & 0xffffu;
+    const unsigned slot = lbase + j2;
+    const bool active = pos_raw < total && slot < limit;
+    const float resp = from_orderable(~(unsigned)(sel2[lofs + j2] >> 32));   // only needed for the output record
     int pitch;
     const uint8_t* src = level_ptr(s, g, img, l, pitch);
     const uint8_t* blr = s.blur + (size_t)img * g.slot_bytes + g.lv[l].off;
@@ -1263,7 +1331,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     }
     {
       ProfScope ps(h, "rank_select_kernel", nullptr, true);
-      hipLaunchKernelGGL(rank_select_kernel, xcd_grid(nl, n), dim3(1024), 0, st, g, n, xcd_map(nl), (const unsigned long long*)sel, sc,
+      hipLaunchKernelGGL(rank_select_kernel, xcd_grid(nl, n), dim3(1024), 0, st, g, n, xcd_map(nl), sel, sc,
                          sel2, kp);
     }
     if (fork) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
@@ -1271,7 +1339,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
       ProfScope ps(h, "describe_kernel", nullptr, true);
       const int blocks_x = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block
       hipLaunchKernelGGL(describe_kernel, xcd_grid(blocks_x, n), dim3(256), 0, st, s, g, n, xcd_map(blocks_x), blocks_x,
-                         (const unsigned long long*)sel2, kp, d_kp + (size_t)img0 * cap_kp, d_desc + (size_t)img0 * cap_kp * 32,
+                         (const unsigned long long*)sel2, (const unsigned long long*)sel, kp, d_kp + (size_t)img0 * cap_kp, d_desc + (size_t)img0 * cap_kp * 32,
                          d_nkp + img0, cap_kp, (float)h->orb.patch_size, h->d_status);
     }
     return ORBX_OK;
