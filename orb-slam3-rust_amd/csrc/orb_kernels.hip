@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void copy_l0_kernel(const uint8_t* __restrict_
 // one unaligned 8-byte window; a tap pair is (window >> 8*o) and the 8.8 horizontal sum is one
 // v_dot4_u32_u8:  cx0*p0 + cx1*p1 = (cx0-1)*p0 + cx1*p1 + p0  (cx0 = 256-cx1 can be 256, cx0-1 fits a byte).
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
-constexpr int RESIZE_ROWS = 2;   // measured: 0.245 ms (1 row) -> 0.196 ms (2 rows) = 4 rows, over the 7 launches of a 128-pair batch
+constexpr int RESIZE_ROWS = 3;   // output rows per thread (y, y+16, y+32): 1 row 0.245 ms, 2 rows 0.196 per 128 pairs; 2 / 3 / 4 rows 0.362 / 0.334 / 0.336 per 256
 // byte 2 of four dwords as one dword: three v_perm_b32 / or instead of four shifts and three shift-ors
 __device__ __forceinline__ unsigned pack_byte2(unsigned a, unsigned b, unsigned c, unsigned d) {
   return __builtin_amdgcn_perm(b, a, 0x0c0c0602u) | __builtin_amdgcn_perm(d, c, 0x06020c0cu);
