@@ -401,17 +401,19 @@ __device__ __forceinline__ int fast_arc_min_pk(int v, const int (&r)[16], bool b
   return max((int)best[0], (int)best[1]);
 }
 
-// Two-phase per tile.  Score region 64 x 32 positions (inner 62 x 30 + 1-position NMS frame), pixel tile
-// 72 x 38 bytes staged so that position i sits at byte i+4 of its LDS row (dword aligned):
+// Two-phase per tile.  Score region 64 x 48 positions (inner 62 x 46 + 1-position NMS frame), pixel tile
+// 72 x 54 bytes staged so that position i sits at byte i+4 of its LDS row (dword aligned):
 //   1. every position, 4 per thread from 5 dword LDS reads: compass pre-test — a 9-arc always contains
 //      two adjacent compass points (0,4,8,12), so a corner needs two adjacent ones both brighter than
 //      v+t or both darker than v-t; survivors (~10 %) are compacted into an LDS list;
 //   2. full arc score only for the listed positions, written into the LDS score tile;
 //   3. 3x3 NMS over the corners phase 2 found (second, much shorter list), block-aggregated append to the
 //      level's candidates.
-constexpr int FT_W = 62, FT_H = 30;          // inner tile
-constexpr int FS_W = 64, FS_H = 32;          // score region
+constexpr int FT_W = 62, FT_H = 46;          // inner tile (heights 30 / 46 / 62: 0.837 / 0.821 / 0.835 ms per 256 pairs)
+constexpr int FS_W = 64, FS_H = 48;          // score region
 constexpr int FP_PITCH = 72, FP_ROWS = FS_H + 6;
+static_assert(FP_ROWS <= 56, "the staging loop covers 2 x 28 rows");
+static_assert((FT_W / 2) * (FT_H / 2) <= 1024, "s_list holds the NMS survivors of a tile");
 
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
 
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   __shared__ __attribute__((aligned(16))) uint8_t ss[FS_H][FS_W];
   __shared__ unsigned short s_pos[FS_W * FS_H];
   __shared__ unsigned short s_cor[FS_W * FS_H];
-  __shared__ unsigned s_list[512];
+  __shared__ unsigned s_list[1024];                 // NMS survivors: at most one per 2x2 positions, 31 x 23
   __shared__ int s_npos, s_cnt, s_ncor;
   __shared__ unsigned s_base;
   int img, tile;
