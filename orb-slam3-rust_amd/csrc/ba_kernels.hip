@@ -558,6 +558,25 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     ok = s_ok;
     if (!ok) break;
     if (tid < nb) srinv[c0 + tid] = s_rv[tid];
+    if (tid == nth - 1) {
+      // the right-hand side is one more row solved against the panel: forward substitution L y = b rides along with the
+      // factorisation (y of this panel here, its effect on the entries below in the update phase), instead of 114
+      // dependent steps in one wave afterwards
+      double x[16];
+#pragma unroll
+      for (int jx = 0; jx < 16; ++jx) x[jx] = (jx < nb) ? sb[c0 + jx] : 0.0;
+#pragma unroll
+      for (int jx = 0; jx < 16; ++jx) {
+        if (jx < nb) {
+          double v = x[jx];
+#pragma unroll
+          for (int t = 0; t < jx; ++t) v = fma(-x[t], S[(size_t)(c0 + jx) * n + c0 + t], v);
+          x[jx] = v * s_rv[jx];
+        }
+      }
+#pragma unroll
+      for (int jx = 0; jx < 16; ++jx) if (jx < nb) sb[c0 + jx] = x[jx];
+    }
     {
       const int r = c0 + nb + tid;                                             // rows below the panel
       if (r < n) {
@@ -580,6 +599,12 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     __syncthreads();
     const int c1 = c0 + 16, m = n - c1;
     if (m > 0) {
+      if (tid < m) {                                                           // b_below -= L21 y_panel
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(S[(size_t)(c1 + tid) * n + c0 + k], sb[c0 + k], acc);
+        sb[c1 + tid] -= acc;
+      }
       const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2, nw = nth >> 6;
       for (int unit = tid >> 6; unit < units; unit += nw) {                    // wave-uniform
         int ti = 0, rem = unit;
@@ -605,33 +630,13 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   ok = s_ok;
   __syncthreads();
   if (ok && tid < 64 && n <= 128) {
-    // forward L y = b then backward L^T x = y, column oriented: lane holds rows `lane` and `lane+64` of the
-    // right-hand side in registers, each step broadcasts one solved entry with v_readlane; columns are
-    // fetched in chunks of 8 one chunk ahead
+    // backward L^T x = y (y is already in sb: the forward substitution ran inside the factorisation), column oriented:
+    // lane holds rows `lane` and `lane+64` of the right-hand side in registers, each step broadcasts one solved entry
+    // with v_readlane; columns are fetched in chunks of 8 one chunk ahead
     const int r0 = min(lane, n - 1), r1 = min(lane + 64, n - 1);
     double b0 = lane < n ? sb[lane] : 0.0, b1 = lane + 64 < n ? sb[lane + 64] : 0.0;
     constexpr int CH = 8;
     double l0[CH], l1[CH], rc[CH], l0n[CH], l1n[CH], rcn[CH];
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { const int c = min(j, n - 1); l0[j] = S[(size_t)r0 * n + c]; l1[j] = S[(size_t)r1 * n + c]; rc[j] = srinv[c]; }
-    for (int c0 = 0; c0 < n; c0 += CH) {
-#pragma unroll
-      for (int j = 0; j < CH; ++j) { const int c = min(c0 + CH + j, n - 1); l0n[j] = S[(size_t)r0 * n + c]; l1n[j] = S[(size_t)r1 * n + c]; rcn[j] = srinv[c]; }
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const int c = c0 + j;
-        if (c < n) {   // uniform
-          const double own = (c < 64) ? b0 : b1;
-          const int src = c & 63;
-          const int lo = __builtin_amdgcn_readlane(__double2loint(own), src), hi = __builtin_amdgcn_readlane(__double2hiint(own), src);
-          const double yc = __hiloint2double(hi, lo) * rc[j];
-          if (lane > c) b0 = fma(-l0[j], yc, b0); else if (lane == c) b0 = yc;
-          if (lane + 64 > c) b1 = fma(-l1[j], yc, b1); else if (lane + 64 == c) b1 = yc;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < CH; ++j) { l0[j] = l0n[j]; l1[j] = l1n[j]; rc[j] = rcn[j]; }
-    }
     // backward: row c of L, chunks run downwards from n-1
 #pragma unroll
     for (int j = 0; j < CH; ++j) { const int c = max(n - 1 - j, 0); l0[j] = S[(size_t)c * n + r0]; l1[j] = S[(size_t)c * n + r1]; rc[j] = srinv[c]; }
@@ -657,13 +662,6 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     if (lane + 64 < n) sb[lane + 64] = b1;
   } else if (ok && tid < 64) {
     // general n: row dot products with shuffle reductions
-    for (int r = 0; r < n; ++r) {
-      double acc = 0.0;
-      for (int k = lane; k < r; k += 64) acc = fma(S[(size_t)r * n + k], sb[k], acc);
-      acc = wave_sum(acc);
-      if (lane == 0) sb[r] = (sb[r] - acc) * srinv[r];
-      __builtin_amdgcn_wave_barrier();
-    }
     for (int r = n - 1; r >= 0; --r) {
       double acc = 0.0;
       for (int k = r + 1 + lane; k < n; k += 64) acc = fma(S[(size_t)k * n + r], sb[k], acc);
