@@ -720,6 +720,7 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
 // Canonical order of the survivors of one (image, level) + retainBest(n_l) with ties.  Up to 2048 keys: bitonic
 // sort in LDS (rank_select_kernel); more (heavy ties): rank sort — keys are unique (x,y differ), so rank = number
 // of smaller keys is a permutation.  E owned keys per thread per pass.
+constexpr int RK_NT = 256;   // threads of rank_select_kernel: one block per (image, level) — most levels hold a few hundred keys
 template <int E>
 __device__ __forceinline__ void rank_pass(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out,
                                           unsigned M, unsigned g0, unsigned long long* chunk, int quota, unsigned* s_thr) {
@@ -729,14 +730,14 @@ __device__ __forceinline__ void rank_pass(const unsigned long long* __restrict__
   unsigned rank[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const unsigned idx = g0 + e * 1024 + tid;
+    const unsigned idx = g0 + e * RK_NT + tid;
     my[e] = idx < M ? in[idx] : ~0ull;
     rank[e] = 0;
   }
   for (unsigned c0 = 0; c0 < M; c0 += CH) {
     const unsigned n = min((unsigned)CH, M - c0);
     __syncthreads();
-    for (unsigned i = tid; i < n; i += 1024) chunk[i] = in[c0 + i];
+    for (unsigned i = tid; i < n; i += RK_NT) chunk[i] = in[c0 + i];
     __syncthreads();
     for (unsigned k = 0; k < n; ++k) {
       const unsigned long long v = chunk[k];
@@ -746,7 +747,7 @@ __device__ __forceinline__ void rank_pass(const unsigned long long* __restrict__
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const unsigned idx = g0 + e * 1024 + tid;
+    const unsigned idx = g0 + e * RK_NT + tid;
     if (idx < M) {
       out[rank[e]] = my[e];
       if ((int)rank[e] == quota - 1) *s_thr = (unsigned)(my[e] >> 32);
@@ -759,7 +760,7 @@ __device__ __forceinline__ void rank_pass(const unsigned long long* __restrict__
 // entry x | y << 16 | slot-in-level << 32.  describe_kernel walks that list, so the 16 keypoints of a block are
 // neighbours in one band and share the cache lines of their patch rows (results go to the keypoint's slot: the order
 // of processing is free).
-__global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img, XcdMap xm, unsigned long long* __restrict__ sel,
+__global__ __launch_bounds__(RK_NT) void rank_select_kernel(OrbGeom g, int n_img, XcdMap xm, unsigned long long* __restrict__ sel,
                                                            const unsigned* __restrict__ sel_count,
                                                            unsigned long long* __restrict__ sel2,
                                                            unsigned* __restrict__ kept) {
@@ -778,12 +779,12 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
   __syncthreads();
   if (M == 0 || quota == 0) { if (tid == 0) kept[il] = 0; return; }
   if (M <= 2048) {
-    // the usual case (M ~ 2 n_l): bitonic sort of the keys in LDS, padded with ~0 to a power of two.  Thread t owns
-    // one compare-exchange per step; steps with stride <= 64 stay inside the 128 keys of the thread's own wave, so
-    // only the strides >= 128 need a block barrier (10 of the 55 steps at 1024 keys).
+    // the usual case (M ~ 2 n_l): bitonic sort of the keys in LDS, padded with ~0 to a power of two.  A thread owns the
+    // compare-exchanges c = tid, tid + RK_NT, ... of a step; steps with stride <= 64 stay inside the 128 keys of one
+    // (wave, c / RK_NT) pair, so only the strides >= 128 need a block barrier (10 of the 55 steps at 1024 keys).
     unsigned P = 128;
     while (P < M) P <<= 1;
-    for (unsigned i = tid; i < P; i += 1024) chunk[i] = i < M ? in[i] : ~0ull;
+    for (unsigned i = tid; i < P; i += RK_NT) chunk[i] = i < M ? in[i] : ~0ull;
     __syncthreads();
     unsigned pj = 128;
     for (unsigned k = 2; k <= P; k <<= 1) {
@@ -791,8 +792,8 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
         if (j >= 128 || pj >= 128) __syncthreads();
         else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // same wave: LDS is in order, keep the compiler honest
         pj = j;
-        if ((unsigned)tid < P / 2) {
-          const unsigned i = (((unsigned)tid & ~(j - 1)) << 1) | ((unsigned)tid & (j - 1));
+        for (unsigned c = tid; c < P / 2; c += RK_NT) {
+          const unsigned i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
           const unsigned ixj = i | j;
           const unsigned long long x = chunk[i], y = chunk[ixj];
           if ((x > y) == ((i & k) == 0)) { chunk[i] = y; chunk[ixj] = x; }
@@ -800,12 +801,12 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
       }
     }
     __syncthreads();
-    for (unsigned i = tid; i < M; i += 1024) out[i] = chunk[i];
+    for (unsigned i = tid; i < M; i += RK_NT) out[i] = chunk[i];
     if (M <= (unsigned)quota) {
       if (tid == 0) { kept[il] = M; s_keep = M; }
     } else {
       const unsigned thr = (unsigned)(chunk[quota - 1] >> 32);   // ~orderable(response of the n-th best); ties with it are kept
-      for (unsigned i = tid; i < M; i += 1024)
+      for (unsigned i = tid; i < M; i += RK_NT)
         if ((unsigned)(chunk[i] >> 32) <= thr && (i + 1 >= M || (unsigned)(chunk[i + 1] >> 32) > thr)) { kept[il] = i + 1; s_keep = i + 1; }
     }
     __syncthreads();
@@ -815,12 +816,13 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
     int rsh = 4;                                                   // 16-row blocks, coarser if the level is huge
     while ((unsigned)(((g.lv[l].w + 127) >> 7) * ((g.lv[l].h >> rsh) + 1)) > 1024u) ++rsh;
     const unsigned nrb = (unsigned)(g.lv[l].h >> rsh) + 1u;
-    skey[tid] = 0u;                                                // histogram in skey[0..1024), positions in skey[1024..)
+    for (int i = tid; i < 1024; i += RK_NT) skey[i] = 0u;          // histogram in skey[0..1024), wave totals behind it
     __syncthreads();
-    unsigned mycell[2], mypos[2];
+    constexpr int KE = 2048 / RK_NT;
+    unsigned mycell[KE], mypos[KE];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const unsigned i = tid + 1024u * e;
+    for (int e = 0; e < KE; ++e) {
+      const unsigned i = tid + (unsigned)RK_NT * e;
       if (i < K) {
         const unsigned xy = (unsigned)chunk[i];
         mycell[e] = ((xy & 0xffffu) >> 7) * nrb + ((xy >> 16) >> rsh);
@@ -828,10 +830,13 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
       }
     }
     __syncthreads();
-    // exclusive prefix over the 1024 counters: scan inside each wave, then add the totals of the waves before
+    // exclusive prefix over the 1024 counters: 1024 / RK_NT per thread, scan inside each wave, totals of the waves before
     {
-      const unsigned v = skey[tid];
-      unsigned inc = v;
+      constexpr int CE = 1024 / RK_NT;
+      unsigned cv[CE], tot = 0;
+#pragma unroll
+      for (int q = 0; q < CE; ++q) { cv[q] = skey[CE * tid + q]; tot += cv[q]; }
+      unsigned inc = tot;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const unsigned t = __shfl_up(inc, off);
@@ -839,31 +844,31 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
       }
       if ((tid & 63) == 63) skey[1024 + (tid >> 6)] = inc;
       __syncthreads();
-      unsigned before = 0;
-      for (int w = 0; w < (tid >> 6); ++w) before += skey[1024 + w];
-      __syncthreads();
-      skey[tid] = before + inc - v;
+      unsigned run = inc - tot;
+      for (int w = 0; w < (tid >> 6); ++w) run += skey[1024 + w];
+#pragma unroll
+      for (int q = 0; q < CE; ++q) { skey[CE * tid + q] = run; run += cv[q]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const unsigned i = tid + 1024u * e;
+    for (int e = 0; e < KE; ++e) {
+      const unsigned i = tid + (unsigned)RK_NT * e;
       if (i < K) in[skey[mycell[e]] + mypos[e]] = (chunk[i] & 0xffffffffull) | ((unsigned long long)i << 32);
     }
     return;
   }
-  for (unsigned g0 = 0; g0 < M; g0 += 4096) rank_pass<4>(in, out, M, g0, chunk, quota, &s_thr);
+  for (unsigned g0 = 0; g0 < M; g0 += 4 * RK_NT) rank_pass<4>(in, out, M, g0, chunk, quota, &s_thr);
   __syncthreads();
   if (M <= (unsigned)quota) {
     if (tid == 0) kept[il] = M;
     __threadfence();
     __syncthreads();
-    for (unsigned i = tid; i < M; i += 1024) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
+    for (unsigned i = tid; i < M; i += RK_NT) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
     return;
   }
   const unsigned thr = s_thr;   // ~orderable(response of the n-th best); keep hi <= thr
   unsigned cnt = 0;
-  for (unsigned i = tid; i < M; i += 1024) cnt += ((unsigned)(in[i] >> 32) <= thr) ? 1u : 0u;
+  for (unsigned i = tid; i < M; i += RK_NT) cnt += ((unsigned)(in[i] >> 32) <= thr) ? 1u : 0u;
   atomicAdd(&s_keep, cnt);
   __syncthreads();
   if (tid == 0) kept[il] = s_keep;
@@ -871,7 +876,7 @@ __global__ __launch_bounds__(1024) void rank_select_kernel(OrbGeom g, int n_img,
   __threadfence();
   __syncthreads();
   const unsigned K = min(s_keep, M);
-  for (unsigned i = tid; i < K; i += 1024) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
+  for (unsigned i = tid; i < K; i += RK_NT) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
 }
 
 // ---- A.7 orientation + A.8 descriptor: one wave per keypoint ---------------------------------------------
@@ -1333,7 +1338,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     }
     {
       ProfScope ps(h, "rank_select_kernel", nullptr, true);
-      hipLaunchKernelGGL(rank_select_kernel, xcd_grid(nl, n), dim3(1024), 0, st, g, n, xcd_map(nl), sel, sc,
+      hipLaunchKernelGGL(rank_select_kernel, xcd_grid(nl, n), dim3(RK_NT), 0, st, g, n, xcd_map(nl), sel, sc,
                          sel2, kp);
     }
     if (fork) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
