@@ -161,7 +161,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // a ring of row PAIRS of those sums in registers, vertical taps by v_dot2_u32_u16 (16.16), one dword store.
 // Lanes whose 10-px window crosses the image edge rebuild their three dwords with BORDER_REFLECT_101 from the
 // same registers (v_perm_b32, no loads).
-constexpr int BLUR_W = 248, BLUR_STRIP = 64, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo
+constexpr int BLUR_W = 248, BLUR_STRIP = 32, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo;
+// rows per wave 16 / 32 / 48 / 64 / 96 / 128: 0.307 / 0.300 / 0.302 / 0.315 / 0.366 / 0.369 ms per 256 pairs
 
 __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2, unsigned (&hs)[4]) {
   const unsigned G0 = 18u | (34u << 8) | (48u << 16) | (56u << 24);   // px x-3..x
@@ -226,7 +227,7 @@ __device__ __forceinline__ int reflect101_once(int i, int n) { return i < 0 ? -i
 
 // One wave = M row groups of 64/M lanes: group k walks rows [ys + k*64/M, ys + (k+1)*64/M) of a strip (64/M - 2)*4 px
 // wide (first and last lane of a group are halo lanes).  M = 1 is the full 248-px strip; M = 2 (120 px) and M = 4
-// (56 px) take the narrow remainder at the right of a level in 38 resp. 22 row steps instead of 70, so a remainder of
+// (56 px) take the narrow remainder at the right of a level in 22 resp. 14 row steps instead of 38, so a remainder of
 // 8 px (752 = 3*248 + 8) no longer costs a whole strip.  For M > 1 the row index is per lane (VALU), for M = 1 scalar.
 template <int M>
 __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int pitch, int w, int h, uint8_t* __restrict__ dst,
@@ -1129,14 +1130,14 @@ void build_resize_tab(int src, int dst, std::vector<unsigned>& out) {
 }
 
 // Column strips of one level for blur_kernel: (first column, mode).  Full 248-px strips while they fit; the remainder
-// goes to the cheapest cover by narrower strips (cost = row steps of a wave: 70 full, 38 half, 22 quarter).
+// goes to the cheapest cover by narrower strips (cost = row steps of a wave: rows per group + 6 halo rows).
 std::vector<std::pair<int, int>> blur_strips(int w) {
   std::vector<std::pair<int, int>> out;
   int x = 0;
   while (w - x >= BLUR_W) { out.push_back({x, 0}); x += BLUR_W; }
   const int rem = w - x;
   if (rem <= 0) return out;
-  const int wid[3] = {BLUR_W, 120, 56}, cost[3] = {70, 38, 22};
+  const int wid[3] = {BLUR_W, 120, 56}, cost[3] = {BLUR_STRIP + 6, BLUR_STRIP / 2 + 6, BLUR_STRIP / 4 + 6};
   int best_cost = 1 << 30, best[3] = {1, 0, 0};
   for (int a = 0; a <= 1; ++a)
     for (int b = 0; b <= 2; ++b)
