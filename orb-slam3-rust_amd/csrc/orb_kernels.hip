@@ -225,7 +225,7 @@ __device__ __forceinline__ void blur_row(unsigned d1, bool edge, const BlurEdge&
 // BORDER_REFLECT_101 for an index at most n-1 outside [0, n) (levels are at least 8 px, the kernel reaches 3 px out)
 __device__ __forceinline__ int reflect101_once(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
-// One wave = M row groups of 64/M lanes: group k walks rows [ys + k*64/M, ys + (k+1)*64/M) of a strip (64/M - 2)*4 px
+// One wave = M row groups of 64/M lanes: group k walks rows [ys + k*R, ys + (k+1)*R), R = BLUR_STRIP/M, of a strip (64/M - 2)*4 px
 // wide (first and last lane of a group are halo lanes).  M = 1 is the full 248-px strip; M = 2 (120 px) and M = 4
 // (56 px) take the narrow remainder at the right of a level in 22 resp. 14 row steps instead of 38, so a remainder of
 // 8 px (752 = 3*248 + 8) no longer costs a whole strip.  For M > 1 the row index is per lane (VALU), for M = 1 scalar.
