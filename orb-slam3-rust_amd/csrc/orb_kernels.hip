@@ -418,14 +418,17 @@ static_assert((FT_W / 2) * (FT_H / 2) <= 1024, "s_list holds the NMS survivors o
 
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
 
+__attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
                                                    unsigned* __restrict__ cand, unsigned* __restrict__ cand_count,
                                                    unsigned* __restrict__ hist) {
   __shared__ __attribute__((aligned(16))) uint8_t sp[FP_ROWS][FP_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t ss[FS_H][FS_W];
-  __shared__ unsigned short s_pos[FS_W * FS_H];
+  __shared__ __attribute__((aligned(4))) unsigned short s_pos[FS_W * FS_H];
+  // NMS survivors (at most one per 2x2 positions, 31 x 23) reuse the pre-test list, which phase 3 no longer reads
+  unsigned* const s_list = reinterpret_cast<unsigned*>(s_pos);
+  static_assert(sizeof(unsigned short) * FS_W * FS_H >= 4 * 1024, "s_list aliases s_pos");
   __shared__ unsigned short s_cor[FS_W * FS_H];
-  __shared__ unsigned s_list[1024];                 // NMS survivors: at most one per 2x2 positions, 31 x 23
   __shared__ int s_npos, s_cnt, s_ncor;
   __shared__ unsigned s_base;
   int img, tile;
