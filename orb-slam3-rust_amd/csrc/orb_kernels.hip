@@ -944,7 +944,7 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float& c_out, float&
   s_out = (float)sn;
 }
 
-constexpr int PB_ROWS = 37, PB_PITCH = 11;   // blurred 37x37 patch: 10 dwords per row, LDS pitch 11
+constexpr int PB_ROWS = 37, PB_PITCH = 10;   // blurred 37x37 patch: 10 dwords per row (26.7 KB per block with the tables: 6 blocks per CU)
 
 // Intensity-centroid weights (Appendix A.7): the 31x31 patch as 31 rows x 8 dwords (task t = r*8 + c,
 // pixel column 4c+b); per task one dword of 0/1 disc-membership bytes and one of (column index)*membership
