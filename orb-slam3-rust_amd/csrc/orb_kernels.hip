@@ -769,7 +769,7 @@ __global__ __launch_bounds__(RK_NT) void rank_select_kernel(OrbGeom g, int n_img
                                                            unsigned long long* __restrict__ sel2,
                                                            unsigned* __restrict__ kept) {
   __shared__ unsigned long long chunk[2048];
-  __shared__ unsigned skey[2048];
+  __shared__ unsigned skey[1024 + 16];
   __shared__ unsigned s_thr, s_keep;
   int img, l;
   if (!xcd_decode(xm, n_img, img, l)) return;
