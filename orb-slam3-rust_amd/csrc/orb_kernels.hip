@@ -5,21 +5,25 @@
 // covers all images, and all pyramid levels where there is no level-to-level dependency:
 //
 //   copy_l0_kernel        (only if the caller's rows are not 4-byte aligned)
-//   resize_kernel  x7     level l from level l-1, INTER_LINEAR_EXACT fixed point           (A.4)
-//   blur_kernel           7x7 sigma-2 fixed-point Gaussian of every level, LDS tile + halo (A.8)
-//   fast_kernel           FAST-9/16 score + 3x3 NMS + border filter, LDS tile + 4px halo;
-//                         per-level candidate lists + score histograms                     (A.5)
+//   resize_kernel  x7     level l from level l-1, INTER_LINEAR_EXACT fixed point: 4 px x 3 rows per thread,
+//                         8-byte source windows, v_dot4 taps                                  (A.4)
+//   blur_kernel           7x7 sigma-2 fixed-point Gaussian of every level: register window walking down
+//                         column strips (no LDS), DPP neighbours, v_dot4 / v_dot2 taps       (A.8)
+//   fast_kernel           FAST-9/16 score + 3x3 NMS + border filter on 62x46 LDS tiles: packed compass
+//                         pre-test, compacted survivors, arc score; per-level candidate lists + score
+//                         histograms                                                          (A.5)
 //   harris_select_kernel  retainBest(2 n_l) by FAST score via the histogram, Harris response
-//                         of the survivors                                                  (A.6)
-//   rank_select_kernel    canonical order (response desc, y, x) by rank sort in LDS,
-//                         retainBest(n_l) incl. ties with the n-th                          (A.6)
-//   describe_kernel       one wave per keypoint: 31x31 patch in LDS -> intensity-centroid
-//                         angle; 37x37 blurred patch in LDS -> 256 steered BRIEF tests,
-//                         4 x __ballot = the 32 descriptor bytes                        (A.7, A.8)
+//                         of the survivors                                                    (A.6)
+//   rank_select_kernel    canonical order (response desc, y, x) by bitonic sort in LDS, retainBest(n_l)
+//                         incl. ties with the n-th; the kept keypoints again in spatial order  (A.6)
+//   describe_kernel       16 lanes per keypoint, 4 keypoints per wave, walking the spatial list:
+//                         intensity-centroid angle from the level, 37x37 blurred patch in LDS ->
+//                         256 steered BRIEF tests, one __ballot per 16 bits of 4 descriptors (A.7, A.8)
 //
 // Everything is integer/byte work except the Harris response, the angle and the pattern rotation,
 // which are f32/f64 written one IEEE operation at a time (no contraction) so that the results are
-// bit-identical to the CPU specification.  HBM-bound stencil/scan work: no MFMA here by design.
+// bit-identical to the CPU specification.  Byte/integer stencil and scan work: no MFMA here by design; what
+// binds each kernel (VALU issue for FAST and blur) is in DESIGN.md §4 and §8.
 #include <cfloat>
 #include <cmath>
 
@@ -149,10 +153,6 @@ __device__ __forceinline__ void decode_tile(const unsigned* __restrict__ tab, in
   l = (int)(e & 7u); tx = (int)((e >> 3) & 0x3fffu); ty = (int)(e >> 17);
 }
 
-__device__ __forceinline__ int reflect101(int i, int n) {
-  while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
-  return i;
-}
 
 // ---- A.8 Gaussian blur 7x7 sigma 2, taps {18,34,48,56,48,34,18}/256, 8.8 then 16.16 ------------------
 // No LDS: a wave owns a 256-px-wide column strip (lane = 4 consecutive pixels = one dword) and walks
@@ -323,53 +323,8 @@ __global__ __launch_bounds__(256) void blur_kernel(OrbSrc s, OrbGeom g, int n_im
 
 // ---- A.5 FAST-9/16 ------------------------------------------------------------------------------------------
 // score = (max over the 16 arcs of 9 contiguous ring pixels of min(centre - ring), or of
-// min(ring - centre)) - 1 when that maximum exceeds the threshold, else 0.  Sliding-window min/max by
-// doubling (windows 2,4,8,9), all 16 ring differences in registers.
-__device__ __forceinline__ int fast_score16(const int (&d)[16], int t) {
-  int mn1[16], mx1[16], mn2[16], mx2[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { mn1[k] = min(d[k], d[(k + 1) & 15]); mx1[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { mn2[k] = min(mn1[k], mn1[(k + 2) & 15]); mx2[k] = max(mx1[k], mx1[(k + 2) & 15]); }
-  int best = -256;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int mn9 = min(min(mn2[k], mn2[(k + 4) & 15]), d[(k + 8) & 15]);
-    const int mx9 = max(max(mx2[k], mx2[(k + 4) & 15]), d[(k + 8) & 15]);
-    best = max(best, max(mn9, -mx9));
-  }
-  return best > t ? best - 1 : 0;
-}
-
-// The same score on packed 16-bit pairs (v_pk_min_i16 / v_pk_max_i16 / v_alignbit): P[j] = (d[2j], d[2j+1]).
+// min(ring - centre)) - 1 when that maximum exceeds the threshold, else 0.
 typedef short fast_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int fast_score16_pk(int v, const int (&r)[16], int t) {
-  fast_s2 P[8], Q[8], MN[8], MX[8], A[8], B[8];
-  const unsigned vv = (unsigned)v | ((unsigned)v << 16);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const unsigned rp = (unsigned)r[2 * j] | ((unsigned)r[2 * j + 1] << 16);
-    P[j] = __builtin_bit_cast(fast_s2, vv) - __builtin_bit_cast(fast_s2, rp);
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) Q[j] = __builtin_shufflevector(P[j], P[(j + 1) & 7], 1, 2);            // (d[2j+1], d[2j+2])
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { MN[j] = __builtin_elementwise_min(P[j], Q[j]); MX[j] = __builtin_elementwise_max(P[j], Q[j]); }   // window 2
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { A[j] = __builtin_elementwise_min(MN[j], MN[(j + 1) & 7]); B[j] = __builtin_elementwise_max(MX[j], MX[(j + 1) & 7]); }   // 4
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { MN[j] = __builtin_elementwise_min(A[j], A[(j + 2) & 7]); MX[j] = __builtin_elementwise_max(B[j], B[(j + 2) & 7]); }     // 8
-  fast_s2 best = {-256, -256};
-  const fast_s2 zero = {0, 0};
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const fast_s2 mn9 = __builtin_elementwise_min(MN[j], P[(j + 4) & 7]);                                 // 9
-    const fast_s2 mx9 = __builtin_elementwise_max(MX[j], P[(j + 4) & 7]);
-    best = __builtin_elementwise_max(best, __builtin_elementwise_max(mn9, zero - mx9));
-  }
-  const int b = max((int)best[0], (int)best[1]);
-  return b > t ? b - 1 : 0;
-}
 
 // One polarity only: max over the 16 arcs of min over the arc of s*(centre - ring), s = +1 (ring darker) or -1 (ring
 // brighter), on packed 16-bit pairs.  A polarity whose compass pre-test fails cannot exceed the threshold (every
