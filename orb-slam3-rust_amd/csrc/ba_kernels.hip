@@ -6,16 +6,23 @@
 // forms a dense 2N x P Jacobian, a dense J^T J and solves with LU (:1019-1039); the same normal
 // equations are built here in their block structure (last bullet):
 //
-//   ba_pose_kernel     params -> (R,t) of every optimised keyframe
-//   ba_build_kernel    one 32-lane group per map point: residual + Jacobian blocks of its
-//                      observations, V_j = sum B^T B, g_l, damped inverse V*_j^-1, W = A^T B and
-//                      Y = W V*^-1 scattered into the k-major dense operands WT / YT [3M][P]
-//   ba_kf_kernel       one block per keyframe: U_k = sum A^T A, g_p, b_red, fixed summation order
-//   ba_schur_kernel    S_red = YT^T WT  ((6K x 3M) x (3M x 6K)) on v_mfma_f64_16x16x4_f64,
-//                      split-K, upper tiles only — the one dense contraction of the path
-//   ba_solve_kernel    one workgroup: S = U* - S_red (LDS when it fits), Cholesky, delta_p
-//   ba_backsub_kernel  delta_l = V*^-1 (-g_l - W^T delta_p), trial parameters
-//   ba_chi2_kernel     trial residuals
+// Six launches per LM iteration (every block derives the keyframe rotations it needs itself):
+//
+//   ba_build_kernel      one 32-lane group per map point: residual + Jacobian blocks of its
+//                        observations, V_j = sum B^T B, g_l, damped inverse V*_j^-1, W = A^T B and
+//                        Y = W V*^-1 scattered into the k-major dense operands WT / YT [3M][P]
+//   ba_kf_schur_kernel   keyframe partials (U_k = sum A^T A, g_p, b_red, fixed summation order) and, in the
+//                        same launch, S_red = YT^T WT ((6K x 3M) x (3M x 6K)) on v_mfma_f64_16x16x4_f64,
+//                        split-K, upper tiles only — the one dense contraction of the path
+//   ba_gather_kernel     fixed-order reduction of the split-K and keyframe-split partials
+//   ba_solve_lds_kernel  one workgroup: S = U* - S_red in LDS, blocked right-looking Cholesky (MFMA trailing
+//                        updates, forward substitution inside the panels), delta_p
+//                        (n > 135: ba_big_assemble / panel / update / subst kernels, S in global memory)
+//   ba_backsub_kernel    delta_l = V*^-1 (-g_l - W^T delta_p), trial parameters and trial residuals
+//   ba_decide_kernel     sums, accept / reject, lambda, stop tests — the LM state lives on the device
+//
+// plus ba_chi2_kernel (initial error), ba_sum3_kernel (partitioned runs) and the inertial kernels (ba_imu_*,
+// ba_inertial_*) for solve_inertial_ba.
 //
 // Every reduction has a fixed order: results are run-to-run deterministic.  With an all-reduce hook
 // (orbx_ba_set_allreduce) each rank holds a partition of the map points; [S_red, U, g_p, b_red,
