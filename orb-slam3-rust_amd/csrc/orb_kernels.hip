@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
       // task t = it*16 + li: row 2 it + (li >> 3), dword li & 7 (row 31 does not exist: zero weights, re-reads row 30)
       const uint8_t* a0 = src + (unsigned)(__umul24((unsigned)(ky - 15 + (li >> 3)), (unsigned)pitch) + (unsigned)(kx - 15 + 4 * (li & 7)));
       const unsigned astep = 2u * (unsigned)pitch;
-#pragma unroll 4
+#pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int t = it * 16 + li;
         const int r = min(t >> 3, 30);
