@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Freezes the extractor / stereo-matcher specification: writes tests/golden/extract_frozen.json.
+
+The ORB extractor lives in OpenCV, which is absent here, and the reference holds no fixture for it
+(SURVEY.md §8c, F9): `oracle/orb_ref.cpp` is this repo's written CPU specification of cv::ORB, and
+parity with OpenCV itself stays unpinned.  What this file pins is the specification ITSELF: for a set
+of fixed synthetic inputs it records sha256 digests and counts of everything the path produces
+(input images, every pyramid level, every blurred level, the FAST candidate sets, keypoints,
+descriptors, stereo matches, triangulated points) plus the first keypoints in clear, as computed by
+the oracle at the commit that wrote the file.  tests/test_frozen_golden.py then holds
+  - the oracle (CPU, `-m "not gpu"`) and
+  - the HIP path through the C ABI (`-m gpu`)
+to these digests, so the oracle and the kernels cannot drift together unnoticed.  Regenerating the
+file is a deliberate, reviewed act (a change of the specification), not part of any test run.
+
+usage: python scripts/gen_extract_golden.py [--check]
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# (name, seed, frame, width, height, n_features): the sizes VERDICT r1 item 2 asks for + one odd size + a tiny quota
+CASES = [
+    ("euroc_752x480_n1200", 11, 0, 752, 480, 1200),      # configs[0] (main.rs:53 n_features)
+    ("synth_752x480_n2000", 12, 3, 752, 480, 2000),      # configs[1]
+    ("hd_1920x1080_n4000", 13, 1, 1920, 1080, 4000),     # configs[4] image side
+    ("odd_613x389_n700", 14, 2, 613, 389, 700),          # odd width/height: unaligned rows, partial tiles
+    ("small_quota_320x240_n150", 15, 0, 320, 240, 150),
+]
+PATH = os.path.join(ROOT, "tests", "golden", "extract_frozen.json")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def oracle_results(O, cam, L, R, n):
+    """Everything the path produces for one stereo pair, from the CPU oracle."""
+    p = O.orb_params(n)
+    kl, dl = O.orb_extract(L, p)
+    kr, dr = O.orb_extract(R, p)
+    m, pts, has = O.stereo_match(cam, kl, dl, kr, dr)
+    return dict(kl=kl, dl=dl, kr=kr, dr=dr, m=m, pts=pts, has=has,
+                levels=[O.orb_pyramid_level(L, p, l) for l in range(8)],
+                blurs=[O.orb_blur_level(L, p, l) for l in range(8)],
+                cands=[O.orb_fast_level(L, p, l) for l in range(8)])
+
+
+def digest(L, R, r):
+    """Digests of one case from a results dict (keys as oracle_results): the oracle's or the HIP path's."""
+    kl, dl, kr, dr, m, pts, has = r["kl"], r["dl"], r["kr"], r["dr"], r["m"], r["pts"], r["has"]
+    d = dict(image_sha256=[sha(L), sha(R)],
+             n_keypoints=[int(len(kl)), int(len(kr))],
+             keypoints_sha256=[sha(kl), sha(kr)],
+             descriptors_sha256=[sha(dl), sha(dr)],
+             n_matches=int(len(m)), matches_sha256=sha(m),
+             n_points=int(np.sum(has)), has_point_sha256=sha(has), points_sha256=sha(pts[has == 1]),
+             per_octave_left=[int(np.sum(kl["octave"] == l)) for l in range(8)],
+             first_keypoints_left=[[float(k["x"]), float(k["y"]), float(k["size"]), float(k["angle"]), float(k["response"]),
+                                    int(k["octave"]), int(k["class_id"])] for k in kl[:4]],
+             first_descriptor_left=[int(v) for v in dl[0]] if len(dl) else [],
+             first_matches=[[int(x["query_idx"]), int(x["train_idx"]), float(x["distance"])] for x in m[:4]])
+    d["level_sha256"] = [sha(a) for a in r["levels"]]
+    d["blur_sha256"] = [sha(a) for a in r["blurs"]]
+    cs = [np.sort(np.asarray(c, dtype=np.uint32)) for c in r["cands"]]    # candidate SETS: order is free
+    d["n_candidates"] = [int(len(c)) for c in cs]
+    d["candidates_sha256"] = [sha(c) for c in cs]
+    return d
+
+
+def load_synth():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("orbx_synth", os.path.join(ROOT, "orb-slam3-rust_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    return synth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true", help="compare with the committed file instead of writing it")
+    args = ap.parse_args()
+    from oracle import oracle as O
+    synth = load_synth()
+    cam = O.Camera(**synth.EUROC_CAMERA)
+    out = dict(note="frozen digests of the repo's CPU specification (oracle/orb_ref.cpp, match_ref.cpp); generator scripts/gen_extract_golden.py; "
+                    "parity with OpenCV itself is unpinned (SURVEY.md §8c)", camera=dict(synth.EUROC_CAMERA), cases={})
+    for name, seed, frame, w, h, n in CASES:
+        L, R = synth.stereo_pair(seed, frame, w, h)
+        out["cases"][name] = dict(seed=seed, frame=frame, width=w, height=h, n_features=n, **digest(L, R, oracle_results(O, cam, L, R, n)))
+        print(name, out["cases"][name]["n_keypoints"], out["cases"][name]["n_matches"], flush=True)
+    if args.check:
+        want = json.load(open(PATH))
+        assert want["cases"] == out["cases"], "oracle output differs from the frozen specification"
+        print("frozen specification reproduced")
+        return
+    with open(PATH, "w") as f:
+        json.dump(out, f, indent=1)
+    # the smallest case's input images as data, so that one case does not depend on numpy's generator at all
+    name, seed, frame, w, h, n = CASES[-1]
+    L, R = synth.stereo_pair(seed, frame, w, h)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_images.npz"), left=L, right=R)
+    print("written", PATH)
+
+
+if __name__ == "__main__":
+    main()
