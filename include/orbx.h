@@ -344,6 +344,34 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
                          int* iterations, double* initial_error, double* final_error);
 
+/* Many independent windows in ONE call ("many BA windows": one map per stream / per robot).  Each
+ * window is exactly one orbx_ba_solve_visual problem (same arguments, same LM loop, local_ba_lm.rs:1012-1056) with its own
+ * LM state on the device; all windows share every kernel launch — the window is the second grid dimension — so W reduced
+ * systems are factored by W workgroups at once and the point / keyframe / Schur kernels of all windows fill the chip
+ * together, instead of one window's chain of short launches using about 1 % of it.  Nothing is exchanged between windows,
+ * and a window's arithmetic does not depend on what else is in the batch: every window's result equals the result of
+ * orbx_ba_solve_visual on it bit for bit.  Windows may differ in size.  should_stop is polled once per iteration for the
+ * whole batch (and while the work drains); a window that converges early simply stops taking part.
+ *   status: ORBX_OK, or ORBX_ERR_EMPTY for a window the reference answers None for (:923-925) — the call still returns
+ *   ORBX_OK and solves the others.  An observation index out of range fails the whole call (ORBX_ERR_INVALID).
+ * The all-reduce hook / RCCL communicator is not used here (independent windows need no collective). */
+typedef struct {
+  int K;                        /* in: optimised keyframes                         */
+  const double* poses_cw;       /* in: [K][7]                                      */
+  int F;
+  const double* fixed_poses_cw; /* in: [F][7]                                      */
+  int M;
+  double* points;               /* in/out: [M][3]                                  */
+  int N;
+  const orbx_ba_obs* obs;       /* in: [N]                                         */
+  double* poses_wc_out;         /* out: [K][7]                                     */
+  int status;                   /* out                                             */
+  int iterations;               /* out                                             */
+  double initial_error, final_error;   /* out                                      */
+} orbx_ba_window;
+int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int n_windows,
+                               orbx_ba_window* windows, orbx_should_stop_fn should_stop, void* user);
+
 /* Replaces solve_global_ba (src/optimizer/global_ba.rs:184-418): the same LM loop over ALL keyframes of the map
  * with the first one (smallest id, :116-119) fixed, and one difference in the linearisation — an observation whose
  * point is not in front of its camera (z_c <= 0.001) keeps its 100-px residual but contributes zero Jacobian rows
@@ -411,6 +439,16 @@ int orbx_debug_read_level(orbx_handle* h, int image_index, int level, int which,
                           int* w_l, int* h_l);
 int orbx_debug_read_candidates(orbx_handle* h, int image_index, int level, uint32_t* out, int cap,
                                int* n);
+
+/* The per-observation terms of the BA linearisation at the given parameters, from the same device functions the solver's
+ * kernels call: compute_residuals (local_ba_lm.rs:557-588) and the blocks of compute_jacobian (:591-639; jacobian_pose
+ * :216-254, jacobian_point :257-288, huber_weight :291-297), in input order.
+ *   out [N][20] = residual (2) | A = d r / d pose, row-major 2x6 (rot xyz, trans xyz) | B = d r / d point, row-major 2x3,
+ *   all times sqrt(w).  global_mode != 0: the zero-Jacobian rule of solve_global_ba (global_ba.rs:561-563).
+ * This is how the reference's Jacobian known answer (test_jacobian_pose_numerical, :1163-1243) is checked on the GPU. */
+int orbx_debug_ba_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw,
+                         int F, const double* fixed_poses_cw, int M, const double* points, int N, const orbx_ba_obs* obs,
+                         int global_mode, double* out);
 
 #ifdef __cplusplus
 }

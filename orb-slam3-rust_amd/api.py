@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "orbx_extract_batch_device", "orbx_check_status", "orbx_stereo_match",
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
-    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
     "orbx_fuse_search", "orbx_fuse_search_device",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
@@ -92,6 +92,13 @@ class _InertialBaConfig(C.Structure):
 
 class _KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("launches", C.c_int)]
+
+
+class _BaWindow(C.Structure):
+    """orbx_ba_window (include/orbx.h)"""
+    _fields_ = [("K", C.c_int), ("poses_cw", C.c_void_p), ("F", C.c_int), ("fixed_poses_cw", C.c_void_p), ("M", C.c_int),
+                ("points", C.c_void_p), ("N", C.c_int), ("obs", C.c_void_p), ("poses_wc_out", C.c_void_p), ("status", C.c_int),
+                ("iterations", C.c_int), ("initial_error", C.c_double), ("final_error", C.c_double)]
 
 
 SHOULD_STOP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -588,6 +595,49 @@ class Handle:
         self._check(rc)
         return dict(poses_wc=out_wc[:K], points=pts, iterations=it.value, initial_error=e0.value,
                     final_error=e1.value)
+
+    def ba_solve_visual_batch(self, camera, cfg, windows, should_stop=None):
+        """orbx_ba_solve_visual_batch: `windows` = list of dicts with poses_cw, fixed_cw, points, obs (as ba_solve_visual).
+        Returns one result dict per window (None where the reference returns None)."""
+        keep = []
+        arr = (_BaWindow * max(len(windows), 1))()
+        for i, w in enumerate(windows):
+            poses_cw = np.ascontiguousarray(w["poses_cw"], np.float64).reshape(-1, 7)
+            fixed_cw = np.ascontiguousarray(w["fixed_cw"], np.float64).reshape(-1, 7)
+            pts = np.array(w["points"], np.float64, copy=True).reshape(-1, 3)
+            obs = np.ascontiguousarray(w["obs"], BA_OBS)
+            out_wc = np.zeros((max(len(poses_cw), 1), 7))
+            keep.append((poses_cw, fixed_cw, pts, obs, out_wc))
+            a = arr[i]
+            a.K, a.F, a.M, a.N = len(poses_cw), len(fixed_cw), len(pts), len(obs)
+            a.poses_cw = poses_cw.ctypes.data; a.fixed_poses_cw = fixed_cw.ctypes.data; a.points = pts.ctypes.data
+            a.obs = obs.ctypes.data; a.poses_wc_out = out_wc.ctypes.data
+        cb = SHOULD_STOP_FN((lambda user: 1 if should_stop() else 0)) if should_stop else C.cast(None, SHOULD_STOP_FN)
+        cam = camera._c(); c = cfg._c()
+        self._check(self._L.orbx_ba_solve_visual_batch(self._h, C.byref(cam), C.byref(c), C.c_int(len(windows)), arr, cb, None))
+        res = []
+        for i, (poses_cw, fixed_cw, pts, obs, out_wc) in enumerate(keep):
+            a = arr[i]
+            if a.status == ORBX_ERR_EMPTY:
+                res.append(None)
+                continue
+            res.append(dict(poses_wc=out_wc[:len(poses_cw)], points=pts, iterations=a.iterations, initial_error=a.initial_error,
+                            final_error=a.final_error))
+        return res
+
+    def debug_ba_blocks(self, camera, cfg, poses_cw, fixed_cw, points, obs, global_mode=False):
+        """orbx_debug_ba_blocks: (residual [N,2], A [N,2,6], B [N,2,3]) of every observation, from the solver's device functions."""
+        poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)
+        fixed_cw = np.ascontiguousarray(fixed_cw, np.float64).reshape(-1, 7)
+        pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs, BA_OBS)
+        out = np.zeros((max(len(obs), 1), 20))
+        cam = camera._c(); c = cfg._c()
+        self._check(self._L.orbx_debug_ba_blocks(self._h, C.byref(cam), C.byref(c), C.c_int(len(poses_cw)), _vp(poses_cw), C.c_int(len(fixed_cw)),
+                                                 _vp(fixed_cw), C.c_int(len(pts)), _vp(pts), C.c_int(len(obs)), _vp(obs),
+                                                 C.c_int(1 if global_mode else 0), _vp(out)))
+        out = out[:len(obs)]
+        return out[:, 0:2].copy(), out[:, 2:14].reshape(-1, 2, 6).copy(), out[:, 14:20].reshape(-1, 2, 3).copy()
 
     def ba_solve_inertial(self, camera, cfg, poses_wc, velocities, biases, fixed_cw, points, obs, edge_kf, preint, should_stop=None):
         """solve_inertial_ba (local_inertial_ba.rs:1074-1275) on flat arrays; every keyframe of the window is returned."""

@@ -29,8 +29,11 @@
 // chi2, |g_l|^2] is summed over ranks before the solve and [chi2_trial, |delta_l|^2, |p_l|^2] after
 // the back-substitution — two small latency-bound collectives per iteration.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <mutex>
 #include <numeric>
+#include <thread>
 
 #include "orbx_internal.hpp"
 
@@ -65,6 +68,29 @@ struct BaState {
 };
 __device__ __forceinline__ double* ba_cur(const BaState* S, double* P0, double* P1) { return S->sel ? P1 : P0; }
 __device__ __forceinline__ double* ba_trial(const BaState* S, double* P0, double* P1) { return S->sel ? P0 : P1; }
+
+// One window of a batch (orbx_ba_solve_visual_batch; a single solve is a batch of one).  The array lives in device
+// memory; every kernel of the LM loop takes it and picks its window by blockIdx.y, so that W independent windows share
+// each launch: W workgroups factor W reduced systems at once instead of one CU working while 255 idle, and the
+// keyframe / Schur / point kernels of all windows fill the chip together.  Nothing is shared between windows, and a
+// window's arithmetic does not depend on W: every window of a batch equals its single-window result bit for bit.
+struct BaWin {
+  BaDims d;
+  int n;                 // size of the reduced system the solve kernels see (6K; 15K for the inertial window)
+  int use_lds;           // reduced system factored in LDS by ba_solve_lds_kernel (else the ba_big_* kernels)
+  BaState* S;
+  double *P0, *P1;       // the two parameter buffers [6K | 3M (| 9K)]
+  const double* Rt_fix;  // [F+1][12]
+  const int *pt_start, *o_kf, *o_fix;
+  const double* o_uv;
+  const int *kf_start, *kf_obs;
+  double *oA, *oR, *oYg, *Vinv, *gl;
+  double *pt_chi2, *pt_glsq, *pt_dsq, *pt_psq;
+  double *WT, *YT, *kfpart, *part, *rb;
+  double *dp;            // step of the reduced system [n pad 16]
+  double *Sg, *bvec, *ginv;   // global-memory factorisation (n > ~135 and the inertial system)
+  double *res;           // [16] result block, see ba_decide_kernel
+};
 
 // ---- small device math ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
@@ -136,7 +162,8 @@ __device__ __forceinline__ void block_poses(const double* params, int K, int ine
 }
 
 // iteration counter only (windows without points never launch the build kernel)
-__global__ void ba_iter_kernel(BaState* S, int iter) {
+__global__ void ba_iter_kernel(const BaWin* __restrict__ wins, int iter) {
+  BaState* S = wins[blockIdx.y].S;
   if (S->done) return;
   S->iters = iter + 1;                                                  // local_ba_lm.rs:1017
 }
@@ -217,15 +244,20 @@ __device__ __forceinline__ double group_sum32(double v) {
 }
 
 // One 32-lane group per point (2 points per wave).  Observations are stored point-major (CSR).
-__global__ __launch_bounds__(256) void ba_build_kernel(BaDims d, BaCam cam, BaState* S, double* P0, double* P1, int iter,
-    const double* __restrict__ Rt_fix,
-    const int* __restrict__ pt_start, const int* __restrict__ o_kf, const int* __restrict__ o_fix,
-    const double* __restrict__ o_uv, double* __restrict__ oA /*N*12*/, double* __restrict__ oR /*N*2*/,
-    double* __restrict__ oYg /*N*6*/, double* __restrict__ Vinv /*M*9*/, double* __restrict__ gl /*M*3*/,
-    double* __restrict__ pt_chi2 /*M*/, double* __restrict__ pt_glsq /*M*/, double* __restrict__ WT,
-    double* __restrict__ YT) {
+__global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__ wins, BaCam cam, int iter) {
   __shared__ double sRt[12 * BA_MAX_K];
-  if (S->done) return;
+  const BaWin& win = wins[blockIdx.y];
+  const BaDims d = win.d;
+  BaState* S = win.S;
+  if (S->done || (int)blockIdx.x * 8 >= max(d.M, 1)) return;   // (block 0 of a window without points still counts the iteration)
+  double *P0 = win.P0, *P1 = win.P1;
+  const double* __restrict__ Rt_fix = win.Rt_fix;
+  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
+  const double* __restrict__ o_uv = win.o_uv;
+  double* __restrict__ oA = win.oA /*N*12*/; double* __restrict__ oR = win.oR /*N*2*/; double* __restrict__ oYg = win.oYg /*N*6*/;
+  double* __restrict__ Vinv = win.Vinv /*M*9*/; double* __restrict__ gl = win.gl /*M*3*/;
+  double* __restrict__ pt_chi2 = win.pt_chi2 /*M*/; double* __restrict__ pt_glsq = win.pt_glsq /*M*/;
+  double* __restrict__ WT = win.WT; double* __restrict__ YT = win.YT;
   const double lambda = S->lambda;
   const double* params = ba_cur(S, P0, P1);
   if (blockIdx.x == 0 && threadIdx.x == 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
@@ -392,21 +424,23 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaDims& d, const dou
 
 // Both consume the build kernel's output and feed the gather kernel, neither fills the chip (K*8 blocks, and one wave
 // per tile x k-split): one launch, the first nkf blocks take the keyframe partials, the rest the Schur tiles.
-__global__ __launch_bounds__(256) void ba_kf_schur_kernel(BaDims d, const BaState* S, int nkf, const int* __restrict__ kf_start,
-                                                          const int* __restrict__ kf_obs, const double* __restrict__ oA,
-                                                          const double* __restrict__ oR, const double* __restrict__ oYg,
-                                                          double* __restrict__ kfpart, const double* __restrict__ YT,
-                                                          const double* __restrict__ WT, double* __restrict__ part) {
-  if (S->done) return;
-  if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, d, kf_start, kf_obs, oA, oR, oYg, kfpart);
-  else ba_schur_body((int)blockIdx.x - nkf, d, YT, WT, part);
+__global__ __launch_bounds__(256) void ba_kf_schur_kernel(const BaWin* __restrict__ wins) {
+  const BaWin& win = wins[blockIdx.y];
+  if (win.S->done) return;
+  const BaDims d = win.d;
+  const int nkf = d.K * BA_KFSPLIT;
+  if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, d, win.kf_start, win.kf_obs, win.oA, win.oR, win.oYg, win.kfpart);
+  else ba_schur_body((int)blockIdx.x - nkf, d, win.YT, win.WT, win.part);   // (units beyond this window's tiles return inside)
 }
 
 // reduce-buffer layout (doubles): [Sred n*n | U 36K | gp n | bred n | chi2 | glsq], n = 6K
-__global__ __launch_bounds__(256) void ba_gather_kernel(BaDims d, const BaState* S, const double* __restrict__ part,
-                                                        const double* __restrict__ kfpart, const double* __restrict__ pt_chi2,
-                                                        const double* __restrict__ pt_glsq, double* __restrict__ rb) {
-  if (S->done) return;
+__global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict__ wins) {
+  const BaWin& win = wins[blockIdx.y];
+  if (win.S->done) return;
+  const BaDims d = win.d;
+  const double* __restrict__ part = win.part; const double* __restrict__ kfpart = win.kfpart;
+  const double* __restrict__ pt_chi2 = win.pt_chi2; const double* __restrict__ pt_glsq = win.pt_glsq;
+  double* __restrict__ rb = win.rb;
   const int n = 6 * d.K;
   const size_t nn = (size_t)n * n;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
@@ -690,11 +724,11 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   if (tid == 0) { res[2] = (double)ok; res[3] = dsq; res[4] = psq; }
 }
 
-__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(int n, const BaState* St, double* P0, double* P1,
-                                                                        const double* __restrict__ rb, int K,
-                                                                        double* __restrict__ dp, double* __restrict__ res) {
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(const BaWin* __restrict__ wins) {
   extern __shared__ __align__(16) double dyn[];
-  solve_body(n, St, P0, P1, rb, K, dyn, dp, res);
+  const BaWin& win = wins[blockIdx.y];       // one workgroup per window
+  if (!win.use_lds) return;
+  solve_body(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, dyn, win.dp, win.res);
 }
 
 // ---- large reduced systems (n > ~135: S does not fit LDS) -------------------------------------------------------
@@ -706,10 +740,13 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(int n, c
 //   ba_big_subst_kernel      panel-blocked forward / backward substitution, |dp|^2, |p|^2         (1 block)
 constexpr int BB_NB = 16;
 
-__global__ __launch_bounds__(256) void ba_big_assemble_kernel(int n, const BaState* St, double* P0, double* P1,
-                                                              const double* __restrict__ rb, int K, double* __restrict__ Sg,
-                                                              double* __restrict__ bvec, double* __restrict__ res) {
-  if (St->done) return;
+__global__ __launch_bounds__(256) void ba_big_assemble_kernel(const BaWin* __restrict__ wins) {
+  const BaWin& win = wins[blockIdx.y];
+  const BaState* St = win.S;
+  if (win.use_lds || St->done) return;
+  const int n = win.n, K = win.d.K;
+  const double* __restrict__ rb = win.rb;
+  double* __restrict__ Sg = win.Sg; double* __restrict__ bvec = win.bvec; double* __restrict__ res = win.res;
   const double lambda = St->lambda;
   const size_t nn = (size_t)n * n;
   const double* U = rb + nn;
@@ -738,12 +775,14 @@ __global__ __launch_bounds__(256) void ba_big_assemble_kernel(int n, const BaSta
   }
 }
 
-__global__ __launch_bounds__(256) void ba_big_panel_kernel(int n, int c0, const BaState* St, double* __restrict__ Sg,
-                                                           double* __restrict__ ginv, double* __restrict__ res) {
+__global__ __launch_bounds__(256) void ba_big_panel_kernel(const BaWin* __restrict__ wins, int c0) {
   __shared__ double D[BB_NB][BB_NB + 1];
   __shared__ double rinv[BB_NB];
   __shared__ int s_ok;
-  if (St->done || res[2] == 0.0) return;
+  const BaWin& win = wins[blockIdx.y];
+  const int n = win.n;
+  double* __restrict__ Sg = win.Sg; double* __restrict__ ginv = win.ginv; double* __restrict__ res = win.res;
+  if (win.use_lds || c0 >= n || win.S->done || res[2] == 0.0) return;
   const int tid = threadIdx.x, nb = min(BB_NB, n - c0);
   if (tid == 0) s_ok = 1;
   {
@@ -790,9 +829,11 @@ __global__ __launch_bounds__(256) void ba_big_panel_kernel(int n, int c0, const 
 }
 
 // one wave per lower 16x16 tile (ti >= tj) of the trailing matrix [c1, n) x [c1, n), c1 = c0 + 16
-__global__ __launch_bounds__(256) void ba_big_update_kernel(int n, int c0, const BaState* St, double* __restrict__ Sg,
-                                                            const double* __restrict__ res) {
-  if (St->done || res[2] == 0.0) return;
+__global__ __launch_bounds__(256) void ba_big_update_kernel(const BaWin* __restrict__ wins, int c0) {
+  const BaWin& win = wins[blockIdx.y];
+  const int n = win.n;
+  double* __restrict__ Sg = win.Sg;
+  if (win.use_lds || win.S->done || win.res[2] == 0.0) return;
   const int lane = threadIdx.x & 63;
   const int c1 = c0 + BB_NB, m = n - c1;
   if (m <= 0) return;
@@ -819,15 +860,17 @@ __global__ __launch_bounds__(256) void ba_big_update_kernel(int n, int c0, const
   }
 }
 
-__global__ __launch_bounds__(256) void ba_big_subst_kernel(int n, const BaState* St, double* P0, double* P1,
-                                                           const double* __restrict__ Sg, const double* __restrict__ ginv,
-                                                           const double* __restrict__ bvec, double* __restrict__ dp,
-                                                           double* __restrict__ res) {
+__global__ __launch_bounds__(256) void ba_big_subst_kernel(const BaWin* __restrict__ wins) {
   __shared__ double sb[BA_MAX_N];
   __shared__ double y[BB_NB];
   __shared__ double red[256];
-  if (St->done) return;
-  const double* params = ba_cur(St, P0, P1);
+  const BaWin& win = wins[blockIdx.y];
+  const BaState* St = win.S;
+  if (win.use_lds || St->done) return;
+  const int n = win.n;
+  const double* __restrict__ Sg = win.Sg; const double* __restrict__ ginv = win.ginv; const double* __restrict__ bvec = win.bvec;
+  double* __restrict__ dp = win.dp; double* __restrict__ res = win.res;
+  const double* params = ba_cur(St, win.P0, win.P1);
   const int tid = threadIdx.x;
   const int ok = res[2] != 0.0;
   if (ok) {
@@ -921,17 +964,21 @@ __global__ __launch_bounds__(256) void ba_big_subst_kernel(int n, const BaState*
 
 // delta_l = V*^-1 (-g_l - sum_k W_kj^T delta_p_k); trial = params + delta; per-point |delta_l|^2, |p_l|^2.
 // One 32-lane group per point: lanes take the point's observations, fixed shuffle tree for the three sums.
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims d, BaCam cam, const BaState* S, double* P0, double* P1,
-                                                         const double* __restrict__ dp, const int* __restrict__ pt_start,
-                                                         const int* __restrict__ o_kf, const int* __restrict__ o_fix,
-                                                         const double* __restrict__ o_uv, const double* __restrict__ Rt_fix,
-                                                         const double* __restrict__ WT, const double* __restrict__ Vinv,
-                                                         const double* __restrict__ gl, double* __restrict__ pt_dsq,
-                                                         double* __restrict__ pt_psq, double* __restrict__ pt_chi2, int owned_only) {
+__global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict__ wins, BaCam cam, const double* __restrict__ dp_override,
+                                                         int owned_only) {
   // + the trial residuals of the point (local_ba_lm.rs:1047-1048): the group that back-substitutes a point already holds
   // its trial position, and the trial rotations follow from the pose step alone, so chi2(trial) needs no launch of its own
   __shared__ double sRt[12 * BA_MAX_K];
-  if (S->done) return;
+  const BaWin& win = wins[blockIdx.y];
+  const BaDims d = win.d;
+  const BaState* S = win.S;
+  if (S->done || (int)blockIdx.x * 256 >= max(32 * d.M, 6 * d.K)) return;
+  double *P0 = win.P0, *P1 = win.P1;
+  const double* __restrict__ dp = dp_override ? dp_override : win.dp;     // (inertial: the 6-d pose steps scattered out of the 15-d solve)
+  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
+  const double* __restrict__ o_uv = win.o_uv; const double* __restrict__ Rt_fix = win.Rt_fix;
+  const double* __restrict__ WT = win.WT; const double* __restrict__ Vinv = win.Vinv; const double* __restrict__ gl = win.gl;
+  double* __restrict__ pt_dsq = win.pt_dsq; double* __restrict__ pt_psq = win.pt_psq; double* __restrict__ pt_chi2 = win.pt_chi2;
   const double* params = ba_cur(S, P0, P1);
   double* trial = ba_trial(S, P0, P1);
   const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1005,13 +1052,17 @@ __global__ void ba_diff_kernel(size_t n, const double* __restrict__ a, const dou
 }
 
 // chi2 of a parameter vector: per-point partial sums (fixed order)
-__global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const BaState* S, double* P0, double* P1, int which,
-                                                      const double* __restrict__ Rt_fix,
-                                                      const int* __restrict__ pt_start, const int* __restrict__ o_kf,
-                                                      const int* __restrict__ o_fix, const double* __restrict__ o_uv,
-                                                      double* __restrict__ pt_chi2) {
+__global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ wins, BaCam cam, int which) {
   __shared__ double sRt[12 * BA_MAX_K];
-  if (S->done) return;
+  const BaWin& win = wins[blockIdx.y];
+  const BaDims d = win.d;
+  const BaState* S = win.S;
+  if (S->done || (int)blockIdx.x * 8 >= d.M) return;
+  double *P0 = win.P0, *P1 = win.P1;
+  const double* __restrict__ Rt_fix = win.Rt_fix;
+  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
+  const double* __restrict__ o_uv = win.o_uv;
+  double* __restrict__ pt_chi2 = win.pt_chi2;
   const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
   block_poses(params, d.K, cam.inertial, sRt);
   // one 32-lane group per point (as ba_build_kernel): 2000 points alone would fill 8 blocks
@@ -1040,10 +1091,16 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(BaDims d, BaCam cam, const
 }
 
 // out[0..2] = sums over points of up to three per-point arrays, one block, fixed tree
-__global__ __launch_bounds__(256) void ba_sum3_kernel(const BaState* S, int M, const double* __restrict__ a, const double* __restrict__ b,
-                                                      const double* __restrict__ c, double* __restrict__ out) {
+// three = 0: out = res + 12 <- sum pt_chi2 (the initial error); three = 1: res + 5 <- sums of pt_chi2, pt_dsq, pt_psq
+__global__ __launch_bounds__(256) void ba_sum3_kernel(const BaWin* __restrict__ wins, int three) {
   __shared__ double sh[3][256];
+  const BaWin& win = wins[blockIdx.y];
+  const BaState* S = win.S;
   if (S->done) return;
+  const int M = win.d.M;
+  const double* __restrict__ a = win.pt_chi2; const double* __restrict__ b = three ? win.pt_dsq : nullptr;
+  const double* __restrict__ c = three ? win.pt_psq : nullptr;
+  double* __restrict__ out = win.res + (three ? 5 : 12);
   double x = 0.0, y = 0.0, z = 0.0;
   for (int j = threadIdx.x; j < M; j += 256) { x += a[j]; if (b) y += b[j]; if (c) z += c[j]; }
   sh[0][threadIdx.x] = x; sh[1][threadIdx.x] = y; sh[2][threadIdx.x] = z;
@@ -1062,11 +1119,18 @@ __global__ __launch_bounds__(256) void ba_sum3_kernel(const BaState* S, int M, c
 // With M >= 0 the kernel first forms res[5..7] itself — the fixed-order sums of the per-point chi2(trial), |delta_l|^2 and
 // |p_l|^2 the back-substitution left (what ba_sum3_kernel does), plus the IMU / random-walk chi2 of the trial state — so
 // that the single-GPU loop ends in one launch; M < 0: res[5..7] were reduced (and all-reduced) by the caller.
-__global__ __launch_bounds__(256) void ba_decide_kernel(BaState* S, double* __restrict__ res, int M, const double* __restrict__ pt_chi2,
-                                                        const double* __restrict__ pt_dsq, const double* __restrict__ pt_psq,
-                                                        const double* __restrict__ imu_buf, int E) {
+// abort: device-visible word the host sets when should_stop() turns true while the enqueued iterations drain — the solve then
+// ends at the next iteration boundary, as the reference's poll at the top of the loop (:1013) does.  stop_vote (partitioned
+// runs): res[8] holds the all-reduced stop votes of the ranks for the NEXT iteration, so that every rank leaves together.
+__global__ __launch_bounds__(256) void ba_decide_kernel(const BaWin* __restrict__ wins, int reduce_here, const double* __restrict__ imu_buf, int E,
+                                                        const volatile int* __restrict__ abort_flag, int stop_vote) {
   __shared__ double sh[3][256];
+  const BaWin& win = wins[blockIdx.y];
+  BaState* S = win.S;
   if (S->done) return;
+  double* __restrict__ res = win.res;
+  const int M = reduce_here ? win.d.M : -1;
+  const double* __restrict__ pt_chi2 = win.pt_chi2; const double* __restrict__ pt_dsq = win.pt_dsq; const double* __restrict__ pt_psq = win.pt_psq;
   const int tid = threadIdx.x;
   if (M >= 0) {
     double x = 0.0, y = 0.0, z = 0.0;
@@ -1102,6 +1166,8 @@ __global__ __launch_bounds__(256) void ba_decide_kernel(BaState* S, double* __re
   } else {
     S->lambda = fmin(S->lambda * 10.0, 1e10);
   }
+  // should_stop at the top of the next iteration (:1013)
+  if ((abort_flag && *abort_flag) || (stop_vote && res[8] > 0.0)) S->done = 1;
 }
 
 // ---- inertial terms (src/optimizer/local_inertial_ba.rs:661-698, :806-880; src/optimizer/imu_factors.rs:66-103) --------------------
@@ -1304,6 +1370,48 @@ __global__ void ba_inertial_scatter_kernel(const BaState* S, double* P0, double*
   }
 }
 
+// End of a solve: the window's state, result block and CURRENT parameters into one contiguous record of the output blob
+// (one D2H copy for the whole batch).  out: [0] iterations [1] final_sq [2] chi2 of the initial parameters [3] sel
+// [4] done [8...] parameters.
+__global__ __launch_bounds__(256) void ba_finish_kernel(const BaWin* __restrict__ wins, double* __restrict__ out_base,
+                                                        const size_t* __restrict__ out_off, int np_extra_per_kf) {
+  const BaWin& win = wins[blockIdx.y];
+  const BaState* S = win.S;
+  double* out = out_base + out_off[blockIdx.y];
+  const size_t np = 6 * (size_t)win.d.K + 3 * (size_t)win.d.M + (size_t)np_extra_per_kf * win.d.K;
+  const double* cur = ba_cur(S, win.P0, win.P1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = (double)S->iters; out[1] = S->final_sq; out[2] = win.res[12]; out[3] = (double)S->sel; out[4] = (double)S->done;
+  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < np; i += (size_t)gridDim.x * blockDim.x) out[8 + i] = cur[i];
+}
+
+// Stage inspection (orbx_debug_ba_blocks): residual, pose block A (2x6) and point block B (2x3) of every observation at
+// the given parameters, by the same obs_terms / pose_to_Rt the solver's kernels use.  One thread per observation.
+__global__ __launch_bounds__(256) void ba_debug_blocks_kernel(BaCam cam, int K, int N, const double* __restrict__ params,
+                                                              const double* __restrict__ Rt_fix, const int* __restrict__ o_kf,
+                                                              const int* __restrict__ o_fix, const int* __restrict__ o_mp,
+                                                              const double* __restrict__ o_uv, double* __restrict__ out /*N*20*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double Rt[12];
+  const int k = o_kf[i];
+  if (k >= 0) pose_to_Rt(params + 6 * (size_t)k, cam.inertial, Rt);
+  else {
+#pragma unroll
+    for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
+  }
+  const double* X = params + 6 * (size_t)K + 3 * (size_t)o_mp[i];
+  ObsOut o;
+  obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, 0);
+  double* q = out + 20 * (size_t)i;
+  q[0] = o.r0; q[1] = o.r1;
+#pragma unroll
+  for (int a = 0; a < 12; ++a) q[2 + a] = o.A[a];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) q[14 + a] = o.B[a];
+}
+
 // ---- host helpers -----------------------------------------------------------------------------------------------
 void host_quat_rotate(const double* q, const double* v, double* o) {
   // nalgebra `UnitQuaternion * Vector3`
@@ -1350,63 +1458,80 @@ void host_params_to_pose_wc(const double* p6, double* out7) {
 
 }  // namespace
 
-int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
-                    const double* poses_cw, int F, const double* fixed_poses_cw, int M, double* points, int N,
-                    const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
-                    int* iterations, double* initial_error, double* final_error, bool global_mode, const BaInertialHost* inr) {
-  // inr != nullptr: solve_inertial_ba (local_inertial_ba.rs:1074-1275).  `poses_cw` then holds the T_wc poses of the window
-  // and cfg carries max_iterations only; the point elimination, the per-keyframe 6x6 blocks and the Schur product are the
-  // visual solver's kernels, the 15-d keyframe states are assembled and solved on top of them.
-  const bool inertial = inr != nullptr;
-  const bool dist = h->allreduce != nullptr && !inertial;
-  *iterations = 0; *initial_error = 0.0; *final_error = 0.0;
-  // local_ba_lm.rs:923-925 (with a partition the local N may be 0 while the global problem is not)
-  if ((6 * (size_t)K + 3 * (size_t)M == 0) || (N == 0 && !dist && !inertial)) return orbx_fail(h, ORBX_ERR_EMPTY, "no parameters or no residuals");
-  // ---- validate indices on the host before any kernel dereferences them
+// ---- host side of the solver ------------------------------------------------------------------------------------------
+namespace {
+
+constexpr size_t BA_LDS_STATIC = 20736;                              // static LDS of ba_solve_lds_kernel (sb, srinv, s_red, ...), rounded up
+constexpr size_t BA_LDS_DYN_MAX = 160 * 1024 - BA_LDS_STATIC;
+
+struct Carve {                                                       // byte offsets inside one buffer, 256-byte aligned pieces
+  size_t off = 0;
+  size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
+
+// everything about one window that is known from its sizes alone
+struct WinPlan {
+  BaDims d{};
+  int n = 0, use_lds = 0, skip = 0;
+  size_t np = 0, n_upper = 0, rb_len = 0, lds_need = 0;
+  // byte offsets: input blob (host-prepared arrays), scratch arena, WT/YT arena, output blob
+  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_oflag, i_omp;
+  size_t a_p1, a_oA, a_oR, a_oYg, a_vinv, a_gl, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
+  size_t w_wt, w_yt, o_out;
+  int n_kfobs = 0;
+  double n_res = 0.0;
+};
+
+int pinned_reserve(orbx_handle* h, void** p, size_t* have, size_t need) {
+  if (need <= *have) return ORBX_OK;
+  if (*p) { ORBX_HIP(h, hipStreamSynchronize(h->stream)); ORBX_HIP(h, hipHostFree(*p)); *p = nullptr; *have = 0; }
+  const size_t want = (need + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+  ORBX_HIP(h, hipHostMalloc(p, want));
+  *have = want;
+  return ORBX_OK;
+}
+
+// host preprocessing of one window straight into the (pinned) input blob: parameters, fixed poses, point-major CSR of the
+// observations, keyframe CSR over that order.  Returns the index of a bad observation or -1.
+int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inertial, const BaInertialHost* inr) {
+  const int K = w.K, F = w.F, M = w.M, N = w.N;
+  const orbx_ba_obs* obs = w.obs;
   for (int i = 0; i < N; ++i) {
     const orbx_ba_obs& o = obs[i];
-    if (o.mp_idx < 0 || o.mp_idx >= M || o.kf_idx >= K || (o.kf_idx < 0 && o.fixed_idx >= F))
-      return orbx_fail(h, ORBX_ERR_INVALID, "observation %d: index out of range (kf %d/%d, fixed %d/%d, mp %d/%d)", i,
-                       o.kf_idx, K, o.fixed_idx, F, o.mp_idx, M);
+    if (o.mp_idx < 0 || o.mp_idx >= M || o.kf_idx >= K || (o.kf_idx < 0 && o.fixed_idx >= F)) return i;
   }
-  BaDims d{};
-  d.K = K; d.F = F; d.M = M; d.N = N;
-  d.P = std::max(16, (6 * K + 15) & ~15);
-  d.ntile = d.P / 16;
-  d.ksplit = std::max(1, std::min(32, (3 * M + 255) / 256));
-  d.rows = ((3 * M + 4 * d.ksplit - 1) / (4 * d.ksplit)) * (4 * d.ksplit);
-  if (d.rows == 0) d.rows = 4 * d.ksplit;
-  const int n = 6 * K;
-  BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, inertial ? inr->cfg->huber_threshold_mono : cfg->huber_threshold, global_mode ? 1 : 0,
-           inertial ? 1 : 0, inertial ? inr->cfg->huber_threshold_stereo : 0.0, nullptr};
-
-  // ---- host preprocessing: point-major CSR, keyframe CSR over the point-major order
-  std::vector<int> pt_start(M + 1, 0), order(N);
+  double* params = (double*)(blob + pl.i_params);
+  double* Rt_fix = (double*)(blob + pl.i_rtfix);
+  int* pt_start = (int*)(blob + pl.i_ptstart);
+  int* kf_start = (int*)(blob + pl.i_kfstart);
+  int* o_kf = (int*)(blob + pl.i_okf);
+  int* o_fix = (int*)(blob + pl.i_ofix);
+  double* o_uv = (double*)(blob + pl.i_ouv);
+  int* kf_obs = (int*)(blob + pl.i_kfobs);
+  int* o_flag = inertial ? (int*)(blob + pl.i_oflag) : nullptr;
+  for (int j = 0; j <= M; ++j) pt_start[j] = 0;
   for (int i = 0; i < N; ++i) pt_start[obs[i].mp_idx + 1]++;
   for (int j = 0; j < M; ++j) pt_start[j + 1] += pt_start[j];
+  for (int k = 0; k <= K; ++k) kf_start[k] = 0;
   {
-    std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
-    for (int i = 0; i < N; ++i) order[fill[obs[i].mp_idx]++] = i;   // stable: input order within a point
-  }
-  std::vector<int> o_kf(N), o_fix(N), kf_start(K + 1, 0), kf_obs, o_flag(inertial ? N : 0);
-  std::vector<double> o_uv(2 * (size_t)N);
-  for (int t = 0; t < N; ++t) {
-    const orbx_ba_obs& o = obs[order[t]];
-    if (inertial) o_flag[t] = o._pad;
-    o_kf[t] = o.kf_idx >= 0 ? o.kf_idx : -1;
-    o_fix[t] = o.kf_idx >= 0 ? 0 : (o.fixed_idx >= 0 ? o.fixed_idx : F);   // slot F = identity (:569)
-    o_uv[2 * (size_t)t] = o.u; o_uv[2 * (size_t)t + 1] = o.v;
-    if (o.kf_idx >= 0) kf_start[o.kf_idx + 1]++;
+    std::vector<int> fill(pt_start, pt_start + M);
+    for (int i = 0; i < N; ++i) {                                       // stable: input order within a point
+      const orbx_ba_obs& o = obs[i];
+      const int t = fill[o.mp_idx]++;
+      if (inertial) o_flag[t] = o._pad;
+      o_kf[t] = o.kf_idx >= 0 ? o.kf_idx : -1;
+      o_fix[t] = o.kf_idx >= 0 ? 0 : (o.fixed_idx >= 0 ? o.fixed_idx : F);   // slot F = identity (:569)
+      o_uv[2 * (size_t)t] = o.u; o_uv[2 * (size_t)t + 1] = o.v;
+      if (o.kf_idx >= 0) kf_start[o.kf_idx + 1]++;
+    }
   }
   for (int k = 0; k < K; ++k) kf_start[k + 1] += kf_start[k];
-  kf_obs.resize(kf_start[K]);
   {
-    std::vector<int> fill(kf_start.begin(), kf_start.end() - 1);
+    std::vector<int> fill(kf_start, kf_start + K);
     for (int t = 0; t < N; ++t) if (o_kf[t] >= 0) kf_obs[fill[o_kf[t]]++] = t;
   }
-  std::vector<double> params(6 * (size_t)K + 3 * (size_t)M + (inertial ? 9 * (size_t)K : 0)), Rt_fix(12 * (size_t)(F + 1));
-  for (int k = 0; k < K; ++k) host_se3_to_params(poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);   // scaled axis + translation
-  for (int j = 0; j < 3 * M; ++j) params[6 * (size_t)K + j] = points[j];
+  for (int k = 0; k < K; ++k) host_se3_to_params(w.poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);   // scaled axis + translation
+  for (int j = 0; j < 3 * M; ++j) params[6 * (size_t)K + j] = w.points[j];
   if (inertial)                                                          // :1154-1173
     for (int k = 0; k < K; ++k) {
       double* ex = &params[6 * (size_t)K + 3 * (size_t)M + 9 * (size_t)k];
@@ -1415,263 +1540,459 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
     }
   for (int f = 0; f <= F; ++f) {
     const double ident[7] = {1, 0, 0, 0, 0, 0, 0};
-    const double* p = f < F ? fixed_poses_cw + 7 * (size_t)f : ident;
+    const double* p = f < F ? w.fixed_poses_cw + 7 * (size_t)f : ident;
     host_quat_to_R(p, &Rt_fix[12 * (size_t)f]);
     Rt_fix[12 * (size_t)f + 9] = p[4]; Rt_fix[12 * (size_t)f + 10] = p[5]; Rt_fix[12 * (size_t)f + 11] = p[6];
   }
+  return -1;
+}
 
-  // ---- device buffers
-  enum { B_PARAMS, B_TRIAL, B_RTOPT, B_RTFIX, B_PTSTART, B_OKF, B_OFIX, B_OUV, B_KFSTART, B_KFOBS, B_OA, B_OR, B_OYG,
-         B_VINV, B_GL, B_PT, B_WT, B_YT, B_PART, B_UG, B_RB, B_SOLVE, B_RES, B_STATE_, B_OFLAG, B_IMU, B_S15 };
-  const size_t np = params.size();
-  const size_t n_upper = (size_t)d.ntile * (d.ntile + 1) / 2;
-  const size_t rb_len = (size_t)n * n + 36 * (size_t)K + 2 * (size_t)n + 2;
-  struct { int id; size_t bytes; } need[] = {
-      {B_PARAMS, 8 * np}, {B_TRIAL, 8 * np}, {B_RTOPT, 8 * 12 * (size_t)std::max(K, 1)}, {B_RTFIX, 8 * Rt_fix.size()},
-      {B_PTSTART, 4 * (size_t)(M + 1)}, {B_OKF, 4 * (size_t)std::max(N, 1)}, {B_OFIX, 4 * (size_t)std::max(N, 1)},
-      {B_OUV, 16 * (size_t)std::max(N, 1)}, {B_KFSTART, 4 * (size_t)(K + 1)}, {B_KFOBS, 4 * (size_t)std::max<size_t>(kf_obs.size(), 1)},
-      {B_OA, 96 * (size_t)std::max(N, 1)}, {B_OR, 16 * (size_t)std::max(N, 1)}, {B_OYG, 48 * (size_t)std::max(N, 1)},
-      {B_VINV, 72 * (size_t)std::max(M, 1)}, {B_GL, 24 * (size_t)std::max(M, 1)}, {B_PT, 8 * 4 * (size_t)std::max(M, 1)},
-      {B_WT, 8 * (size_t)d.rows * d.P}, {B_YT, 8 * (size_t)d.rows * d.P}, {B_PART, 8 * n_upper * d.ksplit * 256},
-      {B_UG, 8 * (size_t)(33 * BA_KFSPLIT * std::max(K, 1))}, {B_RB, 8 * (rb_len + 8)}, {B_SOLVE, 8 * ((size_t)n * n + 4 * (size_t)n + 64 + BA_SOLVE_THREADS)}, {B_RES, 8 * 16},
-      {B_OFLAG, 4 * (size_t)std::max(N, 1)},
-      // inertial: edges (int [E][2]) | preint [E][11] | per-edge J^T J records
-      {B_IMU, inertial ? 8 * ((size_t)inr->E * (1 + 11 + IMU_REC) + 8) : 8},
-      // inertial: dp15 [n15 pad 16] | S [n15^2] | b [n15] | 1/L_jj [n15] | gradient [n15]
-      {B_S15, inertial ? 8 * ((size_t)(15 * K) * (15 * K) + 4 * (size_t)(15 * K) + 64) : 8}};
-  for (auto& nd : need) if (int rc = orbx_reserve(h, h->ws_ba[nd.id], nd.bytes)) return rc;
-  auto D = [&](int id) { return (double*)h->ws_ba[id].p; };
-  auto I = [&](int id) { return (int*)h->ws_ba[id].p; };
+}  // namespace
+
+// W windows at once (W = 1: orbx_ba_solve_visual / global / inertial).  The all-reduce hook and the inertial mode apply to a
+// single window only.
+int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int W, BaWinHost* win,
+                   orbx_should_stop_fn should_stop, void* user, bool global_mode, const BaInertialHost* inr) {
+  // inr != nullptr: solve_inertial_ba (local_inertial_ba.rs:1074-1275).  `poses_cw` then holds the T_wc poses of the window
+  // and cfg carries max_iterations only; the point elimination, the per-keyframe 6x6 blocks and the Schur product are the
+  // visual solver's kernels, the 15-d keyframe states are assembled and solved on top of them.
+  const bool inertial = inr != nullptr;
+  const bool dist = h->allreduce != nullptr && !inertial && W == 1;
+  if (W <= 0) return ORBX_OK;
+  if ((inertial || (h->allreduce != nullptr && !inertial)) && W != 1)
+    return orbx_fail(h, ORBX_ERR_INVALID, "the inertial mode and the all-reduce hook take one window per call");
+  for (int w = 0; w < W; ++w) { *win[w].iterations = 0; *win[w].initial_error = 0.0; *win[w].final_error = 0.0; win[w].status = ORBX_OK; }
   hipStream_t st = h->stream;
-  ORBX_HIP(h, hipMemcpyAsync(D(B_PARAMS), params.data(), 8 * np, hipMemcpyHostToDevice, st));
-  ORBX_HIP(h, hipMemcpyAsync(D(B_RTFIX), Rt_fix.data(), 8 * Rt_fix.size(), hipMemcpyHostToDevice, st));
-  ORBX_HIP(h, hipMemcpyAsync(I(B_PTSTART), pt_start.data(), 4 * (size_t)(M + 1), hipMemcpyHostToDevice, st));
-  ORBX_HIP(h, hipMemcpyAsync(I(B_KFSTART), kf_start.data(), 4 * (size_t)(K + 1), hipMemcpyHostToDevice, st));
-  if (N > 0) {
-    ORBX_HIP(h, hipMemcpyAsync(I(B_OKF), o_kf.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
-    ORBX_HIP(h, hipMemcpyAsync(I(B_OFIX), o_fix.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
-    ORBX_HIP(h, hipMemcpyAsync(D(B_OUV), o_uv.data(), 16 * (size_t)N, hipMemcpyHostToDevice, st));
+
+  // ---- plan: dimensions and the layout of the four buffers
+  std::vector<WinPlan> plan(W);
+  Carve cin, car, cwt, cout;
+  const size_t i_wins = cin.take(sizeof(BaWin) * (size_t)W);
+  const size_t i_wins15 = cin.take(sizeof(BaWin));                      // inertial: the same window seen by the 15-d solve
+  const size_t i_outoff = cin.take(sizeof(size_t) * (size_t)W);
+  int live = 0;
+  for (int w = 0; w < W; ++w) {
+    const BaWinHost& ww = win[w];
+    WinPlan& pl = plan[w];
+    const int K = ww.K, F = ww.F, M = ww.M, N = ww.N;
+    // local_ba_lm.rs:923-925 (with a partition the local N may be 0 while the global problem is not)
+    if ((6 * (size_t)K + 3 * (size_t)M == 0) || (N == 0 && !dist && !inertial)) {
+      win[w].status = ORBX_ERR_EMPTY;
+      pl.skip = 1;
+    } else ++live;
+    if (6 * K > BA_MAX_N || K > BA_MAX_K) return orbx_fail(h, ORBX_ERR_INVALID, "window %d: at most %d optimised keyframes per window", w, BA_MAX_N / 6);
+    BaDims& d = pl.d;
+    d.K = K; d.F = F; d.M = M; d.N = N;
+    d.P = std::max(16, (6 * K + 15) & ~15);
+    d.ntile = d.P / 16;
+    d.ksplit = std::max(1, std::min(32, (3 * M + 255) / 256));
+    d.rows = ((3 * M + 4 * d.ksplit - 1) / (4 * d.ksplit)) * (4 * d.ksplit);
+    if (d.rows == 0) d.rows = 4 * d.ksplit;
+    pl.n = 6 * K;
+    pl.np = 6 * (size_t)K + 3 * (size_t)M + (inertial ? 9 * (size_t)K : 0);
+    pl.n_upper = (size_t)d.ntile * (d.ntile + 1) / 2;
+    pl.rb_len = (size_t)pl.n * pl.n + 36 * (size_t)K + 2 * (size_t)pl.n + 2;
+    pl.lds_need = 8 * ((size_t)pl.n * pl.n + BA_SOLVE_THREADS);
+    pl.use_lds = pl.lds_need <= BA_LDS_DYN_MAX ? 1 : 0;
+    pl.n_res = 2.0 * (double)N;
+    const size_t n1 = (size_t)std::max(N, 1), m1 = (size_t)std::max(M, 1), k1 = (size_t)std::max(K, 1);
+    pl.i_state = cin.take(sizeof(BaState));
+    pl.i_params = cin.take(8 * std::max<size_t>(pl.np, 1));
+    pl.i_rtfix = cin.take(8 * 12 * (size_t)(F + 1));
+    pl.i_ptstart = cin.take(4 * (size_t)(M + 1));
+    pl.i_kfstart = cin.take(4 * (size_t)(K + 1));
+    pl.i_okf = cin.take(4 * n1);
+    pl.i_ofix = cin.take(4 * n1);
+    pl.i_ouv = cin.take(16 * n1);
+    pl.i_kfobs = cin.take(4 * n1);
+    pl.i_oflag = inertial ? cin.take(4 * n1) : 0;
+    pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
+    pl.a_oA = car.take(96 * n1); pl.a_oR = car.take(16 * n1); pl.a_oYg = car.take(48 * n1);
+    pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
+    pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
+    pl.a_part = car.take(8 * pl.n_upper * d.ksplit * 256);
+    pl.a_rb = car.take(8 * (pl.rb_len + 8));
+    pl.a_solve = car.take(8 * ((size_t)pl.n * pl.n + 4 * (size_t)pl.n + 64 + BA_SOLVE_THREADS));   // dp [n pad 16] | S [n*n] | b [n] | 1/L_jj [n]
+    pl.a_res = car.take(8 * 16);
+    pl.w_wt = cwt.take(8 * (size_t)d.rows * d.P);
+    pl.w_yt = cwt.take(8 * (size_t)d.rows * d.P);
+    pl.o_out = cout.take(8 * (8 + pl.np));
   }
-  if (!kf_obs.empty()) ORBX_HIP(h, hipMemcpyAsync(I(B_KFOBS), kf_obs.data(), 4 * kf_obs.size(), hipMemcpyHostToDevice, st));
+  if (live == 0) {
+    if (W == 1) return orbx_fail(h, ORBX_ERR_EMPTY, "no parameters or no residuals");
+    return ORBX_OK;                                                      // every window reports ORBX_ERR_EMPTY in its status
+  }
+  enum { B_IN, B_ARENA, B_WTYT, B_OUT, B_IMU, B_S15 };
+  const int K0 = win[0].K, M0 = win[0].M;                               // inertial / partitioned: the one window
+  const int n15 = 15 * K0;
+  if (inertial && n15 > BA_MAX_N) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d keyframes per inertial window", BA_MAX_N / 15);
+  if (int rc = orbx_reserve(h, h->ws_ba[B_IN], cin.off)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_ba[B_ARENA], car.off)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_ba[B_WTYT], cwt.off)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_ba[B_OUT], cout.off)) return rc;
+  // inertial: edges (int [E][2]) | preint [E][11] | per-edge J^T J records;  dp15 [n15 pad 16] | S [n15^2] | b | 1/L_jj | gradient
+  if (int rc = orbx_reserve(h, h->ws_ba[B_IMU], inertial ? 8 * ((size_t)inr->E * (1 + 11 + IMU_REC) + 8) : 8)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_ba[B_S15], inertial ? 8 * ((size_t)n15 * n15 + 4 * (size_t)n15 + 64) : 8)) return rc;
+  if (int rc = pinned_reserve(h, &h->h_ba_in, &h->h_ba_in_bytes, cin.off)) return rc;
+  if (int rc = pinned_reserve(h, &h->h_ba_out, &h->h_ba_out_bytes, cout.off)) return rc;
+  if (!h->h_abort) {
+    ORBX_HIP(h, hipHostMalloc((void**)&h->h_abort, 64));
+    ORBX_HIP(h, hipHostGetDevicePointer((void**)&h->d_abort, h->h_abort, 0));
+  }
+  *h->h_abort = 0;
+  uint8_t* hin = (uint8_t*)h->h_ba_in;
+  uint8_t* din = (uint8_t*)h->ws_ba[B_IN].p;
+  uint8_t* dar = (uint8_t*)h->ws_ba[B_ARENA].p;
+  uint8_t* dwt = (uint8_t*)h->ws_ba[B_WTYT].p;
+  double* dout = (double*)h->ws_ba[B_OUT].p;
+
+  // ---- host preprocessing, one window per task (threads when the batch is large enough to pay for them)
+  std::vector<int> bad(W, -1);
+  {
+    auto work = [&](int w) { if (!plan[w].skip) bad[w] = prep_window(win[w], plan[w], hin, inertial, inr); };
+    size_t total_obs = 0;
+    for (int w = 0; w < W; ++w) total_obs += (size_t)win[w].N;
+    int nthr = (int)std::min<size_t>({(size_t)W, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, total_obs / 20000 + 1});
+    if (nthr <= 1) { for (int w = 0; w < W; ++w) work(w); }
+    else {
+      std::atomic<int> next{0};
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthr; ++t) th.emplace_back([&] { for (int w; (w = next.fetch_add(1)) < W;) work(w); });
+      for (auto& t : th) t.join();
+    }
+  }
+  int first_bad = -1;
+  for (int w = 0; w < W && first_bad < 0; ++w) if (bad[w] >= 0) first_bad = w;
+  if (first_bad >= 0 && !dist) {
+    const orbx_ba_obs& o = win[first_bad].obs[bad[first_bad]];
+    return orbx_fail(h, ORBX_ERR_INVALID, "window %d observation %d: index out of range (kf %d/%d, fixed %d/%d, mp %d/%d)", first_bad,
+                     bad[first_bad], o.kf_idx, win[first_bad].K, o.fixed_idx, win[first_bad].F, o.mp_idx, win[first_bad].M);
+  }
+  // window descriptors + LM states into the blob
+  BaWin* hw = (BaWin*)(hin + i_wins);
+  size_t* hoff = (size_t*)(hin + i_outoff);
+  size_t lds_max = 0;
+  int any_lds = 0, any_big = 0, n_big_max = 0, maxM = 0, maxK = 0, max_kfs_blocks = 1, max_gather = 1, max_back = 1, max_asm = 1;
+  for (int w = 0; w < W; ++w) {
+    const WinPlan& pl = plan[w];
+    BaWin& b = hw[w];
+    memset(&b, 0, sizeof(b));
+    b.d = pl.d; b.n = pl.n; b.use_lds = pl.use_lds;
+    b.S = (BaState*)(din + pl.i_state);
+    b.P0 = (double*)(din + pl.i_params); b.P1 = (double*)(dar + pl.a_p1);
+    b.Rt_fix = (const double*)(din + pl.i_rtfix);
+    b.pt_start = (const int*)(din + pl.i_ptstart); b.o_kf = (const int*)(din + pl.i_okf); b.o_fix = (const int*)(din + pl.i_ofix);
+    b.o_uv = (const double*)(din + pl.i_ouv);
+    b.kf_start = (const int*)(din + pl.i_kfstart); b.kf_obs = (const int*)(din + pl.i_kfobs);
+    b.oA = (double*)(dar + pl.a_oA); b.oR = (double*)(dar + pl.a_oR); b.oYg = (double*)(dar + pl.a_oYg);
+    b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl);
+    const size_t m1 = (size_t)std::max(pl.d.M, 1);
+    b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
+    b.WT = (double*)(dwt + pl.w_wt); b.YT = (double*)(dwt + pl.w_yt);
+    b.kfpart = (double*)(dar + pl.a_kfpart); b.part = (double*)(dar + pl.a_part); b.rb = (double*)(dar + pl.a_rb);
+    b.dp = (double*)(dar + pl.a_solve);
+    b.Sg = b.dp + ((pl.n + 15) & ~15); b.bvec = b.Sg + (size_t)pl.n * pl.n; b.ginv = b.bvec + pl.n;
+    b.res = (double*)(dar + pl.a_res);
+    hoff[w] = pl.o_out / 8;
+    BaState& s0 = *(BaState*)(hin + pl.i_state);
+    memset(&s0, 0, sizeof(s0));
+    s0.lambda = inertial ? inr->cfg->initial_lambda : 1e-3;            // :1006-1010 / local_inertial_ba.rs:1195
+    s0.gtol = inertial ? 1e-8 : cfg->gradient_tolerance;              // local_inertial_ba.rs:1213
+    s0.ptol = inertial ? 0.0 : cfg->param_tolerance;                  // the inertial loop has no step-size test
+    s0.done = pl.skip;                                                 // a window the reference answers None for (:923-925) never runs
+    if (pl.skip) continue;
+    if (pl.use_lds && !inertial) { any_lds = 1; lds_max = std::max(lds_max, pl.lds_need); }
+    else if (!inertial) { any_big = 1; n_big_max = std::max(n_big_max, pl.n); }
+    maxM = std::max(maxM, pl.d.M); maxK = std::max(maxK, pl.d.K);
+    max_kfs_blocks = std::max(max_kfs_blocks, pl.d.K * BA_KFSPLIT + (int)((pl.n_upper * pl.d.ksplit + 3) / 4));
+    max_gather = std::max(max_gather, std::min(256, (pl.n * pl.n + 255) / 256));
+    max_back = std::max(max_back, (std::max(32 * pl.d.M, pl.n) + 255) / 256);
+    max_asm = std::max(max_asm, std::min(512, (pl.n * pl.n + 255) / 256));
+  }
+  BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, inertial ? inr->cfg->huber_threshold_mono : cfg->huber_threshold, global_mode ? 1 : 0,
+           inertial ? 1 : 0, inertial ? inr->cfg->huber_threshold_stereo : 0.0, nullptr};
   BaInertialDev ind{};
-  const int n15 = 15 * K;
   double* imu_buf = nullptr;
+  BaWin* d_wins = (BaWin*)(din + i_wins);
+  BaWin* d_wins15 = (BaWin*)(din + i_wins15);
+  double *dp15 = nullptr, *gfull = nullptr;
   if (inertial) {
-    if (n15 > BA_MAX_N) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d keyframes per inertial window", BA_MAX_N / 15);
     for (int e = 0; e < inr->E; ++e)
-      if (inr->edge_kf[2 * e] < 0 || inr->edge_kf[2 * e] >= K || inr->edge_kf[2 * e + 1] < 0 || inr->edge_kf[2 * e + 1] >= K)
+      if (inr->edge_kf[2 * e] < 0 || inr->edge_kf[2 * e] >= K0 || inr->edge_kf[2 * e + 1] < 0 || inr->edge_kf[2 * e + 1] >= K0)
         return orbx_fail(h, ORBX_ERR_INVALID, "IMU edge %d: keyframe index out of range", e);
-    if (N > 0) ORBX_HIP(h, hipMemcpyAsync(I(B_OFLAG), o_flag.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
-    bc.o_flag = I(B_OFLAG);
-    int* d_edges = I(B_IMU);
-    double* d_pre = D(B_IMU) + inr->E;                                   // 2 ints per edge = 1 double slot per edge
+    bc.o_flag = (const int*)(din + plan[0].i_oflag);
+    int* d_edges = (int*)h->ws_ba[B_IMU].p;
+    double* d_pre = (double*)h->ws_ba[B_IMU].p + inr->E;               // 2 ints per edge = 1 double slot per edge
     imu_buf = d_pre + 11 * (size_t)inr->E;
     if (inr->E > 0) {
       ORBX_HIP(h, hipMemcpyAsync(d_edges, inr->edge_kf, 8 * (size_t)inr->E, hipMemcpyHostToDevice, st));
       ORBX_HIP(h, hipMemcpyAsync(d_pre, inr->preint, 88 * (size_t)inr->E, hipMemcpyHostToDevice, st));
     }
-    ind.K = K; ind.M = M; ind.E = inr->E;
+    ind.K = K0; ind.M = M0; ind.E = inr->E;
     ind.gw = std::sqrt(inr->cfg->gyro_rw_info); ind.aw = std::sqrt(inr->cfg->accel_rw_info);
     ind.edge_kf = d_edges; ind.preint = d_pre;
+    // the 15-d system: dp15 [n15 pad 16] | S [n15^2] | b [n15] | 1/L_jj [n15] | gradient [n15]
+    BaWin& b15 = *(BaWin*)(hin + i_wins15);
+    b15 = hw[0];
+    b15.n = n15; b15.use_lds = 0;
+    dp15 = (double*)h->ws_ba[B_S15].p;
+    b15.dp = dp15;
+    b15.Sg = dp15 + ((n15 + 15) & ~15); b15.bvec = b15.Sg + (size_t)n15 * n15; b15.ginv = b15.bvec + n15;
+    gfull = b15.ginv + n15;
   }
+  ORBX_HIP(h, hipMemcpyAsync(din, hin, cin.off, hipMemcpyHostToDevice, st));         // ONE upload for the whole batch
   // the sparsity pattern of WT/YT is the same every iteration: zero once
-  ORBX_HIP(h, hipMemsetAsync(D(B_WT), 0, 8 * (size_t)d.rows * d.P, st));
-  ORBX_HIP(h, hipMemsetAsync(D(B_YT), 0, 8 * (size_t)d.rows * d.P, st));
-  double* pt_chi2 = D(B_PT); double* pt_glsq = pt_chi2 + std::max(M, 1);
-  double* pt_dsq = pt_glsq + std::max(M, 1); double* pt_psq = pt_dsq + std::max(M, 1);
-  double* kfpart = D(B_UG);
-  double* res = D(B_RES);
-  double hres[16];
-
-  if (n > BA_MAX_N || K > BA_MAX_K) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d optimised keyframes per window", BA_MAX_N / 6);
-  const size_t lds_need = 8 * ((size_t)n * n + BA_SOLVE_THREADS);
-  const bool use_lds = lds_need + 8 * (2 * BA_MAX_N + BA_SOLVE_THREADS) + 64 <= 160 * 1024;
-  if (use_lds && n > 0)
-    ORBX_HIP(h, hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-
-  // device-side LM state
-  if (int rc = orbx_reserve(h, h->ws_ba[23], sizeof(BaState))) return rc;
-  BaState* S = (BaState*)h->ws_ba[23].p;
+  ORBX_HIP(h, hipMemsetAsync(dwt, 0, cwt.off, st));
   {
-    BaState s0{};
-    s0.lambda = inertial ? inr->cfg->initial_lambda : 1e-3;            // :1006-1010 / local_inertial_ba.rs:1195
-    s0.gtol = inertial ? 1e-8 : cfg->gradient_tolerance;              // local_inertial_ba.rs:1213
-    s0.ptol = inertial ? 0.0 : cfg->param_tolerance;                  // the inertial loop has no step-size test
-    ORBX_HIP(h, hipMemcpyAsync(S, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
-    ORBX_HIP(h, hipStreamSynchronize(st));                             // s0 is a stack object
+    static std::once_flag once[64];                                    // process-wide function attribute: set once per device to
+    hipError_t e_attr = hipSuccess;                                    // the largest size any window may ask for
+    std::call_once(once[h->device & 63], [&] {
+      e_attr = hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_LDS_DYN_MAX);
+    });
+    ORBX_HIP(h, e_attr);
   }
-  double* P0 = D(B_PARAMS);
-  double* P1 = D(B_TRIAL);
+  const BaWin& w0 = hw[0];                                              // host copies of the device pointers of window 0
+  double* res0 = w0.res;
+  const dim3 gW1(1, W);
   auto allreduce = [&](double* dptr, size_t cnt) -> int {
     if (!dist) return ORBX_OK;
     if (h->allreduce(h->allreduce_user, dptr, cnt, (void*)st) != 0) return orbx_fail(h, ORBX_ERR_HIP, "all-reduce hook failed");
     return ORBX_OK;
   };
-  auto chi2_sum = [&](int which, double* out_sum3, const double* b2, const double* c2) {
-    hipLaunchKernelGGL(ba_sum3_kernel, dim3(1), dim3(256), 0, st, S, M, pt_chi2, b2, c2, out_sum3);
+  auto chi2_sum = [&](int which, int three) {
+    hipLaunchKernelGGL(ba_sum3_kernel, gW1, dim3(256), 0, st, d_wins, three);
     if (inertial && inr->E > 0) {                                        // + IMU and bias-random-walk residuals (:661-698)
-      hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, S, P0, P1, which, 0, ind, imu_buf);
-      hipLaunchKernelGGL(ba_imu_addchi_kernel, dim3(1), dim3(1), 0, st, S, inr->E, imu_buf, out_sum3, 0);
+      hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, w0.S, w0.P0, w0.P1, which, 0, ind, imu_buf);
+      hipLaunchKernelGGL(ba_imu_addchi_kernel, dim3(1), dim3(1), 0, st, w0.S, inr->E, imu_buf, res0 + (three ? 5 : 12), 0);
     }
   };
-  auto chi2_of = [&](int which, double* out_sum3, const double* b2, const double* c2) {
-    if (M > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, which, D(B_RTFIX),
-                                  I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), pt_chi2);
-    chi2_sum(which, out_sum3, b2, c2);
-  };
-  // total residual count over all ranks (for the RMS error): all-reduce one double when partitioned
-  double n_res = 2.0 * (double)N;
+  // Partitioned over ranks: every rank must issue the same sequence of collectives, whatever its own should_stop() or its
+  // own partition says — so the decisions travel with the collectives.  [total residual count | stop votes for
+  // iteration 0 | ranks with a bad observation index] first (host-read), then the votes for iteration i+1 ride on the second
+  // all-reduce of iteration i (res[8], read by ba_decide_kernel); a rank whose should_stop() fired keeps enqueueing.
+  double n_res = plan[0].n_res;
+  std::vector<double> votes((size_t)std::max(cfg->max_iterations, 0) + 2, 0.0);
+  bool my_stop = false;
   if (dist) {
-    ORBX_HIP(h, hipMemcpyAsync(res + 8, &n_res, 8, hipMemcpyHostToDevice, st));
+    my_stop = should_stop && should_stop(user);
+    const double head[3] = {n_res, my_stop ? 1.0 : 0.0, first_bad >= 0 ? 1.0 : 0.0};
+    ORBX_HIP(h, hipMemcpyAsync(res0 + 8, head, 24, hipMemcpyHostToDevice, st));
     ORBX_HIP(h, hipStreamSynchronize(st));
-    if (int rc = allreduce(res + 8, 1)) return rc;
-    ORBX_HIP(h, hipMemcpyAsync(&n_res, res + 8, 8, hipMemcpyDeviceToHost, st));
+    if (int rc = allreduce(res0 + 8, 3)) return rc;
+    double tot[3];
+    ORBX_HIP(h, hipMemcpyAsync(tot, res0 + 8, 24, hipMemcpyDeviceToHost, st));
     ORBX_HIP(h, hipStreamSynchronize(st));
+    if (tot[2] > 0.0) return orbx_fail(h, ORBX_ERR_INVALID, "an observation index is out of range on %d rank(s)%s", (int)tot[2], first_bad >= 0 ? " (this one too)" : "");
+    n_res = tot[0];
     if (n_res == 0.0) return orbx_fail(h, ORBX_ERR_EMPTY, "no residuals on any rank");
+    my_stop = tot[1] > 0.0;                                              // the collective decision for iteration 0
   }
 
   // initial error (:1000-1001) -> res[12]
   {
     ProfScope ps(h, "ba_chi2");
-    chi2_of(0, res + 12, nullptr, nullptr);
+    if (maxM > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((maxM * 32 + 255) / 256, W), dim3(256), 0, st, d_wins, bc, 0);
+    chi2_sum(0, 0);
   }
-  if (int rc = allreduce(res + 12, 1)) return rc;
+  if (int rc = allreduce(res0 + 12, 1)) return rc;
 
   // The loop only polls should_stop (:1013) and enqueues; nothing below waits for the GPU.
-  for (int iter = 0; iter < cfg->max_iterations; ++iter) {           // :1012
-    if (should_stop && should_stop(user)) break;                     // :1013
+  bool stopped = my_stop;
+  for (int iter = 0; iter < cfg->max_iterations && !(dist && iter == 0 && my_stop); ++iter) {           // :1012
+    if (!dist && should_stop && should_stop(user)) { stopped = true; break; }                           // :1013
     {
       ProfScope ps(h, "ba_build_kernel");
-      if (M > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, iter,
-                                    D(B_RTFIX), I(B_PTSTART), I(B_OKF), I(B_OFIX), D(B_OUV), D(B_OA), D(B_OR), D(B_OYG),
-                                    D(B_VINV), D(B_GL), pt_chi2, pt_glsq, D(B_WT), D(B_YT));
-      else hipLaunchKernelGGL(ba_iter_kernel, dim3(1), dim3(1), 0, st, S, iter);
+      if (maxM > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((maxM * 32 + 255) / 256, W), dim3(256), 0, st, d_wins, bc, iter);
+      else hipLaunchKernelGGL(ba_iter_kernel, gW1, dim3(1), 0, st, d_wins, iter);
     }
-    if (K > 0) {
+    if (maxK > 0) {
       ProfScope ps(h, "ba_kf_schur_kernel");
-      const int units = (int)n_upper * d.ksplit, nkf = K * BA_KFSPLIT;
-      hipLaunchKernelGGL(ba_kf_schur_kernel, dim3(nkf + (units + 3) / 4), dim3(256), 0, st, d, S, nkf, I(B_KFSTART), I(B_KFOBS), D(B_OA),
-                         D(B_OR), D(B_OYG), kfpart, D(B_YT), D(B_WT), D(B_PART));
+      hipLaunchKernelGGL(ba_kf_schur_kernel, dim3(max_kfs_blocks, W), dim3(256), 0, st, d_wins);
     }
     {
       ProfScope ps(h, "ba_gather_kernel");
-      const int blocks = std::max(1, std::min(256, (n * n + 255) / 256));
-      hipLaunchKernelGGL(ba_gather_kernel, dim3(blocks), dim3(256), 0, st, d, S, D(B_PART), kfpart, pt_chi2, pt_glsq, D(B_RB));
+      hipLaunchKernelGGL(ba_gather_kernel, dim3(max_gather, W), dim3(256), 0, st, d_wins);
     }
-    if (int rc = allreduce(D(B_RB), rb_len)) return rc;
+    if (int rc = allreduce(w0.rb, plan[0].rb_len)) return rc;
     if (inertial) {
       ProfScope ps(h, "ba_inertial_solve");
-      double* dp15 = D(B_S15);
-      double* Sg = dp15 + ((n15 + 15) & ~15);
-      double* bvec = Sg + (size_t)n15 * n15;
-      double* ginv = bvec + n15;
-      double* gfull = ginv + n15;
-      if (inr->E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, S, P0, P1, 0, 1, ind, imu_buf);
-      hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, S, P0, P1, ind, D(B_RB), imu_buf, Sg, bvec, gfull, res);
+      const BaWin& b15 = *(const BaWin*)(hin + i_wins15);
+      if (inr->E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, w0.S, w0.P0, w0.P1, 0, 1, ind, imu_buf);
+      hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, ind, w0.rb, imu_buf, b15.Sg, b15.bvec, gfull, res0);
       for (int c0 = 0; c0 < n15; c0 += BB_NB) {
-        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(1), dim3(256), 0, st, n15, c0, S, Sg, ginv, res);
+        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15, c0);
         const int m = n15 - c0 - BB_NB;
         if (m > 0) {
           const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2;
-          hipLaunchKernelGGL(ba_big_update_kernel, dim3((units + 3) / 4), dim3(256), 0, st, n15, c0, S, Sg, res);
+          hipLaunchKernelGGL(ba_big_update_kernel, dim3((units + 3) / 4, 1), dim3(256), 0, st, d_wins15, c0);
         }
       }
-      hipLaunchKernelGGL(ba_big_subst_kernel, dim3(1), dim3(256), 0, st, n15, S, P0, P1, Sg, ginv, bvec, dp15, res);
-      hipLaunchKernelGGL(ba_inertial_scatter_kernel, dim3(1), dim3(256), 0, st, S, P0, P1, K, M, dp15, D(B_SOLVE));
+      hipLaunchKernelGGL(ba_big_subst_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15);
+      hipLaunchKernelGGL(ba_inertial_scatter_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, K0, M0, dp15, w0.dp);
     } else {
       ProfScope ps(h, "ba_solve_kernel");
-      if (use_lds) {
-        hipLaunchKernelGGL(ba_solve_lds_kernel, dim3(1), dim3(BA_SOLVE_THREADS), lds_need, st, n, S, P0, P1, D(B_RB), K, D(B_SOLVE), res);
-      } else {
-        // B_SOLVE layout: dp [n pad 16] | S [n*n] | b [n] | 1/L_jj [n]
-        double* dpv = D(B_SOLVE);
-        double* Sg = dpv + ((n + 15) & ~15);
-        double* bvec = Sg + (size_t)n * n;
-        double* ginv = bvec + n;
-        hipLaunchKernelGGL(ba_big_assemble_kernel, dim3(std::min(512, (n * n + 255) / 256)), dim3(256), 0, st, n, S, P0, P1, D(B_RB), K, Sg, bvec, res);
-        for (int c0 = 0; c0 < n; c0 += BB_NB) {
-          hipLaunchKernelGGL(ba_big_panel_kernel, dim3(1), dim3(256), 0, st, n, c0, S, Sg, ginv, res);
-          const int m = n - c0 - BB_NB;
+      if (any_lds) hipLaunchKernelGGL(ba_solve_lds_kernel, gW1, dim3(BA_SOLVE_THREADS), lds_max, st, d_wins);
+      if (any_big) {
+        hipLaunchKernelGGL(ba_big_assemble_kernel, dim3(max_asm, W), dim3(256), 0, st, d_wins);
+        for (int c0 = 0; c0 < n_big_max; c0 += BB_NB) {
+          hipLaunchKernelGGL(ba_big_panel_kernel, gW1, dim3(256), 0, st, d_wins, c0);
+          const int m = n_big_max - c0 - BB_NB;
           if (m > 0) {
             const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2;
-            hipLaunchKernelGGL(ba_big_update_kernel, dim3((units + 3) / 4), dim3(256), 0, st, n, c0, S, Sg, res);
+            hipLaunchKernelGGL(ba_big_update_kernel, dim3((units + 3) / 4, W), dim3(256), 0, st, d_wins, c0);
           }
         }
-        hipLaunchKernelGGL(ba_big_subst_kernel, dim3(1), dim3(256), 0, st, n, S, P0, P1, Sg, ginv, bvec, dpv, res);
+        hipLaunchKernelGGL(ba_big_subst_kernel, gW1, dim3(256), 0, st, d_wins);
       }
     }
     {
       ProfScope ps(h, "ba_backsub_kernel");
-      const int cnt = std::max(32 * M, n);
-      hipLaunchKernelGGL(ba_backsub_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, d, bc, S, P0, P1, D(B_SOLVE), I(B_PTSTART), I(B_OKF),
-                         I(B_OFIX), D(B_OUV), D(B_RTFIX), D(B_WT), D(B_VINV), D(B_GL), pt_dsq, pt_psq, pt_chi2, dist ? 1 : 0);
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3(max_back, W), dim3(256), 0, st, d_wins, bc, (const double*)nullptr, dist ? 1 : 0);
     }
     // trial residuals (:1047-1048): res[5] = chi2(trial), res[6] = |delta_l|^2, res[7] = |p_l|^2 from the per-point parts the
     // back-substitution kernel left; then the accept / reject / stop decision (:1041-1055)
     if (dist) {
       {
         ProfScope ps(h, "ba_chi2");
-        chi2_sum(1, res + 5, pt_dsq, pt_psq);
+        chi2_sum(1, 1);
       }
-      if (int rc = allreduce(res + 5, 3)) return rc;
+      // this rank's vote on running iteration iter + 1 (polled here, once per iteration as :1013)
+      if (!stopped && iter + 1 < cfg->max_iterations && should_stop && should_stop(user)) stopped = true;
+      votes[(size_t)iter] = stopped ? 1.0 : 0.0;
+      ORBX_HIP(h, hipMemcpyAsync(res0 + 8, &votes[(size_t)iter], 8, hipMemcpyHostToDevice, st));
+      if (int rc = allreduce(res0 + 5, 4)) return rc;
       ProfScope ps(h, "ba_decide_kernel");
-      hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(256), 0, st, S, res, -1, (const double*)nullptr, (const double*)nullptr,
-                         (const double*)nullptr, (const double*)nullptr, 0);
+      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(256), 0, st, d_wins, 0, (const double*)nullptr, 0, (const volatile int*)nullptr, 1);
     } else {
       ProfScope ps(h, "ba_decide_kernel");
       const int E = inertial ? inr->E : 0;
-      if (E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(E), dim3(64), 0, st, S, P0, P1, 1, 0, ind, imu_buf);
-      hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(256), 0, st, S, res, M, pt_chi2, pt_dsq, pt_psq, imu_buf, E);
+      if (E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(E), dim3(64), 0, st, w0.S, w0.P0, w0.P1, 1, 0, ind, imu_buf);
+      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(256), 0, st, d_wins, 1, (const double*)imu_buf, E, (const volatile int*)h->d_abort, 0);
     }
   }
-  BaState sh{};
-  ORBX_HIP(h, hipMemcpyAsync(hres, res, 8 * 16, hipMemcpyDeviceToHost, st));
-  ORBX_HIP(h, hipMemcpyAsync(&sh, S, sizeof(sh), hipMemcpyDeviceToHost, st));
+  {
+    size_t np_max = 1;
+    for (int w = 0; w < W; ++w) np_max = std::max(np_max, plan[w].np);
+    hipLaunchKernelGGL(ba_finish_kernel, dim3((unsigned)std::min<size_t>(64, (np_max + 255) / 256), W), dim3(256), 0, st, d_wins, dout,
+                       (const size_t*)(din + i_outoff), inertial ? 9 : 0);
+  }
+  double* hout = (double*)h->h_ba_out;
+  ORBX_HIP(h, hipMemcpyAsync(hout, dout, cout.off, hipMemcpyDeviceToHost, st));   // ONE download
+  // While the enqueued iterations drain, keep asking should_stop: a stop requested now (the local mapper's "new keyframe
+  // arrived") ends the solve at the next iteration boundary, as in the reference, instead of being seen only by the polls
+  // at enqueue time, which are all over within the first few hundred microseconds.
+  if (should_stop && !dist && !stopped) {
+    while (hipStreamQuery(st) == hipErrorNotReady)
+      if (should_stop(user)) { *(volatile int*)h->h_abort = 1; break; }
+  }
   ORBX_HIP(h, hipStreamSynchronize(st));
   ORBX_HIP(h, hipGetLastError());
-  *iterations = sh.iters;
-  const double final_sq = sh.iters > 0 ? sh.final_sq : hres[12];
-  if (inertial) {                                                      // |r|, not RMS (local_inertial_ba.rs:1191, :1244)
-    *initial_error = std::sqrt(hres[12]);
-    *final_error = std::sqrt(final_sq);
-  } else {
-    *initial_error = std::sqrt(hres[12]) / std::sqrt(n_res);
-    *final_error = std::sqrt(final_sq) / std::sqrt(n_res);            // :1059-1060
-  }
-  double* cur = sh.sel ? P1 : P0;
-  std::vector<double> init_pts;
-  if (dist && M > 0) {
-    // every point moved only on the rank that owns it: sum the per-rank updates
-    init_pts.assign(params.begin() + 6 * (size_t)K, params.end());
-    double* other = (cur == D(B_PARAMS)) ? D(B_TRIAL) : D(B_PARAMS);
-    ORBX_HIP(h, hipMemcpyAsync(other, init_pts.data(), 8 * 3 * (size_t)M, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(ba_diff_kernel, dim3(64), dim3(256), 0, st, 3 * (size_t)M, cur + 6 * (size_t)K, other, other + 3 * (size_t)M);
-    if (int rc = allreduce(other + 3 * (size_t)M, 3 * (size_t)M)) return rc;
-    ORBX_HIP(h, hipMemcpyAsync(params.data(), cur, 8 * 6 * (size_t)K, hipMemcpyDeviceToHost, st));
-    std::vector<double> upd(3 * (size_t)M);
-    ORBX_HIP(h, hipMemcpyAsync(upd.data(), other + 3 * (size_t)M, 8 * 3 * (size_t)M, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(h, hipStreamSynchronize(st));
-    for (size_t j = 0; j < 3 * (size_t)M; ++j) params[6 * (size_t)K + j] = init_pts[j] + upd[j];
-  } else {
-    ORBX_HIP(h, hipMemcpyAsync(params.data(), cur, 8 * np, hipMemcpyDeviceToHost, st));
-    ORBX_HIP(h, hipStreamSynchronize(st));
-  }
-  if (inertial) {                                                      // extract_pose / velocity / bias (:584-608, :1250-1254)
-    for (int k = 0; k < K; ++k) {
-      const double* p6 = &params[6 * (size_t)k];
-      double* o = poses_wc_out + 7 * (size_t)k;
-      const double v[3] = {p6[0] / 2.0, p6[1] / 2.0, p6[2] / 2.0};
-      const double nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], eps = 2.220446049250313e-16;
-      if (nn <= eps * eps) { o[0] = 1.0; o[1] = o[2] = o[3] = 0.0; }
-      else { const double nv = std::sqrt(nn), sn = 1.0 * std::sin(nv) / nv; o[0] = 1.0 * std::cos(nv); o[1] = v[0] * sn; o[2] = v[1] * sn; o[3] = v[2] * sn; }
-      o[4] = p6[3]; o[5] = p6[4]; o[6] = p6[5];
-      const double* ex = &params[6 * (size_t)K + 3 * (size_t)M + 9 * (size_t)k];
-      for (int i = 0; i < 3; ++i) inr->vel_out[3 * (size_t)k + i] = ex[i];
-      for (int i = 0; i < 6; ++i) inr->bias_out[6 * (size_t)k + i] = ex[3 + i];
+
+  for (int w = 0; w < W; ++w) {
+    if (plan[w].skip) continue;
+    const WinPlan& pl = plan[w];
+    const BaWinHost& ww = win[w];
+    const int K = ww.K, M = ww.M;
+    const double* o = hout + pl.o_out / 8;
+    const int iters = (int)o[0];
+    *ww.iterations = iters;
+    const double init_sq = o[2], final_sq = iters > 0 ? o[1] : o[2];
+    if (inertial) {                                                      // |r|, not RMS (local_inertial_ba.rs:1191, :1244)
+      *ww.initial_error = std::sqrt(init_sq);
+      *ww.final_error = std::sqrt(final_sq);
+    } else {
+      const double nr = dist ? n_res : pl.n_res;
+      *ww.initial_error = std::sqrt(init_sq) / std::sqrt(nr);
+      *ww.final_error = std::sqrt(final_sq) / std::sqrt(nr);           // :1059-1060
     }
-  } else {
-    for (int k = 0; k < K; ++k) host_params_to_pose_wc(&params[6 * (size_t)k], poses_wc_out + 7 * (size_t)k);
+    std::vector<double> merged;
+    const double* params = o + 8;
+    if (dist && M > 0) {
+      // every point moved only on the rank that owns it: sum the per-rank updates
+      const double* init_pts = (const double*)(hin + pl.i_params) + 6 * (size_t)K;   // the blob still holds the initial parameters
+      double* cur = o[3] != 0.0 ? w0.P1 : w0.P0;
+      double* other = o[3] != 0.0 ? w0.P0 : w0.P1;
+      ORBX_HIP(h, hipMemcpyAsync(other, init_pts, 8 * 3 * (size_t)M, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(ba_diff_kernel, dim3(64), dim3(256), 0, st, 3 * (size_t)M, cur + 6 * (size_t)K, other, other + 3 * (size_t)M);
+      if (int rc = allreduce(other + 3 * (size_t)M, 3 * (size_t)M)) return rc;
+      std::vector<double> upd(3 * (size_t)M);
+      ORBX_HIP(h, hipMemcpyAsync(upd.data(), other + 3 * (size_t)M, 8 * 3 * (size_t)M, hipMemcpyDeviceToHost, st));
+      ORBX_HIP(h, hipStreamSynchronize(st));
+      merged.assign(params, params + pl.np);
+      for (size_t j = 0; j < 3 * (size_t)M; ++j) merged[6 * (size_t)K + j] = init_pts[j] + upd[j];
+      params = merged.data();
+    }
+    if (inertial) {                                                      // extract_pose / velocity / bias (:584-608, :1250-1254)
+      for (int k = 0; k < K; ++k) {
+        const double* p6 = &params[6 * (size_t)k];
+        double* q = ww.poses_wc_out + 7 * (size_t)k;
+        const double v[3] = {p6[0] / 2.0, p6[1] / 2.0, p6[2] / 2.0};
+        const double nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], eps = 2.220446049250313e-16;
+        if (nn <= eps * eps) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; }
+        else { const double nv = std::sqrt(nn), sn = 1.0 * std::sin(nv) / nv; q[0] = 1.0 * std::cos(nv); q[1] = v[0] * sn; q[2] = v[1] * sn; q[3] = v[2] * sn; }
+        q[4] = p6[3]; q[5] = p6[4]; q[6] = p6[5];
+        const double* ex = &params[6 * (size_t)K + 3 * (size_t)M + 9 * (size_t)k];
+        for (int i = 0; i < 3; ++i) inr->vel_out[3 * (size_t)k + i] = ex[i];
+        for (int i = 0; i < 6; ++i) inr->bias_out[6 * (size_t)k + i] = ex[3 + i];
+      }
+    } else {
+      for (int k = 0; k < K; ++k) host_params_to_pose_wc(&params[6 * (size_t)k], ww.poses_wc_out + 7 * (size_t)k);
+    }
+    for (int j = 0; j < 3 * M; ++j) ww.points[j] = params[6 * (size_t)K + j];
   }
-  for (int j = 0; j < 3 * M; ++j) points[j] = params[6 * (size_t)K + j];
+  return ORBX_OK;
+}
+
+int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+                    const double* poses_cw, int F, const double* fixed_poses_cw, int M, double* points, int N,
+                    const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
+                    int* iterations, double* initial_error, double* final_error, bool global_mode, const BaInertialHost* inr) {
+  BaWinHost w{K, F, M, N, poses_cw, fixed_poses_cw, points, obs, poses_wc_out, iterations, initial_error, final_error, ORBX_OK};
+  return ba_solve_batch(h, cam, cfg, 1, &w, should_stop, user, global_mode, inr);
+}
+
+// residual / Jacobian blocks of every observation at the given parameters (input order): out [N][20] = r (2) | A (12) | B (6)
+int ba_debug_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                    const double* fixed_poses_cw, int M, const double* points, int N, const orbx_ba_obs* obs, int global_mode,
+                    double* out) {
+  if (N == 0) return ORBX_OK;
+  for (int i = 0; i < N; ++i) {
+    const orbx_ba_obs& o = obs[i];
+    if (o.mp_idx < 0 || o.mp_idx >= M || o.kf_idx >= K || (o.kf_idx < 0 && o.fixed_idx >= F))
+      return orbx_fail(h, ORBX_ERR_INVALID, "observation %d: index out of range", i);
+  }
+  std::vector<double> params(6 * (size_t)K + 3 * (size_t)M), Rt_fix(12 * (size_t)(F + 1)), uv(2 * (size_t)N);
+  std::vector<int> okf(N), ofix(N), omp(N);
+  for (int k = 0; k < K; ++k) host_se3_to_params(poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);
+  for (int j = 0; j < 3 * M; ++j) params[6 * (size_t)K + j] = points[j];
+  for (int f = 0; f <= F; ++f) {
+    const double ident[7] = {1, 0, 0, 0, 0, 0, 0};
+    const double* p = f < F ? fixed_poses_cw + 7 * (size_t)f : ident;
+    host_quat_to_R(p, &Rt_fix[12 * (size_t)f]);
+    Rt_fix[12 * (size_t)f + 9] = p[4]; Rt_fix[12 * (size_t)f + 10] = p[5]; Rt_fix[12 * (size_t)f + 11] = p[6];
+  }
+  for (int i = 0; i < N; ++i) {
+    okf[i] = obs[i].kf_idx >= 0 ? obs[i].kf_idx : -1;
+    ofix[i] = obs[i].kf_idx >= 0 ? 0 : (obs[i].fixed_idx >= 0 ? obs[i].fixed_idx : F);
+    omp[i] = obs[i].mp_idx; uv[2 * (size_t)i] = obs[i].u; uv[2 * (size_t)i + 1] = obs[i].v;
+  }
+  Carve c;
+  const size_t o_p = c.take(8 * params.size()), o_r = c.take(8 * Rt_fix.size()), o_k = c.take(4 * (size_t)N), o_f = c.take(4 * (size_t)N),
+               o_m = c.take(4 * (size_t)N), o_u = c.take(16 * (size_t)N), o_o = c.take(160 * (size_t)N);
+  if (int rc = orbx_reserve(h, h->ws_ba[6], c.off)) return rc;
+  uint8_t* d = (uint8_t*)h->ws_ba[6].p;
+  hipStream_t st = h->stream;
+  ORBX_HIP(h, hipMemcpyAsync(d + o_p, params.data(), 8 * params.size(), hipMemcpyHostToDevice, st));
+  ORBX_HIP(h, hipMemcpyAsync(d + o_r, Rt_fix.data(), 8 * Rt_fix.size(), hipMemcpyHostToDevice, st));
+  ORBX_HIP(h, hipMemcpyAsync(d + o_k, okf.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
+  ORBX_HIP(h, hipMemcpyAsync(d + o_f, ofix.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
+  ORBX_HIP(h, hipMemcpyAsync(d + o_m, omp.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
+  ORBX_HIP(h, hipMemcpyAsync(d + o_u, uv.data(), 16 * (size_t)N, hipMemcpyHostToDevice, st));
+  BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, cfg->huber_threshold, global_mode ? 1 : 0, 0, 0.0, nullptr};
+  hipLaunchKernelGGL(ba_debug_blocks_kernel, dim3((N + 255) / 256), dim3(256), 0, st, bc, K, N, (const double*)(d + o_p), (const double*)(d + o_r),
+                     (const int*)(d + o_k), (const int*)(d + o_f), (const int*)(d + o_m), (const double*)(d + o_u), (double*)(d + o_o));
+  ORBX_HIP(h, hipMemcpyAsync(out, d + o_o, 160 * (size_t)N, hipMemcpyDeviceToHost, st));
+  ORBX_HIP(h, hipStreamSynchronize(st));
+  ORBX_HIP(h, hipGetLastError());
   return ORBX_OK;
 }

@@ -1113,6 +1113,15 @@ std::vector<std::pair<int, int>> blur_strips(int w) {
 
 int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
   if (h->geom_w == w && h->geom_h == h_px) return ORBX_OK;
+  // A new image size rewrites the resize / tile tables IN PLACE (the buffer rarely grows, so orbx_reserve does not see
+  // it): work of earlier asynchronous calls may still be reading them — the blocking copy below runs on the null stream,
+  // which the handle's non-blocking streams do not order against — and a captured hipGraph of orbx_process_stereo has the
+  // old OrbGeom and table offsets baked into its kernel nodes.  Drain the streams and drop the graph first.
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->s_aux) ORBX_HIP(h, hipStreamSynchronize(h->s_aux));
+  if (h->pair_graph) { hipGraphExecDestroy(h->pair_graph); h->pair_graph = nullptr; }
+  h->pg_calls = 0;
+  h->geom_w = 0; h->geom_h = 0;     // nothing valid until the new tables are up
   const orbx_orb_params& p = h->orb;
   OrbGeom g{};
   g.n_levels = p.n_levels;

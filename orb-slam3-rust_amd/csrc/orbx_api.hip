@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include <algorithm>
+#include <vector>
 
 #include "orbx_internal.hpp"
 
@@ -156,6 +157,9 @@ void orbx_destroy(orbx_handle* h) {
   for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
   if (h->pair_graph) hipGraphExecDestroy(h->pair_graph);
   if (h->h_stage) hipHostFree(h->h_stage);
+  if (h->h_ba_in) hipHostFree(h->h_ba_in);
+  if (h->h_ba_out) hipHostFree(h->h_ba_out);
+  if (h->h_abort) hipHostFree(h->h_abort);
   if (h->d_status) hipFree(h->d_status);
   if (h->h_status) hipHostFree(h->h_status);
   hipStreamDestroy(h->stream);
@@ -695,7 +699,10 @@ int orbx_process_stereo(orbx_handle* h, const uint8_t* left, size_t lstride, con
   // unchanged configuration (all workspaces allocated, tables uploaded) it is captured into a hipGraph once and
   // replayed with a single launch per frame.  ORBX_NO_GRAPH=1 or profiling keeps the eager path.
   static const bool no_graph = getenv("ORBX_NO_GRAPH") != nullptr;
-  const bool same = h->pg_w == w && h->pg_h == h_px && h->pg_cap == cap_kp && h->pg_img == (void*)d_img && h->pg_out == (void*)d_out;
+  // (the geometry test covers an extract / batch call at another image size in between: it rewrites the tables the
+  // graph's kernels read — orb_prepare_geometry drops the graph itself, this keeps the eager-call count honest too)
+  const bool same = h->pg_w == w && h->pg_h == h_px && h->pg_cap == cap_kp && h->pg_img == (void*)d_img && h->pg_out == (void*)d_out &&
+                    h->geom_w == w && h->geom_h == h_px;
   if (!same) {
     if (h->pair_graph) { hipGraphExecDestroy(h->pair_graph); h->pair_graph = nullptr; }
     h->pg_w = w; h->pg_h = h_px; h->pg_cap = cap_kp; h->pg_img = d_img; h->pg_out = d_out; h->pg_calls = 0;
@@ -825,6 +832,43 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
   orbx_prof_begin_call(h);
   return ba_solve_visual(h, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, should_stop, user,
                          poses_wc_out, iterations, initial_error, final_error);
+}
+
+int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int n_windows,
+                               orbx_ba_window* windows, orbx_should_stop_fn should_stop, void* user) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || !cfg || n_windows < 0 || (n_windows > 0 && !windows))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_batch: bad argument");
+  if (n_windows > 65535) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_batch: at most 65535 windows per call");
+  std::vector<BaWinHost> w((size_t)n_windows);
+  for (int i = 0; i < n_windows; ++i) {
+    orbx_ba_window& q = windows[i];
+    if (q.K < 0 || q.F < 0 || q.M < 0 || q.N < 0 || (q.K > 0 && (!q.poses_cw || !q.poses_wc_out)) || (q.F > 0 && !q.fixed_poses_cw) ||
+        (q.M > 0 && !q.points) || (q.N > 0 && !q.obs))
+      return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_batch: window %d: bad argument", i);
+    w[i] = BaWinHost{q.K, q.F, q.M, q.N, q.poses_cw, q.fixed_poses_cw, q.points, q.obs, q.poses_wc_out, &q.iterations,
+                     &q.initial_error, &q.final_error, ORBX_OK};
+  }
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  orbx_allreduce_fn saved = h->allreduce;          // independent windows: no collective
+  h->allreduce = nullptr;
+  const int rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), should_stop, user);
+  h->allreduce = saved;
+  for (int i = 0; i < n_windows; ++i) windows[i].status = rc == ORBX_OK ? w[i].status : rc;
+  return rc;
+}
+
+int orbx_debug_ba_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                         const double* fixed_poses_cw, int M, const double* points, int N, const orbx_ba_obs* obs, int global_mode,
+                         double* out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || !cfg || K < 0 || F < 0 || M < 0 || N < 0 || (K > 0 && !poses_cw) || (F > 0 && !fixed_poses_cw) || (M > 0 && !points) ||
+      (N > 0 && (!obs || !out)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_debug_ba_blocks: bad argument");
+  if (K > 128) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_debug_ba_blocks: at most 128 keyframes");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  return ba_debug_blocks(h, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, global_mode, out);
 }
 
 void orbx_default_inertial_ba_config(orbx_inertial_ba_config* c) {       // local_inertial_ba.rs:126-141

@@ -96,6 +96,9 @@ struct orbx_handle {
   // BA
   orbx_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  void* h_ba_in = nullptr;   size_t h_ba_in_bytes = 0;    // pinned mirrors of the batch input / output blobs (ba_solve_batch)
+  void* h_ba_out = nullptr;  size_t h_ba_out_bytes = 0;
+  int* h_abort = nullptr;    int* d_abort = nullptr;       // pinned, device-visible: should_stop() seen while the iterations drain
   // profiling
   bool profiling = false;
   std::vector<KernelTimer> timers;
@@ -160,6 +163,18 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
                     double* points, int N, const orbx_ba_obs* obs, orbx_should_stop_fn should_stop,
                     void* user, double* poses_wc_out, int* iterations, double* initial_error,
                     double* final_error, bool global_mode = false, const struct BaInertialHost* inr = nullptr);
+// one window of a batch as the caller hands it over (orbx_ba_solve_visual_batch); status: ORBX_OK or ORBX_ERR_EMPTY
+struct BaWinHost {
+  int K, F, M, N;
+  const double* poses_cw; const double* fixed_poses_cw; double* points; const orbx_ba_obs* obs;
+  double* poses_wc_out; int* iterations; double* initial_error; double* final_error;
+  int status;
+};
+int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int W, BaWinHost* win,
+                   orbx_should_stop_fn should_stop, void* user, bool global_mode = false, const struct BaInertialHost* inr = nullptr);
+int ba_debug_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
+                    const double* fixed_poses_cw, int M, const double* points, int N, const orbx_ba_obs* obs, int global_mode,
+                    double* out);
 // the extra inputs / outputs of solve_inertial_ba (local_inertial_ba.rs:1074-1275) for ba_solve_visual's inertial mode
 struct BaInertialHost {
   const orbx_inertial_ba_config* cfg;

@@ -33,13 +33,21 @@ enum Op {
   OP_ADD_U32, OP_AND_B32, OP_LSHRREV, OP_PK_MIN_I16, OP_PK_MAX_I16, OP_PK_SUB_I16, OP_PK_MAD_I16, OP_PK_MIN_OPSEL,
   OP_PERM, OP_ALIGNBYTE, OP_DOT4_U8, OP_DOT2_U16, OP_MUL_U24, OP_MAD_U24, OP_MUL_LO_U32, OP_MAD_U64_U32, OP_MIN_I32, OP_MIN3_I32,
   OP_CNDMASK, OP_CMP_GT, OP_MBCNT, OP_DPP_SHR, OP_CVT_F32_U32, OP_FMA_F32, OP_PK_FMA_F32, OP_FMA_F64, OP_BFE, OP_SAD_U8,
-  OP_MIX_SALU, OP_MIX_LDS, OP_COUNT
+  OP_OR_B32, OP_XOR_B32, OP_SUB_U32, OP_LSHLREV, OP_MOV_B32, OP_MIN_F32, OP_MAX_F32, OP_MAX3_F32, OP_MIN3_F32, OP_ADD_F32, OP_MUL_F32,
+  OP_PK_MIN_F16, OP_PK_MAX_F16, OP_PK_ADD_F16, OP_PK_MIN3_F16, OP_PK_MAX3_F16, OP_PK_MAX3_F16_OPSEL, OP_BITOP3, OP_AND_OR, OP_LSHL_OR, OP_ADD3, OP_LSHL_ADD,
+  OP_BCNT, OP_ADD_SDWA, OP_CNDMASK_SGPR, OP_CVT_F32_UBYTE0, OP_MIN_U16, OP_MAX3_I16, OP_PK_SUB_U16_CLAMP, OP_MSAD_U8, OP_MAD_I32_I24, OP_CVT_PKRTZ,
+  OP_MIX_SALU, OP_MIX_LDS, OP_MIX_LDS_ATOMIC, OP_COUNT
 };
 static const char* kOpName[OP_COUNT] = {
   "v_add_u32", "v_and_b32", "v_lshrrev_b32", "v_pk_min_i16", "v_pk_max_i16", "v_pk_sub_i16", "v_pk_mad_i16", "v_pk_min_i16 op_sel",
   "v_perm_b32", "v_alignbyte_b32", "v_dot4_u32_u8", "v_dot2_u32_u16", "v_mul_u32_u24", "v_mad_u32_u24", "v_mul_lo_u32", "v_mad_u64_u32",
   "v_min_i32", "v_min3_i32", "v_cndmask_b32", "v_cmp_gt_u32", "v_mbcnt_lo_u32_b32", "v_mov_b32 dpp wave_shr:1", "v_cvt_f32_u32", "v_fma_f32",
-  "v_pk_fma_f32", "v_fma_f64", "v_bfe_u32", "v_sad_u8", "2 v_add_u32 : 1 s_add_u32 (VALU counted)", "4 v_add_u32 : 1 ds_read_b32 (VALU counted)"};
+  "v_pk_fma_f32", "v_fma_f64", "v_bfe_u32", "v_sad_u8",
+  "v_or_b32", "v_xor_b32", "v_sub_u32", "v_lshlrev_b32", "v_mov_b32", "v_min_f32", "v_max_f32", "v_max3_f32", "v_min3_f32", "v_add_f32", "v_mul_f32",
+  "v_pk_min_f16", "v_pk_max_f16", "v_pk_add_f16", "v_pk_minimum3_f16", "v_pk_maximum3_f16", "v_pk_maximum3_f16 op_sel", "v_bitop3_b32", "v_and_or_b32",
+  "v_lshl_or_b32", "v_add3_u32", "v_lshl_add_u32", "v_bcnt_u32_b32", "v_add_u32_sdwa (byte selects)", "v_cndmask_b32 (sgpr-pair mask)",
+  "v_cvt_f32_ubyte0", "v_min_u16", "v_max3_i16", "v_pk_sub_u16 clamp", "v_msad_u8", "v_mad_i32_i24", "v_cvt_pkrtz_f16_f32",
+  "2 v_add_u32 : 1 s_add_u32 (VALU counted)", "4 v_add_u32 : 1 ds_read_b32 (VALU counted)", "4 v_add_u32 : 1 ds_add_rtn_u32, 16 lanes/wave one address"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void probe(unsigned* __restrict__ sink, unsigned long long* __restrict__ cyc, int iters) {
@@ -49,6 +57,7 @@ __global__ __launch_bounds__(1024) void probe(unsigned* __restrict__ sink, unsig
   if (OP == OP_MIX_LDS) { lds[threadIdx.x] = a0; __syncthreads(); }
   unsigned long long d0 = a0, d1 = a1;       // 64-bit accumulators for the f64 / u64 rows
   unsigned s = 0;
+  if (OP == OP_CNDMASK_SGPR) asm volatile("s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x55555555" ::: "s20", "s21");
   __builtin_amdgcn_s_barrier();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
@@ -77,6 +86,50 @@ __global__ __launch_bounds__(1024) void probe(unsigned* __restrict__ sink, unsig
     else if (OP == OP_FMA_F32) { REP64("v_fma_f32 %0, %0, %1, %2") }
     else if (OP == OP_BFE) { REP64("v_bfe_u32 %0, %0, 3, 8") }
     else if (OP == OP_SAD_U8) { REP64("v_sad_u8 %0, %1, %2, %0") }
+    else if (OP == OP_OR_B32) { REP64("v_or_b32 %0, %0, %1") }
+    else if (OP == OP_XOR_B32) { REP64("v_xor_b32 %0, %0, %1") }
+    else if (OP == OP_SUB_U32) { REP64("v_sub_u32 %0, %0, %1") }
+    else if (OP == OP_LSHLREV) { REP64("v_lshlrev_b32 %0, 1, %0") }
+    else if (OP == OP_MOV_B32) { REP64("v_mov_b32 %0, %1") }
+    else if (OP == OP_MIN_F32) { REP64("v_min_f32 %0, %0, %1") }
+    else if (OP == OP_MAX_F32) { REP64("v_max_f32 %0, %0, %1") }
+    else if (OP == OP_MAX3_F32) { REP64("v_max3_f32 %0, %0, %1, %2") }
+    else if (OP == OP_MIN3_F32) { REP64("v_min3_f32 %0, %0, %1, %2") }
+    else if (OP == OP_ADD_F32) { REP64("v_add_f32 %0, %0, %1") }
+    else if (OP == OP_MUL_F32) { REP64("v_mul_f32 %0, %0, %1") }
+    else if (OP == OP_PK_MIN_F16) { REP64("v_pk_min_f16 %0, %0, %1") }
+    else if (OP == OP_PK_MAX_F16) { REP64("v_pk_max_f16 %0, %0, %1") }
+    else if (OP == OP_PK_ADD_F16) { REP64("v_pk_add_f16 %0, %0, %1") }
+    else if (OP == OP_PK_MIN3_F16) { REP64("v_pk_minimum3_f16 %0, %0, %1, %2") }
+    else if (OP == OP_PK_MAX3_F16) { REP64("v_pk_maximum3_f16 %0, %0, %1, %2") }
+    else if (OP == OP_PK_MAX3_F16_OPSEL) { REP64("v_pk_maximum3_f16 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]") }
+    else if (OP == OP_BITOP3) { REP64("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96") }
+    else if (OP == OP_AND_OR) { REP64("v_and_or_b32 %0, %0, %1, %2") }
+    else if (OP == OP_LSHL_OR) { REP64("v_lshl_or_b32 %0, %0, 3, %2") }
+    else if (OP == OP_ADD3) { REP64("v_add3_u32 %0, %0, %1, %2") }
+    else if (OP == OP_LSHL_ADD) { REP64("v_lshl_add_u32 %0, %0, 2, %1") }
+    else if (OP == OP_BCNT) { REP64("v_bcnt_u32_b32 %0, %1, %0") }
+    else if (OP == OP_ADD_SDWA) { REP64("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2") }
+    else if (OP == OP_CNDMASK_SGPR) { REP64("v_cndmask_b32 %0, %0, %1, s[20:21]") }
+    else if (OP == OP_CVT_F32_UBYTE0) { REP64("v_cvt_f32_ubyte0 %0, %0") }
+    else if (OP == OP_MIN_U16) { REP64("v_min_u16 %0, %0, %1") }
+    else if (OP == OP_MAX3_I16) { REP64("v_max3_i16 %0, %0, %1, %2") }
+    else if (OP == OP_PK_SUB_U16_CLAMP) { REP64("v_pk_sub_u16 %0, %0, %1 clamp") }
+    else if (OP == OP_MSAD_U8) { REP64("v_msad_u8 %0, %1, %2, %0") }
+    else if (OP == OP_MAD_I32_I24) { REP64("v_mad_i32_i24 %0, %0, %1, %2") }
+    else if (OP == OP_CVT_PKRTZ) { REP64("v_cvt_pkrtz_f16_f32 %0, %0, %1") }
+    else if (OP == OP_MIX_LDS_ATOMIC) {
+      const unsigned addr = 4096u;                 // one address; the lanes 0, 4, 8, ... of the wave add to it
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        unsigned r = 0;
+        if ((threadIdx.x & 3u) == 0u) asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r) : "v"(addr), "v"(c1));
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(a0) : "v"(c0)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(a1) : "v"(c0));
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(a2) : "v"(c0)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(a3) : "v"(c0));
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        a4 ^= r;
+      }
+    }
     else if (OP == OP_PK_FMA_F32 || OP == OP_FMA_F64 || OP == OP_MAD_U64_U32) {
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
@@ -87,7 +140,7 @@ __global__ __launch_bounds__(1024) void probe(unsigned* __restrict__ sink, unsig
     } else if (OP == OP_MIX_SALU) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-#define MIX3(x, y) asm volatile("v_add_u32 %0, %0, %3\n v_add_u32 %1, %1, %3\n s_add_u32 %2, %2, 1" : "+v"(x), "+v"(y), "+s"(s) : "v"(c0));
+#define MIX3(x, y) asm volatile("v_add_u32 %0, %0, %3\n v_add_u32 %1, %1, %3\n s_add_u32 %2, %2, 1" : "+v"(x), "+v"(y), "+s"(s) : "v"(c0) : "scc");
         MIX3(a0, a1) MIX3(a2, a3) MIX3(a4, a5) MIX3(a6, a7)
 #undef MIX3
       }                                                             // 64 VALU + 32 SALU per iteration
@@ -124,13 +177,13 @@ __global__ void clock_probe(unsigned long long* out, int iters) {
 template <int OP>
 static void run(int n_cu, unsigned* d_sink, unsigned long long* d_cyc, std::vector<std::string>& rows, double clock_ghz) {
   const int iters = 2000;
-  char line[512];
+  char line[640];
   int off = snprintf(line, sizeof line, "%-44s", kOpName[OP]);
   const int per_iter = 64;        // VALU instructions counted per iteration in every variant
   for (int wps : {1, 2, 4, 8}) {
-    const int threads = std::min(1024, 256 * wps);
+    const int threads = wps == 8 ? 512 : std::min(1024, 256 * wps);
     const int blocks_per_cu = wps * 256 / threads;
-    const size_t lds = (160 * 1024) / blocks_per_cu - (blocks_per_cu > 1 ? 1024 : 0);
+    const size_t lds = (160 * 1024) / blocks_per_cu - (blocks_per_cu > 1 ? 2048 : 0);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = n_cu * blocks_per_cu;
     hipEvent_t e0, e1;
@@ -151,11 +204,13 @@ static void run(int n_cu, unsigned* d_sink, unsigned long long* d_cyc, std::vect
     const double med = (double)c[n_waves / 2], n_instr = (double)iters * per_iter;
     const double cyc_per_instr_wave = med / n_instr;
     const double rate = (double)n_waves * n_instr / (ms * 1e-3) / 1e9;
-    off += snprintf(line + off, sizeof line - off, " | %5.2f %5.2f %7.1f", cyc_per_instr_wave, cyc_per_instr_wave / wps, rate);
+    // resident = how much of the launch ran concurrently: (sum of the waves' own durations) / (waves x wall time), from the
+    // clock measured under load; well under 1 means the blocks did not all fit at once and the column is not that occupancy
+    const double resident = med / (clock_ghz * 1e9) / (ms * 1e-3);
+    off += snprintf(line + off, sizeof line - off, " | %5.2f %5.2f %6.1f %4.2f", cyc_per_instr_wave, cyc_per_instr_wave / wps, rate, resident);
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
   }
   rows.push_back(line);
-  (void)clock_ghz;
 }
 
 template <int OP>
@@ -186,8 +241,8 @@ int main() {
          "# chip-wide G wave-instructions/s from HIP-event wall time.  4 SIMDs x %d CUs = %d SIMDs; at I cycles per instruction and f GHz the\n"
          "# chip issues %d * f / I G wave-instr/s (2 cycles at 2.4 GHz: %.1f; 4 cycles: %.1f).\n",
          n_cu, 4 * n_cu, 4 * n_cu, 4 * n_cu * 2.4 / 2, 4 * n_cu * 2.4 / 4);
-  printf("%-44s | %-19s | %-19s | %-19s | %-19s\n", "instruction", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD", "8 waves/SIMD");
-  printf("%-44s | %-19s | %-19s | %-19s | %-19s\n", "", "cyc/w  simd   G/s", "cyc/w  simd   G/s", "cyc/w  simd   G/s", "cyc/w  simd   G/s");
+  printf("%-44s | %-23s | %-23s | %-23s | %-23s\n", "instruction", "1 wave/SIMD", "2 waves/SIMD", "4 waves/SIMD", "8 waves/SIMD");
+  printf("%-44s | %-23s | %-23s | %-23s | %-23s\n", "", "cyc/w  simd   G/s  res", "cyc/w  simd   G/s  res", "cyc/w  simd   G/s  res", "cyc/w  simd   G/s  res");
   std::vector<std::string> rows;
   run_all<0>(n_cu, d_sink, d_cyc, rows, ghz);
   for (auto& r : rows) printf("%s\n", r.c_str());

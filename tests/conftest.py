@@ -47,3 +47,36 @@ def records_equal(a, b):
     """bit-exact comparison of two structured arrays (NaN-safe: compares raw bytes)."""
     a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
     return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def pose_errors(a, b):
+    """Per-keyframe errors between two pose arrays [K,7] (qw,qx,qy,qz,tx,ty,tz): (largest rotation angle of
+    q_a * conj(q_b) in radians, largest |dt| / |t_b|).  This is the north star's "poses within 1e-6 relative error"
+    taken pose by pose — not a max-abs over a mixed quaternion/translation array, which is an absolute bound on the
+    quaternion entries and a window-scale-relative one on the translations."""
+    a = np.asarray(a, np.float64).reshape(-1, 7); b = np.asarray(b, np.float64).reshape(-1, 7)
+    assert a.shape == b.shape
+    if len(a) == 0:
+        return 0.0, 0.0
+    qa, qb = a[:, :4], b[:, :4] * np.array([1.0, -1.0, -1.0, -1.0])
+    w = qa[:, 0] * qb[:, 0] - (qa[:, 1:] * qb[:, 1:]).sum(1)
+    v = qa[:, :1] * qb[:, 1:] + qb[:, :1] * qa[:, 1:] + np.cross(qa[:, 1:], qb[:, 1:])
+    ang = 2.0 * np.arctan2(np.linalg.norm(v, axis=1), np.abs(w))
+    dt = np.linalg.norm(a[:, 4:] - b[:, 4:], axis=1) / np.maximum(np.linalg.norm(b[:, 4:], axis=1), 1e-12)
+    return float(ang.max()), float(dt.max())
+
+
+def point_errors(a, b):
+    """Largest per-point |dX| / |X_b| between two point arrays [M,3]."""
+    a = np.asarray(a, np.float64).reshape(-1, 3); b = np.asarray(b, np.float64).reshape(-1, 3)
+    if len(a) == 0:
+        return 0.0
+    return float((np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-12)).max())
+
+
+def assert_ba_close(got, want, tol=1e-6):
+    """optimised poses and points of two solves: every keyframe's rotation within `tol` rad and translation within `tol`
+    relative, every point within `tol` relative."""
+    ang, dt = pose_errors(got["poses_wc"], want["poses_wc"])
+    dx = point_errors(got["points"], want["points"])
+    assert ang < tol and dt < tol and dx < tol, "rotation %.3e rad, translation %.3e rel, points %.3e rel (tol %.1e)" % (ang, dt, dx, tol)

@@ -268,3 +268,33 @@ def test_graph_replay_survives_workspace_growth(oracle, pkg):
     ok, od = oracle.orb_extract(L, oracle.orb_params(700))
     assert records_equal(first[0][0], ok) and np.array_equal(first[0][1], od)
     h.close()
+
+
+def test_graph_replay_survives_geometry_change(oracle, pkg):
+    """a call at ANOTHER image size between two replays rewrites the resize / tile tables in place (same
+    buffer, no re-allocation) — the captured graph has the old geometry baked in and must be dropped, and the table
+    upload must not race kernels still in flight.  Alternates two sizes around the captured graph, both bit-exact."""
+    import torch
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 600, device=0, max_w=752, max_h=480, max_batch=2)
+    L, R = pkg.synth.stereo_pair(81, 0)
+    l2, r2 = pkg.synth.stereo_pair(82, 0, 416, 304)
+    p = oracle.orb_params(600)
+    okL, odL = oracle.orb_extract(L, p)
+    ok2, od2 = oracle.orb_extract(l2, p)
+    small = torch.from_numpy(np.stack([l2, r2])[None]).cuda()
+    out = h.alloc_batch_outputs(1, 1200)
+    big0 = [h.process_stereo(L, R) for _ in range(5)]              # eager calls, capture, replays
+    for rnd in range(3):
+        h.process_stereo_batch_device(small, out)                  # asynchronous, other geometry: tables rewritten
+        again = [h.process_stereo(L, R) for _ in range(4 if rnd == 1 else 1)]   # must not replay the stale graph
+        h.check_status()
+        fl, fr, m, pts, has = h.unpack_batch_outputs(out, 0)
+        assert records_equal(fl.keypoints, ok2) and np.array_equal(fl.descriptors, od2), "round %d small" % rnd
+        for r in again:
+            assert all(a.tobytes() == b.tobytes() for a, b in zip(big0[0], r)), "round %d" % rnd
+        k2 = h.process_stereo(l2, r2)                              # the host-buffer form at the small size as well
+        assert records_equal(k2[0], ok2) and np.array_equal(k2[1], od2)
+    assert records_equal(big0[0][0], okL) and np.array_equal(big0[0][1], odL)
+    for r in big0[1:]:
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(big0[0], r))
+    h.close()
