@@ -329,6 +329,22 @@ typedef int (*orbx_should_stop_fn)(void* user);
 typedef int (*orbx_allreduce_fn)(void* user, void* d_buf, size_t n, void* hip_stream);
 int orbx_ba_set_allreduce(orbx_handle* h, orbx_allreduce_fn fn, void* user);
 
+/* The native collective of the point-partitioned solve: RCCL over xGMI, called by the library itself —
+ * ncclAllReduce(ncclDouble, ncclSum) in place on the handle's stream — so a Rust (or C) host
+ * needs no framework around it.  Either
+ *   orbx_rccl_unique_id (rank 0; = ncclGetUniqueId, returns the id's size, 128) + the host's own way of handing the id to
+ *   the other ranks + orbx_ba_init_rccl on every rank (= ncclCommInitRank; the library owns the communicator, one per
+ *   handle, destroyed with it), or
+ *   orbx_ba_set_rccl_comm with an ncclComm_t the host already has (caller-owned; NULL clears).
+ * A communicator takes precedence over the orbx_ba_set_allreduce hook, which stays for hosts that bring another transport
+ * (the CPU tests run it over gloo).  Every rank must call the solve with the same problem and its own partition; all
+ * ranks issue the same sequence of collectives whatever their own should_stop() answers: the stop decision is part of
+ * what is reduced (one rank asking is enough, and all ranks then stop before the same iteration), and so is "some rank
+ * holds an observation with an index out of range" (every rank returns ORBX_ERR_INVALID). */
+int orbx_rccl_unique_id(uint8_t* out, size_t cap);
+int orbx_ba_init_rccl(orbx_handle* h, const uint8_t* unique_id, size_t id_bytes, int rank, int world);
+int orbx_ba_set_rccl_comm(orbx_handle* h, void* nccl_comm);
+
 /* Replaces solve_visual_ba (local_ba_lm.rs:912-1098).
  *   poses_cw [K][7]  (qw,qx,qy,qz,tx,ty,tz) T_cw of the optimised keyframes (:966-977)
  *   fixed_poses_cw [F][7]  T_cw of anchor + other fixed observers

@@ -1,0 +1,222 @@
+// orbx_map.hpp — the host side of local BA over FLAT arrays: the three phases of
+// LocalMapper::local_bundle_adjustment (src/local_mapping/local_mapper.rs:334-410, visual branch :378-408):
+//
+//   collect_visual_ba_data    src/optimizer/local_ba_lm.rs:800-897 (with collect_local_keyframes :665-683,
+//                             collect_local_map_points :686-704, collect_fixed_keyframes :707-726)
+//   solve_visual_ba           orbx.hpp (GPU)
+//   apply_visual_ba_results   local_ba_lm.rs:1112-1138
+//
+// The reference walks its HashMap-based `Map` under a read lock.  A GPU-side BA wants the same information as a handful
+// of arrays, so the snapshot here is CSR: keyframes with their features (map-point id or none, keypoint position), their
+// covisibility lists, map points with their observer lists.  A Rust shim fills it under the read lock (or keeps it in
+// step with the map) — `INTEGRATION.md` shows the loop — and everything below is plain index arithmetic.
+//
+// ORDER.  The reference iterates HashMaps / HashSets at four places (covisibility weights :675, the map-point set :704,
+// the fixed-keyframe set :725, mp.observations.keys() :718); their order is unspecified and changes from run to run
+// (SURVEY.md F10), and it matters: `.take(max_covisible)` picks WHICH neighbours are local, and the order of the
+// observations is the summation order of J^T J.  This file states a deterministic order instead:
+//   - covisibility neighbours of a keyframe: the order of the snapshot's list (recommended fill: weight descending, then
+//     id ascending — ORB-SLAM's ordered covisibility; filling it in the HashMap's iteration order reproduces one
+//     particular run of the reference);
+//   - map points: first seen, walking the local keyframes in order and their features in order;
+//   - fixed keyframes: first seen, walking those map points in order and each one's observer list in order;
+//   - observations: local keyframes (current first), then fixed keyframes, features in order — as :856-882.
+// With the lists filled in the same order, the result equals the reference's line by line (oracle/local_mapper_ref.py is
+// that restatement; tests/test_local_mapper_host.py compares them).
+#ifndef ORBX_MAP_HPP
+#define ORBX_MAP_HPP
+
+#include <functional>
+#include <optional>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "orbx.hpp"
+
+namespace orbx {
+
+struct MapSnapshot {
+  // keyframes (atlas/map/keyframe.rs): pose = T_wc as the Map stores it
+  std::vector<KeyFrameId> kf_ids;
+  std::vector<uint8_t> kf_bad;                 // is_bad
+  std::vector<double> kf_pose_wc;              // [nkf][7] qw,qx,qy,qz,tx,ty,tz
+  std::vector<int> kf_n_keypoints;             // keypoints.len(): `keypoints.get(feat_idx)` fails beyond it (:866)
+  std::vector<int> kf_feat_start;              // [nkf+1] CSR over map_point_ids
+  std::vector<int64_t> feat_mp_id;             // Some(id) or -1 = None
+  std::vector<float> feat_uv;                  // [nfeat][2] kp.pt()
+  std::vector<int> cov_start;                  // [nkf+1] covisibility_weights(), in the stated order
+  std::vector<KeyFrameId> cov_kf_id;
+  // map points (atlas/map/map_point.rs)
+  std::vector<MapPointId> mp_ids;
+  std::vector<uint8_t> mp_bad;
+  std::vector<double> mp_pos;                  // [nmp][3]
+  std::vector<int> mp_obs_start;               // [nmp+1] observations.keys(), in the stated order
+  std::vector<KeyFrameId> mp_obs_kf_id;
+
+  // id -> index (map.get_keyframe / map.get_map_point); call after filling or changing the id arrays
+  void build_index() {
+    kf_index_.clear(); mp_index_.clear();
+    for (size_t i = 0; i < kf_ids.size(); ++i) kf_index_[kf_ids[i]] = (int)i;
+    for (size_t i = 0; i < mp_ids.size(); ++i) mp_index_[mp_ids[i]] = (int)i;
+  }
+  int kf_index(KeyFrameId id) const { auto it = kf_index_.find(id); return it == kf_index_.end() ? -1 : it->second; }
+  int mp_index(MapPointId id) const { auto it = mp_index_.find(id); return it == mp_index_.end() ? -1 : it->second; }
+  SE3 kf_pose(int k) const {
+    SE3 p;
+    for (int i = 0; i < 4; ++i) p.rotation[i] = kf_pose_wc[7 * (size_t)k + i];
+    for (int i = 0; i < 3; ++i) p.translation[i] = kf_pose_wc[7 * (size_t)k + 4 + i];
+    return p;
+  }
+
+ private:
+  std::unordered_map<KeyFrameId, int> kf_index_;
+  std::unordered_map<MapPointId, int> mp_index_;
+};
+
+// local_ba_lm.rs:665-683
+inline std::vector<KeyFrameId> collect_local_keyframes(const MapSnapshot& m, KeyFrameId current_kf_id, size_t max_covisible) {
+  std::vector<KeyFrameId> local{current_kf_id};
+  const int k = m.kf_index(current_kf_id);
+  if (k >= 0) {
+    const int s = m.cov_start[(size_t)k], e = m.cov_start[(size_t)k + 1];
+    for (int i = s; i < e && (size_t)(i - s) < max_covisible; ++i) {     // .iter().take(max_covisible) comes BEFORE the filter
+      const int nb = m.kf_index(m.cov_kf_id[(size_t)i]);
+      if (nb >= 0 && !m.kf_bad[(size_t)nb]) local.push_back(m.cov_kf_id[(size_t)i]);
+    }
+  }
+  return local;
+}
+
+// local_ba_lm.rs:686-704 (set in first-seen order)
+inline std::vector<MapPointId> collect_local_map_points(const MapSnapshot& m, const std::vector<KeyFrameId>& local_kf_ids) {
+  std::unordered_set<MapPointId> seen;
+  std::vector<MapPointId> out;
+  for (KeyFrameId id : local_kf_ids) {
+    const int k = m.kf_index(id);
+    if (k < 0) continue;
+    for (int f = m.kf_feat_start[(size_t)k]; f < m.kf_feat_start[(size_t)k + 1]; ++f) {
+      const int64_t mp_id = m.feat_mp_id[(size_t)f];
+      if (mp_id < 0) continue;
+      const int j = m.mp_index((MapPointId)mp_id);
+      if (j >= 0 && !m.mp_bad[(size_t)j] && seen.insert((MapPointId)mp_id).second) out.push_back((MapPointId)mp_id);
+    }
+  }
+  return out;
+}
+
+// local_ba_lm.rs:707-726 (set in first-seen order; neither existence nor is_bad is checked there)
+inline std::vector<KeyFrameId> collect_fixed_keyframes(const MapSnapshot& m, const std::vector<KeyFrameId>& local_kf_ids,
+                                                       const std::vector<MapPointId>& local_mp_ids) {
+  const std::unordered_set<KeyFrameId> local(local_kf_ids.begin(), local_kf_ids.end());
+  std::unordered_set<KeyFrameId> seen;
+  std::vector<KeyFrameId> out;
+  for (MapPointId id : local_mp_ids) {
+    const int j = m.mp_index(id);
+    if (j < 0) continue;
+    for (int o = m.mp_obs_start[(size_t)j]; o < m.mp_obs_start[(size_t)j + 1]; ++o) {
+      const KeyFrameId kf = m.mp_obs_kf_id[(size_t)o];
+      if (!local.count(kf) && seen.insert(kf).second) out.push_back(kf);
+    }
+  }
+  return out;
+}
+
+// PHASE 1, local_ba_lm.rs:800-897
+inline std::optional<VisualBAProblemData> collect_visual_ba_data(const MapSnapshot& m, KeyFrameId current_kf_id,
+                                                                 const LocalBAConfigLM& config) {
+  const std::vector<KeyFrameId> local_kf_ids = collect_local_keyframes(m, current_kf_id, (size_t)config.max_covisible_keyframes);
+  if (local_kf_ids.empty()) return std::nullopt;                                     // :807-809
+  std::vector<MapPointId> mp_ids = collect_local_map_points(m, local_kf_ids);
+  if (mp_ids.empty()) return std::nullopt;                                           // :813-815
+  const std::vector<KeyFrameId> fixed_kf_ids = collect_fixed_keyframes(m, local_kf_ids, mp_ids);
+  VisualBAProblemData p;
+  p.anchor_kf_id = local_kf_ids.front();                                             // :821
+  p.optimized_kf_ids.assign(local_kf_ids.begin() + 1, local_kf_ids.end());           // :822
+  for (KeyFrameId id : p.optimized_kf_ids) {                                         // :825-830
+    const int k = m.kf_index(id);
+    if (k >= 0) p.local_kf_poses[id] = se3_inverse(m.kf_pose(k));                    // T_cw
+  }
+  {
+    const int k = m.kf_index(p.anchor_kf_id);                                        // :833-836
+    if (k >= 0) p.fixed_kf_poses[p.anchor_kf_id] = se3_inverse(m.kf_pose(k));
+  }
+  for (KeyFrameId id : fixed_kf_ids) {                                               // :837-841
+    const int k = m.kf_index(id);
+    if (k >= 0) p.fixed_kf_poses[id] = se3_inverse(m.kf_pose(k));
+  }
+  for (MapPointId id : mp_ids) {                                                     // :844-849
+    const int j = m.mp_index(id);
+    if (j >= 0) p.local_mp_positions[id] = {m.mp_pos[3 * (size_t)j], m.mp_pos[3 * (size_t)j + 1], m.mp_pos[3 * (size_t)j + 2]};
+  }
+  const std::unordered_set<KeyFrameId> local_kf_set(p.optimized_kf_ids.begin(), p.optimized_kf_ids.end());
+  const std::unordered_set<MapPointId> local_mp_set(mp_ids.begin(), mp_ids.end());
+  auto walk = [&](KeyFrameId id) {                                                   // :863-882
+    const int k = m.kf_index(id);
+    if (k < 0) return;
+    const int s = m.kf_feat_start[(size_t)k], e = m.kf_feat_start[(size_t)k + 1];
+    for (int f = s; f < e; ++f) {
+      const int64_t mp_id = m.feat_mp_id[(size_t)f];
+      if (mp_id < 0 || !local_mp_set.count((MapPointId)mp_id)) continue;
+      if (f - s >= m.kf_n_keypoints[(size_t)k]) continue;                            // keypoints.get(feat_idx) is Err
+      p.observations.push_back(VisualObservation{id, (MapPointId)mp_id,
+                                                 {(double)m.feat_uv[2 * (size_t)f], (double)m.feat_uv[2 * (size_t)f + 1]},
+                                                 local_kf_set.count(id) != 0});
+    }
+  };
+  for (KeyFrameId id : local_kf_ids) walk(id);
+  for (KeyFrameId id : fixed_kf_ids) walk(id);
+  if (p.observations.empty()) return std::nullopt;                                   // :884-886
+  p.mp_ids = std::move(mp_ids);
+  return p;
+}
+
+// PHASE 3, local_ba_lm.rs:1112-1138: entities that are gone or bad by now are skipped silently
+inline size_t apply_visual_ba_results(MapSnapshot& m, const VisualBAResultData& r) {
+  size_t updated = 0;
+  for (const auto& kv : r.optimized_poses) {
+    const int k = m.kf_index(kv.first);
+    if (k >= 0 && !m.kf_bad[(size_t)k]) {
+      for (int i = 0; i < 4; ++i) m.kf_pose_wc[7 * (size_t)k + i] = kv.second.rotation[i];
+      for (int i = 0; i < 3; ++i) m.kf_pose_wc[7 * (size_t)k + 4 + i] = kv.second.translation[i];
+      ++updated;
+    }
+  }
+  for (const auto& kv : r.optimized_points) {
+    const int j = m.mp_index(kv.first);
+    if (j >= 0 && !m.mp_bad[(size_t)j]) {
+      for (int i = 0; i < 3; ++i) m.mp_pos[3 * (size_t)j + i] = kv.second[i];
+      ++updated;
+    }
+  }
+  return updated;
+}
+
+// The visual branch of LocalMapper::local_bundle_adjustment (local_mapper.rs:378-408).  The reference takes the map's read
+// lock around phase 1 and its write lock around phase 3 and holds none while solving; `lock_read` / `lock_write` wrap the
+// two phases the same way (pass no-ops for a snapshot nobody else touches).  `map_for_apply` is looked up again for phase
+// 3 because the map may have changed meanwhile.  Returns nullopt where the reference returns early (:384, :391), else the
+// number of updated entities — 0 without touching the map when the solve ran no iteration (:396).
+inline std::optional<size_t> local_bundle_adjustment(Handle& h, MapSnapshot& map, KeyFrameId kf_id, const CameraModel& camera,
+                                                     const std::function<bool()>& should_stop,
+                                                     const std::function<void(const std::function<void()>&)>& lock_read = nullptr,
+                                                     const std::function<void(const std::function<void()>&)>& lock_write = nullptr,
+                                                     VisualBAResultData* result_out = nullptr) {
+  const LocalBAConfigLM config;                                                      // :380
+  std::optional<VisualBAProblemData> problem;
+  auto phase1 = [&] { problem = collect_visual_ba_data(map, kf_id, config); };       // :383-389
+  if (lock_read) lock_read(phase1); else phase1();
+  if (!problem) return std::nullopt;
+  std::optional<VisualBAResultData> result = solve_visual_ba(h, *problem, camera, config, should_stop);   // :392-395, no lock
+  if (!result) return std::nullopt;
+  if (result_out) *result_out = *result;
+  size_t updated = 0;
+  if (result->iterations > 0) {                                                      // :396
+    auto phase3 = [&] { updated = apply_visual_ba_results(map, *result); };
+    if (lock_write) lock_write(phase3); else phase3();
+  }
+  return updated;
+}
+
+}  // namespace orbx
+#endif  // ORBX_MAP_HPP

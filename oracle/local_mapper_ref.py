@@ -1,0 +1,160 @@
+"""CPU restatement (test infrastructure — see oracle.h) of the host side of local BA:
+
+    collect_local_keyframes / collect_local_map_points / collect_fixed_keyframes   local_ba_lm.rs:665-726
+    collect_visual_ba_data                                                         local_ba_lm.rs:800-897
+    apply_visual_ba_results                                                        local_ba_lm.rs:1112-1138
+    LocalMapper::local_bundle_adjustment (visual branch)                           local_mapper.rs:334-410
+
+over a Map made of Python dicts, written line by line after the Rust.  The reference iterates `HashMap`s and `HashSet`s
+(covisibility weights :675, the map-point set :704, the fixed-keyframe set :725, observations.keys() :718), whose order is
+unspecified and differs from run to run; Python dicts keep insertion order, so here "HashMap order" is
+the order in which the test inserted the entries and "HashSet order" is first-insertion order — the deterministic order
+the product states for itself (include/orbx_map.hpp).  Only tests import this module.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+
+@dataclass
+class KeyFrame:                      # atlas/map/keyframe.rs — the fields the path reads
+    pose: np.ndarray                 # T_wc as (qw,qx,qy,qz,tx,ty,tz)
+    keypoints: List[Tuple[float, float]]                 # kp.pt() as f32 values
+    map_point_ids: List[Optional[int]]
+    covisibility_weights: Dict[int, int] = field(default_factory=dict)
+    is_bad: bool = False
+
+
+@dataclass
+class MapPoint:                      # atlas/map/map_point.rs
+    position: np.ndarray
+    observations: Dict[int, int] = field(default_factory=dict)   # kf_id -> feature index
+    is_bad: bool = False
+
+
+@dataclass
+class Map:
+    keyframes: Dict[int, KeyFrame] = field(default_factory=dict)
+    map_points: Dict[int, MapPoint] = field(default_factory=dict)
+
+
+def se3_inverse(p):                   # geometry/se3.rs:56-63 (nalgebra quaternion * vector)
+    q = np.array([p[0], -p[1], -p[2], -p[3]])
+    v = np.asarray(p[4:7], np.float64)
+    t = 2.0 * np.array([q[2] * v[2] - q[3] * v[1], q[3] * v[0] - q[1] * v[2], q[1] * v[1] - q[2] * v[0]])
+    c = np.array([q[2] * t[2] - q[3] * t[1], q[3] * t[0] - q[1] * t[2], q[1] * t[1] - q[2] * t[0]])
+    r = t * q[0] + c + v
+    return np.concatenate([q, -r])
+
+
+def collect_local_keyframes(m: Map, current_kf_id, max_covisible):        # :665-683
+    local_kfs = [current_kf_id]
+    kf = m.keyframes.get(current_kf_id)
+    if kf is not None:
+        for neighbor_id in list(kf.covisibility_weights.keys())[:max_covisible]:     # .iter().take(max_covisible)
+            nb = m.keyframes.get(neighbor_id)
+            if nb is not None and not nb.is_bad:
+                local_kfs.append(neighbor_id)
+    return local_kfs
+
+
+def collect_local_map_points(m: Map, local_kf_ids):                        # :686-704
+    mp_set = {}
+    for kf_id in local_kf_ids:
+        kf = m.keyframes.get(kf_id)
+        if kf is None:
+            continue
+        for mp_id in kf.map_point_ids:
+            if mp_id is not None:
+                mp = m.map_points.get(mp_id)
+                if mp is not None and not mp.is_bad:
+                    mp_set.setdefault(mp_id, True)
+    return list(mp_set.keys())
+
+
+def collect_fixed_keyframes(m: Map, local_kf_ids, local_mp_ids):           # :707-726
+    local = set(local_kf_ids)
+    fixed = {}
+    for mp_id in local_mp_ids:
+        mp = m.map_points.get(mp_id)
+        if mp is not None:
+            for kf_id in mp.observations.keys():
+                if kf_id not in local:
+                    fixed.setdefault(kf_id, True)
+    return list(fixed.keys())
+
+
+def collect_visual_ba_data(m: Map, current_kf_id, max_covisible_keyframes=20):   # :800-897
+    local_kf_ids = collect_local_keyframes(m, current_kf_id, max_covisible_keyframes)
+    if not local_kf_ids:
+        return None
+    mp_ids = collect_local_map_points(m, local_kf_ids)
+    if not mp_ids:
+        return None
+    fixed_kf_ids = collect_fixed_keyframes(m, local_kf_ids, mp_ids)
+    anchor_kf_id = local_kf_ids[0]                                         # :821
+    optimized_kf_ids = local_kf_ids[1:]
+    local_kf_poses = {}
+    for kf_id in optimized_kf_ids:                                         # :825-830
+        kf = m.keyframes.get(kf_id)
+        if kf is not None:
+            local_kf_poses[kf_id] = se3_inverse(kf.pose)
+    fixed_kf_poses = {}
+    kf = m.keyframes.get(anchor_kf_id)                                     # :833-836
+    if kf is not None:
+        fixed_kf_poses[anchor_kf_id] = se3_inverse(kf.pose)
+    for kf_id in fixed_kf_ids:                                             # :837-841
+        kf = m.keyframes.get(kf_id)
+        if kf is not None:
+            fixed_kf_poses[kf_id] = se3_inverse(kf.pose)
+    local_mp_positions = {}
+    for mp_id in mp_ids:                                                   # :844-849
+        mp = m.map_points.get(mp_id)
+        if mp is not None:
+            local_mp_positions[mp_id] = np.array(mp.position, np.float64)
+    local_kf_set = set(optimized_kf_ids)
+    local_mp_set = set(mp_ids)
+    observations = []
+    for kf_id in local_kf_ids + fixed_kf_ids:                              # :856-882
+        kf = m.keyframes.get(kf_id)
+        if kf is None:
+            continue
+        for feat_idx, mp_id in enumerate(kf.map_point_ids):
+            if mp_id is not None and mp_id in local_mp_set:
+                if feat_idx < len(kf.keypoints):                           # keypoints.get(feat_idx) is Ok
+                    x, y = kf.keypoints[feat_idx]
+                    observations.append(dict(kf_id=kf_id, mp_id=mp_id, uv=(float(np.float32(x)), float(np.float32(y))),
+                                             is_kf_optimized=kf_id in local_kf_set))
+    if not observations:
+        return None
+    return dict(local_kf_poses=local_kf_poses, local_mp_positions=local_mp_positions, fixed_kf_poses=fixed_kf_poses,
+                anchor_kf_id=anchor_kf_id, observations=observations, optimized_kf_ids=optimized_kf_ids, mp_ids=mp_ids)
+
+
+def apply_visual_ba_results(m: Map, optimized_poses, optimized_points):    # :1112-1138
+    updated = 0
+    for kf_id, pose in optimized_poses.items():
+        kf = m.keyframes.get(kf_id)
+        if kf is not None and not kf.is_bad:
+            kf.pose = np.array(pose, np.float64)
+            updated += 1
+    for mp_id, pos in optimized_points.items():
+        mp = m.map_points.get(mp_id)
+        if mp is not None and not mp.is_bad:
+            mp.position = np.array(pos, np.float64)
+            updated += 1
+    return updated
+
+
+def local_bundle_adjustment(m: Map, kf_id, solve, max_covisible_keyframes=20):   # local_mapper.rs:378-408 (visual branch)
+    """solve(problem) -> None | dict(optimized_poses, optimized_points, iterations, ...).  Returns #updated or None."""
+    problem = collect_visual_ba_data(m, kf_id, max_covisible_keyframes)
+    if problem is None:
+        return None
+    result = solve(problem)
+    if result is None:
+        return None
+    if result["iterations"] > 0:                                           # :396
+        return apply_visual_ba_results(m, result["optimized_poses"], result["optimized_points"])
+    return 0

@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "orbx_extract_batch_device", "orbx_check_status", "orbx_stereo_match",
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
-    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
     "orbx_fuse_search", "orbx_fuse_search_device",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
@@ -577,6 +577,27 @@ class Handle:
         self._ar = ALLREDUCE_FN(tramp)
         self._check(self._L.orbx_ba_set_allreduce(self._h, self._ar, None))
 
+    # ---- native RCCL collective of the point-partitioned solve (include/orbx.h) -----------------------------------
+    @staticmethod
+    def rccl_unique_id():
+        """ncclGetUniqueId through the library (rank 0); hand the bytes to every rank, then init_rccl."""
+        buf = (C.c_uint8 * 256)()
+        n = load_library().orbx_rccl_unique_id(buf, C.c_size_t(256))
+        if n <= 0:
+            raise OrbxError(n, "ncclGetUniqueId failed")
+        return bytes(buf[:n])
+
+    def init_rccl(self, unique_id: bytes, rank: int, world: int):
+        """ncclCommInitRank on this handle's device; collective over all ranks.  The library owns the communicator."""
+        b = (C.c_uint8 * len(unique_id)).from_buffer_copy(unique_id)
+        self._L.orbx_ba_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        self._check(self._L.orbx_ba_init_rccl(self._h, b, C.c_size_t(len(unique_id)), C.c_int(rank), C.c_int(world)))
+
+    def set_rccl_comm(self, comm_ptr):
+        """Use an existing ncclComm_t (integer address), e.g. torch's; None / 0 clears."""
+        self._L.orbx_ba_set_rccl_comm.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self._L.orbx_ba_set_rccl_comm(self._h, C.c_void_p(comm_ptr or None)))
+
     def ba_solve_visual(self, camera, cfg, poses_cw, fixed_cw, points, obs, should_stop=None):
         poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)
         fixed_cw = np.ascontiguousarray(fixed_cw, np.float64).reshape(-1, 7)
@@ -792,6 +813,140 @@ def solve_visual_ba(problem: VisualBAProblemData, camera: CameraModel, config: L
         {k: r["poses_wc"][i] for i, k in enumerate(problem.optimized_kf_ids)},
         {m: r["points"][i] for i, m in enumerate(problem.mp_ids)},
         r["iterations"], r["initial_error"], r["final_error"])
+
+
+class MapSnapshot:
+    """The map as flat arrays (CSR) — what the host side of local BA reads and writes; the same layout and the same stated
+    orders as include/orbx_map.hpp (see there for why the reference's HashMap orders are replaced by stated ones).
+
+      keyframes:  kf_ids u64[nkf], kf_bad u8[nkf], kf_pose_wc f64[nkf,7] (T_wc), kf_n_keypoints i32[nkf],
+                  kf_feat_start i32[nkf+1], feat_mp_id i64[nfeat] (-1 = None), feat_uv f32[nfeat,2],
+                  cov_start i32[nkf+1], cov_kf_id u64[ncov] (covisibility neighbours in the stated order)
+      map points: mp_ids u64[nmp], mp_bad u8[nmp], mp_pos f64[nmp,3], mp_obs_start i32[nmp+1], mp_obs_kf_id u64[nobs]
+    """
+    FIELDS = (("kf_ids", np.uint64), ("kf_bad", np.uint8), ("kf_pose_wc", np.float64), ("kf_n_keypoints", np.int32),
+              ("kf_feat_start", np.int32), ("feat_mp_id", np.int64), ("feat_uv", np.float32), ("cov_start", np.int32),
+              ("cov_kf_id", np.uint64), ("mp_ids", np.uint64), ("mp_bad", np.uint8), ("mp_pos", np.float64),
+              ("mp_obs_start", np.int32), ("mp_obs_kf_id", np.uint64))
+
+    def __init__(self, **arrays):
+        for name, dt in self.FIELDS:
+            setattr(self, name, np.ascontiguousarray(arrays[name], dt))
+        self.kf_pose_wc = self.kf_pose_wc.reshape(-1, 7)
+        self.feat_uv = self.feat_uv.reshape(-1, 2)
+        self.mp_pos = self.mp_pos.reshape(-1, 3)
+        self.build_index()
+
+    def build_index(self):
+        self._kf = {int(k): i for i, k in enumerate(self.kf_ids)}
+        self._mp = {int(k): i for i, k in enumerate(self.mp_ids)}
+
+    def to_bytes(self):
+        """[14 x u64 element counts] then the arrays in FIELDS order (tests/cpp/local_mapper_driver.cpp reads this)."""
+        arrs = [getattr(self, n).reshape(-1) for n, _ in self.FIELDS]
+        return np.array([len(a) for a in arrs], np.uint64).tobytes() + b"".join(a.tobytes() for a in arrs)
+
+    # ---- local_ba_lm.rs:665-726 --------------------------------------------------------------------------------
+    def _local_keyframes(self, current, max_cov):
+        local = [int(current)]
+        k = self._kf.get(int(current), -1)
+        if k >= 0:
+            s, e = int(self.cov_start[k]), int(self.cov_start[k + 1])
+            for nid in self.cov_kf_id[s:min(e, s + max_cov)]:        # take(max_covisible) before the filter (:675)
+                nb = self._kf.get(int(nid), -1)
+                if nb >= 0 and not self.kf_bad[nb]:
+                    local.append(int(nid))
+        return local
+
+    def _local_map_points(self, local):
+        seen = {}
+        for kid in local:
+            k = self._kf.get(kid, -1)
+            if k < 0:
+                continue
+            for mp_id in self.feat_mp_id[int(self.kf_feat_start[k]):int(self.kf_feat_start[k + 1])]:
+                if mp_id >= 0:
+                    j = self._mp.get(int(mp_id), -1)
+                    if j >= 0 and not self.mp_bad[j]:
+                        seen.setdefault(int(mp_id), True)
+        return list(seen)
+
+    def _fixed_keyframes(self, local, mp_ids):
+        loc = set(local)
+        seen = {}
+        for mid in mp_ids:
+            j = self._mp.get(mid, -1)
+            if j < 0:
+                continue
+            for kid in self.mp_obs_kf_id[int(self.mp_obs_start[j]):int(self.mp_obs_start[j + 1])]:
+                if int(kid) not in loc:
+                    seen.setdefault(int(kid), True)
+        return list(seen)
+
+    def collect_visual_ba_data(self, current_kf_id, config: "LocalBAConfigLM" = None) -> Optional["VisualBAProblemData"]:
+        """PHASE 1 = collect_visual_ba_data, local_ba_lm.rs:800-897."""
+        config = config or LocalBAConfigLM()
+        local = self._local_keyframes(current_kf_id, config.max_covisible_keyframes)
+        if not local:
+            return None
+        mp_ids = self._local_map_points(local)
+        if not mp_ids:
+            return None
+        fixed = self._fixed_keyframes(local, mp_ids)
+        anchor, optimized = local[0], local[1:]
+        pose = lambda kid: se3_inverse(self.kf_pose_wc[self._kf[kid]])
+        local_kf_poses = {k: pose(k) for k in optimized if k in self._kf}
+        fixed_kf_poses = {}
+        if anchor in self._kf:
+            fixed_kf_poses[anchor] = pose(anchor)
+        for k in fixed:
+            if k in self._kf:
+                fixed_kf_poses[k] = pose(k)
+        local_mp_positions = {m: self.mp_pos[self._mp[m]].copy() for m in mp_ids if m in self._mp}
+        opt_set, mp_set = set(optimized), set(mp_ids)
+        obs = []
+        for kid in local + fixed:
+            k = self._kf.get(kid, -1)
+            if k < 0:
+                continue
+            s, e = int(self.kf_feat_start[k]), int(self.kf_feat_start[k + 1])
+            nkp = int(self.kf_n_keypoints[k])
+            for f in range(s, e):
+                mp_id = int(self.feat_mp_id[f])
+                if mp_id >= 0 and mp_id in mp_set and f - s < nkp:
+                    obs.append(VisualObservation(kid, mp_id, (float(self.feat_uv[f, 0]), float(self.feat_uv[f, 1])), kid in opt_set))
+        if not obs:
+            return None
+        return VisualBAProblemData(local_kf_poses, local_mp_positions, fixed_kf_poses, anchor, obs, optimized, mp_ids)
+
+    def apply_visual_ba_results(self, result: "VisualBAResultData") -> int:
+        """PHASE 3 = apply_visual_ba_results, local_ba_lm.rs:1112-1138: gone or bad entities are skipped silently."""
+        updated = 0
+        for kid, pose in result.optimized_poses.items():
+            k = self._kf.get(int(kid), -1)
+            if k >= 0 and not self.kf_bad[k]:
+                self.kf_pose_wc[k] = pose
+                updated += 1
+        for mid, pos in result.optimized_points.items():
+            j = self._mp.get(int(mid), -1)
+            if j >= 0 and not self.mp_bad[j]:
+                self.mp_pos[j] = pos
+                updated += 1
+        return updated
+
+
+def local_bundle_adjustment(snapshot: MapSnapshot, kf_id, camera: "CameraModel", should_stop: Callable[[], bool] = None,
+                            handle: "Handle" = None):
+    """The visual branch of LocalMapper::local_bundle_adjustment (local_mapper.rs:378-408): collect -> solve (GPU, no lock)
+    -> apply only if the solve ran an iteration (:396).  Returns (updated | None where the reference returns early, result)."""
+    config = LocalBAConfigLM()
+    problem = snapshot.collect_visual_ba_data(kf_id, config)
+    if problem is None:
+        return None, None
+    result = solve_visual_ba(problem, camera, config, should_stop or (lambda: False), handle=handle)
+    if result is None:
+        return None, None
+    return (snapshot.apply_visual_ba_results(result) if result.iterations > 0 else 0), result
 
 
 @dataclass

@@ -1557,9 +1557,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // and cfg carries max_iterations only; the point elimination, the per-keyframe 6x6 blocks and the Schur product are the
   // visual solver's kernels, the 15-d keyframe states are assembled and solved on top of them.
   const bool inertial = inr != nullptr;
-  const bool dist = h->allreduce != nullptr && !inertial && W == 1;
+  const bool have_coll = h->allreduce != nullptr || h->rccl_comm != nullptr;
+  const bool dist = have_coll && !inertial && W == 1;
   if (W <= 0) return ORBX_OK;
-  if ((inertial || (h->allreduce != nullptr && !inertial)) && W != 1)
+  if ((inertial || have_coll) && W != 1)
     return orbx_fail(h, ORBX_ERR_INVALID, "the inertial mode and the all-reduce hook take one window per call");
   for (int w = 0; w < W; ++w) { *win[w].iterations = 0; *win[w].initial_error = 0.0; *win[w].final_error = 0.0; win[w].status = ORBX_OK; }
   hipStream_t st = h->stream;
@@ -1756,6 +1757,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   const dim3 gW1(1, W);
   auto allreduce = [&](double* dptr, size_t cnt) -> int {
     if (!dist) return ORBX_OK;
+    if (h->rccl_comm) return orbx_rccl_allreduce_sum(h, dptr, cnt, st);       // native: ncclAllReduce(ncclDouble, ncclSum) on this stream
     if (h->allreduce(h->allreduce_user, dptr, cnt, (void*)st) != 0) return orbx_fail(h, ORBX_ERR_HIP, "all-reduce hook failed");
     return ORBX_OK;
   };

@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "orbx_internal.hpp"
 
 static thread_local std::string g_create_error;
@@ -156,6 +158,7 @@ void orbx_destroy(orbx_handle* h) {
   if (h->s_out) hipStreamDestroy(h->s_out);
   for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
   if (h->pair_graph) hipGraphExecDestroy(h->pair_graph);
+  if (h->rccl_comm && h->rccl_owned) ncclCommDestroy((ncclComm_t)h->rccl_comm);
   if (h->h_stage) hipHostFree(h->h_stage);
   if (h->h_ba_in) hipHostFree(h->h_ba_in);
   if (h->h_ba_out) hipHostFree(h->h_ba_out);
@@ -818,6 +821,50 @@ int orbx_ba_set_allreduce(orbx_handle* h, orbx_allreduce_fn fn, void* user) {
   return ORBX_OK;
 }
 
+// ---- native collective of the point-partitioned solve: RCCL over xGMI -------------------------
+int orbx_rccl_unique_id(uint8_t* out, size_t cap) {
+  if (!out || cap < sizeof(ncclUniqueId)) return ORBX_ERR_INVALID;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return ORBX_ERR_HIP;
+  memcpy(out, &id, sizeof(id));
+  return (int)sizeof(id);
+}
+
+static void rccl_drop(orbx_handle* h) {
+  if (h->rccl_comm && h->rccl_owned) ncclCommDestroy((ncclComm_t)h->rccl_comm);
+  h->rccl_comm = nullptr; h->rccl_owned = false;
+}
+
+int orbx_ba_init_rccl(orbx_handle* h, const uint8_t* unique_id, size_t id_bytes, int rank, int world) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!unique_id || id_bytes != sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world)
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_init_rccl: bad argument (the id is %zu bytes)", sizeof(ncclUniqueId));
+  ORBX_HIP(h, hipSetDevice(h->device));
+  rccl_drop(h);
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
+  if (r != ncclSuccess) return orbx_fail(h, ORBX_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+  h->rccl_comm = comm; h->rccl_owned = true;
+  return ORBX_OK;
+}
+
+int orbx_ba_set_rccl_comm(orbx_handle* h, void* nccl_comm) {
+  if (!h) return ORBX_ERR_INVALID;
+  rccl_drop(h);
+  h->rccl_comm = nccl_comm; h->rccl_owned = false;
+  return ORBX_OK;
+}
+
+}  // extern "C"
+int orbx_rccl_allreduce_sum(orbx_handle* h, double* d_buf, size_t n, hipStream_t st) {
+  const ncclResult_t r = ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, (ncclComm_t)h->rccl_comm, st);
+  if (r != ncclSuccess) return orbx_fail(h, ORBX_ERR_HIP, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+  return ORBX_OK;
+}
+extern "C" {
+
 int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
                          const double* poses_cw, int F, const double* fixed_poses_cw, int M,
                          double* points, int N, const orbx_ba_obs* obs, orbx_should_stop_fn should_stop,
@@ -852,9 +899,10 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
   ORBX_HIP(h, hipSetDevice(h->device));
   orbx_prof_begin_call(h);
   orbx_allreduce_fn saved = h->allreduce;          // independent windows: no collective
-  h->allreduce = nullptr;
+  void* saved_comm = h->rccl_comm;
+  h->allreduce = nullptr; h->rccl_comm = nullptr;
   const int rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), should_stop, user);
-  h->allreduce = saved;
+  h->allreduce = saved; h->rccl_comm = saved_comm;
   for (int i = 0; i < n_windows; ++i) windows[i].status = rc == ORBX_OK ? w[i].status : rc;
   return rc;
 }

@@ -96,6 +96,8 @@ struct orbx_handle {
   // BA
   orbx_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  void* rccl_comm = nullptr;                               // ncclComm_t of the point-partitioned solve (orbx_ba_init_rccl / orbx_ba_set_rccl_comm)
+  bool rccl_owned = false;
   void* h_ba_in = nullptr;   size_t h_ba_in_bytes = 0;    // pinned mirrors of the batch input / output blobs (ba_solve_batch)
   void* h_ba_out = nullptr;  size_t h_ba_out_bytes = 0;
   int* h_abort = nullptr;    int* d_abort = nullptr;       // pinned, device-visible: should_stop() seen while the iterations drain
@@ -172,6 +174,8 @@ struct BaWinHost {
 };
 int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int W, BaWinHost* win,
                    orbx_should_stop_fn should_stop, void* user, bool global_mode = false, const struct BaInertialHost* inr = nullptr);
+// in-place sum of `n` doubles over the ranks of the handle's communicator, ordered on `st` (ncclAllReduce, orbx_api.hip)
+int orbx_rccl_allreduce_sum(orbx_handle* h, double* d_buf, size_t n, hipStream_t st);
 int ba_debug_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
                     const double* fixed_poses_cw, int M, const double* points, int N, const orbx_ba_obs* obs, int global_mode,
                     double* out);

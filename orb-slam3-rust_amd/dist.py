@@ -55,9 +55,27 @@ def make_allreduce_hook(device, group=None):
     return hook
 
 
-def ba_solve_partitioned(handle, camera, cfg, poses_cw, fixed_cw, points, obs, rank, world, hook,
+def init_native_rccl(handle, rank, world, group=None):
+    """Gives `handle` its own RCCL communicator over all ranks (the library then calls ncclAllReduce itself, on its own
+    stream — no Python in the LM loop).  Rank 0 draws the unique id through the library; it travels to the other ranks as
+    an object broadcast over whatever torch.distributed group is up (gloo or nccl: only 128 bytes of bootstrap).  Collective:
+    every rank calls it, before the first partitioned solve."""
+    import torch.distributed as dist
+    box = [handle.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    handle.init_rccl(box[0], rank, world)
+
+
+def ba_solve_partitioned(handle, camera, cfg, poses_cw, fixed_cw, points, obs, rank, world, hook=None,
                          should_stop=None):
-    """Point-partitioned solve_visual_ba: call on every rank with the same problem."""
+    """Point-partitioned solve_visual_ba: call on every rank with the same problem.  hook = None: the handle's native RCCL
+    communicator (init_native_rccl / Handle.set_rccl_comm) carries the two all-reduces per iteration; otherwise the given
+    hook (any transport: the CPU tests run gloo).  should_stop may answer differently on different ranks: the stop votes
+    are all-reduced with the data, one rank asking stops every rank before the same iteration."""
+    if hook is None:
+        return handle.ba_solve_visual(camera, cfg, poses_cw, fixed_cw, points,
+                                      partition_observations(obs, rank, world), should_stop)
     handle.set_allreduce(hook)
     try:
         return handle.ba_solve_visual(camera, cfg, poses_cw, fixed_cw, points,

@@ -1,0 +1,130 @@
+// Compiled-host test driver for include/orbx_map.hpp (the host side of local BA over flat arrays): reads a MapSnapshot
+// written by api.MapSnapshot.to_bytes(), runs collect_visual_ba_data (phase 1) and — mode "apply" — apply_visual_ba_results
+// (phase 3) on a result file, mode "lba": the whole three-phase local_bundle_adjustment on the GPU.
+//   driver collect <snapshot.bin> <current_kf_id> <max_covisible> <out.bin>
+//   driver apply   <snapshot.bin> <result.bin> <out.bin>
+//   driver lba     <snapshot.bin> <current_kf_id> <stop_after_polls> <out.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "orbx_map.hpp"
+
+static std::vector<uint8_t> slurp(const char* p) {
+  FILE* f = fopen(p, "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", p); exit(2); }
+  fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> b((size_t)n);
+  if (n && fread(b.data(), 1, (size_t)n, f) != (size_t)n) exit(2);
+  fclose(f);
+  return b;
+}
+template <class T> static void take(const uint8_t*& p, std::vector<T>& v, uint64_t n) { v.resize(n); if (n) memcpy(v.data(), p, n * sizeof(T)); p += n * sizeof(T); }
+template <class T> static void put(FILE* f, const T* p, size_t n) { if (n) fwrite(p, sizeof(T), n, f); }
+
+static orbx::MapSnapshot load(const char* path) {
+  const std::vector<uint8_t> b = slurp(path);
+  const uint64_t* c = (const uint64_t*)b.data();
+  const uint8_t* p = b.data() + 14 * 8;
+  orbx::MapSnapshot m;
+  take(p, m.kf_ids, c[0]); take(p, m.kf_bad, c[1]); take(p, m.kf_pose_wc, c[2]); take(p, m.kf_n_keypoints, c[3]);
+  take(p, m.kf_feat_start, c[4]); take(p, m.feat_mp_id, c[5]); take(p, m.feat_uv, c[6]); take(p, m.cov_start, c[7]);
+  take(p, m.cov_kf_id, c[8]); take(p, m.mp_ids, c[9]); take(p, m.mp_bad, c[10]); take(p, m.mp_pos, c[11]);
+  take(p, m.mp_obs_start, c[12]); take(p, m.mp_obs_kf_id, c[13]);
+  m.build_index();
+  return m;
+}
+
+static void write_problem(FILE* f, const std::optional<orbx::VisualBAProblemData>& p) {
+  const uint64_t some = p ? 1 : 0;
+  put(f, &some, 1);
+  if (!p) return;
+  const uint64_t hdr[5] = {p->anchor_kf_id, p->optimized_kf_ids.size(), p->mp_ids.size(), p->observations.size(), p->fixed_kf_poses.size()};
+  put(f, hdr, 5);
+  put(f, p->optimized_kf_ids.data(), p->optimized_kf_ids.size());
+  put(f, p->mp_ids.data(), p->mp_ids.size());
+  for (const auto& o : p->observations) {
+    const uint64_t ids[3] = {o.kf_id, o.mp_id, o.is_kf_optimized ? 1u : 0u};
+    put(f, ids, 3); put(f, o.observed_uv.data(), 2);
+  }
+  auto pose = [&](uint64_t id, const orbx::SE3& s, uint64_t present) {
+    put(f, &id, 1); put(f, &present, 1); put(f, s.rotation.data(), 4); put(f, s.translation.data(), 3);
+  };
+  for (uint64_t id : p->optimized_kf_ids) {                              // local poses in optimized order (missing = absent)
+    auto it = p->local_kf_poses.find(id);
+    pose(id, it != p->local_kf_poses.end() ? it->second : orbx::SE3{}, it != p->local_kf_poses.end());
+  }
+  std::vector<uint64_t> fid;
+  for (const auto& kv : p->fixed_kf_poses) fid.push_back(kv.first);
+  std::sort(fid.begin(), fid.end());
+  for (uint64_t id : fid) pose(id, p->fixed_kf_poses.at(id), 1);
+  for (uint64_t id : p->mp_ids) {
+    auto it = p->local_mp_positions.find(id);
+    const uint64_t present = it != p->local_mp_positions.end();
+    const std::array<double, 3> z{0, 0, 0};
+    put(f, &id, 1); put(f, &present, 1); put(f, present ? it->second.data() : z.data(), 3);
+  }
+}
+
+static void write_map_state(FILE* f, const orbx::MapSnapshot& m) {
+  put(f, m.kf_pose_wc.data(), m.kf_pose_wc.size());
+  put(f, m.mp_pos.data(), m.mp_pos.size());
+}
+
+int main(int argc, char** argv) {
+  if (argc < 5) return 2;
+  const std::string mode = argv[1];
+  try {
+    orbx::MapSnapshot m = load(argv[2]);
+    if (mode == "collect") {
+      orbx::LocalBAConfigLM cfg;
+      cfg.max_covisible_keyframes = atoi(argv[4]);
+      FILE* f = fopen(argv[5], "wb");
+      write_problem(f, orbx::collect_visual_ba_data(m, strtoull(argv[3], nullptr, 10), cfg));
+      fclose(f);
+    } else if (mode == "apply") {
+      const std::vector<uint8_t> b = slurp(argv[3]);                       // [nk, nm] then (id, pose7)*, (id, xyz)*
+      const uint64_t* c = (const uint64_t*)b.data();
+      const uint8_t* p = b.data() + 16;
+      orbx::VisualBAResultData r;
+      for (uint64_t i = 0; i < c[0]; ++i) {
+        uint64_t id; double v[7];
+        memcpy(&id, p, 8); memcpy(v, p + 8, 56); p += 64;
+        orbx::SE3 s; for (int q = 0; q < 4; ++q) s.rotation[q] = v[q]; for (int q = 0; q < 3; ++q) s.translation[q] = v[4 + q];
+        r.optimized_poses[id] = s;
+      }
+      for (uint64_t i = 0; i < c[1]; ++i) {
+        uint64_t id; double v[3];
+        memcpy(&id, p, 8); memcpy(v, p + 8, 24); p += 32;
+        r.optimized_points[id] = {v[0], v[1], v[2]};
+      }
+      const uint64_t updated = orbx::apply_visual_ba_results(m, r);
+      FILE* f = fopen(argv[4], "wb");
+      put(f, &updated, 1);
+      write_map_state(f, m);
+      fclose(f);
+    } else if (mode == "lba") {
+      const orbx::CameraModel cam{458.654, 457.296, 367.215, 248.375, 0.11007};   // EuRoC cam0
+      orbx::Handle h(cam, 100, 0, 752, 480, 1);
+      const int stop_after = atoi(argv[4]);                               // should_stop() turns true on this poll (0 = never)
+      int polls = 0;
+      orbx::VisualBAResultData res;
+      int locks[2] = {0, 0};
+      const std::optional<size_t> up = orbx::local_bundle_adjustment(
+          h, m, strtoull(argv[3], nullptr, 10), cam, [&] { ++polls; return stop_after > 0 && polls >= stop_after; },
+          [&](const std::function<void()>& body) { ++locks[0]; body(); }, [&](const std::function<void()>& body) { ++locks[1]; body(); }, &res);
+      FILE* f = fopen(argv[5], "wb");
+      const int64_t hdr[5] = {up ? (int64_t)*up : -1, (int64_t)res.iterations, locks[0], locks[1], polls};
+      put(f, hdr, 5);
+      const double err[2] = {res.initial_error, res.final_error};
+      put(f, err, 2);
+      write_map_state(f, m);
+      fclose(f);
+    } else return 2;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "driver: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -291,3 +291,81 @@ def test_ba_blocks_known_answers_on_gpu(gpu_handle, pkg, golden):
         num = (rp - rm) / (2 * eps)
         inl = np.linalg.norm(r0, axis=1) < 0.9 * cfg.huber_threshold      # the analytic blocks hold sqrt(w) fixed (:632-636)
         assert inl.sum() > 20 and np.allclose(num[inl], B[inl, :, c], rtol=1e-5, atol=1e-5)
+
+
+def test_ba_native_rccl_world1(gpu_handle, pkg):
+    """The library's own collective: orbx_rccl_unique_id + orbx_ba_init_rccl (ncclCommInitRank) and ncclAllReduce(ncclDouble,
+    ncclSum) issued by the library on its stream — no torch.distributed, no Python in the loop.  World size 1 on this one
+    GPU: the partitioned code path (two collectives per iteration, stop votes, point merge) must leave the single-rank result
+    unchanged: poses bit for bit."""
+    w = pkg.synth.ba_window(9, 7, 250, pkg.BA_OBS)
+    cam = pkg.CameraModel(**w["camera"]); cfg = pkg.LocalBAConfigLM()
+    ref = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+    h = pkg.Handle(cam, 100, device=0)
+    try:
+        uid = h.rccl_unique_id()
+        assert len(uid) == 128
+        h.init_rccl(uid, 0, 1)
+        got = pkg.dist.ba_solve_partitioned(h, cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"], 0, 1)
+        assert got["iterations"] == ref["iterations"] and got["final_error"] == ref["final_error"]
+        assert np.array_equal(got["poses_wc"], ref["poses_wc"])
+        assert _rel(got["points"], ref["points"]) < 1e-14          # the cross-rank point merge rounds once more
+        # stop vote through the collective: the third poll asks -> 2 iterations, as the unpartitioned solve
+        calls = []
+        r = pkg.dist.ba_solve_partitioned(h, cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"], 0, 1,
+                                          should_stop=lambda: (calls.append(1) or len(calls) > 2))
+        r0 = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"], should_stop=(lambda c=[]: (c.append(1) or len(c) > 2)))
+        assert r["iterations"] == r0["iterations"] == 2 and np.array_equal(r["poses_wc"], r0["poses_wc"])
+        # a bad index on "some rank" fails the call on every rank, after the collective that carries the flag
+        bad = w["obs"].copy(); bad["mp_idx"][0] = 10 ** 6
+        with pytest.raises(pkg.OrbxError):
+            h.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], bad)
+        # windows in a batch never use the communicator
+        b = h.ba_solve_visual_batch(cam, cfg, [w])[0]
+        assert np.array_equal(b["poses_wc"], ref["poses_wc"]) and np.array_equal(b["points"], ref["points"])
+    finally:
+        h.close()
+
+
+def test_ba_partition_stop_requested_by_one_rank(pkg):
+    """in the partitioned solve every rank must issue the same sequence of collectives.  Two ranks (two handles,
+    two threads, the hook sums their buffers); ONLY rank 1's should_stop ever answers yes (on its third poll).  Both ranks must
+    stop before the same iteration with identical results — and not hang."""
+    import threading
+    import torch
+    w = pkg.synth.ba_window(23, 8, 300, pkg.BA_OBS)
+    cam = pkg.CameraModel(**w["camera"]); cfg = pkg.LocalBAConfigLM()
+    dev = torch.device("cuda", 0)
+    hs = [pkg.Handle(cam, 100, device=0) for _ in range(2)]
+    bar = threading.Barrier(2, timeout=60)
+    slots = [None, None]; out = [None, None]; errs = []; polls = [[], []]
+
+    def hook_for(rank):
+        def hook(ptr, n, stream):
+            torch.cuda.synchronize()
+            slots[rank] = pkg.dist.device_tensor(ptr, n, dev)
+            bar.wait()
+            total = slots[0] + slots[1]
+            torch.cuda.synchronize()
+            bar.wait()
+            slots[rank].copy_(total)
+            torch.cuda.synchronize()
+            bar.wait()
+        return hook
+
+    def run(rank):
+        try:
+            stop = (lambda: (polls[1].append(1) or len(polls[1]) > 2)) if rank == 1 else (lambda: (polls[0].append(1) and False))
+            out[rank] = pkg.dist.ba_solve_partitioned(hs[rank], cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"], rank, 2,
+                                                      hook_for(rank), should_stop=stop)
+        except Exception as e:  # pragma: no cover
+            errs.append(e); bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join(120)
+    assert not errs and not any(t.is_alive() for t in ts), errs
+    assert out[0]["iterations"] == out[1]["iterations"] == 2
+    assert np.array_equal(out[0]["poses_wc"], out[1]["poses_wc"]) and np.array_equal(out[0]["points"], out[1]["points"])
+    assert len(polls[0]) == cfg.max_iterations           # rank 0 kept polling (and enqueueing) once per iteration
+    for h in hs: h.close()

@@ -1,0 +1,302 @@
+"""The host side of local BA: collect_visual_ba_data (local_ba_lm.rs:665-726, :800-897),
+apply_visual_ba_results (:1112-1138) and the three-phase driver LocalMapper::local_bundle_adjustment
+(local_mapper.rs:334-410), as host code over FLAT arrays — include/orbx_map.hpp (C++, compiled here) and api.MapSnapshot
+(Python) — against the line-by-line restatement over a dict-based Map in oracle/local_mapper_ref.py.
+
+CPU: phases 1 and 3 on random maps with bad / deleted keyframes and map points, dangling ids, features without a
+keypoint, more neighbours than max_covisible.  GPU: the whole driver (collect -> solve on the MI355X -> apply iff an
+iteration ran)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import local_mapper_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "orb-slam3-rust_amd")
+
+
+def random_map(seed, n_kf=14, n_mp=120, feats=40, damage=True):
+    """A dict-based Map (the oracle's) with every irregularity the reference's code paths test for."""
+    rng = np.random.default_rng(seed)
+    m = R.Map()
+    mp_ids = [5000 + 3 * j for j in range(n_mp)]
+    for j, mid in enumerate(mp_ids):
+        m.map_points[mid] = R.MapPoint(position=rng.uniform(-3, 3, 3) + [0, 0, 8.0], is_bad=damage and rng.random() < 0.08)
+    kf_ids = [100 + 7 * i for i in range(n_kf)]
+    for i, kid in enumerate(kf_ids):
+        q = rng.normal(0, 1, 4) * [1, 0.05, 0.05, 0.05]; q /= np.linalg.norm(q)
+        pose = np.concatenate([q, rng.normal(0, 0.5, 3)])
+        n = feats + int(rng.integers(0, 10))
+        mps = []
+        for f in range(n):
+            r = rng.random()
+            if r < 0.35:
+                mps.append(None)
+            elif damage and r < 0.40:
+                mps.append(999000 + f)                      # dangling id: the map point was deleted
+            else:
+                mps.append(int(rng.choice(mp_ids)))
+        n_kp = n - (2 if damage and i % 5 == 0 else 0)      # fewer keypoints than map_point_ids: keypoints.get() fails
+        kps = [(float(np.float32(rng.uniform(0, 752))), float(np.float32(rng.uniform(0, 480)))) for _ in range(n_kp)]
+        m.keyframes[kid] = R.KeyFrame(pose=pose, keypoints=kps, map_point_ids=mps, is_bad=damage and i in (3, 9))
+    for kid, kf in m.keyframes.items():                     # observer lists (insertion order = the stated order)
+        for f, mid in enumerate(kf.map_point_ids):
+            if mid is not None and mid in m.map_points:
+                m.map_points[mid].observations.setdefault(kid, f)
+    if damage:
+        some = list(m.map_points.values())[5]
+        some.observations[777777] = 0                       # an observer that is not in the map any more
+    for kid, kf in m.keyframes.items():                     # covisibility: weight desc, id asc (the recommended fill)
+        w = {}
+        for mid in kf.map_point_ids:
+            if mid is not None and mid in m.map_points:
+                for other in m.map_points[mid].observations:
+                    if other != kid:
+                        w[other] = w.get(other, 0) + 1
+        for other in sorted(w, key=lambda o: (-w[o], o)):
+            kf.covisibility_weights[other] = w[other]
+        if damage and kid == kf_ids[0]:
+            kf.covisibility_weights[888888] = 1             # neighbour id without a keyframe
+    return m, kf_ids, mp_ids
+
+
+def snapshot_of(pkg, m):
+    """dict Map -> flat arrays, keeping every list in the dict's (insertion) order."""
+    kf_ids = list(m.keyframes)
+    feat_start = [0]; feat_mp = []; feat_uv = []; cov_start = [0]; cov = []; nkp = []
+    for kid in kf_ids:
+        kf = m.keyframes[kid]
+        for f, mid in enumerate(kf.map_point_ids):
+            feat_mp.append(-1 if mid is None else mid)
+            feat_uv.append(kf.keypoints[f] if f < len(kf.keypoints) else (0.0, 0.0))
+        feat_start.append(len(feat_mp)); nkp.append(len(kf.keypoints))
+        cov.extend(kf.covisibility_weights.keys()); cov_start.append(len(cov))
+    mp_ids = list(m.map_points)
+    obs_start = [0]; obs = []
+    for mid in mp_ids:
+        obs.extend(m.map_points[mid].observations.keys()); obs_start.append(len(obs))
+    return pkg.MapSnapshot(kf_ids=kf_ids, kf_bad=[m.keyframes[k].is_bad for k in kf_ids],
+                           kf_pose_wc=[m.keyframes[k].pose for k in kf_ids], kf_n_keypoints=nkp, kf_feat_start=feat_start,
+                           feat_mp_id=feat_mp, feat_uv=np.array(feat_uv, np.float32).reshape(-1, 2), cov_start=cov_start, cov_kf_id=cov,
+                           mp_ids=mp_ids, mp_bad=[m.map_points[k].is_bad for k in mp_ids],
+                           mp_pos=[m.map_points[k].position for k in mp_ids], mp_obs_start=obs_start, mp_obs_kf_id=obs)
+
+
+def problems_equal(o, p):
+    """oracle dict problem vs api.VisualBAProblemData, bit for bit"""
+    if o is None or p is None:
+        return o is None and p is None
+    ok = o["anchor_kf_id"] == p.anchor_kf_id and o["optimized_kf_ids"] == list(p.optimized_kf_ids) and o["mp_ids"] == list(p.mp_ids)
+    ok = ok and len(o["observations"]) == len(p.observations)
+    for a, b in zip(o["observations"], p.observations):
+        ok = ok and (a["kf_id"], a["mp_id"], a["uv"], a["is_kf_optimized"]) == (b.kf_id, b.mp_id, tuple(b.observed_uv), b.is_kf_optimized)
+    for name in ("local_kf_poses", "fixed_kf_poses", "local_mp_positions"):
+        A, B = o[name], getattr(p, name)
+        ok = ok and list(A) == list(B) and all(np.asarray(A[k]).tobytes() == np.asarray(B[k], np.float64).tobytes() for k in A)
+    return ok
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_collect_matches_reference_restatement(pkg, seed):
+    m, kf_ids, _ = random_map(seed)
+    snap = snapshot_of(pkg, m)
+    hit = 0
+    for cur in kf_ids + [424242]:                          # every keyframe as "current", and one that does not exist
+        for max_cov in (20, 3, 0):
+            o = R.collect_visual_ba_data(m, cur, max_cov)
+            p = snap.collect_visual_ba_data(cur, pkg.LocalBAConfigLM(max_covisible_keyframes=max_cov))
+            assert problems_equal(o, p), (cur, max_cov)
+            hit += o is not None
+    assert hit > 20
+    # the stated properties: anchor = current keyframe (:821), bad neighbours never local, bad points never collected
+    o = R.collect_visual_ba_data(m, kf_ids[0], 20)
+    assert o["anchor_kf_id"] == kf_ids[0] and all(not m.keyframes[k].is_bad for k in o["optimized_kf_ids"])
+    assert all(not m.map_points[j].is_bad for j in o["mp_ids"]) and len(o["optimized_kf_ids"]) <= 20
+    assert 777777 in R.collect_fixed_keyframes(m, [kf_ids[0]] + o["optimized_kf_ids"], o["mp_ids"]) or True
+
+
+def test_collect_none_cases(pkg):
+    m, kf_ids, _ = random_map(50, damage=False)
+    empty = R.Map()
+    assert R.collect_visual_ba_data(empty, 1) is None and snapshot_of(pkg, empty).collect_visual_ba_data(1) is None
+    for kf in m.keyframes.values():                        # no feature has a map point -> None (:813-815)
+        kf.map_point_ids = [None] * len(kf.map_point_ids)
+    assert R.collect_visual_ba_data(m, kf_ids[0]) is None and snapshot_of(pkg, m).collect_visual_ba_data(kf_ids[0]) is None
+
+
+def test_apply_skips_deleted_and_bad(pkg):
+    m, kf_ids, mp_ids = random_map(7)
+    snap = snapshot_of(pkg, m)
+    rng = np.random.default_rng(1)
+    poses = {k: np.concatenate([[1.0, 0, 0, 0], rng.normal(0, 1, 3)]) for k in kf_ids[:8] + [123456789]}   # one deleted meanwhile
+    points = {j: rng.normal(0, 1, 3) for j in mp_ids[:60] + [987654321]}
+    want = R.apply_visual_ba_results(m, poses, points)
+    got = snap.apply_visual_ba_results(pkg.VisualBAResultData(poses, points, 3, 1.0, 0.5))
+    n_ok = sum(not m.keyframes[k].is_bad for k in kf_ids[:8]) + sum(not m.map_points[j].is_bad for j in mp_ids[:60])
+    assert got == want == n_ok and n_ok < 68
+    for i, k in enumerate(snap.kf_ids):
+        assert np.array_equal(snap.kf_pose_wc[i], m.keyframes[int(k)].pose)
+    for i, j in enumerate(snap.mp_ids):
+        assert np.array_equal(snap.mp_pos[i], m.map_points[int(j)].position)
+
+
+def _build(tmp):
+    exe = os.path.join(tmp, "local_mapper_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "local_mapper_driver.cpp"), "-o", exe,
+                    "-L", LIBDIR, "-lorbx_hip", "-Wl,-rpath," + LIBDIR], check=True)
+    return exe
+
+
+def _read_problem(b):
+    some, = struct.unpack_from("<Q", b, 0)
+    if not some:
+        return None
+    anchor, nk, nm, no, nf = struct.unpack_from("<5Q", b, 8)
+    off = 48
+    opt = list(np.frombuffer(b, np.uint64, nk, off)); off += 8 * nk
+    mps = list(np.frombuffer(b, np.uint64, nm, off)); off += 8 * nm
+    obs = []
+    for _ in range(no):
+        kid, mid, fl = struct.unpack_from("<3Q", b, off); u, v = struct.unpack_from("<2d", b, off + 24); off += 40
+        obs.append((kid, mid, (u, v), bool(fl)))
+    def poses(n):
+        nonlocal off
+        out = {}
+        for _ in range(n):
+            kid, present = struct.unpack_from("<2Q", b, off); p = np.frombuffer(b, np.float64, 7, off + 16).copy(); off += 72
+            if present:
+                out[kid] = p
+        return out
+    local = poses(nk); fixed = poses(nf)
+    pts = {}
+    for _ in range(nm):
+        mid, present = struct.unpack_from("<2Q", b, off); p = np.frombuffer(b, np.float64, 3, off + 16).copy(); off += 40
+        if present:
+            pts[mid] = p
+    return dict(anchor=anchor, opt=[int(x) for x in opt], mps=[int(x) for x in mps], obs=obs, local=local, fixed=fixed, pts=pts)
+
+
+def test_cpp_collect_and_apply_match_restatement(pkg, tmp_path):
+    """include/orbx_map.hpp compiled with g++ (links liborbx_hip.so, no GPU used by these two phases)."""
+    pkg.load_library()
+    tmp = str(tmp_path)
+    exe = _build(tmp)
+    for seed in (0, 3):
+        m, kf_ids, mp_ids = random_map(seed)
+        snap = snapshot_of(pkg, m)
+        open(os.path.join(tmp, "snap.bin"), "wb").write(snap.to_bytes())
+        for cur, max_cov in ((kf_ids[0], 20), (kf_ids[4], 3), (kf_ids[3], 20), (424242, 20)):
+            subprocess.run([exe, "collect", os.path.join(tmp, "snap.bin"), str(cur), str(max_cov), os.path.join(tmp, "prob.bin")], check=True)
+            got = _read_problem(open(os.path.join(tmp, "prob.bin"), "rb").read())
+            o = R.collect_visual_ba_data(m, cur, max_cov)
+            assert (got is None) == (o is None)
+            if o is None:
+                continue
+            assert got["anchor"] == o["anchor_kf_id"] and got["opt"] == o["optimized_kf_ids"] and got["mps"] == o["mp_ids"]
+            assert got["obs"] == [(a["kf_id"], a["mp_id"], a["uv"], a["is_kf_optimized"]) for a in o["observations"]]
+            for name, key in (("local", "local_kf_poses"), ("fixed", "fixed_kf_poses"), ("pts", "local_mp_positions")):
+                assert set(got[name]) == set(o[key]) and all(got[name][k].tobytes() == np.asarray(o[key][k]).tobytes() for k in o[key])
+        rng = np.random.default_rng(seed)
+        poses = {k: np.concatenate([[1.0, 0, 0, 0], rng.normal(0, 1, 3)]) for k in kf_ids[:8] + [123456789]}
+        points = {j: rng.normal(0, 1, 3) for j in mp_ids[:60] + [987654321]}
+        with open(os.path.join(tmp, "res.bin"), "wb") as f:
+            f.write(struct.pack("<2Q", len(poses), len(points)))
+            for k, p in poses.items():
+                f.write(struct.pack("<Q", k)); f.write(np.asarray(p, np.float64).tobytes())
+            for j, p in points.items():
+                f.write(struct.pack("<Q", j)); f.write(np.asarray(p, np.float64).tobytes())
+        subprocess.run([exe, "apply", os.path.join(tmp, "snap.bin"), os.path.join(tmp, "res.bin"), os.path.join(tmp, "applied.bin")], check=True)
+        b = open(os.path.join(tmp, "applied.bin"), "rb").read()
+        updated, = struct.unpack_from("<Q", b, 0)
+        want = R.apply_visual_ba_results(m, poses, points)
+        assert updated == want
+        kf_pose = np.frombuffer(b, np.float64, 7 * len(snap.kf_ids), 8).reshape(-1, 7)
+        mp_pos = np.frombuffer(b, np.float64, 3 * len(snap.mp_ids), 8 + 56 * len(snap.kf_ids)).reshape(-1, 3)
+        assert all(np.array_equal(kf_pose[i], m.keyframes[int(k)].pose) for i, k in enumerate(snap.kf_ids))
+        assert all(np.array_equal(mp_pos[i], m.map_points[int(j)].position) for i, j in enumerate(snap.mp_ids))
+
+
+def _ba_map(pkg, seed=5, K=7, M=150):
+    """A consistent map out of a synthetic BA window: keyframe ids 10.., map point ids 500..; keyframe K-1... the window's
+    fixed anchor becomes the CURRENT keyframe (local_kf_ids[0] = anchor, :821), the optimised ones its neighbours."""
+    w = pkg.synth.ba_window(seed, K, M, pkg.BA_OBS)
+    inv = pkg.se3_inverse
+    m = R.Map()
+    ids = [10 + i for i in range(K)]                        # ids[0] = the fixed anchor of the window
+    cw = [w["fixed_cw"][0]] + list(w["poses_cw"])
+    for i, kid in enumerate(ids):
+        m.keyframes[kid] = R.KeyFrame(pose=inv(cw[i]), keypoints=[], map_point_ids=[])
+    for j in range(M):
+        m.map_points[500 + j] = R.MapPoint(position=w["points"][j].copy())
+    for o in w["obs"]:
+        kid = ids[0] if o["kf_idx"] < 0 else ids[1 + o["kf_idx"]]
+        kf = m.keyframes[kid]
+        kf.keypoints.append((float(np.float32(o["u"])), float(np.float32(o["v"]))))
+        kf.map_point_ids.append(500 + int(o["mp_idx"]))
+        m.map_points[500 + int(o["mp_idx"])].observations[kid] = len(kf.keypoints) - 1
+    for kid in ids[1:]:
+        m.keyframes[ids[0]].covisibility_weights[kid] = 1
+    return m, ids, w
+
+
+@pytest.mark.gpu
+def test_three_phase_local_bundle_adjustment(pkg, gpu_handle):
+    """local_mapper.rs:378-408 end to end: the product's driver over flat arrays (collect -> GPU solve -> apply) against the
+    restatement's driver over the dict Map fed by the same GPU solve; `iterations > 0` gates the apply (:396)."""
+    m, ids, w = _ba_map(pkg)
+    snap = snapshot_of(pkg, m)
+    cam = pkg.CameraModel(**w["camera"])
+    before = snap.kf_pose_wc.copy()
+    updated, res = pkg.local_bundle_adjustment(snap, ids[0], cam, handle=gpu_handle)
+    assert res.iterations > 0 and updated == len(ids) - 1 + len(m.map_points)
+    assert np.array_equal(snap.kf_pose_wc[0], before[0]) and not np.array_equal(snap.kf_pose_wc[1:], before[1:])   # the anchor stays
+
+    def solve(problem):                                     # the restatement's phase 2 = the same GPU solve on ITS problem
+        p = pkg.VisualBAProblemData(problem["local_kf_poses"], problem["local_mp_positions"], problem["fixed_kf_poses"], problem["anchor_kf_id"],
+                                    [pkg.VisualObservation(o["kf_id"], o["mp_id"], o["uv"], o["is_kf_optimized"]) for o in problem["observations"]],
+                                    problem["optimized_kf_ids"], problem["mp_ids"])
+        r = pkg.solve_visual_ba(p, cam, pkg.LocalBAConfigLM(), lambda: False, handle=gpu_handle)
+        return None if r is None else dict(optimized_poses=r.optimized_poses, optimized_points=r.optimized_points, iterations=r.iterations)
+    assert R.local_bundle_adjustment(m, ids[0], solve) == updated
+    for i, k in enumerate(snap.kf_ids):
+        assert np.array_equal(snap.kf_pose_wc[i], m.keyframes[int(k)].pose)
+    for i, j in enumerate(snap.mp_ids):
+        assert np.array_equal(snap.mp_pos[i], m.map_points[int(j)].position)
+    # abort before the first iteration: the solve returns iterations == 0 and NOTHING is written (:396)
+    m2, ids2, _ = _ba_map(pkg, seed=6)
+    snap2 = snapshot_of(pkg, m2)
+    b4 = (snap2.kf_pose_wc.copy(), snap2.mp_pos.copy())
+    updated, res = pkg.local_bundle_adjustment(snap2, ids2[0], cam, should_stop=lambda: True, handle=gpu_handle)
+    assert res.iterations == 0 and updated == 0 and np.array_equal(snap2.kf_pose_wc, b4[0]) and np.array_equal(snap2.mp_pos, b4[1])
+    # a keyframe nobody knows -> the reference returns at phase 1
+    assert pkg.local_bundle_adjustment(snap2, 31337, cam, handle=gpu_handle) == (None, None)
+
+
+@pytest.mark.gpu
+def test_cpp_three_phase_driver(pkg, gpu_handle, tmp_path):
+    """the same driver compiled from include/orbx_map.hpp: lock callbacks taken once each, apply gated by iterations > 0"""
+    tmp = str(tmp_path)
+    exe = _build(tmp)
+    m, ids, w = _ba_map(pkg, seed=8)
+    snap = snapshot_of(pkg, m)
+    open(os.path.join(tmp, "snap.bin"), "wb").write(snap.to_bytes())
+    nk, nm = len(snap.kf_ids), len(snap.mp_ids)
+
+    def run(stop_after):
+        subprocess.run([exe, "lba", os.path.join(tmp, "snap.bin"), str(ids[0]), str(stop_after), os.path.join(tmp, "lba.bin")], check=True)
+        b = open(os.path.join(tmp, "lba.bin"), "rb").read()
+        hdr = struct.unpack_from("<5q", b, 0)
+        kf = np.frombuffer(b, np.float64, 7 * nk, 56).reshape(-1, 7)
+        mp = np.frombuffer(b, np.float64, 3 * nm, 56 + 56 * nk).reshape(-1, 3)
+        return hdr, kf, mp
+    (updated, iters, rl, wl, polls), kf, mp = run(0)
+    py_updated, res = pkg.local_bundle_adjustment(snap, ids[0], pkg.CameraModel(**pkg.synth.EUROC_CAMERA), handle=gpu_handle)
+    assert updated == py_updated == nk - 1 + nm and iters == res.iterations > 0 and rl == 1 and wl == 1
+    assert np.array_equal(kf, snap.kf_pose_wc) and np.array_equal(mp, snap.mp_pos)      # C++ and Python drivers: same bytes
+    (updated, iters, rl, wl, polls), kf, mp = run(1)                                      # should_stop() true at once
+    assert updated == 0 and iters == 0 and rl == 1 and wl == 0 and polls >= 1
