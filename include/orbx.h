@@ -278,6 +278,39 @@ int orbx_fuse_search_device(orbx_handle* h, const orbx_camera* cam, const double
                             const uint8_t* d_descs, int T, double radius_scale, unsigned desc_threshold, int* d_out_idx,
                             uint32_t* d_out_dist);
 
+/* ---- keyframe hand-off with device-resident features (src/system/messages.rs:19-51) --------------------------------
+ * orbx_keyframe = the payload of NewKeyFrameMsg — keyframe id, timestamp, T_wc pose, keypoints, descriptors, stereo points
+ * (`points_cam`, None where has_point is 0) and the map-point associations (`matched_map_points`) — with the four feature
+ * arrays held in device memory.  It is made straight from the device outputs of the extractor (device-to-device copies on the
+ * handle's stream, asynchronous: slot `b` of orbx_process_stereo_batch_device is d_kp + b*2*cap_kp etc., n = nkp[b][0]), so the
+ * features a frame was just given never leave the GPU between `process` and the searches local mapping runs on them.
+ * The ids of the associations are map bookkeeping and stay on the host; the device holds the is_some() flags the searches
+ * read.  d_points_cam / d_has_point may both be NULL (monocular: every point None).  A keyframe belongs to the handle
+ * that made it and must be destroyed before it.  */
+typedef struct orbx_keyframe orbx_keyframe;
+int orbx_keyframe_create(orbx_handle* h, const orbx_keypoint* d_kp, const uint8_t* d_desc, int n, const double* d_points_cam,
+                         const uint8_t* d_has_point, uint64_t keyframe_id, uint64_t timestamp_ns, const double* pose_wc,
+                         orbx_keyframe** out);
+void orbx_keyframe_destroy(orbx_keyframe* kf);
+int orbx_keyframe_info(const orbx_keyframe* kf, int* n_features, uint64_t* keyframe_id, uint64_t* timestamp_ns, double* pose_wc);
+int orbx_keyframe_set_pose(orbx_keyframe* kf, const double* pose_wc);                 /* after BA / pose refinement       */
+int orbx_keyframe_set_map_points(orbx_keyframe* kf, const int64_t* mp_ids);           /* [n], -1 = None                   */
+int orbx_keyframe_get_map_points(const orbx_keyframe* kf, int64_t* mp_ids);
+/* host copies for consumers that still want Vector<KeyPoint> / Mat (any pointer may be NULL) */
+int orbx_keyframe_download(const orbx_keyframe* kf, orbx_keypoint* kp, uint8_t* desc, double* points_cam, uint8_t* has_point);
+const orbx_keypoint* orbx_keyframe_device_keypoints(const orbx_keyframe* kf);
+const uint8_t* orbx_keyframe_device_descriptors(const orbx_keyframe* kf);
+/* The searches on device-resident keyframes; semantics, tie rules and results exactly those of orbx_guided_match,
+ * orbx_search_for_triangulation (kf1 = the new keyframe, its stereo flags = has_point; poses = the keyframes' own) and
+ * orbx_fuse_search (radius_scale as there) — only the small inputs (queries, map points) and the results cross PCIe. */
+int orbx_keyframe_guided_match(orbx_handle* h, const orbx_keyframe* kf, double img_w, double img_h, const double* q_uv,
+                               const uint8_t* q_desc, int nq, double radius, int mode, int* out_idx, uint32_t* out_dist);
+int orbx_keyframe_search_for_triangulation(orbx_handle* h, const orbx_camera* cam, const orbx_keyframe* kf1,
+                                           const orbx_keyframe* kf2, unsigned max_dist, int* out_pairs, int* n_out);
+int orbx_keyframe_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* positions, const uint8_t* mp_desc, int P,
+                              const orbx_keyframe* const* kfs, int T, double radius_scale, unsigned desc_threshold,
+                              int* out_idx, uint32_t* out_dist);
+
 /* ---- input side (src/io/euroc.rs) ------------------------------------------------------------------------------
  * Host code: the EuRoC `mav0` reader of EurocDataset::new / len / frame_timestamp / stereo_pair (:64-132,
  * load_image_list :189-211, the camera part of load_stereo_calibration :325-360) and the PNG decode that

@@ -50,6 +50,9 @@ ABI_SYMBOLS = [
     "orbx_extract_batch_device", "orbx_check_status", "orbx_stereo_match",
     "orbx_stereo_match_batch_device", "orbx_hamming_match_crosscheck",
     "orbx_hamming_match_crosscheck_device", "orbx_hamming_batch", "orbx_hamming_batch_device",
+    "orbx_keyframe_create", "orbx_keyframe_destroy", "orbx_keyframe_info", "orbx_keyframe_set_pose", "orbx_keyframe_set_map_points",
+    "orbx_keyframe_get_map_points", "orbx_keyframe_download", "orbx_keyframe_device_keypoints", "orbx_keyframe_device_descriptors",
+    "orbx_keyframe_guided_match", "orbx_keyframe_search_for_triangulation", "orbx_keyframe_fuse_search",
     "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
     "orbx_fuse_search", "orbx_fuse_search_device",
@@ -813,6 +816,106 @@ def solve_visual_ba(problem: VisualBAProblemData, camera: CameraModel, config: L
         {k: r["poses_wc"][i] for i, k in enumerate(problem.optimized_kf_ids)},
         {m: r["points"][i] for i, m in enumerate(problem.mp_ids)},
         r["iterations"], r["initial_error"], r["final_error"])
+
+
+class KeyFrame:
+    """orbx_keyframe: NewKeyFrameMsg (system/messages.rs:19-51) with keypoints, descriptors, stereo points and map-point flags
+    resident on the GPU.  Built from the device outputs of the extractor; feeds guided_match / search_for_triangulation /
+    fuse_search without moving the features over PCIe."""
+
+    def __init__(self, handle: "Handle", d_kp, d_desc, n, d_points_cam=None, d_has_point=None, keyframe_id=0, timestamp_ns=0,
+                 pose_wc=(1.0, 0, 0, 0, 0, 0, 0)):
+        self._handle = handle
+        self._L = handle._L
+        L = self._L
+        L.orbx_keyframe_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                           C.c_void_p, C.c_void_p]
+        L.orbx_keyframe_destroy.argtypes = [C.c_void_p]; L.orbx_keyframe_destroy.restype = None
+        for name in ("orbx_keyframe_info", "orbx_keyframe_download"):
+            getattr(L, name).argtypes = [C.c_void_p] * 5
+        for name in ("orbx_keyframe_set_pose", "orbx_keyframe_set_map_points", "orbx_keyframe_get_map_points"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        L.orbx_keyframe_guided_match.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                                 C.c_int, C.c_void_p, C.c_void_p]
+        L.orbx_keyframe_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+        L.orbx_keyframe_fuse_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_uint,
+                                                C.c_void_p, C.c_void_p]
+        self._p = C.c_void_p()
+        pose = np.ascontiguousarray(pose_wc, np.float64).reshape(7)
+        handle._after_torch()
+        handle._check(L.orbx_keyframe_create(handle._h, _vp(d_kp), _vp(d_desc), C.c_int(int(n)), _vp(d_points_cam), _vp(d_has_point),
+                                             C.c_uint64(int(keyframe_id)), C.c_uint64(int(timestamp_ns)), _vp(pose), C.byref(self._p)))
+        self.n = int(n)
+
+    @classmethod
+    def from_batch_outputs(cls, handle, out, pair, keyframe_id=0, timestamp_ns=0, pose_wc=(1.0, 0, 0, 0, 0, 0, 0)):
+        """The LEFT feature set of stereo pair `pair` of alloc_batch_outputs() / process_stereo_batch_device (synchronise first:
+        the keypoint count is read on the host; the features themselves never leave the device)."""
+        n = int(out["nkp"][pair, 0].item())
+        return cls(handle, out["kp"][pair, 0], out["desc"][pair, 0], n, out["points"][pair], out["has_point"][pair], keyframe_id, timestamp_ns, pose_wc)
+
+    def set_pose(self, pose_wc):
+        self._handle._check(self._L.orbx_keyframe_set_pose(self._p, _vp(np.ascontiguousarray(pose_wc, np.float64).reshape(7))))
+
+    def set_map_points(self, mp_ids):
+        """matched_map_points: iterable of ids or None."""
+        a = np.array([-1 if m is None else int(m) for m in mp_ids], np.int64)
+        assert len(a) == self.n
+        self._handle._check(self._L.orbx_keyframe_set_map_points(self._p, _vp(a)))
+
+    def map_points(self):
+        a = np.zeros(max(self.n, 1), np.int64)
+        self._handle._check(self._L.orbx_keyframe_get_map_points(self._p, _vp(a)))
+        return [None if v < 0 else int(v) for v in a[:self.n]]
+
+    def info(self):
+        n = C.c_int(); kid = C.c_uint64(); ts = C.c_uint64(); pose = np.zeros(7)
+        self._handle._check(self._L.orbx_keyframe_info(self._p, C.byref(n), C.byref(kid), C.byref(ts), _vp(pose)))
+        return dict(n=n.value, keyframe_id=kid.value, timestamp_ns=ts.value, pose_wc=pose)
+
+    def download(self):
+        kp = np.zeros(max(self.n, 1), KEYPOINT); desc = np.zeros((max(self.n, 1), 32), np.uint8)
+        pts = np.zeros((max(self.n, 1), 3)); has = np.zeros(max(self.n, 1), np.uint8)
+        self._handle._check(self._L.orbx_keyframe_download(self._p, _vp(kp), _vp(desc), _vp(pts), _vp(has)))
+        return kp[:self.n], desc[:self.n], pts[:self.n], has[:self.n]
+
+    def guided_match(self, img_w, img_h, q_uv, q_desc, radius, mode):
+        q_uv = np.ascontiguousarray(q_uv, np.float64).reshape(-1, 2); q_desc = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        nq = len(q_uv)
+        idx = np.full(max(nq, 1), -1, np.int32); dist = np.zeros(max(nq, 1), np.uint32)
+        self._handle._check(self._L.orbx_keyframe_guided_match(self._handle._h, self._p, float(img_w), float(img_h), _vp(q_uv), _vp(q_desc), nq,
+                                                               float(radius), int(mode), _vp(idx), _vp(dist)))
+        return idx[:nq], dist[:nq]
+
+    def search_for_triangulation(self, camera, other: "KeyFrame", max_dist=50):
+        pairs = np.zeros((max(self.n, 1), 2), np.int32); n = C.c_int()
+        cam = camera._c()
+        self._handle._check(self._L.orbx_keyframe_search_for_triangulation(self._handle._h, C.byref(cam), self._p, other._p, int(max_dist),
+                                                                           _vp(pairs), C.byref(n)))
+        return pairs[:n.value].copy()
+
+    @staticmethod
+    def fuse_search(handle, camera, positions, mp_desc, keyframes, radius_scale, desc_threshold=50):
+        positions = np.ascontiguousarray(positions, np.float64).reshape(-1, 3); mp_desc = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        P, T = len(positions), len(keyframes)
+        arr = (C.c_void_p * max(T, 1))(*[k._p for k in keyframes])
+        idx = np.full((max(P, 1), max(T, 1)), -1, np.int32); dist = np.zeros((max(P, 1), max(T, 1)), np.uint32)
+        cam = camera._c()
+        handle._check(handle._L.orbx_keyframe_fuse_search(handle._h, C.byref(cam), _vp(positions), _vp(mp_desc), P, arr, T, float(radius_scale),
+                                                          int(desc_threshold), _vp(idx), _vp(dist)))
+        return idx[:P, :T], dist[:P, :T]
+
+    def close(self):
+        if self._p:
+            self._L.orbx_keyframe_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            if self._handle._h:
+                self.close()
+        except Exception:
+            pass
 
 
 class MapSnapshot:
