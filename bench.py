@@ -556,10 +556,11 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         K, M = 19, 2000
         P_ = (6 * K + 15) // 16 * 16
         nt = P_ // 16
-        ksplit = max(1, min(32, (3 * M + 255) // 256))
-        rows = ((3 * M + 4 * ksplit - 1) // (4 * ksplit)) * (4 * ksplit)
-        flop = nt * (nt + 1) // 2 * (rows // 4) * 2048.0 * nb
-        sch = kt.get("ba_kf_schur_kernel", (0.0, 1))
+        ksplit = max(1, min(128, (M + 23) // 24))                     # as ba_solve_batch plans it
+        pps = max(8, ((M + ksplit - 1) // ksplit + 7) // 8 * 8)
+        rows = 3 * pps * ksplit
+        flop = nt * (nt + 1) // 2 * (rows // 4) * 2048.0 * nb        # one v_mfma_f64_16x16x4_f64 = 2*16*16*4 flop
+        sch = kt.get("ba_schur_kernel", (0.0, 1))
         sch_ms = sch[0] / max(sch[1], 1)
         out["batched"] = dict(windows=nb, lm_iters_per_s=round(itb / dtb, 1), ms_per_call=round(dtb / nrep * 1e3, 3),
                               vs_single_window=round(itb / dtb / out["lm_iters_per_s"], 2),

@@ -10,10 +10,12 @@
 //
 //   ba_build_kernel      one 32-lane group per map point: residual + Jacobian blocks of its
 //                        observations, V_j = sum B^T B, g_l, damped inverse V*_j^-1, W = A^T B and
-//                        Y = W V*^-1 scattered into the k-major dense operands WT / YT [3M][P]
+//                        Y g_l; W stays per observation (oW [N][18]) — the dense operands of the Schur product exist only as
+//                        LDS tiles
 //   ba_kf_schur_kernel   keyframe partials (U_k = sum A^T A, g_p, b_red, fixed summation order) and, in the
-//                        same launch, S_red = YT^T WT ((6K x 3M) x (3M x 6K)) on v_mfma_f64_16x16x4_f64,
-//                        split-K, upper tiles only — the one dense contraction of the path
+//                        same launch, S_red = Y^T W ((6K x 3M) x (3M x 6K)) on v_mfma_f64_16x16x4_f64: a block owns a
+//                        (128-column block pair, k-split), fills 24-row operand tiles in LDS from oW and V*^-1 and
+//                        accumulates its upper 16x16 tiles in registers — the one dense contraction of the path
 //   ba_gather_kernel     fixed-order reduction of the split-K and keyframe-split partials
 //   ba_solve_lds_kernel  one workgroup: S = U* - S_red in LDS, blocked right-looking Cholesky (MFMA trailing
 //                        updates, forward substitution inside the panels), delta_p
@@ -44,9 +46,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 struct BaDims {
   int K, F, M, N;
   int P;        // 6K padded to a multiple of 16
-  int rows;     // 3M padded to a multiple of 4*KSPLIT
+  int rows;     // 3 * pps * ksplit: the k dimension of the Schur product, padded
   int ksplit;
   int ntile;    // P/16
+  int pps;      // map points per k-split, a multiple of 8 (= 24 rows = one LDS operand tile)
+  int ncb;      // 128-column blocks of the reduced system: ceil(ntile / 8)
 };
 
 struct BaCam {
@@ -86,7 +90,10 @@ struct BaWin {
   const int *kf_start, *kf_obs;
   double *oA, *oR, *oYg, *Vinv, *gl;
   double *pt_chi2, *pt_glsq, *pt_dsq, *pt_psq;
-  double *WT, *YT, *kfpart, *part, *rb;
+  double *oW;            // [N][18] W = A^T B of every observation of an optimised keyframe, w[c][a] (point coordinate major)
+  const int *slot_first; // [M][K] first observation (point-major index) of point j in optimised keyframe k, or -1
+  const int *obs_next;   // [N] next observation of the same (point, keyframe), or -1 (a point seen twice by one keyframe)
+  double *kfpart, *part, *rb;
   double *dp;            // step of the reduced system [n pad 16]
   double *Sg, *bvec, *ginv;   // global-memory factorisation (n > ~135 and the inertial system)
   double *res;           // [16] result block, see ba_decide_kernel
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
   double* __restrict__ oA = win.oA /*N*12*/; double* __restrict__ oR = win.oR /*N*2*/; double* __restrict__ oYg = win.oYg /*N*6*/;
   double* __restrict__ Vinv = win.Vinv /*M*9*/; double* __restrict__ gl = win.gl /*M*3*/;
   double* __restrict__ pt_chi2 = win.pt_chi2 /*M*/; double* __restrict__ pt_glsq = win.pt_glsq /*M*/;
-  double* __restrict__ WT = win.WT; double* __restrict__ YT = win.YT;
+  double* __restrict__ oW = win.oW;
   const double lambda = S->lambda;
   const double* params = ba_cur(S, P0, P1);
   if (blockIdx.x == 0 && threadIdx.x == 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
@@ -334,9 +341,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
       const double y0 = w0 * I[0] + w1 * I[3] + w2 * I[6];
       const double y1 = w0 * I[1] + w1 * I[4] + w2 * I[7];
       const double y2 = w0 * I[2] + w1 * I[5] + w2 * I[8];
-      const size_t col = 6 * (size_t)k + a;
-      WT[(3 * (size_t)j + 0) * d.P + col] = w0; WT[(3 * (size_t)j + 1) * d.P + col] = w1; WT[(3 * (size_t)j + 2) * d.P + col] = w2;
-      YT[(3 * (size_t)j + 0) * d.P + col] = y0; YT[(3 * (size_t)j + 1) * d.P + col] = y1; YT[(3 * (size_t)j + 2) * d.P + col] = y2;
+      oW[18 * (size_t)i + a] = w0; oW[18 * (size_t)i + 6 + a] = w1; oW[18 * (size_t)i + 12 + a] = w2;
       yg[a] = y0 * g[0] + y1 * g[1] + y2 * g[2];
     }
 #pragma unroll
@@ -384,53 +389,244 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaDims& d, const int* _
   if (tid < 33) kfpart[((size_t)k * BA_KFSPLIT + sp) * 33 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
-// S_red partials: one wave per (upper tile, k-split).  A[i][k] = YT[k][i0+i], B[k][j] = WT[k][j0+j].
-// v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4], B[l>>4][l&15]; D[(l>>4)+4r][l&15], r = 0..3.
-__device__ __forceinline__ void ba_schur_body(int bx, const BaDims& d, const double* __restrict__ YT, const double* __restrict__ WT,
-                                              double* __restrict__ part) {
-  const int lane = threadIdx.x & 63;
-  const int unit = bx * 4 + (threadIdx.x >> 6);
-  const int n_upper = d.ntile * (d.ntile + 1) / 2;
-  if (unit >= n_upper * d.ksplit) return;
-  const int tile = unit / d.ksplit, ks = unit - tile * d.ksplit;
-  int ti = 0, rem = tile;
-  while (rem >= d.ntile - ti) { rem -= d.ntile - ti; ++ti; }
-  const int tj = ti + rem;
-  const int krows = d.rows / d.ksplit;
-  const int k0 = ks * krows;
-  const double* a_ptr = YT + (size_t)(k0 + (lane >> 4)) * d.P + ti * 16 + (lane & 15);
-  const double* b_ptr = WT + (size_t)(k0 + (lane >> 4)) * d.P + tj * 16 + (lane & 15);
-  double4_t acc = {0.0, 0.0, 0.0, 0.0};
-  const size_t step = 4 * (size_t)d.P;
-  int k = 0;
-  // 8 k-steps of operands in flight before the dependent MFMA chain (the plain loop did not unroll and every
-  // MFMA waited for its own pair of L2 loads)
-  for (; k + 32 <= krows; k += 32) {
-    double a[8], b[8];
+// S_red partials.  A block owns (column-block pair (bi <= bj) of 128 columns each, k-split ks): the rows (= 3 per map point) of
+// its k-split pass through LDS 24 at a time as two operand tiles, Y (columns of block bi) and W (columns of block bj), filled
+// straight from the per-observation W blocks — slot (point j, keyframe k) = the sum of the W of its observations (almost
+// always one; zero if k does not see j), Y = W V*^-1 with the build kernel's own expression — and every wave accumulates its
+// upper 16x16 tiles of the 8 x 8 tile block in registers over all rows: wave q owns tile rows q and 7 - q (9 tiles each in
+// a diagonal block, 16 in an off-diagonal one).  v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4], B[l>>4][l&15];
+// D[(l>>4)+4r][l&15], r = 0..3.  The dense [3M][6K] operands never exist in memory: per iteration the Schur product reads
+// 144 B per observation instead of 2 x 8 B x 3M x 6K (393 MB at 32 windows of 20 keyframes / 2000 points).
+constexpr int SCH_R = 24;                 // rows per LDS tile (8 points, 6 MFMA k-steps)
+constexpr int SCH_PITCH = 144;            // doubles per LDS row: 128 + 16 — the two 16-lane row groups of a ds_read_b64 half-wave land 32 banks apart
+__device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, double* __restrict__ sY, double* __restrict__ sW) {
+  const BaDims& d = win.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int npair = d.ncb * (d.ncb + 1) / 2;
+  if (bx >= npair * d.ksplit) return;
+  const int pr = bx / d.ksplit, ks = bx - pr * d.ksplit;
+  int bi = 0, rem = pr;
+  while (rem >= d.ncb - bi) { rem -= d.ncb - bi; ++bi; }
+  const int bj = bi + rem;
+  const bool diag = bi == bj;
+  const int j_begin = ks * d.pps;                                   // first map point of this k-split
+  const double* __restrict__ oW = win.oW; const double* __restrict__ Vinv = win.Vinv;
+  const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
+  double4_t acc[2][8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { a[u] = a_ptr[u * step]; b[u] = b_ptr[u * step]; }
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
-    a_ptr += 8 * step; b_ptr += 8 * step;
+    for (int c = 0; c < 8; ++c) acc[a][c] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int trow[2] = {wave, 7 - wave};                             // this wave's two tile rows inside the block
+  const int kf_lo_i = (128 * bi) / 6, kf_lo_j = (128 * bj) / 6;   // first keyframe whose 6 columns reach into the block; at most 23 do
+  constexpr int NPT = SCH_R / 3, NSLOT = NPT * 23;
+  // columns past 6K and slots of keyframes that do not exist are never written below: zero both tiles once
+  for (int u = tid; u < 2 * SCH_R * SCH_PITCH; u += 256) sY[u] = 0.0;   // (sW follows sY)
+  const int nside = diag ? 1 : 2;
+  // slot u of this thread (at most two: 8 points x 23 keyframes x sides over 256 threads) -> first observation of (point,
+  // keyframe), fetched one tile ahead so that the fill is ONE dependent round trip (oW) instead of two
+  auto slot_index = [&](int u, int j0) -> int {
+    if (u >= nside * NSLOT) return -2;
+    const int side = u / NSLOT, v = u - side * NSLOT;
+    const int pj = v / 23, kk = v - pj * 23;
+    const int k = (side ? kf_lo_j : kf_lo_i) + kk, j = j0 + pj;
+    const int cb = (side ? bj : bi) * 128;
+    if (k >= d.K || 6 * k >= cb + 128 || 6 * k + 6 <= cb) return -2;   // no such keyframe, or none of its columns in the block
+    return j < d.M ? slot_first[(size_t)j * d.K + k] : -1;
+  };
+  int nxt[2] = {slot_index(tid, j_begin), slot_index(tid + 256, j_begin)};
+  for (int j0 = j_begin; j0 < j_begin + d.pps; j0 += NPT) {
+    // ---- fill: one thread per (side, point, keyframe): side 0 = the Y tile (columns of block bi; in a diagonal block also the W
+    // tile, same columns), side 1 = the W tile of block bj
+    __syncthreads();                                                // the previous tile has been consumed (and the zero fill is done)
+    const int cur[2] = {nxt[0], nxt[1]};
+    if (j0 + NPT < j_begin + d.pps) { nxt[0] = slot_index(tid, j0 + NPT); nxt[1] = slot_index(tid + 256, j0 + NPT); }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (cur[q] == -2) continue;
+      const int u = tid + 256 * q;
+      const int side = u / NSLOT, v = u - side * NSLOT;
+      const int pj = v / 23, kk = v - pj * 23;
+      const int k = (side ? kf_lo_j : kf_lo_i) + kk, j = j0 + pj;
+      const int cb = (side ? bj : bi) * 128;
+      double w[18];
+#pragma unroll
+      for (int t = 0; t < 18; ++t) w[t] = 0.0;
+      for (int i = cur[q]; i >= 0; i = obs_next[i]) {               // usually once
+#pragma unroll
+        for (int t = 0; t < 18; ++t) w[t] += oW[18 * (size_t)i + t];
+      }
+      if (side == 0) {
+        double I[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) I[t] = j < d.M ? Vinv[9 * (size_t)j + t] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const int col = 6 * k + a - cb;
+          if (col < 0 || col >= 128) continue;
+          const double w0 = w[a], w1 = w[6 + a], w2 = w[12 + a];
+          sY[(3 * pj + 0) * SCH_PITCH + col] = w0 * I[0] + w1 * I[3] + w2 * I[6];       // Y = W V*^-1, as the build kernel forms it for Y g_l
+          sY[(3 * pj + 1) * SCH_PITCH + col] = w0 * I[1] + w1 * I[4] + w2 * I[7];
+          sY[(3 * pj + 2) * SCH_PITCH + col] = w0 * I[2] + w1 * I[5] + w2 * I[8];
+          if (diag) { sW[(3 * pj + 0) * SCH_PITCH + col] = w0; sW[(3 * pj + 1) * SCH_PITCH + col] = w1; sW[(3 * pj + 2) * SCH_PITCH + col] = w2; }
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const int col = 6 * k + a - cb;
+          if (col < 0 || col >= 128) continue;
+          sW[(3 * pj + 0) * SCH_PITCH + col] = w[a]; sW[(3 * pj + 1) * SCH_PITCH + col] = w[6 + a]; sW[(3 * pj + 2) * SCH_PITCH + col] = w[12 + a];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- multiply: 6 k-steps of 4 rows
+#pragma unroll
+    for (int kq = 0; kq < SCH_R / 4; ++kq) {
+      const int row = 4 * kq + (lane >> 4);
+      const double a0 = sY[row * SCH_PITCH + trow[0] * 16 + (lane & 15)];
+      const double a1 = sY[row * SCH_PITCH + trow[1] * 16 + (lane & 15)];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
+        if (!diag || c >= trow[0]) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][c], 0, 0, 0);
+        if (!diag || c >= trow[1]) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][c], 0, 0, 0);
+      }
+    }
   }
-  for (; k < krows; k += 4) {
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(*a_ptr, *b_ptr, acc, 0, 0, 0);
-    a_ptr += step; b_ptr += step;
-  }
-  double* o = part + ((size_t)tile * d.ksplit + ks) * 256;
+  // ---- partials out: the gather kernel's layout, part[(upper tile, ks)][16][16]
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+  for (int a = 0; a < 2; ++a) {
+    const int ti = bi * 8 + trow[a];
+    if (ti >= d.ntile) continue;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int tj = bj * 8 + c;
+      if (tj >= d.ntile || tj < ti) continue;
+      const int tile = ti * d.ntile - ti * (ti - 1) / 2 + (tj - ti);
+      double* o = win.part + ((size_t)tile * d.ksplit + ks) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[a][c][r];
+    }
+  }
 }
 
-// Both consume the build kernel's output and feed the gather kernel, neither fills the chip (K*8 blocks, and one wave
-// per tile x k-split): one launch, the first nkf blocks take the keyframe partials, the rest the Schur tiles.
-__global__ __launch_bounds__(256) void ba_kf_schur_kernel(const BaWin* __restrict__ wins) {
+// The same product for windows whose reduced system fits ONE 128-column block (K <= 21 optimised keyframes: every local-BA
+// window of the reference, max_covisible_keyframes = 20): only the diagonal block pair exists, so
+//   - a wave's 9 upper tiles share 9 accumulators: slot c holds tile (q, c) for c >= q and tile (7-q, 7-c) for c < q, the ninth
+//     the diagonal tile (7-q, 7-q) — 72 registers instead of the 128 of the general body;
+//   - every thread fills at most one (point, keyframe) slot, and the registers saved hold the NEXT tile's W block and V*^-1,
+//     fetched before the MFMA phase of the current tile: the two dependent memory round trips of a fill (slot -> W) hide
+//     behind the matrix instructions instead of standing between them.
+// Same operands, same k order, same v_mfma_f64_16x16x4_f64 sequence per tile as ba_schur_body: bit-identical partials.
+__device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, double* __restrict__ sY, double* __restrict__ sW) {
+  const BaDims& d = win.d;
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;       // wave q owns tile rows q and 7 - q
+  if (bx >= d.ksplit) return;
+  const int ks = bx, j_begin = ks * d.pps;
+  const double* __restrict__ oW = win.oW; const double* __restrict__ Vinv = win.Vinv;
+  const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
+  constexpr int NPT = SCH_R / 3;
+  const int pj = tid / 23, k = tid - pj * 23;                        // this thread's slot: point j0 + pj, keyframe k (columns 6k .. 6k+5)
+  const bool slot = pj < NPT && k < d.K && 6 * k < 128;
+  double4_t acc[8], accx = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+  for (int u = tid; u < 2 * SCH_R * SCH_PITCH; u += 256) sY[u] = 0.0;   // columns past 6K stay zero (sW follows sY)
+  double w[18], I[9];
+  int nxt_chain = -1;
+  auto slot_of = [&](int j0) -> int {                               // first observation of (point j0 + pj, keyframe k), or -1
+    const int j = j0 + pj;
+    return (slot && j < d.M && j0 < j_begin + d.pps) ? slot_first[(size_t)j * d.K + k] : -1;
+  };
+  auto fetch = [&](int j0, int i) {                                 // W block and V*^-1 of that slot -> registers
+    const int j = j0 + pj;
+#pragma unroll
+    for (int t = 0; t < 18; ++t) w[t] = i >= 0 ? oW[18 * (size_t)i + t] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) I[t] = (slot && j < d.M) ? Vinv[9 * (size_t)j + t] : 0.0;
+    nxt_chain = i >= 0 ? obs_next[i] : -1;
+  };
+  // the slot index runs TWO tiles ahead, the W block one: neither of the two dependent loads is waited for where it is issued
+  fetch(j_begin, slot_of(j_begin));
+  int i_next = slot_of(j_begin + NPT);
+  for (int j0 = j_begin; j0 < j_begin + d.pps; j0 += NPT) {
+    __syncthreads();                                                // the previous tile has been consumed (first pass: zero fill done)
+    if (slot) {
+      for (int i = nxt_chain; i >= 0; i = obs_next[i]) {            // a point seen twice by this keyframe: rare, fetched on the spot
+#pragma unroll
+        for (int t = 0; t < 18; ++t) w[t] += oW[18 * (size_t)i + t];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int col = 6 * k + a;
+        if (col >= 128) continue;
+        const double w0 = w[a], w1 = w[6 + a], w2 = w[12 + a];
+        sY[(3 * pj + 0) * SCH_PITCH + col] = w0 * I[0] + w1 * I[3] + w2 * I[6];
+        sY[(3 * pj + 1) * SCH_PITCH + col] = w0 * I[1] + w1 * I[4] + w2 * I[7];
+        sY[(3 * pj + 2) * SCH_PITCH + col] = w0 * I[2] + w1 * I[5] + w2 * I[8];
+        sW[(3 * pj + 0) * SCH_PITCH + col] = w0; sW[(3 * pj + 1) * SCH_PITCH + col] = w1; sW[(3 * pj + 2) * SCH_PITCH + col] = w2;
+      }
+    }
+    if (j0 + NPT < j_begin + d.pps) { fetch(j0 + NPT, i_next); i_next = slot_of(j0 + 2 * NPT); }   // in flight during the MFMA phase below
+    __syncthreads();
+#pragma unroll
+    for (int kq = 0; kq < SCH_R / 4; ++kq) {
+      const int row = 4 * kq + (lane >> 4);
+      const double a0 = sY[row * SCH_PITCH + q * 16 + (lane & 15)];
+      const double a1 = sY[row * SCH_PITCH + (7 - q) * 16 + (lane & 15)];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
+        if (c >= q) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[c], 0, 0, 0);              // tile (q, c)
+        if (c > 7 - q) acc[7 - c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[7 - c], 0, 0, 0);  // tile (7-q, c) in slot 7-c < q
+        if (c == 7 - q) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accx, 0, 0, 0);              // tile (7-q, 7-q)
+      }
+    }
+  }
+  auto store = [&](int ti, int tj, const double4_t& v) {
+    if (ti >= d.ntile || tj >= d.ntile) return;
+    const int tile = ti * d.ntile - ti * (ti - 1) / 2 + (tj - ti);
+    double* o = win.part + ((size_t)tile * d.ksplit + ks) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = v[r];
+  };
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c >= q) store(q, c, acc[c]);
+    else store(7 - q, 7 - c, acc[c]);
+  }
+  store(7 - q, 7 - q, accx);
+}
+
+// One window: keyframe partials and Schur blocks in ONE launch (both consume the build kernel's output and feed the solve;
+// a launch less on a latency-bound chain, and ~200 blocks do not compete for LDS or registers).  Same block bodies: same results.
+template <bool DIAG>
+__global__ __launch_bounds__(256, 2) void ba_kf_schur_kernel(const BaWin* __restrict__ wins) {
+  __shared__ double s_tiles[2 * SCH_R * SCH_PITCH];
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done) return;
-  const BaDims d = win.d;
-  const int nkf = d.K * BA_KFSPLIT;
-  if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, d, win.kf_start, win.kf_obs, win.oA, win.oR, win.oYg, win.kfpart);
-  else ba_schur_body((int)blockIdx.x - nkf, d, win.YT, win.WT, win.part);   // (units beyond this window's tiles return inside)
+  const int nkf = win.d.K * BA_KFSPLIT;
+  if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, win.d, win.kf_start, win.kf_obs, win.oA, win.oR, win.oYg, win.kfpart);
+  else if (DIAG) ba_schur_diag_body((int)blockIdx.x - nkf, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+  else ba_schur_body((int)blockIdx.x - nkf, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+}
+
+// (their own launches in a batch: 51 KB of LDS and ~200 VGPRs per block would otherwise throttle the thousands of small keyframe blocks too)
+__global__ __launch_bounds__(256) void ba_kf_kernel(const BaWin* __restrict__ wins) {
+  const BaWin& win = wins[blockIdx.y];
+  if (win.S->done || (int)blockIdx.x >= win.d.K * BA_KFSPLIT) return;
+  ba_kf_body((int)blockIdx.x, win.d, win.kf_start, win.kf_obs, win.oA, win.oR, win.oYg, win.kfpart);
+}
+
+// DIAG: every window of the launch has a reduced system of at most 128 columns (host-checked)
+template <bool DIAG>
+__global__ __launch_bounds__(256, 2) void ba_schur_kernel(const BaWin* __restrict__ wins) {
+  __shared__ double s_tiles[2 * SCH_R * SCH_PITCH];                 // Y and W operand tiles (51 KB)
+  const BaWin& win = wins[blockIdx.y];
+  if (win.S->done) return;
+  if (DIAG) ba_schur_diag_body((int)blockIdx.x, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+  else ba_schur_body((int)blockIdx.x, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);   // (blocks beyond this window's need return inside)
 }
 
 // reduce-buffer layout (doubles): [Sred n*n | U 36K | gp n | bred n | chi2 | glsq], n = 6K
@@ -444,16 +640,34 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict_
   const int n = 6 * d.K;
   const size_t nn = (size_t)n * n;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-  for (size_t idx = tid; idx < nn; idx += nth) {
-    const int i = (int)(idx / n), j = (int)(idx - (size_t)i * n);
-    const int ti = min(i, j) >> 4, tj = max(i, j) >> 4;     // upper tile holding (min,max)
-    const int r = (i <= j ? i : j) & 15, c = (i <= j ? j : i) & 15;
-    // S_red is symmetric; element (i,j) with i<=j sits at row i%16, col j%16 of tile (ti,tj)
-    const int tile = ti * d.ntile - ti * (ti - 1) / 2 + (tj - ti);
-    const double* p = part + (size_t)tile * d.ksplit * 256 + r * 16 + c;
+  // S_red = sum of the k-split partials, upper triangle computed, mirrored on store.  Four lanes per element: each adds a
+  // quarter of the k-splits in order (eight loads in flight), then ((q0 + q1) + (q2 + q3)) — a fixed tree, the same for every
+  // launch shape.  (One lane per element walked 40-80 dependent-latency loads: a quarter of a batch's iteration.)
+  const int ksq = (d.ksplit + 3) >> 2;
+  const int qd = threadIdx.x & 3;
+  const int k_lo = min(qd * ksq, d.ksplit), k_hi = min(k_lo + ksq, d.ksplit);
+  for (size_t idx = (size_t)(tid >> 2); idx < ((nn + 63) & ~(size_t)63); idx += (size_t)(nth >> 2)) {   // whole waves stay in the loop (shuffles below)
+    const bool in = idx < nn;
+    const int i = in ? (int)(idx / n) : 0, j = in ? (int)(idx - (size_t)i * n) : 0;
     double s = 0.0;
-    for (int ks = 0; ks < d.ksplit; ++ks) s += p[(size_t)ks * 256];
-    rb[idx] = s;
+    if (in && i <= j) {
+      // element (i,j) with i<=j sits at row i%16, col j%16 of the upper tile (i/16, j/16)
+      const int ti = i >> 4, tj = j >> 4;
+      const int tile = ti * d.ntile - ti * (ti - 1) / 2 + (tj - ti);
+      const double* p = part + (size_t)tile * d.ksplit * 256 + (i & 15) * 16 + (j & 15);
+      int ks = k_lo;
+      for (; ks + 8 <= k_hi; ks += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(ks + q) * 256];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+      }
+      for (; ks < k_hi; ++ks) s += p[(size_t)ks * 256];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (in && i <= j && qd == 0) { rb[idx] = s; rb[(size_t)j * n + i] = s; }
   }
   double* q = rb + nn;                 // U [36K] | gp [n] | bred [n] | chi2 | glsq
   for (int i = tid; i < 33 * d.K; i += nth) {
@@ -977,7 +1191,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   const double* __restrict__ dp = dp_override ? dp_override : win.dp;     // (inertial: the 6-d pose steps scattered out of the 15-d solve)
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
   const double* __restrict__ o_uv = win.o_uv; const double* __restrict__ Rt_fix = win.Rt_fix;
-  const double* __restrict__ WT = win.WT; const double* __restrict__ Vinv = win.Vinv; const double* __restrict__ gl = win.gl;
+  const double* __restrict__ oW = win.oW; const double* __restrict__ Vinv = win.Vinv; const double* __restrict__ gl = win.gl;
   double* __restrict__ pt_dsq = win.pt_dsq; double* __restrict__ pt_psq = win.pt_psq; double* __restrict__ pt_chi2 = win.pt_chi2;
   const double* params = ba_cur(S, P0, P1);
   double* trial = ba_trial(S, P0, P1);
@@ -1002,7 +1216,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     for (int a = 0; a < 6; ++a) dk[a] = dp[6 * (size_t)k + a];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double* w = WT + (3 * (size_t)j + c) * d.P + 6 * (size_t)k;
+      const double* w = oW + 18 * (size_t)i + 6 * c;
       double sum = 0.0;
 #pragma unroll
       for (int a = 0; a < 6; ++a) sum += w[a] * dk[a];
@@ -1474,10 +1688,10 @@ struct WinPlan {
   BaDims d{};
   int n = 0, use_lds = 0, skip = 0;
   size_t np = 0, n_upper = 0, rb_len = 0, lds_need = 0;
-  // byte offsets: input blob (host-prepared arrays), scratch arena, WT/YT arena, output blob
-  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_oflag, i_omp;
-  size_t a_p1, a_oA, a_oR, a_oYg, a_vinv, a_gl, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
-  size_t w_wt, w_yt, o_out;
+  // byte offsets: input blob (host-prepared arrays), scratch arena, output blob
+  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_oflag, i_slot, i_next;
+  size_t a_p1, a_oA, a_oR, a_oYg, a_oW, a_vinv, a_gl, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
+  size_t o_out;
   int n_kfobs = 0;
   double n_res = 0.0;
 };
@@ -1530,6 +1744,24 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
     std::vector<int> fill(kf_start, kf_start + K);
     for (int t = 0; t < N; ++t) if (o_kf[t] >= 0) kf_obs[fill[o_kf[t]]++] = t;
   }
+  // (point, keyframe) -> its observation(s): what fills the operand tiles of the Schur product.  A point seen twice by one
+  // keyframe (two features of it carry the same map point) has its W blocks chained; the tile slot holds their sum, as J^T J does.
+  {
+    int* slot_first = (int*)(blob + pl.i_slot);
+    int* obs_next = (int*)(blob + pl.i_next);
+    for (size_t q = 0; q < (size_t)M * (size_t)std::max(K, 1); ++q) slot_first[q] = -1;
+    std::vector<int> last((size_t)std::max(K, 1), -1);
+    for (int j = 0; j < M; ++j) {
+      for (int t = pt_start[j]; t < pt_start[j + 1]; ++t) {
+        obs_next[t] = -1;
+        const int k = o_kf[t];
+        if (k < 0) continue;
+        int& head = slot_first[(size_t)j * K + k];
+        if (head < 0) head = t; else obs_next[last[(size_t)k]] = t;
+        last[(size_t)k] = t;
+      }
+    }
+  }
   for (int k = 0; k < K; ++k) host_se3_to_params(w.poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);   // scaled axis + translation
   for (int j = 0; j < 3 * M; ++j) params[6 * (size_t)K + j] = w.points[j];
   if (inertial)                                                          // :1154-1173
@@ -1567,7 +1799,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
 
   // ---- plan: dimensions and the layout of the four buffers
   std::vector<WinPlan> plan(W);
-  Carve cin, car, cwt, cout;
+  Carve cin, car, cout;
   const size_t i_wins = cin.take(sizeof(BaWin) * (size_t)W);
   const size_t i_wins15 = cin.take(sizeof(BaWin));                      // inertial: the same window seen by the 15-d solve
   const size_t i_outoff = cin.take(sizeof(size_t) * (size_t)W);
@@ -1586,9 +1818,14 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     d.K = K; d.F = F; d.M = M; d.N = N;
     d.P = std::max(16, (6 * K + 15) & ~15);
     d.ntile = d.P / 16;
-    d.ksplit = std::max(1, std::min(32, (3 * M + 255) / 256));
-    d.rows = ((3 * M + 4 * d.ksplit - 1) / (4 * d.ksplit)) * (4 * d.ksplit);
-    if (d.rows == 0) d.rows = 4 * d.ksplit;
+    d.ncb = (d.ntile + 7) / 8;
+    // k-splits of the Schur product: ~24 map points each, at most 128 of them; a function of the window alone (never of the
+    // batch it travels in: the split fixes the summation order of S_red)
+    // (24 points per split measured best for one window of 20 keyframes / 2000 points — 8, 16, 24, 32, 48, 96, 192 tried: the
+    // Schur blocks take 8.5 us + 3.6 us per 8 points, the reduction of the partials grows with the number of splits)
+    d.ksplit = std::max(1, std::min(128, (M + 23) / 24));
+    d.pps = std::max(8, (((M + d.ksplit - 1) / d.ksplit) + 7) & ~7);
+    d.rows = 3 * d.pps * d.ksplit;
     pl.n = 6 * K;
     pl.np = 6 * (size_t)K + 3 * (size_t)M + (inertial ? 9 * (size_t)K : 0);
     pl.n_upper = (size_t)d.ntile * (d.ntile + 1) / 2;
@@ -1607,29 +1844,28 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.i_ouv = cin.take(16 * n1);
     pl.i_kfobs = cin.take(4 * n1);
     pl.i_oflag = inertial ? cin.take(4 * n1) : 0;
+    pl.i_slot = cin.take(4 * m1 * k1);
+    pl.i_next = cin.take(4 * n1);
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
-    pl.a_oA = car.take(96 * n1); pl.a_oR = car.take(16 * n1); pl.a_oYg = car.take(48 * n1);
+    pl.a_oA = car.take(96 * n1); pl.a_oR = car.take(16 * n1); pl.a_oYg = car.take(48 * n1); pl.a_oW = car.take(144 * n1);
     pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
     pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
     pl.a_part = car.take(8 * pl.n_upper * d.ksplit * 256);
     pl.a_rb = car.take(8 * (pl.rb_len + 8));
     pl.a_solve = car.take(8 * ((size_t)pl.n * pl.n + 4 * (size_t)pl.n + 64 + BA_SOLVE_THREADS));   // dp [n pad 16] | S [n*n] | b [n] | 1/L_jj [n]
     pl.a_res = car.take(8 * 16);
-    pl.w_wt = cwt.take(8 * (size_t)d.rows * d.P);
-    pl.w_yt = cwt.take(8 * (size_t)d.rows * d.P);
     pl.o_out = cout.take(8 * (8 + pl.np));
   }
   if (live == 0) {
     if (W == 1) return orbx_fail(h, ORBX_ERR_EMPTY, "no parameters or no residuals");
     return ORBX_OK;                                                      // every window reports ORBX_ERR_EMPTY in its status
   }
-  enum { B_IN, B_ARENA, B_WTYT, B_OUT, B_IMU, B_S15 };
+  enum { B_IN, B_ARENA, B_OUT, B_IMU, B_S15 };
   const int K0 = win[0].K, M0 = win[0].M;                               // inertial / partitioned: the one window
   const int n15 = 15 * K0;
   if (inertial && n15 > BA_MAX_N) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d keyframes per inertial window", BA_MAX_N / 15);
   if (int rc = orbx_reserve(h, h->ws_ba[B_IN], cin.off)) return rc;
   if (int rc = orbx_reserve(h, h->ws_ba[B_ARENA], car.off)) return rc;
-  if (int rc = orbx_reserve(h, h->ws_ba[B_WTYT], cwt.off)) return rc;
   if (int rc = orbx_reserve(h, h->ws_ba[B_OUT], cout.off)) return rc;
   // inertial: edges (int [E][2]) | preint [E][11] | per-edge J^T J records;  dp15 [n15 pad 16] | S [n15^2] | b | 1/L_jj | gradient
   if (int rc = orbx_reserve(h, h->ws_ba[B_IMU], inertial ? 8 * ((size_t)inr->E * (1 + 11 + IMU_REC) + 8) : 8)) return rc;
@@ -1644,7 +1880,6 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   uint8_t* hin = (uint8_t*)h->h_ba_in;
   uint8_t* din = (uint8_t*)h->ws_ba[B_IN].p;
   uint8_t* dar = (uint8_t*)h->ws_ba[B_ARENA].p;
-  uint8_t* dwt = (uint8_t*)h->ws_ba[B_WTYT].p;
   double* dout = (double*)h->ws_ba[B_OUT].p;
 
   // ---- host preprocessing, one window per task (threads when the batch is large enough to pay for them)
@@ -1673,7 +1908,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   BaWin* hw = (BaWin*)(hin + i_wins);
   size_t* hoff = (size_t*)(hin + i_outoff);
   size_t lds_max = 0;
-  int any_lds = 0, any_big = 0, n_big_max = 0, maxM = 0, maxK = 0, max_kfs_blocks = 1, max_gather = 1, max_back = 1, max_asm = 1;
+  int any_lds = 0, any_big = 0, n_big_max = 0, maxM = 0, maxK = 0, max_schur_blocks = 1, all_diag = 1, max_gather = 1, max_back = 1, max_asm = 1;
   for (int w = 0; w < W; ++w) {
     const WinPlan& pl = plan[w];
     BaWin& b = hw[w];
@@ -1689,7 +1924,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl);
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
     b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
-    b.WT = (double*)(dwt + pl.w_wt); b.YT = (double*)(dwt + pl.w_yt);
+    b.oW = (double*)(dar + pl.a_oW);
+    b.slot_first = (const int*)(din + pl.i_slot); b.obs_next = (const int*)(din + pl.i_next);
     b.kfpart = (double*)(dar + pl.a_kfpart); b.part = (double*)(dar + pl.a_part); b.rb = (double*)(dar + pl.a_rb);
     b.dp = (double*)(dar + pl.a_solve);
     b.Sg = b.dp + ((pl.n + 15) & ~15); b.bvec = b.Sg + (size_t)pl.n * pl.n; b.ginv = b.bvec + pl.n;
@@ -1705,8 +1941,9 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if (pl.use_lds && !inertial) { any_lds = 1; lds_max = std::max(lds_max, pl.lds_need); }
     else if (!inertial) { any_big = 1; n_big_max = std::max(n_big_max, pl.n); }
     maxM = std::max(maxM, pl.d.M); maxK = std::max(maxK, pl.d.K);
-    max_kfs_blocks = std::max(max_kfs_blocks, pl.d.K * BA_KFSPLIT + (int)((pl.n_upper * pl.d.ksplit + 3) / 4));
-    max_gather = std::max(max_gather, std::min(256, (pl.n * pl.n + 255) / 256));
+    max_schur_blocks = std::max(max_schur_blocks, pl.d.ncb * (pl.d.ncb + 1) / 2 * pl.d.ksplit);
+    if (pl.d.ncb != 1) all_diag = 0;
+    max_gather = std::max(max_gather, std::min(256, (4 * pl.n * pl.n + 255) / 256));
     max_back = std::max(max_back, (std::max(32 * pl.d.M, pl.n) + 255) / 256);
     max_asm = std::max(max_asm, std::min(512, (pl.n * pl.n + 255) / 256));
   }
@@ -1742,8 +1979,6 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     gfull = b15.ginv + n15;
   }
   ORBX_HIP(h, hipMemcpyAsync(din, hin, cin.off, hipMemcpyHostToDevice, st));         // ONE upload for the whole batch
-  // the sparsity pattern of WT/YT is the same every iteration: zero once
-  ORBX_HIP(h, hipMemsetAsync(dwt, 0, cwt.off, st));
   {
     static std::once_flag once[64];                                    // process-wide function attribute: set once per device to
     hipError_t e_attr = hipSuccess;                                    // the largest size any window may ask for
@@ -1807,9 +2042,19 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       if (maxM > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((maxM * 32 + 255) / 256, W), dim3(256), 0, st, d_wins, bc, iter);
       else hipLaunchKernelGGL(ba_iter_kernel, gW1, dim3(1), 0, st, d_wins, iter);
     }
-    if (maxK > 0) {
+    if (maxK > 0 && W == 1) {
       ProfScope ps(h, "ba_kf_schur_kernel");
-      hipLaunchKernelGGL(ba_kf_schur_kernel, dim3(max_kfs_blocks, W), dim3(256), 0, st, d_wins);
+      const dim3 g(maxK * BA_KFSPLIT + max_schur_blocks, 1);
+      if (all_diag) hipLaunchKernelGGL(ba_kf_schur_kernel<true>, g, dim3(256), 0, st, d_wins);
+      else hipLaunchKernelGGL(ba_kf_schur_kernel<false>, g, dim3(256), 0, st, d_wins);
+    } else if (maxK > 0) {
+      {
+        ProfScope ps(h, "ba_kf_kernel");
+        hipLaunchKernelGGL(ba_kf_kernel, dim3(maxK * BA_KFSPLIT, W), dim3(256), 0, st, d_wins);
+      }
+      ProfScope ps(h, "ba_schur_kernel", nullptr, true);
+      if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins);
+      else hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins);
     }
     {
       ProfScope ps(h, "ba_gather_kernel");

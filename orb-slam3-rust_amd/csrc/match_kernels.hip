@@ -14,7 +14,6 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
-#include <mutex>
 
 #include "orbx_internal.hpp"
 
@@ -70,8 +69,7 @@ __global__ __launch_bounds__(SB_THREADS) void stereo_bucket_kernel(const orbx_ke
                                                                    const int* __restrict__ nkp, int cap,
                                                                    int* __restrict__ bstart /*[pair][SB_ROWS+1]*/,
                                                                    int* __restrict__ sidx /*[pair][cap]*/,
-                                                                   float2* __restrict__ sxy /*[pair][cap]*/,
-                                                                   int2* __restrict__ lrange /*[pair][cap]*/) {
+                                                                   float2* __restrict__ sxy /*[pair][cap]*/) {
   __shared__ int cnt[SB_ROWS];
   __shared__ int wsum[SB_THREADS / 64];
   const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,18 +95,6 @@ __global__ __launch_bounds__(SB_THREADS) void stereo_bucket_kernel(const orbx_ke
 #pragma unroll
   for (int k = 0; k < 4; ++k) { bs[4 * tid + k] = base; cnt[4 * tid + k] = base; base += c[k]; }
   if (tid == SB_THREADS - 1) bs[SB_ROWS] = base;
-  __syncthreads();
-  // the slice [lo, hi) of the sorted list every LEFT keypoint will scan (rows floor(vl)-3 .. floor(vl)+3): one load in the
-  // matcher instead of a keypoint -> bucket -> two bucket-start loads chain
-  {
-    const orbx_keypoint* kpL = kp + (size_t)(2 * pair) * cap;
-    const int nL = min(nkp[2 * pair], cap);
-    for (int i = tid; i < nL; i += SB_THREADS) {
-      const int rb = row_bucket(kpL[i].y);
-      const int hb = min(rb + 3, SB_ROWS - 1) + 1;
-      lrange[(size_t)pair * cap + i] = make_int2(cnt[max(rb - 3, 0)], hb < SB_ROWS ? cnt[hb] : nR);
-    }
-  }
   __syncthreads();
   for (int i = tid; i < nR; i += SB_THREADS) {
     const float x = kpR[i].x, y = kpR[i].y;
@@ -176,82 +162,6 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
       const bool emit = has && (((float)b < 0.9f * (float)s) || s == TH_HIGH);   // stereo.rs:145-148
       tmp[(size_t)pair * cap + li] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
     }
-  }
-}
-
-// The same matcher with the right descriptors of the pair staged ONCE per block in LDS, in row-bucket order (slot t = the
-// t-th entry of the sorted list: the sidx indirection disappears from the inner loop).  The variant above gathers a 32-byte
-// descriptor from global memory for every admissible (left, right) pair — ~10 per left keypoint, each a random line: 225 MB
-// of HBM traffic per 256 pairs for 45 MB of compulsory bytes (profiles/pmc_traffic.json) — here a block reads the
-// pair's right descriptors (64 KB at 2000 keypoints) exactly once, coalesced per 16-byte half.  `bpp` blocks share a pair
-// (small batches: more parallelism; each stages the whole right set and takes every bpp-th group of left keypoints).
-// Same candidate sets, same order-independent (distance, index) top-2 -> bit-identical matches.
-constexpr int SML_THREADS = 512;
-constexpr int SML_GROUPS = SML_THREADS / 16;
-constexpr int SML_MAX_RIGHT = 4608;          // 32 B x 4608 = 144 KiB of the 160 KiB LDS; larger sets use stereo_match_kernel
-
-__global__ __launch_bounds__(SML_THREADS) void stereo_match_lds_kernel(
-    const orbx_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
-    const int* __restrict__ nkp, int cap, float max_disp, float min_disp,
-    const int2* __restrict__ lrange, const int* __restrict__ sidx, const float2* __restrict__ sxy,
-    int2* __restrict__ tmp, int bpp) {
-  extern __shared__ __align__(16) uint4 s_desc[];                            // [nR][2]
-  const int pair = blockIdx.y;
-  const orbx_keypoint* kpL = kp + (size_t)(2 * pair) * cap;
-  const uint8_t* dL = desc + (size_t)(2 * pair) * cap * 32;
-  const uint4* dR16 = reinterpret_cast<const uint4*>(dL + (size_t)cap * 32);
-  const int nL = min(nkp[2 * pair], cap), nR = min(nkp[2 * pair + 1], cap);
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-  const int grp = lane >> 4, gl = lane & 15;
-  const int2* lr = lrange + (size_t)pair * cap;
-  const int* si = sidx + (size_t)pair * cap;
-  const float2* sx = sxy + (size_t)pair * cap;
-  for (int i = tid; i < 2 * nR; i += SML_THREADS) s_desc[i] = dR16[2 * (size_t)si[i >> 1] + (i & 1)];
-  const int stride = bpp * SML_GROUPS;
-  int li = (int)blockIdx.x * SML_GROUPS + wave * 4 + grp;                    // uniform over the 16-lane group
-  // everything a left keypoint needs from global memory in ONE round trip, fetched one keypoint ahead
-  float ul = 0.f, vl = 0.f;
-  int2 rg = make_int2(0, 0);
-  Desc256 dl{};
-  if (li < nL) { ul = kpL[li].x; vl = kpL[li].y; rg = lr[li]; dl = load_desc(dL + (size_t)li * 32); }
-  __syncthreads();
-  while (li < nL) {
-    const int nli = li + stride;
-    float nul = 0.f, nvl = 0.f;
-    int2 nrg = make_int2(0, 0);
-    Desc256 ndl{};
-    if (nli < nL) { nul = kpL[nli].x; nvl = kpL[nli].y; nrg = lr[nli]; ndl = load_desc(dL + (size_t)nli * 32); }
-    const float min_u = fmaxf(ul - max_disp, 0.0f);                          // stereo.rs:100
-    const float lim = ((float)nR * ul) / (float)nL;                          // stereo.rs:102
-    const float max_u = fminf(ul - min_disp, lim);                           // stereo.rs:101
-    unsigned b = TH_HIGH, s = TH_HIGH;
-    int bi = 0x7fffffff;
-    for (int t = rg.x + gl; t < rg.y; t += 16) {
-      const float2 r = sx[t];
-      const int ri = si[t];
-      if (fabsf(vl - r.y) > 2.0f) continue;                                  // stereo.rs:117
-      if (r.x < min_u || r.x > max_u) continue;                              // stereo.rs:122
-      if (ul <= r.x) continue;                                               // stereo.rs:127
-      const uint4 r0 = s_desc[2 * t], r1 = s_desc[2 * t + 1];
-      Desc256 dr;
-      dr.w[0] = (unsigned long long)r0.x | ((unsigned long long)r0.y << 32); dr.w[1] = (unsigned long long)r0.z | ((unsigned long long)r0.w << 32);
-      dr.w[2] = (unsigned long long)r1.x | ((unsigned long long)r1.y << 32); dr.w[3] = (unsigned long long)r1.z | ((unsigned long long)r1.w << 32);
-      const unsigned d = hamming(dl, dr);                                    // stereo.rs:132-133
-      if (d < TH_HIGH) push_top2(b, bi, s, d, ri);                           // :135-141 (d >= 100 never enters)
-    }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {                                 // xor < 16 stays inside the group
-      const unsigned ob = __shfl_xor(b, off);
-      const int obi = __shfl_xor(bi, off);
-      const unsigned os = __shfl_xor(s, off);
-      merge_top2(b, bi, s, ob, obi, os);
-    }
-    if (gl == 0) {
-      const bool has = bi != 0x7fffffff;
-      const bool emit = has && (((float)b < 0.9f * (float)s) || s == TH_HIGH);   // stereo.rs:145-148
-      tmp[(size_t)pair * cap + li] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
-    }
-    li = nli; ul = nul; vl = nvl; rg = nrg; dl = ndl;
   }
 }
 
@@ -811,12 +721,11 @@ int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, co
   if (batch <= 0) return ORBX_OK;
   // workspace: tmp int2[batch*cap] | bstart int[batch*(SB_ROWS+1)] | sidx int[batch*cap] | sxy float2[batch*cap]
   const size_t n_tmp = (size_t)batch * cap_kp;
-  const size_t bytes = 2 * sizeof(int2) * n_tmp + sizeof(int) * (size_t)batch * (SB_ROWS + 1) + sizeof(int) * n_tmp +
+  const size_t bytes = sizeof(int2) * n_tmp + sizeof(int) * (size_t)batch * (SB_ROWS + 1) + sizeof(int) * n_tmp +
                        sizeof(float2) * n_tmp + 64;
   if (int rc = orbx_reserve(h, h->ws_match, bytes)) return rc;
   int2* tmp = (int2*)h->ws_match.p;
-  int2* lrange = tmp + n_tmp;
-  float2* sxy = (float2*)(lrange + n_tmp);
+  float2* sxy = (float2*)(tmp + n_tmp);
   int* sidx = (int*)(sxy + n_tmp);
   int* bstart = sidx + n_tmp;
   // stereo.rs:84-90: f64 product/quotient, then `as f32`
@@ -824,21 +733,9 @@ int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, co
   const float min_disp = (float)(h->cam.fx * h->cam.baseline / 40.0);
   {
     ProfScope ps(h, "stereo_bucket_kernel");
-    hipLaunchKernelGGL(stereo_bucket_kernel, dim3(batch), dim3(SB_THREADS), 0, h->stream, d_kp, d_nkp, cap_kp, bstart, sidx, sxy, lrange);
+    hipLaunchKernelGGL(stereo_bucket_kernel, dim3(batch), dim3(SB_THREADS), 0, h->stream, d_kp, d_nkp, cap_kp, bstart, sidx, sxy);
   }
-  if (cap_kp <= SML_MAX_RIGHT) {
-    ProfScope ps(h, "stereo_match_kernel", nullptr, true);
-    static std::once_flag once[64];
-    hipError_t e_attr = hipSuccess;
-    std::call_once(once[h->device & 63], [&] {
-      e_attr = hipFuncSetAttribute((const void*)stereo_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * SML_MAX_RIGHT);
-    });
-    ORBX_HIP(h, e_attr);
-    // blocks per pair: enough blocks to fill the chip at small batches, one per pair once the batch does that by itself
-    const int bpp = std::max(1, std::min({8, 512 / batch, (cap_kp + SML_GROUPS - 1) / SML_GROUPS}));
-    hipLaunchKernelGGL(stereo_match_lds_kernel, dim3(bpp, batch), dim3(SML_THREADS), 32 * (size_t)cap_kp, h->stream, d_kp, d_desc, d_nkp,
-                       cap_kp, max_disp, min_disp, (const int2*)lrange, sidx, sxy, tmp, bpp);
-  } else {
+  {
     ProfScope ps(h, "stereo_match_kernel", nullptr, true);
     dim3 grid((cap_kp + SM_LEFT_PER_BLOCK - 1) / SM_LEFT_PER_BLOCK, batch);
     hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(SM_THREADS), 0, h->stream, d_kp, d_desc, d_nkp,

@@ -369,3 +369,20 @@ def test_ba_partition_stop_requested_by_one_rank(pkg):
     assert np.array_equal(out[0]["poses_wc"], out[1]["poses_wc"]) and np.array_equal(out[0]["points"], out[1]["points"])
     assert len(polls[0]) == cfg.max_iterations           # rank 0 kept polling (and enqueueing) once per iteration
     for h in hs: h.close()
+
+
+def test_ba_point_seen_twice_by_one_keyframe(gpu_handle, oracle, pkg):
+    """Two features of one keyframe carrying the same map point (the reference's maps allow it): both rows enter J^T J, so
+    W_jk is the SUM of the two W blocks.  The dense W operand of round 1 let the second overwrite the first; the tile slot
+    of the Schur kernel now sums the chain.  Against the oracle's literal dense formulation."""
+    w = pkg.synth.ba_window(61, 6, 120, pkg.BA_OBS)
+    rng = np.random.default_rng(61)
+    opt = np.nonzero(w["obs"]["kf_idx"] >= 0)[0]
+    dup = w["obs"][rng.choice(opt, 40, replace=False)].copy()
+    dup["u"] += rng.normal(0, 0.7, len(dup)); dup["v"] += rng.normal(0, 0.7, len(dup))
+    obs = np.concatenate([w["obs"], dup, dup[:5]])               # some pairs three times
+    cam = pkg.CameraModel(**w["camera"]); ocam = oracle.Camera(**w["camera"])
+    g = gpu_handle.ba_solve_visual(cam, pkg.LocalBAConfigLM(), w["poses_cw"], w["fixed_cw"], w["points"], obs)
+    o = oracle.ba_solve_dense(ocam, oracle.ba_config(), w["poses_cw"], w["fixed_cw"], w["points"], obs)
+    assert g["iterations"] == o["iterations"] and abs(g["final_error"] - o["final_error"]) < 1e-8 * o["final_error"]
+    assert_ba_close(g, o, POSE_TOL)
