@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""The bench's batched local-BA leg alone (32 windows of 20 keyframes / 2000 points through orbx_ba_solve_visual_batch), for
+rocprofv3 passes:  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA
+GRBM_GUI_ACTIVE SQ_WAVES -- python3 scripts/ba_batch_profile.py [windows [K M]]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import orb_slam3_rust_amd as P
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+M = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+cam = P.CameraModel(**P.synth.EUROC_CAMERA)
+h = P.Handle(cam, 100)
+wins = [P.synth.ba_window(200 + i, K, M, P.BA_OBS) for i in range(W)]
+cfg = P.LocalBAConfigLM()
+h.ba_solve_visual_batch(cam, cfg, wins)
+t0 = time.perf_counter()
+reps = 3
+its = 0
+for _ in range(reps):
+    its += sum(r["iterations"] for r in h.ba_solve_visual_batch(cam, cfg, wins))
+dt = time.perf_counter() - t0
+print("%d windows (K=%d, M=%d, %d observations each): %.3f ms per call, %.0f LM iterations/s" % (W, K, M, len(wins[0]["obs"]), dt / reps * 1e3, its / dt))
