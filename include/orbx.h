@@ -257,6 +257,23 @@ int orbx_bow_transform(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* 
 int orbx_bow_transform_device(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* d_desc, int n, int levels_up,
                               uint32_t* d_word, uint32_t* d_leaf, uint32_t* d_node, double* d_weight);
 
+/* The two maps OrbVocabulary::transform returns (mod.rs:296-325; transform_bow_only :327-355 is the first alone), built on the
+ * device from the per-descriptor results above:
+ *   BowVector     bow_word [n_bow] ascending word ids, bow_weight [n_bow]: per word the sum of its features' leaf weights in feature
+ *                 order, then L1-normalised (:316-321; the norm is summed in ascending word order — the reference's HashMap order
+ *                 is unspecified);
+ *   FeatureVector fv_node [n_fv] ascending node ids, the features of node i = fv_index[fv_start[i] .. fv_start[i+1]) ascending.
+ * Arrays are sized for n entries (fv_start n+1); at most 8192 descriptors per call.  _device: everything in device memory,
+ * d_counts [2] = {n_bow, n_fv}, asynchronous.  orbx_bow_score = OrbVocabulary::score (:357-374) on two such BowVectors (host
+ * arithmetic, no handle needed; word ids must ascend). */
+int orbx_bow_vectors(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* desc, int n, int levels_up, uint32_t* bow_word,
+                     double* bow_weight, int* n_bow, uint32_t* fv_node, int* fv_start, int* fv_index, int* n_fv);
+int orbx_bow_vectors_device(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* d_desc, int n, int levels_up,
+                            uint32_t* d_bow_word, double* d_bow_weight, uint32_t* d_fv_node, int* d_fv_start, int* d_fv_index,
+                            int* d_counts);
+int orbx_bow_score(const uint32_t* word1, const double* weight1, int n1, const uint32_t* word2, const double* weight2, int n2,
+                   double* score);
+
 /* = the search of fuse_points_into_keyframes (src/local_mapping/search_in_neighbors.rs:273-343, with
  * KeyFrame::get_features_in_area, src/atlas/map/keyframe.rs:408-443) for every (map point, target keyframe) pair:
  * project the point with the keyframe's inverse pose, skip it behind the camera or outside [0,2cx)x[0,2cy), radius

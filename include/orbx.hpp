@@ -370,30 +370,37 @@ class OrbVocabulary {   // mod.rs:83-94; the tree lives in device memory, transf
   size_t num_nodes() const { int n; orbx_vocab_info(v_, nullptr, nullptr, &n, nullptr); return (size_t)n; }
   const orbx_vocabulary* get() const { return v_; }
 
-  // mod.rs:296-325.  The L1 normalisation sums in ascending word id (the reference sums in HashMap order).
+  // mod.rs:296-325: descent, accumulation of the two maps and the L1 normalisation on the GPU (orbx_bow_vectors; the norm is summed
+  // in ascending word id, the reference sums in HashMap order).
   std::pair<BowVector, FeatureVector> transform(const std::vector<uint8_t>& descriptors, size_t levels_up) const {
     const int n = (int)(descriptors.size() / 32);
-    std::vector<uint32_t> word((size_t)n), leaf((size_t)n), node((size_t)n);
-    std::vector<double> w((size_t)n);
-    h_->check(orbx_bow_transform(h_->get(), v_, descriptors.data(), n, (int)levels_up, word.data(), leaf.data(), node.data(), w.data()));
+    std::vector<uint32_t> bw((size_t)std::max(n, 1)), fn((size_t)std::max(n, 1));
+    std::vector<double> bv((size_t)std::max(n, 1));
+    std::vector<int> fs((size_t)n + 1), fi((size_t)std::max(n, 1));
+    int nb = 0, nf = 0;
+    h_->check(orbx_bow_vectors(h_->get(), v_, descriptors.data(), n, (int)levels_up, bw.data(), bv.data(), &nb, fn.data(), fs.data(), fi.data(), &nf));
     BowVector bow;
     FeatureVector feat;
-    for (int i = 0; i < n; ++i) { bow[word[(size_t)i]] += w[(size_t)i]; feat[node[(size_t)i]].push_back((size_t)i); }
-    std::vector<uint32_t> keys;
-    for (const auto& kv : bow) keys.push_back(kv.first);
-    std::sort(keys.begin(), keys.end());
-    double sum = 0.0;
-    for (uint32_t k : keys) sum += bow[k];
-    if (sum > 0.0) for (auto& kv : bow) kv.second /= sum;
+    for (int i = 0; i < nb; ++i) bow[bw[(size_t)i]] = bv[(size_t)i];
+    for (int i = 0; i < nf; ++i) {
+      std::vector<size_t>& l = feat[fn[(size_t)i]];
+      for (int t = fs[(size_t)i]; t < fs[(size_t)i + 1]; ++t) l.push_back((size_t)fi[(size_t)t]);
+    }
     return {std::move(bow), std::move(feat)};
   }
   BowVector transform_bow_only(const std::vector<uint8_t>& descriptors) const { return transform(descriptors, 0).first; }   // mod.rs:330-356
 
-  static double score(const BowVector& v1, const BowVector& v2) {          // mod.rs:362-380
-    double diff = 0.0;
-    for (const auto& kv : v1) { auto it = v2.find(kv.first); diff += std::fabs(kv.second - (it != v2.end() ? it->second : 0.0)); }
-    for (const auto& kv : v2) if (!v1.count(kv.first)) diff += std::fabs(kv.second);
-    return 1.0 - 0.5 * diff;
+  static double score(const BowVector& v1, const BowVector& v2) {          // mod.rs:357-374 (orbx_bow_score: terms in ascending word id)
+    auto flat = [](const BowVector& v, std::vector<uint32_t>& k, std::vector<double>& w) {
+      for (const auto& kv : v) k.push_back(kv.first);
+      std::sort(k.begin(), k.end());
+      for (uint32_t x : k) w.push_back(v.at(x));
+    };
+    std::vector<uint32_t> k1, k2; std::vector<double> w1, w2;
+    flat(v1, k1, w1); flat(v2, k2, w2);
+    double s = 0.0;
+    if (orbx_bow_score(k1.data(), w1.data(), (int)k1.size(), k2.data(), w2.data(), (int)k2.size(), &s) != ORBX_OK) throw Error(ORBX_ERR_INVALID, "orbx_bow_score");
+    return s;
   }
 
  private:

@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
     "orbx_fuse_search", "orbx_fuse_search_device",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
-    "orbx_bow_transform", "orbx_bow_transform_device",
+    "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors", "orbx_bow_vectors_device", "orbx_bow_score",
     "orbx_png_decode_gray8", "orbx_euroc_open", "orbx_euroc_close", "orbx_euroc_len", "orbx_euroc_last_error",
     "orbx_euroc_frame_timestamp", "orbx_euroc_calibration", "orbx_euroc_read_pairs",
     "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
@@ -1187,17 +1187,24 @@ class OrbVocabulary:
         h._check(h._L.orbx_bow_transform(h._h, self._v, _vp(d), C.c_int(n), C.c_int(levels_up), _vp(word), _vp(leaf), _vp(node), _vp(w)))
         return word, leaf, node, w
 
+    def vectors_arrays(self, descriptors, levels_up=4):
+        """orbx_bow_vectors: the two maps of OrbVocabulary::transform accumulated ON THE DEVICE ->
+        (bow_word [nb] ascending, bow_weight [nb] L1-normalised, fv_node [nf] ascending, fv_start [nf+1], fv_index [n])."""
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64); fn = np.zeros(max(n, 1), np.uint32)
+        fs = np.zeros(n + 1, np.int32); fi = np.zeros(max(n, 1), np.int32); nb = C.c_int(); nf = C.c_int()
+        h = self._handle
+        h._L.orbx_bow_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+        h._check(h._L.orbx_bow_vectors(h._h, self._v, _vp(d), n, int(levels_up), _vp(bw), _vp(bv), C.byref(nb), _vp(fn), _vp(fs), _vp(fi), C.byref(nf)))
+        return bw[:nb.value], bv[:nb.value], fn[:nf.value], fs[:nf.value + 1], fi[:n]
+
     def transform(self, descriptors, levels_up=4):
-        """mod.rs:296-325 -> (BowVector dict word -> weight, FeatureVector dict node -> [feature indices]).  The L1
-        normalisation sums in ascending word id (the reference sums in HashMap order: same value up to rounding)."""
-        word, _leaf, node, w = self.transform_arrays(descriptors, levels_up)
-        bow, feat = {}, {}
-        for i in range(len(word)):
-            bow[int(word[i])] = bow.get(int(word[i]), 0.0) + float(w[i])
-            feat.setdefault(int(node[i]), []).append(i)
-        total = sum(bow[k] for k in sorted(bow))
-        if total > 0.0:
-            bow = {k: v / total for k, v in bow.items()}
+        """mod.rs:296-325 -> (BowVector dict word -> weight, FeatureVector dict node -> [feature indices]); descent, accumulation
+        and L1 normalisation on the GPU (the norm is summed in ascending word id: the reference sums in HashMap order)."""
+        bw, bv, fn, fs, fi = self.vectors_arrays(descriptors, levels_up)
+        bow = {int(k): float(v) for k, v in zip(bw, bv)}
+        feat = {int(fn[i]): [int(x) for x in fi[fs[i]:fs[i + 1]]] for i in range(len(fn))}
         return bow, feat
 
     def transform_bow_only(self, descriptors):
@@ -1206,9 +1213,16 @@ class OrbVocabulary:
 
     @staticmethod
     def score(v1, v2):
-        """mod.rs:362-380: 1 - 0.5 * |v1 - v2|_1"""
-        diff = sum(abs(w1 - v2.get(k, 0.0)) for k, w1 in v1.items()) + sum(abs(w2) for k, w2 in v2.items() if k not in v1)
-        return 1.0 - 0.5 * diff
+        """mod.rs:357-374: 1 - 0.5 * |v1 - v2|_1 (orbx_bow_score; terms added in ascending word id)"""
+        k1 = np.array(sorted(v1), np.uint32); k2 = np.array(sorted(v2), np.uint32)
+        w1 = np.array([v1[int(k)] for k in k1], np.float64); w2 = np.array([v2[int(k)] for k in k2], np.float64)
+        out = C.c_double()
+        L = load_library()
+        L.orbx_bow_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        rc = L.orbx_bow_score(_vp(k1), _vp(w1), len(k1), _vp(k2), _vp(w2), len(k2), C.byref(out))
+        if rc != 0:
+            raise OrbxError(rc, "orbx_bow_score: bad argument")
+        return out.value
 
     def close(self):
         if self._v:

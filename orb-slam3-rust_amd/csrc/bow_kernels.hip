@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 
+#include <cmath>
+
 #include "orbx_internal.hpp"
 
 struct orbx_vocabulary {
@@ -109,6 +111,103 @@ void vocab_free_device(orbx_vocabulary* v) {
 
 // nodes -> device tables.  parent[0] is the root's (ignored); links as load_from_text makes them (:196-198): a node is
 // appended to its parent's child list only when the parent already exists, i.e. parent id < own id.
+// ---- BowVector / FeatureVector accumulation (mod.rs:296-325): the two maps of OrbVocabulary::transform built on the device ----------
+// One block.  Keys (word << 32 | feature index) are sorted in LDS (bitonic, padded with ~0); a run of equal words is one BowVector
+// entry whose weight is the sum of its features' leaf weights IN FEATURE ORDER (what `*bow.entry(word).or_insert(0.0) += weight` does
+// over i = 0..rows); the L1 norm (:316-321) is summed over the entries in ASCENDING WORD order — the reference sums a HashMap's values
+// in an unspecified order, this is the order stated instead — and every weight divided by it.  The same sort on (node << 32 | index)
+// gives the FeatureVector as CSR: node ids ascending, the feature indices of a node ascending (= push order, :312).
+constexpr int BOWV_THREADS = 1024, BOWV_MAX = 8192;
+__device__ __forceinline__ void bowv_sort(unsigned long long* key, int P) {
+  const int tid = threadIdx.x;
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int c = tid; c < P / 2; c += BOWV_THREADS) {
+        const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1)), ixj = i | j;
+        const unsigned long long x = key[i], y = key[ixj];
+        if ((x > y) == ((i & k) == 0)) { key[i] = y; key[ixj] = x; }
+      }
+    }
+  __syncthreads();
+}
+// heads of runs of equal high words -> compact positions (block-wide exclusive count); returns the number of runs
+__device__ __forceinline__ int bowv_heads(const unsigned long long* key, int n, int* pos /*[n]: run index of element i*/, int* s_w) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int run = 0;
+  for (int base = 0; base < n; base += BOWV_THREADS) {
+    const int i = base + tid;
+    const bool head = i < n && (i == 0 || (unsigned)(key[i] >> 32) != (unsigned)(key[i - 1] >> 32));
+    const unsigned long long m = __ballot(head);
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int before = run;
+    for (int w = 0; w < wave; ++w) before += s_w[w];
+    int tot = 0;
+    for (int w = 0; w < BOWV_THREADS / 64; ++w) tot += s_w[w];
+    if (i < n) pos[i] = before + __popcll(m & ((1ull << lane) - 1ull)) + (head ? 0 : -1);
+    run += tot;
+    __syncthreads();
+  }
+  return run;
+}
+__global__ __launch_bounds__(BOWV_THREADS) void bow_vectors_kernel(const uint32_t* __restrict__ word, const uint32_t* __restrict__ node,
+                                                                   const double* __restrict__ weight, int n, uint32_t* __restrict__ bow_word,
+                                                                   double* __restrict__ bow_weight, uint32_t* __restrict__ fv_node,
+                                                                   int* __restrict__ fv_start, int* __restrict__ fv_index,
+                                                                   int* __restrict__ counts /*[2]: n_bow, n_fv*/) {
+  __shared__ unsigned long long key[BOWV_MAX];
+  __shared__ int s_w[BOWV_THREADS / 64];
+  __shared__ double s_total;
+  const int tid = threadIdx.x;
+  int P = 64;
+  while (P < n) P <<= 1;
+  int* pos = fv_index;                                             // scratch until the FeatureVector pass overwrites it
+  // ---- BowVector
+  for (int i = tid; i < P; i += BOWV_THREADS) key[i] = i < n ? ((unsigned long long)word[i] << 32) | (unsigned)i : ~0ull;
+  bowv_sort(key, P);
+  const int n_bow = bowv_heads(key, n, pos, s_w);
+  for (int i = tid; i < n; i += BOWV_THREADS) {
+    const unsigned w = (unsigned)(key[i] >> 32);
+    if (i == 0 || w != (unsigned)(key[i - 1] >> 32)) {              // head of a run: its features in index order
+      double sum = 0.0;
+      for (int t = i; t < n && (unsigned)(key[t] >> 32) == w; ++t) sum += weight[(unsigned)key[t]];
+      bow_word[pos[i]] = w; bow_weight[pos[i]] = sum;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    double total = 0.0;
+    for (int e = 0; e < n_bow; ++e) total += bow_weight[e];         // ascending word id
+    s_total = total;
+    counts[0] = n_bow;
+  }
+  __syncthreads();
+  if (s_total > 0.0)
+    for (int e = tid; e < n_bow; e += BOWV_THREADS) bow_weight[e] /= s_total;
+  __syncthreads();
+  // ---- FeatureVector
+  for (int i = tid; i < P; i += BOWV_THREADS) key[i] = i < n ? ((unsigned long long)node[i] << 32) | (unsigned)i : ~0ull;
+  bowv_sort(key, P);
+  // (run index of every element -> registers first: `pos` aliases fv_index, which is written next)
+  const int n_fv = bowv_heads(key, n, pos, s_w);
+  __syncthreads();
+  int myrun[BOWV_MAX / BOWV_THREADS];
+#pragma unroll
+  for (int q = 0; q < BOWV_MAX / BOWV_THREADS; ++q) { const int i = tid + q * BOWV_THREADS; myrun[q] = i < n ? pos[i] : -1; }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < BOWV_MAX / BOWV_THREADS; ++q) {
+    const int i = tid + q * BOWV_THREADS;
+    if (i < n) {
+      fv_index[i] = (int)(unsigned)key[i];
+      if (i == 0 || (unsigned)(key[i] >> 32) != (unsigned)(key[i - 1] >> 32)) { fv_node[myrun[q]] = (unsigned)(key[i] >> 32); fv_start[myrun[q]] = i; }
+    }
+  }
+  if (tid == 0) { fv_start[n_fv] = n; counts[1] = n_fv; }
+}
+
 int vocab_upload(orbx_handle* h, orbx_vocabulary* v) {
   const int n = v->n_nodes;
   std::vector<int> cs((size_t)n + 1, 0);
@@ -265,6 +364,72 @@ int orbx_bow_transform(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* 
   ORBX_HIP(h, hipMemcpyAsync(out_node, d_node, 4 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
   ORBX_HIP(h, hipMemcpyAsync(out_weight, d_w, 8 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
   ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  return ORBX_OK;
+}
+
+int orbx_bow_vectors_device(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* d_desc, int n, int levels_up, uint32_t* d_bow_word,
+                            double* d_bow_weight, uint32_t* d_fv_node, int* d_fv_start, int* d_fv_index, int* d_counts) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!v || n < 0 || levels_up < 0 || !d_counts || (n > 0 && (!d_desc || !d_bow_word || !d_bow_weight || !d_fv_node || !d_fv_start || !d_fv_index)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_bow_vectors: bad argument");
+  if (n > BOWV_MAX) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_bow_vectors: at most %d descriptors per call", BOWV_MAX);
+  ORBX_HIP(h, hipSetDevice(h->device));
+  if (n == 0) { ORBX_HIP(h, hipMemsetAsync(d_counts, 0, 2 * sizeof(int), h->stream)); return ORBX_OK; }
+  if (int rc = orbx_reserve(h, h->ws_io[9], (12 + 8) * (size_t)n)) return rc;
+  double* d_w = (double*)h->ws_io[9].p;
+  uint32_t* d_word = (uint32_t*)(d_w + n); uint32_t* d_leaf = d_word + n; uint32_t* d_node = d_leaf + n;
+  if (int rc = orbx_bow_transform_device(h, v, d_desc, n, levels_up, d_word, d_leaf, d_node, d_w)) return rc;
+  ProfScope ps(h, "bow_vectors_kernel");
+  hipLaunchKernelGGL(bow_vectors_kernel, dim3(1), dim3(BOWV_THREADS), 0, h->stream, d_word, d_node, d_w, n, d_bow_word, d_bow_weight, d_fv_node,
+                     d_fv_start, d_fv_index, d_counts);
+  ORBX_HIP(h, hipGetLastError());
+  return ORBX_OK;
+}
+
+int orbx_bow_vectors(orbx_handle* h, const orbx_vocabulary* v, const uint8_t* desc, int n, int levels_up, uint32_t* bow_word, double* bow_weight,
+                     int* n_bow, uint32_t* fv_node, int* fv_start, int* fv_index, int* n_fv) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!v || n < 0 || !n_bow || !n_fv || (n > 0 && (!desc || !bow_word || !bow_weight || !fv_node || !fv_start || !fv_index)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_bow_vectors: bad argument");
+  *n_bow = 0; *n_fv = 0;
+  if (n == 0) return ORBX_OK;
+  ORBX_HIP(h, hipSetDevice(h->device));
+  const size_t nn = (size_t)n;
+  if (int rc = orbx_reserve(h, h->ws_io[0], 32 * nn)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_io[1], 8 * nn + 4 * nn + 4 * nn + 4 * (nn + 1) + 4 * nn + 64)) return rc;
+  uint8_t* d_desc = (uint8_t*)h->ws_io[0].p;
+  double* d_bw = (double*)h->ws_io[1].p;
+  uint32_t* d_bword = (uint32_t*)(d_bw + n); uint32_t* d_fnode = d_bword + n;
+  int* d_fstart = (int*)(d_fnode + n); int* d_findex = d_fstart + n + 1; int* d_counts = d_findex + n;
+  ORBX_HIP(h, hipMemcpyAsync(d_desc, desc, 32 * nn, hipMemcpyHostToDevice, h->stream));
+  if (int rc = orbx_bow_vectors_device(h, v, d_desc, n, levels_up, d_bword, d_bw, d_fnode, d_fstart, d_findex, d_counts)) return rc;
+  int cnt[2];
+  ORBX_HIP(h, hipMemcpyAsync(cnt, d_counts, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+  ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  *n_bow = cnt[0]; *n_fv = cnt[1];
+  ORBX_HIP(h, hipMemcpy(bow_word, d_bword, 4 * (size_t)cnt[0], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(bow_weight, d_bw, 8 * (size_t)cnt[0], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(fv_node, d_fnode, 4 * (size_t)cnt[1], hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(fv_start, d_fstart, 4 * ((size_t)cnt[1] + 1), hipMemcpyDeviceToHost));
+  ORBX_HIP(h, hipMemcpy(fv_index, d_findex, 4 * nn, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+// OrbVocabulary::score (mod.rs:357-374): 1 - 0.5 * ||v1 - v2||_1 of two BowVectors given as (ascending word id, weight) arrays — the
+// form orbx_bow_vectors returns.  Host arithmetic (two sorted lists of ~1000 entries); the terms are added in ascending word order over
+// the union, where the reference walks two HashMaps in unspecified order.
+int orbx_bow_score(const uint32_t* word1, const double* weight1, int n1, const uint32_t* word2, const double* weight2, int n2, double* score) {
+  if (!score || n1 < 0 || n2 < 0 || (n1 > 0 && (!word1 || !weight1)) || (n2 > 0 && (!word2 || !weight2))) return ORBX_ERR_INVALID;
+  for (int i = 1; i < n1; ++i) if (word1[i] <= word1[i - 1]) return ORBX_ERR_INVALID;
+  for (int i = 1; i < n2; ++i) if (word2[i] <= word2[i - 1]) return ORBX_ERR_INVALID;
+  double diff = 0.0;
+  int a = 0, b = 0;
+  while (a < n1 || b < n2) {
+    if (b >= n2 || (a < n1 && word1[a] < word2[b])) { diff += std::fabs(weight1[a] - 0.0); ++a; }        // (w1 - 0).abs(), :364
+    else if (a >= n1 || word2[b] < word1[a]) { diff += std::fabs(weight2[b]); ++b; }                      // :370
+    else { diff += std::fabs(weight1[a] - weight2[b]); ++a; ++b; }
+  }
+  *score = 1.0 - 0.5 * diff;
   return ORBX_OK;
 }
 

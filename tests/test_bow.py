@@ -166,3 +166,39 @@ def test_gpu_bow_search_matches_oracle(gpu_handle, seed, n, k, depth):
     args = (s["kp1"], s["desc1"], s["mp1"], s["stereo1"], n1, s["kp2"], s["desc2"], s["mp2"], n2, s["pose1_wc"], s["pose2_wc"])
     assert np.array_equal(gpu_handle.search_for_triangulation_bow(P.CameraModel(**s["camera"]), *args, 80),
                           O.search_for_triangulation_bow(O.Camera(**s["camera"]), *args, 80))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,depth,n,lu", [(10, 4, 6000, 2), (10, 3, 2000, 1), (6, 3, 700, 0), (4, 2, 64, 4)])
+def test_gpu_bow_vectors_match_restatement(gpu_handle, k, depth, n, lu):
+    """BowVector / FeatureVector accumulated on the device (orbx_bow_vectors) against the literal loop of transform
+    (mod.rs:296-325) over the ORACLE's per-descriptor results: weights summed per word in feature order, the L1 norm summed in
+    ascending word id (the stated order), feature lists in push order — bit for bit.  score (mod.rs:357-374) against its formula."""
+    parent, leaf, desc, weight = P.synth.vocabulary(11, k=k, depth=depth)
+    ov = O.Vocabulary.from_arrays(parent, leaf, desc, weight, k, depth)
+    gv = P.OrbVocabulary.from_nodes(parent, leaf, desc, weight, k, depth, handle=gpu_handle)
+    q = np.concatenate([_queries(12, desc, n), np.random.default_rng(13).integers(0, 256, (100, 32), dtype=np.uint8)])
+    word, _leaf, node, w = ov.transform(q, lu)
+    bow, feat = {}, {}
+    for i in range(len(q)):
+        bow[int(word[i])] = bow.get(int(word[i]), 0.0) + float(w[i])
+        feat.setdefault(int(node[i]), []).append(i)
+    total = 0.0
+    for kk in sorted(bow):
+        total += bow[kk]
+    want_bow = {kk: (v / total if total > 0.0 else v) for kk, v in bow.items()}
+    bw, bv, fn, fs, fi = gv.vectors_arrays(q, lu)
+    assert list(bw) == sorted(want_bow) and np.array_equal(bv, np.array([want_bow[int(x)] for x in bw]))
+    assert list(fn) == sorted(feat) and fs[0] == 0 and fs[-1] == len(q)
+    for i, nd in enumerate(fn):
+        assert list(fi[fs[i]:fs[i + 1]]) == feat[int(nd)]
+    gb, gf = gv.transform(q, lu)
+    assert gb == want_bow and gf == feat and gv.transform_bow_only(q) == gv.transform(q, 0)[0]
+    # score: identical vectors -> 1; disjoint -> 0; general case against the formula
+    assert gv.score(gb, gb) == 1.0
+    other, _ = gv.transform(q[::-1][: len(q) // 2], lu)
+    lit = 1.0 - 0.5 * (sum(abs(a - other.get(kk, 0.0)) for kk, a in gb.items()) + sum(abs(b) for kk, b in other.items() if kk not in gb))
+    assert abs(gv.score(gb, other) - lit) < 1e-14 and 0.0 <= gv.score(gb, other) <= 1.0
+    assert gv.score({1: 1.0}, {2: 1.0}) == 0.0 and gv.score({}, {}) == 1.0
+    assert gv.vectors_arrays(q[:0], lu)[0].shape == (0,)
+    gv.close()
