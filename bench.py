@@ -125,8 +125,8 @@ def cpu_baseline(P, frames_mt, frames_1t, w, h, n_features):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)      # 60 x 2.3 ms: a timed region of ~0.14 s (20 steps = 45 ms was thin)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step per GPU")
     ap.add_argument("--n-batches", type=int, default=3)
     ap.add_argument("--features", type=int, default=2000)

@@ -375,7 +375,7 @@ def test_ba_point_seen_twice_by_one_keyframe(gpu_handle, oracle, pkg):
     """Two features of one keyframe carrying the same map point (the reference's maps allow it): both rows enter J^T J, so
     W_jk is the SUM of the two W blocks.  The dense W operand of round 1 let the second overwrite the first; the tile slot
     of the Schur kernel now sums the chain.  Against the oracle's literal dense formulation."""
-    w = pkg.synth.ba_window(61, 6, 120, pkg.BA_OBS)
+    w = pkg.synth.ba_window(61, 7, 120, pkg.BA_OBS, n_fixed_extra=1)     # two fixed keyframes: no free scale gauge for rounding to drift along
     rng = np.random.default_rng(61)
     opt = np.nonzero(w["obs"]["kf_idx"] >= 0)[0]
     dup = w["obs"][rng.choice(opt, 40, replace=False)].copy()
