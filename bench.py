@@ -80,6 +80,30 @@ def make_batches(P, torch, dev, seed, batch, n_batches, w, h):
     return out
 
 
+def make_batches_small(P, torch, dev, seed, batch, n_batches, w, h):
+    """--small-gen (profiler passes only): 32 numpy-generated pairs expanded by flips and brightness offsets — the same kernels see
+    the same kind of images, without the ~50 000 tiny torch dispatches of the GPU generator, which rocprofv3's counter collection
+    does not survive on this stack (SIGSEGV inside a torch elementwise launch under --pmc)."""
+    uniq = min(32, batch * n_batches)
+    base = torch.from_numpy(P.synth.stereo_batch(seed, 0, uniq, w, h)).to(dev)
+    out = []
+    k = 0
+    for _ in range(n_batches):
+        items = []
+        for _ in range(batch):
+            img = base[k % uniq]
+            v = k // uniq
+            if v & 1:
+                img = torch.flip(img, dims=[1])
+            off = ((v >> 1) % 5) * 3 - 6
+            if off:
+                img = (img.to(torch.int16) + off).clamp_(0, 255).to(torch.uint8)
+            items.append(img)
+            k += 1
+        out.append(torch.stack(items).contiguous())
+    return out
+
+
 def cpu_baseline(P, frames_mt, frames_1t, w, h, n_features):
     """The CPU oracle (a restatement of the reference algorithm, kind 'port') on a bounded sample of the
     same workload, timed on this box's host cores."""
@@ -136,6 +160,7 @@ def main():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-files", action="store_true", help="skip the EuRoC-directory (PNG decode inclusive) leg")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / PCIe-inclusive / latency / config0 legs")
+    ap.add_argument("--small-gen", action="store_true", help="profiler passes: 32 numpy pairs expanded instead of the GPU scene generator")
     args = ap.parse_args()
 
     import torch
@@ -171,7 +196,8 @@ def main():
     cap = args.features + 304
     out = h.alloc_batch_outputs(args.batch, cap)
     # rank r owns stream r (seed 1000*r+1): frames shard across ranks, no collective
-    batches = make_batches(P, torch, dev, 1000 * P.dist.shard_streams(world, rank, world)[0] + 1, args.batch, args.n_batches, W, H)
+    batches = (make_batches_small if args.small_gen else make_batches)(P, torch, dev, 1000 * P.dist.shard_streams(world, rank, world)[0] + 1,
+                                                                        args.batch, args.n_batches, W, H)
     torch.cuda.synchronize()
 
     def barrier():
@@ -271,7 +297,8 @@ def main():
                config=dict(workload="Synthetic %dx%d stereo, %d ORB/frame, extract+match+triangulate (BASELINE configs[%d])"
                                     % (W, H, args.features, 1 if (W, H, args.features) == (752, 480, 2000) else 4),
                            image=[W, H], n_features=args.features, batch_pairs_per_gpu=args.batch,
-                           distinct_batches=args.n_batches, parallelism="frames sharded, %d rank(s), no collective%s" % (world, " (REHEARSAL: ranks share GPUs, gloo)" if rehearse else ""),
+                           distinct_batches=args.n_batches, unique_pairs=(min(32, args.batch * args.n_batches) if args.small_gen else args.batch * args.n_batches),
+                           parallelism="frames sharded, %d rank(s), no collective%s" % (world, " (REHEARSAL: ranks share GPUs, gloo)" if rehearse else ""),
                            mean_keypoints_per_image=round(n_kp, 1), mean_matches_per_frame=round(n_matches, 1)),
                roofline=roofline, value_unprofiled=round(args.batch * args.steps * world / elapsed_np, 2))
 

@@ -8,10 +8,10 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 python bench.py > $O/bench_b256.json 2> $O/bench_b256.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-files > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files > /dev/null 2> $O/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files > /dev/null 2> $O/pmc_sq.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-files --no-extras > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files --no-extras --small-gen > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files --no-extras --small-gen > /dev/null 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files --no-extras --small-gen > /dev/null 2> $O/pmc_sq.err
 cd $R
 python scripts/pmc_summary.py $(ls $O/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $O/pmc_write/*/*counter_collection.csv | head -1) 256 2000 $O/pmc_traffic.json $(ls $O/pmc_sq/*/*counter_collection.csv | head -1) > $O/pmc_hbm_traffic_b256.txt
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/bench_b256_kernel_stats.csv
