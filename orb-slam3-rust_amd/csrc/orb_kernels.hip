@@ -357,6 +357,39 @@ __device__ __forceinline__ int fast_arc_min_pk(int v, const int (&r)[16], bool b
   return max((int)best[0], (int)best[1]);
 }
 
+// The same maximum over the 16 arcs in packed f16 with the three-input minimum / maximum of gfx950 (v_pk_minimum3_f16,
+// v_pk_maximum3_f16: one issue slot like every packed instruction, two comparisons per lane instead of one).  Pixels enter as
+// 1024 + p (0x6400 | p: exact in f16, ulp 1 on [1024, 2048)), so s*(centre - ring) is an exact small integer and every min / max
+// is exact: 9-windows as min3 of min3 (X[j..j+2], then windows j, j+3, j+6) instead of a 2-4-8(+1) ladder — 16 + 4 instructions
+// for the window minima and their maximum instead of 39.
+typedef _Float16 fast_h2 __attribute__((ext_vector_type(2)));
+// minimum3 with the 2nd / 3rd operand half-swapped (ring position + 8 lives in the other half of the register)
+__device__ __forceinline__ fast_h2 pk_min3_00(fast_h2 a, fast_h2 b, fast_h2 c) { fast_h2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ fast_h2 pk_min3_01(fast_h2 a, fast_h2 b, fast_h2 c) { fast_h2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ fast_h2 pk_min3_11(fast_h2 a, fast_h2 b, fast_h2 c) { fast_h2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ fast_h2 pk_max3(fast_h2 a, fast_h2 b, fast_h2 c) { fast_h2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ int fast_arc_min_h(int v, const int (&r)[16], bool brighter) {
+  fast_h2 X[8], B[8], W[8];
+  const unsigned cbits = 0x6400u | (unsigned)v;                       // 1024 + centre
+  const _Float16 cf = __builtin_bit_cast(_Float16, (unsigned short)cbits);
+  const _Float16 one = (_Float16)1.0f;
+  const fast_h2 m = brighter ? fast_h2{one, one} : fast_h2{-one, -one};
+  const fast_h2 c = brighter ? fast_h2{-cf, -cf} : fast_h2{cf, cf};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned rp = ((unsigned)r[j] | ((unsigned)r[j + 8] << 16)) | 0x64006400u;
+    X[j] = __builtin_elementwise_fma(__builtin_bit_cast(fast_h2, rp), m, c);   // s*(centre - ring), exact: one v_pk_fma_f16
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)                                         // windows of 3: positions j, j+1, j+2
+    B[j] = j + 2 < 8 ? pk_min3_00(X[j], X[j + 1], X[j + 2]) : (j + 1 < 8 ? pk_min3_01(X[j], X[j + 1], X[j - 6]) : pk_min3_11(X[j], X[j - 7], X[j - 6]));
+#pragma unroll
+  for (int j = 0; j < 8; ++j)                                         // windows of 9: windows of 3 at j, j+3, j+6
+    W[j] = j + 6 < 8 ? pk_min3_00(B[j], B[j + 3], B[j + 6]) : (j + 3 < 8 ? pk_min3_01(B[j], B[j + 3], B[j - 2]) : pk_min3_11(B[j], B[j - 5], B[j - 2]));
+  const fast_h2 best = __builtin_elementwise_max(pk_max3(W[0], W[1], W[2]), pk_max3(W[3], W[4], pk_max3(W[5], W[6], W[7])));
+  return (int)(best[0] > best[1] ? best[0] : best[1]);
+}
+
 // Two-phase per tile.  Score region 64 x 48 positions (inner 62 x 46 + 1-position NMS frame), pixel tile
 // 72 x 54 bytes staged so that position i sits at byte i+4 of its LDS row (dword aligned):
 //   1. every position, 4 per thread from 5 dword LDS reads: compass pre-test — a 9-arc always contains
@@ -368,11 +401,58 @@ __device__ __forceinline__ int fast_arc_min_pk(int v, const int (&r)[16], bool b
 constexpr int FT_W = 62, FT_H = 46;          // inner tile (heights 30 / 46 / 62: 0.837 / 0.821 / 0.835 ms per 256 pairs)
 constexpr int FS_W = 64, FS_H = 48;          // score region
 constexpr int FP_PITCH = 72, FP_ROWS = FS_H + 6;
-static_assert(FP_ROWS <= 56, "the staging loop covers 2 x 28 rows");
+static_assert(FP_ROWS <= 84, "the staging loop covers up to 3 x 28 rows");
 static_assert((FT_W / 2) * (FT_H / 2) <= 1024, "s_list holds the NMS survivors of a tile");
 
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
 
+// ---- byte-parallel compass pre-test (thresholds below 128) ---------------------------------------------------------
+// The probe (profiles/r02_valu_issue_probe.txt) shows two issue classes on this chip: the packed-i16 / v_perm / v_cmp code of the
+// pre-test above issues every 4 cycles, plain add / sub / and / or / xor / shift-right and v_bitop3_b32 every 2.  The same test on
+// the four pixels of a dword at once, in those 2-cycle instructions only (the compiler folds the boolean expressions into
+// v_bitop3_b32): per byte  hi = min(v + t, 255), lo = max(v - t, 0)  and the unsigned comparisons  hi >= r,  r >= lo  by the
+// borrow of (a | 0x80) - (b & 0x7f) combined with the top bits.  Result: bit 7 of byte k set iff position k passes — exactly
+// the positions the packed-i16 form passes (r > v + t can only hold for v + t < 255, r < v - t only for v - t > 0).
+// v_bitop3_b32 look-up tables: bit (a << 2 | b << 1 | c) of the immediate is f(a, b, c).  (Written as C expressions the compiler
+// emits separate and / or / xor / not instructions: 182 instead of 88 for two dwords.)
+#define ORBX_BITOP3(a, b, c, lut) __builtin_amdgcn_bitop3_b32((a), (b), (c), (lut))
+__device__ __forceinline__ unsigned swar_ge(unsigned a, unsigned aH /* a | 0x80.. */, unsigned b, unsigned bL /* b & 0x7f.. */) {
+  const unsigned d = aH - bL;                      // per byte (128 + a_lo) - b_lo >= 1: no borrow crosses a byte; bit 7 = [a_lo >= b_lo]
+  return ORBX_BITOP3(a, b, d, 0xB2);               // (a & ~b) | (~(a ^ b) & d): bit 7 of every byte = [a >= b] (other bits unused)
+}
+__device__ __forceinline__ unsigned swar_compass_pass(unsigned v, unsigned r0, unsigned r4, unsigned r8, unsigned r12, unsigned T) {
+  const unsigned H = 0x80808080u, L = 0x7f7f7f7fu;
+  const unsigned vH = v & H;
+  const unsigned s = (v & L) + T;                  // low seven bits + t <= 0xfe: no carry crosses a byte
+  const unsigned o = ORBX_BITOP3(v, s, H, 0x80);   // v & s & H: the byte overflows (v >= 128 and low sum >= 128)
+  const unsigned hi = ORBX_BITOP3(s, vH, o - (o >> 7), 0xFE);          // s | vH | 0x7f there: min(v + t, 255)
+  const unsigned d = (v | H) - T;                  // (128 + v_lo) - t >= 1
+  const unsigned w = ORBX_BITOP3(v, d, H, 0xA8);   // (v | d) & H: v - t >= 0 in this byte
+  const unsigned lo = ORBX_BITOP3(d, w - (w >> 7), vH, 0xE0);          // d & (mask | vH): max(v - t, 0)
+  const unsigned hiH = hi | H, loL = lo & L;
+  const unsigned g0 = swar_ge(hi, hiH, r0, r0 & L), g8 = swar_ge(hi, hiH, r8, r8 & L);
+  const unsigned g4 = swar_ge(hi, hiH, r4, r4 & L), g12 = swar_ge(hi, hiH, r12, r12 & L);
+  const unsigned e0 = swar_ge(r0, r0 | H, lo, loL), e8 = swar_ge(r8, r8 | H, lo, loL);
+  const unsigned e4 = swar_ge(r4, r4 | H, lo, loL), e12 = swar_ge(r12, r12 | H, lo, loL);
+  const unsigned nb = ORBX_BITOP3(g0 & g8, g4, g12, 0xF8);             // (r0 <= hi and r8 <= hi) or (r4 <= hi and r12 <= hi): not brighter
+  const unsigned nd = ORBX_BITOP3(e0 & e8, e4, e12, 0xF8);             // likewise not darker
+  return ORBX_BITOP3(nb, nd, H, 0x2A);             // ~(nb & nd) & H: two adjacent compass points brighter than v + t, or darker than v - t
+}
+// bits 7, 15, 23, 31 -> bits 0..3
+__device__ __forceinline__ unsigned swar_movemask(unsigned p) { return (p * 0x00204081u) >> 28; }
+// inclusive prefix sum over the 64 lanes of a wave (DPP row shifts + row broadcasts)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+  return v;
+}
+
+// SWAR: phase 1 in the byte-parallel form, eight positions per task (fast_threshold < 128; launch_orb_extract picks the variant)
+template <bool SWAR>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
                                                    unsigned* __restrict__ cand, unsigned* __restrict__ cand_count,
@@ -407,7 +487,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   {
     const int r0 = tid / 9, c = tid - 9 * r0;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < (FP_ROWS + 27) / 28; ++k) {
       const int r = r0 + 28 * k;
       if (r0 < 28 && r < ah + 6) {
         const int gy = min(y0 - 4 + r, h - 1), gx = min(x0 - 5 + 8 * c, pitch - 8);
@@ -420,6 +500,41 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   for (int i = tid; i < FS_W * FS_H / 4; i += 256) reinterpret_cast<unsigned*>(&ss[0][0])[i] = 0u;
   __syncthreads();
   const int t = g.fast_threshold;
+  if (SWAR) {
+    // phase 1, byte-parallel: a task = 8 consecutive positions of a row = the two centre dwords 2g+1, 2g+2 of LDS row j+3 (position
+    // i sits at byte i+4); the positions that pass go to the list by ONE wave prefix sum per task (count per lane, DPP scan) and a
+    // short loop over each lane's set bits — no ballot per position
+    const int qpr8 = (aw + 7) >> 3;                                  // 8-position tasks per row, 1..8
+    const int ntask8 = qpr8 * ah;
+    const unsigned inv8 = (unsigned)(65536.f / (float)qpr8) + 1u;
+    const unsigned T = (unsigned)t * 0x01010101u;
+    for (int task0 = 0; task0 < ntask8; task0 += 256) {
+      const int task = task0 + tid;
+      unsigned m8 = 0;
+      int j = 0, gq = 0;
+      if (task < ntask8) {
+        j = (int)(__umul24((unsigned)task, inv8) >> 16); gq = task - (int)__umul24((unsigned)j, (unsigned)qpr8);
+        const uint2 ca = *reinterpret_cast<const uint2*>(&sp[j + 3][8 * gq]);            // dwords 2g, 2g+1
+        const uint2 cb = *reinterpret_cast<const uint2*>(&sp[j + 3][8 * gq + 8]);        // dwords 2g+2, 2g+3
+        const unsigned* upr = reinterpret_cast<const unsigned*>(&sp[j][8 * gq + 4]);
+        const unsigned* dnr = reinterpret_cast<const unsigned*>(&sp[j + 6][8 * gq + 4]);
+        const unsigned up0 = upr[0], up1 = upr[1], dn0 = dnr[0], dn1 = dnr[1];
+        const unsigned p0 = swar_compass_pass(ca.y, dn0, __builtin_amdgcn_alignbyte(cb.x, ca.y, 3), up0, __builtin_amdgcn_alignbyte(ca.y, ca.x, 1), T);
+        const unsigned p1 = swar_compass_pass(cb.x, dn1, __builtin_amdgcn_alignbyte(cb.y, cb.x, 3), up1, __builtin_amdgcn_alignbyte(cb.x, ca.y, 1), T);
+        m8 = swar_movemask(p0) | (swar_movemask(p1) << 4);
+      }
+      const int cnt = __popc(m8);
+      const int incl = wave_scan_incl(cnt);
+      const int wtot = __builtin_amdgcn_readlane(incl, 63);
+      if (wtot) {                                                    // wave-uniform
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_npos, wtot);
+        int off = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+        const unsigned short pbase = (unsigned short)(j * FS_W + 8 * gq);
+        for (unsigned mm = m8; mm; mm &= mm - 1u) s_pos[off++] = (unsigned short)(pbase + (__ffs((int)mm) - 1));
+      }
+    }
+  } else
   // phase 1: compass pre-test, 4 positions per task
   for (int task = tid; task < ntask; task += 256) {
     const int j = (int)(__umul24((unsigned)task, inv) >> 16), tq = task - (int)__umul24((unsigned)j, (unsigned)qpr);   // (v_mul_lo_u32 is quarter rate)
@@ -485,8 +600,8 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     const int hi = v + t, lo = v - t;
     const bool brighter = min(max(r[0], r[8]), max(r[4], r[12])) > hi;
     const bool darker = max(min(r[0], r[8]), min(r[4], r[12])) < lo;
-    int b = fast_arc_min_pk(v, r, brighter);
-    if (brighter && darker) b = max(b, fast_arc_min_pk(v, r, false));   // both passed (rare)
+    int b = fast_arc_min_h(v, r, brighter);
+    if (brighter && darker) b = max(b, fast_arc_min_h(v, r, false));    // both passed (rare)
     const int sc = b > t ? b - 1 : 0;
     ss[j][i] = (uint8_t)sc;
     // corners inside the tile and the border-filtered region go on to NMS (a few per cent of the survivors: the
@@ -1296,8 +1411,12 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     if (fork) ORBX_HIP(h, hipEventRecord(h->ev_join, h->s_aux));
     if (g.ftiles_total > 0) {
       ProfScope ps(h, "fast_kernel", nullptr, true);
-      hipLaunchKernelGGL(fast_kernel, xcd_grid(g.ftiles_total, n), dim3(256), 0, st, s, g, n, xcd_map(g.ftiles_total),
-                         tab + h->ftile_tab_off, cand, cc, hs);
+      if (g.fast_threshold < 128)
+        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(g.ftiles_total, n), dim3(256), 0, st, s, g, n, xcd_map(g.ftiles_total),
+                           tab + h->ftile_tab_off, cand, cc, hs);
+      else
+        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(g.ftiles_total, n), dim3(256), 0, st, s, g, n, xcd_map(g.ftiles_total),
+                           tab + h->ftile_tab_off, cand, cc, hs);
     }
     {
       ProfScope ps(h, "harris_select_kernel", nullptr, true);

@@ -8,7 +8,7 @@ mkdir -p $O
 for rep in 1 2; do
   for so in "$@"; do
     n=$(basename $so .so)
-    ORBX_LIBRARY=$PWD/$so python bench.py --no-cpu-baseline --no-ba --no-files > $O/${n}_$rep.json 2> $O/${n}_$rep.err
+    ORBX_LIBRARY=$PWD/$so python bench.py --no-cpu-baseline --no-ba --no-files --no-extras --steps 20 > $O/${n}_$rep.json 2> $O/${n}_$rep.err
     python - "$O/${n}_$rep.json" "$n" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

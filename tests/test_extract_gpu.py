@@ -236,7 +236,8 @@ def test_pipelined_host_batch_equals_device_batch(pkg):
     h.close(); h2.close()
 
 
-@pytest.mark.parametrize("over", [dict(n_levels=4), dict(fast_threshold=10), dict(fast_threshold=45, n_levels=6),
+@pytest.mark.parametrize("over", [dict(n_levels=4), dict(fast_threshold=10), dict(fast_threshold=45, n_levels=6), dict(fast_threshold=127), dict(fast_threshold=128),
+                                  dict(fast_threshold=150, n_levels=3), dict(fast_threshold=1, n_levels=2),
                                   dict(scale_factor=1.3), dict(scale_factor=1.5, n_levels=5), dict(n_levels=1)])
 def test_orb_parameter_variations(oracle, pkg, over):
     """the ORB parameters the ABI lets vary (levels, scale factor, FAST threshold) — still bit-exact"""
@@ -248,8 +249,8 @@ def test_orb_parameter_variations(oracle, pkg, over):
     kpL, dL, kpR, dR, m, pts, has = h.process_stereo(L, R)
     ok, od = oracle.orb_extract(L, p)
     assert records_equal(kpL, ok), _first_diff(kpL, ok) if len(kpL) == len(ok) else "%d vs %d" % (len(kpL), len(ok))
-    assert np.array_equal(dL, od) and len(ok) > 300
-    assert int(kpL["octave"].max()) == p.n_levels - 1
+    assert np.array_equal(dL, od) and len(ok) > (300 if p.fast_threshold < 100 else 0)
+    assert len(ok) == 0 or int(kpL["octave"].max()) <= p.n_levels - 1
     h.close()
 
 
