@@ -358,36 +358,39 @@ __device__ __forceinline__ int fast_arc_min_pk(int v, const int (&r)[16], bool b
 }
 
 // The same maximum over the 16 arcs in packed f16 with the three-input minimum / maximum of gfx950 (v_pk_minimum3_f16,
-// v_pk_maximum3_f16: one issue slot like every packed instruction, two comparisons per lane instead of one).  Pixels enter as
-// 1024 + p (0x6400 | p: exact in f16, ulp 1 on [1024, 2048)), so s*(centre - ring) is an exact small integer and every min / max
-// is exact: 9-windows as min3 of min3 (X[j..j+2], then windows j, j+3, j+6) instead of a 2-4-8(+1) ladder — 16 + 4 instructions
-// for the window minima and their maximum instead of 39.
+// v_pk_maximum3_f16: one issue slot like every packed instruction, two comparisons per lane instead of one).  A pixel byte p IS
+// an f16 bit pattern: the denormal p * 2^-24 (the kernels run with f16 denormals kept, .amdhsa_float_denorm_mode_16_64 3), and
+// denormals order and add exactly like the integers they hold.  The score of a polarity s (+1 brighter, -1 darker) is
+//     max over the 16 arcs of min over the arc of s*(ring - centre)  =  [max over arcs of min over the arc of s*ring] - s*centre,
+// so the centre leaves the window ladder: s*ring is the sign bit (one v_or_b32, 2-cycle class, instead of a v_pk_fma_f16 per pair),
+// 9-windows are min3 of min3 (X[j..j+2], then windows j, j+3, j+6: 16 instructions instead of the 2-4-8(+1) ladder's 32), their
+// maximum is 5 maximum3, and one v_add_f16 of -s*centre gives the score, whose bits read as an int16 are the score itself when it
+// is positive and a negative number otherwise (sign-magnitude, -0 included).
 typedef _Float16 fast_h2 __attribute__((ext_vector_type(2)));
 // minimum3 with the 2nd / 3rd operand half-swapped (ring position + 8 lives in the other half of the register)
 __device__ __forceinline__ fast_h2 pk_min3_00(fast_h2 a, fast_h2 b, fast_h2 c) { fast_h2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ fast_h2 pk_min3_01(fast_h2 a, fast_h2 b, fast_h2 c) { fast_h2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ fast_h2 pk_min3_11(fast_h2 a, fast_h2 b, fast_h2 c) { fast_h2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ fast_h2 pk_max3(fast_h2 a, fast_h2 b, fast_h2 c) { fast_h2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ int fast_arc_min_h(int v, const int (&r)[16], bool brighter) {
+// low half = max(a.lo, a.hi) (high half unused)
+__device__ __forceinline__ fast_h2 pk_max_halves(fast_h2 a) { fast_h2 d; asm("v_pk_maximum3_f16 %0, %1, %1, %1 op_sel:[0,1,1]" : "=v"(d) : "v"(a)); return d; }
+// P[j] = ring[j] | ring[j + 8] << 16; returns the arc score of the polarity when it is positive, a negative number otherwise
+__device__ __forceinline__ int fast_arc_score_h(unsigned v, const unsigned (&P)[8], bool brighter) {
   fast_h2 X[8], B[8], W[8];
-  const unsigned cbits = 0x6400u | (unsigned)v;                       // 1024 + centre
-  const _Float16 cf = __builtin_bit_cast(_Float16, (unsigned short)cbits);
-  const _Float16 one = (_Float16)1.0f;
-  const fast_h2 m = brighter ? fast_h2{one, one} : fast_h2{-one, -one};
-  const fast_h2 c = brighter ? fast_h2{-cf, -cf} : fast_h2{cf, cf};
+  const unsigned sgn = brighter ? 0u : 0x80008000u;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const unsigned rp = ((unsigned)r[j] | ((unsigned)r[j + 8] << 16)) | 0x64006400u;
-    X[j] = __builtin_elementwise_fma(__builtin_bit_cast(fast_h2, rp), m, c);   // s*(centre - ring), exact: one v_pk_fma_f16
-  }
+  for (int j = 0; j < 8; ++j) X[j] = __builtin_bit_cast(fast_h2, P[j] ^ sgn);
 #pragma unroll
   for (int j = 0; j < 8; ++j)                                         // windows of 3: positions j, j+1, j+2
     B[j] = j + 2 < 8 ? pk_min3_00(X[j], X[j + 1], X[j + 2]) : (j + 1 < 8 ? pk_min3_01(X[j], X[j + 1], X[j - 6]) : pk_min3_11(X[j], X[j - 7], X[j - 6]));
 #pragma unroll
   for (int j = 0; j < 8; ++j)                                         // windows of 9: windows of 3 at j, j+3, j+6
     W[j] = j + 6 < 8 ? pk_min3_00(B[j], B[j + 3], B[j + 6]) : (j + 3 < 8 ? pk_min3_01(B[j], B[j + 3], B[j - 2]) : pk_min3_11(B[j], B[j - 5], B[j - 2]));
-  const fast_h2 best = __builtin_elementwise_max(pk_max3(W[0], W[1], W[2]), pk_max3(W[3], W[4], pk_max3(W[5], W[6], W[7])));
-  return (int)(best[0] > best[1] ? best[0] : best[1]);
+  const fast_h2 m1 = pk_max3(W[0], W[1], W[2]), m2 = pk_max3(W[3], W[4], W[5]), m3 = pk_max3(W[6], W[7], m1);
+  const fast_h2 best = pk_max_halves(pk_max3(m2, m3, m3));
+  const _Float16 mc = __builtin_bit_cast(_Float16, (unsigned short)(brighter ? (v | 0x8000u) : v));   // -s * centre
+  const _Float16 b = best[0] + mc;
+  return (int)__builtin_bit_cast(short, b);
 }
 
 // Two-phase per tile.  Score region 64 x 48 positions (inner 62 x 46 + 1-position NMS frame), pixel tile
@@ -588,20 +591,25 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   for (int q = tid; q < npos; q += 256) {
     const int p = s_pos[q], j = p >> 6, i = p & 63;
     const int cy = j + 3, cx = i + 4;
-    const int v = sp[cy][cx];
-    int r[16];
+    const unsigned v = sp[cy][cx];
+    unsigned r[16];
     r[0] = sp[cy + 3][cx];      r[1] = sp[cy + 3][cx + 1];  r[2] = sp[cy + 2][cx + 2];
     r[3] = sp[cy + 1][cx + 3];  r[4] = sp[cy][cx + 3];      r[5] = sp[cy - 1][cx + 3];
     r[6] = sp[cy - 2][cx + 2];  r[7] = sp[cy - 3][cx + 1];  r[8] = sp[cy - 3][cx];
     r[9] = sp[cy - 3][cx - 1];  r[10] = sp[cy - 2][cx - 2]; r[11] = sp[cy - 1][cx - 3];
     r[12] = sp[cy][cx - 3];     r[13] = sp[cy + 1][cx - 3]; r[14] = sp[cy + 2][cx - 2];
     r[15] = sp[cy + 3][cx - 1];
+    // (one unaligned LDS read per ring row, 2 x b32 + 5 x b64, plus a v_perm_b32 per pair measured 1.10 ms against 0.63: the
+    // unaligned reads are slow)
     // which polarity passed the compass pre-test (the other one cannot exceed the threshold)
-    const int hi = v + t, lo = v - t;
-    const bool brighter = min(max(r[0], r[8]), max(r[4], r[12])) > hi;
-    const bool darker = max(min(r[0], r[8]), min(r[4], r[12])) < lo;
-    int b = fast_arc_min_h(v, r, brighter);
-    if (brighter && darker) b = max(b, fast_arc_min_h(v, r, false));    // both passed (rare)
+    const int hi = (int)v + t, lo = (int)v - t;
+    const bool brighter = (int)min(max(r[0], r[8]), max(r[4], r[12])) > hi;
+    const bool darker = (int)max(min(r[0], r[8]), min(r[4], r[12])) < lo;
+    unsigned P[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P[k] = r[k] | (r[k + 8] << 16);
+    int b = fast_arc_score_h(v, P, brighter);
+    if (brighter && darker) b = max(b, fast_arc_score_h(v, P, false));    // both passed (rare)
     const int sc = b > t ? b - 1 : 0;
     ss[j][i] = (uint8_t)sc;
     // corners inside the tile and the border-filtered region go on to NMS (a few per cent of the survivors: the
