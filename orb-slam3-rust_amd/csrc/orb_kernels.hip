@@ -47,8 +47,7 @@ __constant__ __attribute__((aligned(16))) signed char c_pattern[256 * 4];
 // step — these kernels launch 100k+ short blocks and a generic division is ~40 scalar instructions
 // of prologue.  Speed only; any placement gives the same results.
 struct XcdMap { unsigned per_img, magic; };
-__device__ __forceinline__ bool xcd_decode(XcdMap m, int n_img, int& img, int& b) {
-  const unsigned L = blockIdx.x;
+__device__ __forceinline__ bool xcd_decode_at(XcdMap m, int n_img, unsigned L, int& img, int& b) {
   const unsigned x = L & 7u, slot = L >> 3;
   unsigned grp = __umulhi(slot, m.magic);
   unsigned r = slot - grp * m.per_img;
@@ -57,6 +56,7 @@ __device__ __forceinline__ bool xcd_decode(XcdMap m, int n_img, int& img, int& b
   img = (int)(grp * 8u + x);
   return img < n_img;
 }
+__device__ __forceinline__ bool xcd_decode(XcdMap m, int n_img, int& img, int& b) { return xcd_decode_at(m, n_img, blockIdx.x, img, b); }
 static inline XcdMap xcd_map(int per_img) {
   return XcdMap{(unsigned)per_img, per_img > 1 ? (unsigned)(0x100000000ull / (unsigned)per_img) : 0xffffffffu};
 }
@@ -404,6 +404,10 @@ __device__ __forceinline__ int fast_arc_score_h(unsigned v, const unsigned (&P)[
 constexpr int FT_W = 62, FT_H = 46;          // inner tile (heights 30 / 46 / 62: 0.837 / 0.821 / 0.835 ms per 256 pairs)
 constexpr int FS_W = 64, FS_H = 48;          // score region
 constexpr int FP_PITCH = 72, FP_ROWS = FS_H + 6;
+#ifndef ORBX_FAST_CHAIN
+#define ORBX_FAST_CHAIN 3
+#endif
+constexpr int FAST_CHAIN = ORBX_FAST_CHAIN;   // tiles per block
 static_assert(FP_ROWS <= 84, "the staging loop covers up to 3 x 28 rows");
 static_assert((FT_W / 2) * (FT_H / 2) <= 1024, "s_list holds the NMS survivors of a tile");
 
@@ -459,7 +463,7 @@ template <bool SWAR>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
                                                    unsigned* __restrict__ cand, unsigned* __restrict__ cand_count,
-                                                   unsigned* __restrict__ hist) {
+                                                   unsigned* __restrict__ hist, int n_tiles) {
   __shared__ __attribute__((aligned(16))) uint8_t sp[FP_ROWS][FP_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t ss[FS_H][FS_W];
   __shared__ __attribute__((aligned(4))) unsigned short s_pos[FS_W * FS_H];
@@ -469,39 +473,59 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   __shared__ unsigned short s_cor[FS_W * FS_H];
   __shared__ int s_npos, s_cnt, s_ncor;
   __shared__ unsigned s_base;
-  int img, tile;
-  if (!xcd_decode(xm, n_img, img, tile)) return;
-  int l, tx, ty;
-  decode_tile(tile_tab, tile, l, tx, ty);
-  int pitch;
-  const uint8_t* src = level_ptr(s, g, img, l, pitch);
-  const int w = g.lv[l].w, h = g.lv[l].h;
-  const int x0 = EDGE + tx * FT_W, y0 = EDGE + ty * FT_H;   // first inner pixel; score position (i,j) = pixel (x0-1+i, y0-1+j)
+  // A block works through FAST_CHAIN consecutive tiles of one image and loads the NEXT tile's pixels into registers while it works
+  // on the current one: with one tile per block the chain  kernel arguments -> tile table -> pixels  (about 2 us) is exposed in
+  // every block (phase-skipping builds measured staging alone at 0.18 ms of 0.63 per 256 pairs, added to the compute phases rather
+  // than hidden under the other blocks of the CU).  Short chains keep the hardware's dynamic block dispatch as the load balancer:
+  // fully persistent blocks measured worse both ways — a fixed stride 0.71 ms (tile costs differ, the slowest of 2048 fixed shares
+  // sets the time) and tickets from 8 per-XCD queues 2.0 ms (170k same-address device atomics serialise at ~100 ns each).
   const int tid = threadIdx.x, lane = tid & 63;
+  const int st_r0 = tid / 9, st_c = tid - 9 * st_r0;               // staging: 9 lanes x 8 bytes per 72-byte row, 28 rows per pass
+  constexpr int ST_PASS = (FP_ROWS + 27) / 28;
+  unsigned long long pf[ST_PASS];
+  struct Tile { int img, l, x0, y0, w, h, aw, ah; };
+  Tile cur, nxt;
+  // tile -> geometry, and the loads of its pixels into pf
+  auto fetch = [&](int img_, int tile, Tile& c) {
+    c.img = img_;
+    int tx, ty;
+    decode_tile(tile_tab, tile, c.l, tx, ty);
+    int pitch;
+    const uint8_t* src = level_ptr(s, g, c.img, c.l, pitch);
+    c.w = g.lv[c.l].w; c.h = g.lv[c.l].h;
+    c.x0 = EDGE + tx * FT_W; c.y0 = EDGE + ty * FT_H;   // first inner pixel; score position (i,j) = pixel (x0-1+i, y0-1+j)
+    // score positions this tile needs (inner part that lies inside the border-filtered region + the NMS frame): tiles on
+    // the right / bottom edge of a level are partial — 28 % of all tile area at 752x480 — and only pay for what they hold
+    c.aw = min(FT_W, c.w - EDGE - c.x0) + 2; c.ah = min(FT_H, c.h - EDGE - c.y0) + 2;
+    // pixel tile: LDS row r = image row y0-4+r, byte b = image column x0-5+b
+#pragma unroll
+    for (int k = 0; k < ST_PASS; ++k) {
+      const int r = st_r0 + 28 * k;
+      if (st_r0 < 28 && r < c.ah + 6) {
+        const int gy = min(c.y0 - 4 + r, c.h - 1), gx = min(c.x0 - 5 + 8 * st_c, pitch - 8);
+        __builtin_memcpy(&pf[k], src + (size_t)gy * pitch + gx, 8);
+      }
+    }
+  };
+  int img0, chain;
+  if (!xcd_decode(xm, n_img, img0, chain)) return;
+  const int tile0 = chain * FAST_CHAIN, tile_end = min(tile0 + FAST_CHAIN, n_tiles);
+  fetch(img0, tile0, cur);
+  for (int tile = tile0; tile < tile_end; ++tile) {
+  const int img = cur.img, l = cur.l, x0 = cur.x0, y0 = cur.y0, w = cur.w, h = cur.h, aw = cur.aw, ah = cur.ah;
   if (tid == 0) { s_npos = 0; s_cnt = 0; s_ncor = 0; }
-  // score positions this tile needs (inner part that lies inside the border-filtered region + the NMS frame): tiles on
-  // the right / bottom edge of a level are partial — 28 % of all tile area at 752x480 — and only pay for what they hold
-  const int aw = min(FT_W, w - EDGE - x0) + 2, ah = min(FT_H, h - EDGE - y0) + 2;
   const int qpr = (aw + 3) >> 2;                                   // 4-position tasks per row, 1..16
   const int ntask = qpr * ah;
   const unsigned inv = (unsigned)(65536.f / (float)qpr) + 1u;      // task / qpr = (task * inv) >> 16, exact for task < 512
-  // pixel tile: LDS row r = image row y0-4+r, byte b = image column x0-5+b.  9 lanes x 8 bytes per 72-byte row, 28 rows
-  // per pass (the division by 9 is of tid, once)
-  {
-    const int r0 = tid / 9, c = tid - 9 * r0;
 #pragma unroll
-    for (int k = 0; k < (FP_ROWS + 27) / 28; ++k) {
-      const int r = r0 + 28 * k;
-      if (r0 < 28 && r < ah + 6) {
-        const int gy = min(y0 - 4 + r, h - 1), gx = min(x0 - 5 + 8 * c, pitch - 8);
-        unsigned long long v;
-        __builtin_memcpy(&v, src + (size_t)gy * pitch + gx, 8);
-        *reinterpret_cast<unsigned long long*>(&sp[r][8 * c]) = v;
-      }
-    }
+  for (int k = 0; k < ST_PASS; ++k) {
+    const int r = st_r0 + 28 * k;
+    if (st_r0 < 28 && r < ah + 6) *reinterpret_cast<unsigned long long*>(&sp[r][8 * st_c]) = pf[k];
   }
   for (int i = tid; i < FS_W * FS_H / 4; i += 256) reinterpret_cast<unsigned*>(&ss[0][0])[i] = 0u;
   __syncthreads();
+  // the next tile's pixels travel while this one is processed (the barriers below wait for LDS only, not for these loads)
+  if (tile + 1 < tile_end) fetch(img0, tile + 1, nxt);
   const int t = g.fast_threshold;
   if (SWAR) {
     // phase 1, byte-parallel: a task = 8 consecutive positions of a row = the two centre dwords 2g+1, 2g+2 of LDS row j+3 (position
@@ -650,6 +674,10 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     const unsigned c = s_list[q];
     cand[(size_t)img * g.cand_total + g.lv[l].cand_off + s_base + q] = c;
     atomicAdd(&hist[(size_t)il * 256 + (c >> 24)], 1u);
+  }
+  // (no barrier here: the next round writes only what this tail does not read — pixels, scores and the three counters — before
+  // its first barrier, and the list / s_base after it)
+  cur = nxt;
   }
 }
 
@@ -1419,12 +1447,11 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     if (fork) ORBX_HIP(h, hipEventRecord(h->ev_join, h->s_aux));
     if (g.ftiles_total > 0) {
       ProfScope ps(h, "fast_kernel", nullptr, true);
+      const int chains = (g.ftiles_total + FAST_CHAIN - 1) / FAST_CHAIN;
       if (g.fast_threshold < 128)
-        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(g.ftiles_total, n), dim3(256), 0, st, s, g, n, xcd_map(g.ftiles_total),
-                           tab + h->ftile_tab_off, cand, cc, hs);
+        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(chains, n), dim3(256), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total);
       else
-        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(g.ftiles_total, n), dim3(256), 0, st, s, g, n, xcd_map(g.ftiles_total),
-                           tab + h->ftile_tab_off, cand, cc, hs);
+        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(chains, n), dim3(256), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total);
     }
     {
       ProfScope ps(h, "harris_select_kernel", nullptr, true);

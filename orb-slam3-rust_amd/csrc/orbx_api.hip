@@ -125,6 +125,7 @@ int orbx_create(const orbx_camera* cam, const orbx_orb_params* orb, int device, 
                      device, prop.gcnArchName);
   orbx_handle* h = new orbx_handle();
   h->device = device; h->cam = *cam; h->orb = *orb;
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   h->max_w = max_w; h->max_h = max_h; h->max_batch = max_batch;
   if (hipSetDevice(device) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||

@@ -62,6 +62,7 @@ struct KernelTimer {
 
 struct orbx_handle {
   int device = -1;
+  int n_cu = 256;                 // compute units of the device (persistent launches size their grids by it)
   hipStream_t stream = nullptr;
   orbx_camera cam{};
   orbx_orb_params orb{};
