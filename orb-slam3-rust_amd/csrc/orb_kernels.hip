@@ -467,11 +467,8 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   __shared__ __attribute__((aligned(16))) uint8_t sp[FP_ROWS][FP_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t ss[FS_H][FS_W];
   __shared__ __attribute__((aligned(4))) unsigned short s_pos[FS_W * FS_H];
-  // NMS survivors (at most one per 2x2 positions, 31 x 23) reuse the pre-test list, which phase 3 no longer reads
-  unsigned* const s_list = reinterpret_cast<unsigned*>(s_pos);
-  static_assert(sizeof(unsigned short) * FS_W * FS_H >= 4 * 1024, "s_list aliases s_pos");
-  __shared__ unsigned short s_cor[FS_W * FS_H];
-  __shared__ int s_npos, s_cnt, s_ncor;
+  __shared__ unsigned s_list[(FT_W / 2) * (FT_H / 2) + 1];   // NMS survivors: at most one per 2x2 positions
+  __shared__ int s_npos, s_cnt;
   __shared__ unsigned s_base;
   // A block works through FAST_CHAIN consecutive tiles of one image and loads the NEXT tile's pixels into registers while it works
   // on the current one: with one tile per block the chain  kernel arguments -> tile table -> pixels  (about 2 us) is exposed in
@@ -511,9 +508,21 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   if (!xcd_decode(xm, n_img, img0, chain)) return;
   const int tile0 = chain * FAST_CHAIN, tile_end = min(tile0 + FAST_CHAIN, n_tiles);
   fetch(img0, tile0, cur);
+  // The append of a tile's corners to its level's list needs a returning global atomic (about 2 us); it is issued when the tile's
+  // NMS is done and consumed one phase into the NEXT tile, so only the last tile of a chain waits for it.
+  int pend_cnt = 0, pend_il = 0;
+  unsigned pend_off = 0, pend_base = 0;
+  auto flush = [&]() {
+    for (int q = tid; q < pend_cnt; q += 256) {
+      const unsigned c = s_list[q];
+      cand[(size_t)img0 * g.cand_total + pend_off + s_base + q] = c;
+      atomicAdd(&hist[(size_t)pend_il * 256 + (c >> 24)], 1u);
+    }
+  };
+  if (tid == 0) s_cnt = 0;
   for (int tile = tile0; tile < tile_end; ++tile) {
   const int img = cur.img, l = cur.l, x0 = cur.x0, y0 = cur.y0, w = cur.w, h = cur.h, aw = cur.aw, ah = cur.ah;
-  if (tid == 0) { s_npos = 0; s_cnt = 0; s_ncor = 0; }
+  if (tid == 0) s_npos = 0;
   const int qpr = (aw + 3) >> 2;                                   // 4-position tasks per row, 1..16
   const int ntask = qpr * ah;
   const unsigned inv = (unsigned)(65536.f / (float)qpr) + 1u;      // task / qpr = (task * inv) >> 16, exact for task < 512
@@ -522,7 +531,8 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     const int r = st_r0 + 28 * k;
     if (st_r0 < 28 && r < ah + 6) *reinterpret_cast<unsigned long long*>(&sp[r][8 * st_c]) = pf[k];
   }
-  for (int i = tid; i < FS_W * FS_H / 4; i += 256) reinterpret_cast<unsigned*>(&ss[0][0])[i] = 0u;
+  static_assert(FS_W * FS_H / 16 <= 256, "one 16-byte store per thread clears the score tile");
+  if (tid < FS_W * FS_H / 16) reinterpret_cast<uint4*>(&ss[0][0])[tid] = uint4{0u, 0u, 0u, 0u};
   __syncthreads();
   // the next tile's pixels travel while this one is processed (the barriers below wait for LDS only, not for these loads)
   if (tile + 1 < tile_end) fetch(img0, tile + 1, nxt);
@@ -533,7 +543,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     // short loop over each lane's set bits — no ballot per position
     const int qpr8 = (aw + 7) >> 3;                                  // 8-position tasks per row, 1..8
     const int ntask8 = qpr8 * ah;
-    const unsigned inv8 = (unsigned)(65536.f / (float)qpr8) + 1u;
+    const unsigned inv8 = (unsigned)(65536.f * __builtin_amdgcn_rcpf((float)qpr8)) + 1u;   // (v_rcp_f32 is within 1 ulp: the floor is the quotient's for 1..8)
     const unsigned T = (unsigned)t * 0x01010101u;
     for (int task0 = 0; task0 < ntask8; task0 += 256) {
       const int task = task0 + tid;
@@ -609,8 +619,10 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
       if (pk3) s_pos[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, 0u))] = p0 + 3;
     }
   }
+  if (tid == 0 && pend_cnt > 0) { s_base = pend_base; s_cnt = 0; }   // (the wait for the previous tile's atomic, one phase later)
   __syncthreads();
   const int npos = s_npos;
+  flush();                                                           // previous tile's corners; phase 3 below rewrites s_list
   // phase 2: full score of the pre-test survivors
   for (int q = tid; q < npos; q += 256) {
     const int p = s_pos[q], j = p >> 6, i = p & 63;
@@ -636,49 +648,37 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     if (brighter && darker) b = max(b, fast_arc_score_h(v, P, false));    // both passed (rare)
     const int sc = b > t ? b - 1 : 0;
     ss[j][i] = (uint8_t)sc;
-    // corners inside the tile and the border-filtered region go on to NMS (a few per cent of the survivors: the
-    // pre-test also passes every straight edge)
-    const bool corner = sc > 0 && i >= 1 && i <= FT_W && j >= 1 && j <= FT_H && x0 + i - 1 < w - EDGE && y0 + j - 1 < h - EDGE;
-    const unsigned long long cm = __ballot(corner);
-    if (cm) {
-      const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
-      int base = 0;
-      if (lane == leader) base = atomicAdd(&s_ncor, __popcll(cm));
-      base = __builtin_amdgcn_readlane(base, leader);
-      if (corner) s_cor[base + __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] = (unsigned short)p;
-    }
   }
   __syncthreads();
-  // phase 3: NMS (strictly greater than the 8 neighbours) + runByImageBorder, over the list
-  const int ncor = s_ncor;
-  for (int q = tid; q < ncor; q += 256) {
-    const int p = s_cor[q];
+  // phase 3: NMS (strictly greater than the 8 neighbours) + runByImageBorder, over the same list: corners inside the tile and the
+  // border-filtered region (a few per cent of the survivors — the pre-test also passes every straight edge)
+  for (int q = tid; q < npos; q += 256) {
+    const int p = s_pos[q];
     const int j = p >> 6, i = p & 63;
     const int x = x0 + i - 1, y = y0 + j - 1;
     const int sc = ss[j][i];
-    {
-      const bool keep = sc > ss[j - 1][i - 1] && sc > ss[j - 1][i] && sc > ss[j - 1][i + 1] && sc > ss[j][i - 1] &&
-                        sc > ss[j][i + 1] && sc > ss[j + 1][i - 1] && sc > ss[j + 1][i] && sc > ss[j + 1][i + 1];
-      if (keep) {
+    const bool corner = sc > 0 && i >= 1 && i <= FT_W && j >= 1 && j <= FT_H && x < w - EDGE && y < h - EDGE;
+    if (corner) {
+      const int m = max(max(max((int)ss[j - 1][i - 1], (int)ss[j - 1][i]), max((int)ss[j - 1][i + 1], (int)ss[j][i - 1])),
+                        max(max((int)ss[j][i + 1], (int)ss[j + 1][i - 1]), max((int)ss[j + 1][i], (int)ss[j + 1][i + 1])));
+      if (sc > m) {
         const int pos = atomicAdd(&s_cnt, 1);
         s_list[pos] = ((unsigned)sc << 24) | ((unsigned)y << 12) | (unsigned)x;
       }
     }
   }
   __syncthreads();
-  const int il = img * g.n_levels + l;
-  const int cnt = s_cnt;
-  if (tid == 0 && cnt > 0) s_base = atomicAdd(&cand_count[il], (unsigned)cnt);
-  __syncthreads();
-  for (int q = tid; q < cnt; q += 256) {
-    const unsigned c = s_list[q];
-    cand[(size_t)img * g.cand_total + g.lv[l].cand_off + s_base + q] = c;
-    atomicAdd(&hist[(size_t)il * 256 + (c >> 24)], 1u);
-  }
-  // (no barrier here: the next round writes only what this tail does not read — pixels, scores and the three counters — before
-  // its first barrier, and the list / s_base after it)
+  pend_cnt = s_cnt;
+  pend_il = img * g.n_levels + l;
+  pend_off = g.lv[l].cand_off;
+  if (tid == 0 && pend_cnt > 0) pend_base = atomicAdd(&cand_count[pend_il], (unsigned)pend_cnt);
+  // (no barrier here: the next round writes pixels, scores and s_npos before its first barrier, the position list after it, and
+  // s_cnt / s_base / s_list only after the flush above)
   cur = nxt;
   }
+  if (tid == 0 && pend_cnt > 0) s_base = pend_base;
+  __syncthreads();
+  flush();
 }
 
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p) {   // unaligned dword load (global_load_dword)
