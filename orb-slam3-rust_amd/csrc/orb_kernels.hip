@@ -5,13 +5,14 @@
 // covers all images, and all pyramid levels where there is no level-to-level dependency:
 //
 //   copy_l0_kernel        (only if the caller's rows are not 4-byte aligned)
-//   resize_kernel  x7     level l from level l-1, INTER_LINEAR_EXACT fixed point: 4 px x 3 rows per thread,
+//   resize_kernel  x7     level l from level l-1, INTER_LINEAR_EXACT fixed point: 4 px x 6 rows per thread from an LDS-staged source tile,
 //                         8-byte source windows, v_dot4 taps                                  (A.4)
 //   blur_kernel           7x7 sigma-2 fixed-point Gaussian of every level: register window walking down
 //                         column strips (no LDS), DPP neighbours, v_dot4 / v_dot2 taps       (A.8)
-//   fast_kernel           FAST-9/16 score + 3x3 NMS + border filter on 62x46 LDS tiles: packed compass
-//                         pre-test, compacted survivors, arc score; per-level candidate lists + score
-//                         histograms                                                          (A.5)
+//   fast_kernel           FAST-9/16 score + 3x3 NMS + border filter on 62x46 LDS tiles, 3 tiles per block with the next
+//                         tile's pixels prefetched: byte-parallel compass pre-test (v_bitop3_b32), compacted survivors,
+//                         arc score on f16 denormals (v_pk_minimum3/maximum3_f16), deferred append; per-level
+//                         candidate lists + score histograms                                  (A.5)
 //   harris_select_kernel  retainBest(2 n_l) by FAST score via the histogram, Harris response
 //                         of the survivors                                                    (A.6)
 //   rank_select_kernel    canonical order (response desc, y, x) by bitonic sort in LDS, retainBest(n_l)
@@ -85,7 +86,12 @@ __global__ __launch_bounds__(256) void copy_l0_kernel(const uint8_t* __restrict_
 // one unaligned 8-byte window; a tap pair is (window >> 8*o) and the 8.8 horizontal sum is one
 // v_dot4_u32_u8:  cx0*p0 + cx1*p1 = (cx0-1)*p0 + cx1*p1 + p0  (cx0 = 256-cx1 can be 256, cx0-1 fits a byte).
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
-constexpr int RESIZE_ROWS = 3;   // output rows per thread (y, y+16, y+32): 1 row 0.245 ms, 2 rows 0.196 per 128 pairs; 2 / 3 / 4 rows 0.362 / 0.334 / 0.336 per 256
+#ifndef ORBX_RESIZE_ROWS
+#define ORBX_RESIZE_ROWS 6
+#endif
+// output rows per thread (y, y+16, ...).  Direct-load form: 2 / 3 / 4 rows 0.362 / 0.334 / 0.336 ms per 256 pairs; LDS-staged form
+// (below): 2 / 3 / 4 / 6 / 8 rows 0.343 / 0.300 / 0.291 / 0.260 / ~0.27
+constexpr int RESIZE_ROWS = ORBX_RESIZE_ROWS;
 // byte 2 of four dwords as one dword: three v_perm_b32 / or instead of four shifts and three shift-ors
 __device__ __forceinline__ unsigned pack_byte2(unsigned a, unsigned b, unsigned c, unsigned d) {
   return __builtin_amdgcn_perm(b, a, 0x0c0c0602u) | __builtin_amdgcn_perm(d, c, 0x06020c0cu);
@@ -96,53 +102,117 @@ __device__ __forceinline__ unsigned resize_h(unsigned long long win, int o, unsi
   return __builtin_amdgcn_udot4(pr, coef, pr & 0xffu, false);
 }
 
-__global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l, int n_img, XcdMap xm, int tiles_x, int tiles_y,
+// What bound the first form of this kernel (every thread loading its own unaligned 8-byte windows from global memory, 6 per thread)
+// was the texture addresser: TA busy 73 % at 2.5 TB/s of traffic, VALU half idle (profiles/r01l_pmc_sq_b256.txt).  Now the block
+// stages its source rectangle — at most 73 rows x 128 bytes for scale factors up to 1.5 — with aligned 16-byte loads (a quarter of
+// the lane requests) and the windows come from LDS as three aligned dwords + two v_alignbyte_b32 (unaligned LDS reads are slow).
+constexpr int RZ_LP = 128;                                               // LDS row pitch: 8 x 16 bytes (60 * 1.5 + 8 + 15 = 113)
+constexpr int RZ_SRC_ROWS = (16 * RESIZE_ROWS - 1) * 3 / 2 + 3;          // source rows under 16*RESIZE_ROWS output rows at scale 1.5
+#ifndef ORBX_RESIZE_CHAIN
+#define ORBX_RESIZE_CHAIN 1
+#endif
+// consecutive tiles per block with the next one's source loads in flight under the current one's arithmetic: 1 / 2 / 3 tiles
+// 0.260 / 0.304 / 0.334 ms per 256 pairs — the upper levels have too few tiles to give any away (level 7: 8 per image)
+constexpr int RESIZE_CHAIN = ORBX_RESIZE_CHAIN;
+__global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l, int n_img, XcdMap xm, int tiles_x, int n_tiles,
                                                      const unsigned* __restrict__ xtab,
                                                      const unsigned* __restrict__ ytab) {
-  int img, tb;
-  if (!xcd_decode(xm, n_img, img, tb)) return;
-  const int tby = tb / tiles_x, tbx = tb - tby * tiles_x;
+  __shared__ __attribute__((aligned(16))) uint8_t st[RZ_SRC_ROWS * RZ_LP + 16];
+  int img, chain;
+  if (!xcd_decode(xm, n_img, img, chain)) return;
   int sp;
   const uint8_t* src = level_ptr(s, g, img, l - 1, sp);
   const int sh = g.lv[l - 1].h;
   const int w = g.lv[l].w, h = g.lv[l].h, dp = g.lv[l].pitch;
   uint8_t* dst = s.pyr + (size_t)img * g.slot_bytes + g.lv[l].off;
-  // RESIZE_ROWS output rows per thread (y, y+16, ...): the dependent chain table -> source rows -> arithmetic is
-  // latency-bound, so every row's loads are issued before the first row is computed
-  const int x0 = tbx * 64 + (threadIdx.x & 15) * 4;
-  const int yb = tby * (16 * RESIZE_ROWS) + (threadIdx.x >> 4);
-  if (yb >= h || x0 >= w) return;
-  const uint4 xt4 = *reinterpret_cast<const uint4*>(xtab + x0);      // table padded to a multiple of 4 entries
-  unsigned yt[RESIZE_ROWS];
+  const int tid = threadIdx.x;
+  constexpr int NP = (RZ_SRC_ROWS + 31) / 32;          // staging passes: every pass's load is issued before the first store waits for one
+  struct Tile { int X0, Y0, ax, ncol, sy_lo, nrow, off; };
+  uint4 v[NP];
+  // a tile's source rectangle (block-uniform): columns from the first pixel's left tap (16-byte aligned, inside the row) to the
+  // last active thread's window end, rows from the first output row's upper tap to the last one's lower tap; and its loads
+  auto fetch = [&](int tb, Tile& t) {
+    const int tby = tb / tiles_x, tbx = tb - tby * tiles_x;
+    t.X0 = tbx * 64; t.Y0 = tby * (16 * RESIZE_ROWS);
+    const int sx_lo = (int)(xtab[t.X0] >> 16);
+    const int xb_last = min((int)(xtab[min(t.X0 + 60, ((w + 3) & ~3) - 4)] >> 16), sp - 8);
+    t.ax = min(sx_lo & ~15, sp - 16);
+    t.ncol = (xb_last + 8 - t.ax + 15) >> 4;                          // 16-byte columns, at most 8
+    t.sy_lo = (int)(ytab[t.Y0] >> 16);
+    const int sy_hi = min((int)(ytab[min(t.Y0 + 16 * RESIZE_ROWS - 1, h - 1)] >> 16) + 1, sh - 1);
+    t.nrow = sy_hi - t.sy_lo + 1;
+    const int c = tid & 7;
+    // (a column that would run past the row end is pulled back inside it: it then repeats bytes of its neighbour)
+    const int cs = min(t.ax + 16 * c, sp - 16);
+    t.off = cs - t.ax;
+    const uint8_t* gp = src + (unsigned)(__umul24((unsigned)(t.sy_lo + (tid >> 3)), (unsigned)sp) + (unsigned)cs);
+    const unsigned gstep = 32u * (unsigned)sp;
 #pragma unroll
-  for (int r = 0; r < RESIZE_ROWS; ++r) yt[r] = ytab[min(yb + 16 * r, h - 1)];
-  const unsigned xt[4] = {xt4.x, xt4.y, xt4.z, xt4.w};
-  // window start, pulled back at the right edge so that the 8 bytes stay inside the row (offsets then reach 7; the
-  // second tap of a pixel clamped at the edge has weight 0, so the zero shifted in for it is never used)
-  const int xb = min((int)(xt[0] >> 16), sp - 8);
-  unsigned long long w0[RESIZE_ROWS], w1[RESIZE_ROWS];
+    for (int k = 0; k < NP; ++k)
+      if (c < t.ncol && (tid >> 3) + 32 * k < t.nrow) __builtin_memcpy(&v[k], gp + (unsigned)k * gstep, 16);
+  };
+  const int tb0 = chain * RESIZE_CHAIN, tb_end = min(tb0 + RESIZE_CHAIN, n_tiles);
+  Tile cur, nxt;
+  fetch(tb0, cur);
+  for (int tb = tb0; tb < tb_end; ++tb) {
+    const int x0 = cur.X0 + (tid & 15) * 4;
+    const int yb = cur.Y0 + (tid >> 4);
+    const bool active = yb < h && x0 < w;
+    uint4 xt4 = {0u, 0u, 0u, 0u};
+    unsigned yt[RESIZE_ROWS];
+    if (active) {
+      xt4 = *reinterpret_cast<const uint4*>(xtab + x0);      // table padded to a multiple of 4 entries
 #pragma unroll
-  for (int r = 0; r < RESIZE_ROWS; ++r) {
-    const int y0 = (int)(yt[r] >> 16), y1 = min(y0 + 1, sh - 1);
-    __builtin_memcpy(&w0[r], src + (unsigned)(__umul24((unsigned)y0, (unsigned)sp) + (unsigned)xb), 8);   // one unaligned global_load_dwordx2
-    __builtin_memcpy(&w1[r], src + (unsigned)(__umul24((unsigned)y1, (unsigned)sp) + (unsigned)xb), 8);   // per source row, 32-bit offset
-  }
-#pragma unroll
-  for (int r = 0; r < RESIZE_ROWS; ++r) {
-    const int y = yb + 16 * r;
-    if (y >= h) break;
-    const unsigned cy1 = yt[r] & 0xffffu, cy0 = 256u - cy1;
-    unsigned vv[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                           // (pixels past the row end compute garbage into the row padding)
-      const int o = (int)(xt[k] >> 16) - xb;               // 0..7
-      const unsigned cx1 = xt[k] & 0xffffu;
-      const unsigned coef = (255u - cx1) | (cx1 << 8);     // (cx0 - 1, cx1)
-      const unsigned h0 = resize_h(w0[r], o, coef), h1 = resize_h(w1[r], o, coef);   // 8.8
-      vv[k] = __umul24(cy0, h0) + __umul24(cy1, h1) + 32768u;                                        // 16.16, rounded
+      for (int r = 0; r < RESIZE_ROWS; ++r) yt[r] = ytab[min(yb + 16 * r, h - 1)];
     }
-    const unsigned packed = pack_byte2(vv[0], vv[1], vv[2], vv[3]);
-    *reinterpret_cast<unsigned*>(dst + (unsigned)(__umul24((unsigned)y, (unsigned)dp) + (unsigned)x0)) = packed;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int r = (tid >> 3) + 32 * k;
+      if ((tid & 7) < cur.ncol && r < cur.nrow) {
+        if ((cur.off & 15) == 0) *reinterpret_cast<uint4*>(&st[r * RZ_LP + cur.off]) = v[k];
+        else {
+          unsigned* q = reinterpret_cast<unsigned*>(&st[r * RZ_LP + cur.off]);
+          q[0] = v[k].x; q[1] = v[k].y; q[2] = v[k].z; q[3] = v[k].w;
+        }
+      }
+    }
+    __syncthreads();
+    if (tb + 1 < tb_end) fetch(tb + 1, nxt);
+    if (active) {
+      const unsigned xt[4] = {xt4.x, xt4.y, xt4.z, xt4.w};
+      // window start, pulled back at the right edge so that the 8 bytes stay inside the row (offsets then reach 7; the
+      // second tap of a pixel clamped at the edge has weight 0, so the zero shifted in for it is never used)
+      const int xb = min((int)(xt[0] >> 16), sp - 8);
+      const int col = xb - cur.ax, sh8 = col & 3;
+      const uint8_t* lp = st + (col & ~3);
+#pragma unroll
+      for (int r = 0; r < RESIZE_ROWS; ++r) {
+        const int y = yb + 16 * r;
+        if (y >= h) break;
+        const int y0 = (int)(yt[r] >> 16), y1 = min(y0 + 1, sh - 1);
+        const unsigned* p0 = reinterpret_cast<const unsigned*>(lp + (y0 - cur.sy_lo) * RZ_LP);
+        const unsigned* p1 = reinterpret_cast<const unsigned*>(lp + (y1 - cur.sy_lo) * RZ_LP);
+        const unsigned a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+        const unsigned long long w0 = (unsigned long long)__builtin_amdgcn_alignbyte(a1, a0, (unsigned)sh8) |
+                                      ((unsigned long long)__builtin_amdgcn_alignbyte(a2, a1, (unsigned)sh8) << 32);
+        const unsigned long long w1 = (unsigned long long)__builtin_amdgcn_alignbyte(b1, b0, (unsigned)sh8) |
+                                      ((unsigned long long)__builtin_amdgcn_alignbyte(b2, b1, (unsigned)sh8) << 32);
+        const unsigned cy1 = yt[r] & 0xffffu, cy0 = 256u - cy1;
+        unsigned vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                           // (pixels past the row end compute garbage into the row padding)
+          const int o = (int)(xt[k] >> 16) - xb;               // 0..7
+          const unsigned cx1 = xt[k] & 0xffffu;
+          const unsigned coef = (255u - cx1) | (cx1 << 8);     // (cx0 - 1, cx1)
+          const unsigned h0 = resize_h(w0, o, coef), h1 = resize_h(w1, o, coef);   // 8.8
+          vv[k] = __umul24(cy0, h0) + __umul24(cy1, h1) + 32768u;                                        // 16.16, rounded
+        }
+        const unsigned packed = pack_byte2(vv[0], vv[1], vv[2], vv[3]);
+        *reinterpret_cast<unsigned*>(dst + (unsigned)(__umul24((unsigned)y, (unsigned)dp) + (unsigned)x0)) = packed;
+      }
+    }
+    __syncthreads();   // the tile is consumed before the next one overwrites it
+    cur = nxt;
   }
 }
 
@@ -1420,7 +1490,8 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
       ProfScope ps(h, "resize_kernel");
       for (int l = 1; l < nl; ++l) {
         const int tx = (g.lv[l].w + 63) / 64, ty = (g.lv[l].h + 16 * RESIZE_ROWS - 1) / (16 * RESIZE_ROWS);
-        hipLaunchKernelGGL(resize_kernel, xcd_grid(tx * ty, n), dim3(256), 0, st, s, g, l, n, xcd_map(tx * ty), tx, ty,
+        const int chains = (tx * ty + RESIZE_CHAIN - 1) / RESIZE_CHAIN;
+        hipLaunchKernelGGL(resize_kernel, xcd_grid(chains, n), dim3(256), 0, st, s, g, l, n, xcd_map(chains), tx, tx * ty,
                            tab + h->resize_tab_off[2 * l], tab + h->resize_tab_off[2 * l + 1]);
       }
     }
