@@ -35,7 +35,6 @@ namespace {
 #include "orb_pattern_31.inc"
 
 constexpr int EDGE = 31;             // edgeThreshold, stereo.rs:42
-constexpr int HARRIS_CHUNKS = 8;
 
 __constant__ __attribute__((aligned(16))) signed char c_pattern[256 * 4];
 
@@ -231,6 +230,10 @@ __device__ __forceinline__ void decode_tile(const unsigned* __restrict__ tab, in
 // a ring of row PAIRS of those sums in registers, vertical taps by v_dot2_u32_u16 (16.16), one dword store.
 // Lanes whose 10-px window crosses the image edge rebuild their three dwords with BORDER_REFLECT_101 from the
 // same registers (v_perm_b32, no loads).
+#ifndef ORBX_BLUR_PF
+#define ORBX_BLUR_PF 2
+#endif
+constexpr int BLUR_PF = ORBX_BLUR_PF;   // input rows in flight per lane
 constexpr int BLUR_W = 248, BLUR_STRIP = 32, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo;
 // rows per wave 16 / 32 / 48 / 64 / 96 / 128: 0.307 / 0.300 / 0.302 / 0.315 / 0.366 / 0.369 ms per 256 pairs
 
@@ -279,11 +282,13 @@ __device__ __forceinline__ BlurEdge blur_edge_setup(int x0, int w, bool active) 
 }
 
 // d1 = this lane's dword of the row, loaded two rows ahead by the caller so that the load latency overlaps the
-// arithmetic of the rows in between; edge = some lane of this wave sits on the image edge (wave-uniform)
-__device__ __forceinline__ void blur_row(unsigned d1, bool edge, const BlurEdge& e, unsigned (&hs)[4]) {
+// arithmetic of the rows in between; EDGE = some lane of this wave sits on the image edge (wave-uniform: two copies of the row
+// loop — as a run-time flag the compiler turned the branch into 3 v_perm + 5 v_cndmask in every wave's every row, a sixth of it)
+template <bool EDGE>
+__device__ __forceinline__ void blur_row(unsigned d1, const BlurEdge& e, unsigned (&hs)[4]) {
   unsigned d0 = __builtin_amdgcn_update_dpp(0u, d1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
   unsigned d2 = __builtin_amdgcn_update_dpp(0u, d1, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-  if (edge) {
+  if (EDGE) {
     const unsigned n0 = e.left ? __builtin_amdgcn_perm(d2, d1, 0x01020304u) : d0;
     const unsigned n2 = __builtin_amdgcn_perm(e.hi ? d2 : d1, e.hi ? d1 : d0, e.s2);
     d1 = __builtin_amdgcn_perm(d1, d0, e.s1);
@@ -299,26 +304,21 @@ __device__ __forceinline__ int reflect101_once(int i, int n) { return i < 0 ? -i
 // wide (first and last lane of a group are halo lanes).  M = 1 is the full 248-px strip; M = 2 (120 px) and M = 4
 // (56 px) take the narrow remainder at the right of a level in 22 resp. 14 row steps instead of 38, so a remainder of
 // 8 px (752 = 3*248 + 8) no longer costs a whole strip.  For M > 1 the row index is per lane (VALU), for M = 1 scalar.
-template <int M>
-__device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int pitch, int w, int h, uint8_t* __restrict__ dst,
-                                           int dpitch, int xbase, int ys_wave, int lane) {
-  constexpr int GL = 64 / M, R = BLUR_STRIP / M;
-  const int gl = lane & (GL - 1);
-  int ys = ys_wave + (lane / GL) * R;
-  const int nrows = min(R, h - ys_wave);          // wave-uniform: group 0 has the most rows
-  int nrows_l = min(R, h - ys);                    // this lane's group (M > 1: can be <= 0 below the image)
-  if (M > 1 && nrows_l <= 0) { ys = ys_wave; nrows_l = 0; }   // idle group: walk group 0's rows, store nothing
-  const int x0 = xbase + (gl - 1) * 4;
-  const bool active = gl >= 1 && gl <= GL - 2 && x0 < w && nrows_l > 0;
-  const BlurEdge be = blur_edge_setup(x0, w, active);
-  const bool edge = __ballot(be.left || !be.hi || be.s2 != 0x07060504u) != 0ull;
+template <int M, bool EDGE>
+__device__ __forceinline__ void blur_strip_e(const uint8_t* __restrict__ src, int pitch, int h, uint8_t* __restrict__ dst, int dpitch,
+                                             const BlurEdge& be, int x0, bool active, int ys, int nrows, int nrows_l) {
   const int xl = max(0, min(x0, pitch - 4));
   // input rows q = 0 .. nrows+5 are image rows reflect(ys-3+q); p0/p1 hold this lane's dword of rows q and q+1
   const int last = (M > 1 ? max(nrows_l, 1) : nrows) + 5;
   // 32-bit byte offsets from the (wave-uniform) level base: scalar base + one VGPR offset per access instead of 64-bit
   // per-lane pointer arithmetic (v_mad_u64_u32 is a quarter-rate instruction: four of them per row were a fifth of the row)
   auto rowp = [&](int q) { return src + (unsigned)(__umul24((unsigned)reflect101_once(ys - 3 + min(q, last), h), (unsigned)pitch) + (unsigned)xl); };
-  unsigned p0 = *reinterpret_cast<const unsigned*>(rowp(0)), p1 = *reinterpret_cast<const unsigned*>(rowp(1));
+  // this lane's dwords of the next BLUR_PF input rows are in flight.  2 / 3 / 4 / 6 rows ahead: 0.298 / 0.298 / 0.298 / 0.303 ms per
+  // 256 pairs, and dropping the edge code from the waves without an edge lane (a sixth of their VALU work) changed nothing either:
+  // at 1.5 GB of counter traffic in 0.298 ms = 5.0 TB/s the kernel sits on what HBM delivers for a half-read half-write stream
+  unsigned pq[BLUR_PF];
+#pragma unroll
+  for (int k = 0; k < BLUR_PF; ++k) pq[k] = *reinterpret_cast<const unsigned*>(rowp(k));
   // Vertical taps on PAIRS of rows: the 8.8 horizontal sums fit 16 bits, so two consecutive rows of one pixel share a
   // register and v_dot2_u32_u16 applies two taps at once: out(y) = (w0,w1).(18,34) + (w2,w3).(48,56) + (w4,w5).(48,34)
   // + 18 w6 — three dot2 and one mad instead of three adds and four multiplies.  pr[q % 6] = rows (q, q+1).
@@ -326,11 +326,12 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
   unsigned pr[6][4], hprev[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const unsigned cur = p0;
-    p0 = p1;
-    p1 = *reinterpret_cast<const unsigned*>(rowp(i + 2));
+    const unsigned cur = pq[0];
+#pragma unroll
+    for (int k = 0; k + 1 < BLUR_PF; ++k) pq[k] = pq[k + 1];
+    pq[BLUR_PF - 1] = *reinterpret_cast<const unsigned*>(rowp(i + BLUR_PF));
     unsigned hs[4];
-    blur_row(cur, edge, be, hs);
+    blur_row<EDGE>(cur, be, hs);
     if (i > 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) pr[i - 1][k] = hprev[k] | (hs[k] << 16);
@@ -345,11 +346,12 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
       const int y = y0 + i;
       if (y < nrows) {   // wave-uniform
         // input row q = y+6 (image row ys+y+3) arrives; window rows are q = y .. y+6
-        const unsigned cur = p0;
-        p0 = p1;
-        p1 = *reinterpret_cast<const unsigned*>(rowp(y + 8));
+        const unsigned cur = pq[0];
+#pragma unroll
+        for (int k = 0; k + 1 < BLUR_PF; ++k) pq[k] = pq[k + 1];
+        pq[BLUR_PF - 1] = *reinterpret_cast<const unsigned*>(rowp(y + 6 + BLUR_PF));
         unsigned hs[4];
-        blur_row(cur, edge, be, hs);
+        blur_row<EDGE>(cur, be, hs);
         unsigned vv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -365,6 +367,23 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
       }
     }
   }
+}
+
+template <int M>
+__device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int pitch, int w, int h, uint8_t* __restrict__ dst,
+                                           int dpitch, int xbase, int ys_wave, int lane) {
+  constexpr int GL = 64 / M, R = BLUR_STRIP / M;
+  const int gl = lane & (GL - 1);
+  int ys = ys_wave + (lane / GL) * R;
+  const int nrows = min(R, h - ys_wave);          // wave-uniform: group 0 has the most rows
+  int nrows_l = min(R, h - ys);                    // this lane's group (M > 1: can be <= 0 below the image)
+  if (M > 1 && nrows_l <= 0) { ys = ys_wave; nrows_l = 0; }   // idle group: walk group 0's rows, store nothing
+  const int x0 = xbase + (gl - 1) * 4;
+  const bool active = gl >= 1 && gl <= GL - 2 && x0 < w && nrows_l > 0;
+  const BlurEdge be = blur_edge_setup(x0, w, active);
+  // some lane of this wave sits on the image edge (wave-uniform)
+  if (__ballot(be.left || !be.hi || be.s2 != 0x07060504u) != 0ull) blur_strip_e<M, true>(src, pitch, h, dst, dpitch, be, x0, active, ys, nrows, nrows_l);
+  else blur_strip_e<M, false>(src, pitch, h, dst, dpitch, be, x0, active, ys, nrows, nrows_l);
 }
 
 // 8 waves/SIMD (<= 64 VGPRs, no scratch since the edge lanes stopped gathering bytes from memory — that gather, 12
@@ -818,12 +837,12 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
                                                             const unsigned* __restrict__ cand_count,
                                                             const unsigned* __restrict__ hist,
                                                             unsigned long long* __restrict__ sel,
-                                                            unsigned* __restrict__ sel_count) {
+                                                            unsigned* __restrict__ sel_count, int chunk_shift) {
   __shared__ unsigned sh[256];
   __shared__ int s_thr;
   int img, bb;
   if (!xcd_decode(xm, n_img, img, bb)) return;
-  const int l = bb / HARRIS_CHUNKS, chunk = bb - l * HARRIS_CHUNKS;
+  const int l = bb >> chunk_shift, chunk = bb & ((1 << chunk_shift) - 1), n_chunks = 1 << chunk_shift;
   const int il = img * g.n_levels + l;
   const int tid = threadIdx.x;
   const unsigned count = cand_count[il];
@@ -855,7 +874,7 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
   __shared__ unsigned s_pass[1024];
   __shared__ unsigned s_np;
   const int lane = tid & 63;
-  const unsigned per = (count + HARRIS_CHUNKS - 1) / HARRIS_CHUNKS;                    // this block's contiguous share
+  const unsigned per = (count + n_chunks - 1) >> chunk_shift;                          // this block's contiguous share
   const unsigned lim = min(count, (chunk + 1) * per);
   for (unsigned base = chunk * per; base < lim; base += 1024u) {                       // block-uniform bounds
     if (tid == 0) s_np = 0;
@@ -875,22 +894,21 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
     }
     __syncthreads();
     const unsigned np = s_np;
+    // the round's output slots are reserved by one atomic per wave issued BEFORE the responses are computed (every wave knows its
+    // share of the list: entries wave*64 + 256 m), so its round trip (about 2 us) runs under their loads and arithmetic
+    unsigned mine = 0;                                                                 // this wave's entries of the round
+    for (unsigned q0 = (unsigned)(tid & ~63); q0 < np; q0 += 256) mine += min(64u, np - q0);
+    unsigned pos0 = 0;
+    if (lane == 0 && mine) pos0 = atomicAdd(&sel_count[il], mine);
     for (unsigned q0 = 0; q0 < np; q0 += 256) {                                        // block-uniform bound
       const unsigned q = q0 + tid;
-      const bool act = q < np;
-      unsigned long long key = 0;
-      if (act) {
+      if (q < np) {
         const unsigned c = s_pass[q];
         const int x = (int)(c & 0xfffu), y = (int)((c >> 12) & 0xfffu);
         const float r = harris_response(src, pitch, x, y);
-        key = ((unsigned long long)(~orderable(r)) << 32) | ((unsigned)y << 16) | (unsigned)x;
-      }
-      const unsigned long long m = __ballot(act);
-      if (m) {
-        unsigned pos0 = 0;
-        if (lane == 0) pos0 = atomicAdd(&sel_count[il], (unsigned)__popcll(m));
-        pos0 = __builtin_amdgcn_readfirstlane(pos0);
-        if (act) out[pos0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = key;
+        const unsigned long long key = ((unsigned long long)(~orderable(r)) << 32) | ((unsigned)y << 16) | (unsigned)x;
+        // wave's slots: its earlier passes hold 64 entries each (only the last one can be partial)
+        out[__builtin_amdgcn_readfirstlane(pos0) + (q0 >> 8) * 64u + (unsigned)lane] = key;
       }
     }
     __syncthreads();
@@ -1526,8 +1544,12 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     }
     {
       ProfScope ps(h, "harris_select_kernel", nullptr, true);
-      hipLaunchKernelGGL(harris_select_kernel, xcd_grid(nl * HARRIS_CHUNKS, n), dim3(256), 0, st, s, g, n, xcd_map(nl * HARRIS_CHUNKS),
-                         (const unsigned*)cand, cc, hs, sel, sc);
+      // 8 blocks per (image, level).  1 / 2 / 4 / 8 / 16 / 32 blocks: 0.210 / 0.169 / 0.153 / 0.150 / 0.204 / 0.375 ms per 256 pairs:
+      // a level's 2 x quota survivors are a few hundred, so a block is one latency chain (histogram -> candidates -> 27 loads per
+      // response -> store) and the kernel lives on how many of them are in flight
+      constexpr int cshift = 3;
+      hipLaunchKernelGGL(harris_select_kernel, xcd_grid(nl << cshift, n), dim3(256), 0, st, s, g, n, xcd_map(nl << cshift),
+                         (const unsigned*)cand, cc, hs, sel, sc, cshift);
     }
     {
       ProfScope ps(h, "rank_select_kernel", nullptr, true);
