@@ -269,9 +269,17 @@ def main():
             # reach the 2-cycle rate the guide quotes (950-1080 G/s: VALU_PEAK_2CYC).  frac is against the 4-cycle class.
             if kd.get("valu_wave_instr_per_launch") and dom_ms > 0:
                 rate = kd["valu_wave_instr_per_launch"] / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9
+                busy = kd.get("valu_busy_frac")
                 valu = dict(wave_instr_per_launch=kd["valu_wave_instr_per_launch"], achieved=round(rate, 1), peak=VALU_PEAK_4CYC,
-                            peak_simple_ops=VALU_PEAK_2CYC, unit="G wave-instr/s", frac=round(rate / VALU_PEAK_4CYC, 4),
-                            source="profiles/r02_valu_issue_probe.txt")
+                            peak_simple_ops=VALU_PEAK_2CYC, unit="G wave-instr/s",
+                            # the counter's busy fraction where the pass has it; else the instruction rate against the 4-cycle class
+                            frac=(busy if busy is not None else round(rate / VALU_PEAK_4CYC, 4)),
+                            frac_of_4cycle_class_rate=round(rate / VALU_PEAK_4CYC, 4),
+                            source="profiles/r02_valu_issue_probe.txt, profiles/pmc_traffic.json",
+                            # fraction of all SIMD cycles the VALU was issuing, from SQ_ACTIVE_INST_VALU of the counter pass (the
+                            # kernels now mix 2- and 4-cycle opcodes, which an instruction count alone no longer prices)
+                            busy_frac_pmc=kd.get("valu_busy_frac"), lds_busy_frac_pmc=kd.get("lds_busy_frac"),
+                            lds_bank_conflict_share_pmc=kd.get("lds_bank_conflict_share"))
     except Exception:
         traffic = None
     # the >= 60 % HBM goal is assessed on the streaming kernels — algorithmic bytes / measured time / 8 TB/s each

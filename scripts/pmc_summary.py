@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per kernel.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [batch n_features out.json [sq_counter_collection.csv]]
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [batch n_features out.json [sq_counter_collection.csv [sq2_counter_collection.csv]]]
 The optional SQ pass (SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES) adds wave-instruction counts per launch, from
 which bench.py prices the VALU issue rate of the dominant kernel (one wave64 VALU instruction = 4 cycles of a SIMD).
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of a wide coalesced
@@ -17,6 +17,8 @@ def load(path, tag):
             continue
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
         name = re.split(r"[(<]", name)[0].strip()
+        if name.startswith("void "):          # template instances carry their return type
+            name = name[5:]
         if name.startswith("void at::") or "rocclr" in name or name.startswith("at::"):
             continue
         acc[name].append(float(r["Counter_Value"]))
@@ -37,9 +39,35 @@ if len(sys.argv) > 6:
         for k in c:
             if k in out["kernels"]:
                 out["kernels"][k][key + "_per_launch"] = int(sum(c[k]) / len(c[k]))
+if len(sys.argv) > 7:
+    # second SQ pass: SQ_ACTIVE_INST_VALU counts quad-cycles the VALU is issuing (one per 4-cycle-class instruction, half of one per
+    # 2-cycle-class instruction), GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs -> fraction of all SIMD cycles spent issuing
+    # VALU work, measured (no per-opcode price list needed); LDS pipe activity and its bank-conflict share beside it
+    extra = {t: load(sys.argv[7], t) for t in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT")}
+    for k in out["kernels"]:
+        if k in extra["SQ_ACTIVE_INST_VALU"] and k in extra["GRBM_GUI_ACTIVE"]:
+            act = sum(extra["SQ_ACTIVE_INST_VALU"][k]) / len(extra["SQ_ACTIVE_INST_VALU"][k])
+            gui = sum(extra["GRBM_GUI_ACTIVE"][k]) / len(extra["GRBM_GUI_ACTIVE"][k])
+            d = out["kernels"][k]
+            d["valu_active_quadcycles_per_launch"] = int(act)
+            d["gui_active_cycles_per_launch"] = int(gui)
+            d["valu_busy_frac"] = round(act * 4 / (gui / 8 * 1024), 4) if gui > 0 else None
+            if k in extra["SQ_LDS_IDX_ACTIVE"]:
+                la = sum(extra["SQ_LDS_IDX_ACTIVE"][k]) / len(extra["SQ_LDS_IDX_ACTIVE"][k])
+                lc = sum(extra["SQ_LDS_BANK_CONFLICT"].get(k, [0])) / max(len(extra["SQ_LDS_BANK_CONFLICT"].get(k, [0])), 1)
+                d["lds_busy_frac"] = round(la / (gui / 8 * 256), 4) if gui > 0 else None
+                d["lds_bank_conflict_share"] = round(lc / la, 4) if la > 0 else None
 if len(sys.argv) > 5:
     json.dump(out, open(sys.argv[5], "w"), indent=1)
 print("%-28s %8s %14s %14s %14s" % ("kernel", "launches", "FETCH KiB", "FETCHx2 MB", "WRITE MB"))
 for k in sorted(f):
     fm = sum(f[k]) / len(f[k]); wm = sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1)
     print("%-28s %8d %14.1f %14.2f %14.2f" % (k, len(f[k]), fm, 2 * fm * 1024 / 1e6, wm * 1024 / 1e6))
+if len(sys.argv) > 7:
+    print()
+    print("%-28s %14s %14s %10s %10s %12s" % ("kernel", "VALU instr", "VALU active x4", "VALU busy", "LDS busy", "LDS conflict"))
+    for k in sorted(out["kernels"]):
+        d = out["kernels"][k]
+        if "valu_busy_frac" in d:
+            print("%-28s %14.3e %14.3e %9.1f%% %9.1f%% %11.1f%%" % (k, d.get("valu_wave_instr_per_launch", 0), 4.0 * d["valu_active_quadcycles_per_launch"],
+                  100 * (d["valu_busy_frac"] or 0), 100 * (d.get("lds_busy_frac") or 0), 100 * (d.get("lds_bank_conflict_share") or 0)))
