@@ -299,7 +299,7 @@ def main():
 
     frames = args.batch * args.steps * world
     value = frames / elapsed
-    res = dict(metric="stereo frames/sec ORB extract+match @752x480", value=round(value, 2), unit="stereo frames/s",
+    res = dict(metric="stereo frames/sec ORB extract+match @%dx%d" % (W, H), value=round(value, 2), unit="stereo frames/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8", data="synthetic",
                config=dict(workload="Synthetic %dx%d stereo, %d ORB/frame, extract+match+triangulate (BASELINE configs[%d])"
