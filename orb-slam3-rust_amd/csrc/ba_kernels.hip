@@ -739,10 +739,26 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 //
 // Blocked right-looking Cholesky with panels of 16 columns (described at the loop); srinv[c] = 1 / L_cc.
 
+#ifdef ORBX_SOLVE_STAMPS
+// debug build only (-DORBX_SOLVE_STAMPS, scripts/build_stamps.sh + scripts/ba_solve_stamps.py): s_memtime ticks per phase of the
+// one-workgroup solve, summed over solves.  (Ticks are only comparable within one run: the counter's rate is not the shader clock's.)
+__device__ unsigned long long g_solve_stamps[16];
+#define SOLVE_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); g_solve_stamps[k] += now_ - t_prev_; t_prev_ = now_; } } while (0)
+extern "C" int orbx_debug_solve_stamps(unsigned long long* out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_solve_stamps), 128) != hipSuccess) return -1;
+  if (reset) { const unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_solve_stamps), z, 128) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define SOLVE_STAMP(k) do { } while (0)
+#endif
 template <typename SPtr>
 __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0, double* P1, const double* __restrict__ rb, int K, SPtr S,
                            double* __restrict__ dp, double* __restrict__ res) {
   if (St->done) return;
+#ifdef ORBX_SOLVE_STAMPS
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   const double lambda = St->lambda;
   const double* params = ba_cur(St, P0, P1);
   __shared__ double sb[BA_MAX_N];
@@ -777,11 +793,13 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   // row thread factored redundantly, at n = 114.)
   __shared__ int s_ok;
   __shared__ double s_rv[16];
+  SOLVE_STAMP(0);
   if (tid == 0) s_ok = 1;
   int ok = 1;
   for (int c0 = 0; c0 < n; c0 += 16) {
     const int nb = min(16, n - c0);
     __syncthreads();
+    SOLVE_STAMP(1);
     ok = s_ok;
     if (!ok) break;
     if (tid < 64) {
@@ -810,6 +828,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       }
     }
     __syncthreads();
+    SOLVE_STAMP(2);
     ok = s_ok;
     if (!ok) break;
     if (tid < nb) srinv[c0 + tid] = s_rv[tid];
@@ -852,6 +871,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       }
     }
     __syncthreads();
+    SOLVE_STAMP(3);
     const int c1 = c0 + 16, m = n - c1;
     if (m > 0) {
       if (tid < m) {                                                           // b_below -= L21 y_panel
@@ -882,6 +902,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     }
   }
   __syncthreads();
+  SOLVE_STAMP(4);
   ok = s_ok;
   __syncthreads();
   if (ok && tid < 64 && n <= 128) {
@@ -926,6 +947,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     }
   }
   __syncthreads();
+  SOLVE_STAMP(5);
   double dsq = 0.0, psq = 0.0;
   for (int i = tid; i < n; i += nth) {
     const double v = ok ? sb[i] : 0.0;
@@ -936,6 +958,10 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   dsq = block_sum_fixed(dsq, s_red);
   psq = block_sum_fixed(psq, s_red);
   if (tid == 0) { res[2] = (double)ok; res[3] = dsq; res[4] = psq; }
+  SOLVE_STAMP(6);
+#ifdef ORBX_SOLVE_STAMPS
+  if (threadIdx.x == 0) g_solve_stamps[15] += 1;
+#endif
 }
 
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(const BaWin* __restrict__ wins) {

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Phase split of ba_solve_lds_kernel from a -DORBX_SOLVE_STAMPS build of the library (scripts/build_stamps.sh -> build_ab/bast.so):
+ORBX_LIBRARY=$PWD/build_ab/bast.so python scripts/ba_solve_stamps.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import orb_slam3_rust_amd as P
+L = P.load_library()
+cam = P.CameraModel(**P.synth.EUROC_CAMERA)
+h = P.Handle(cam, 100)
+w = P.synth.ba_window(42, 20, 2000, P.BA_OBS)
+cfg = P.LocalBAConfigLM()
+h.ba_solve_visual_batch(cam, cfg, [w])
+buf = (C.c_ulonglong * 16)()
+L.orbx_debug_solve_stamps(buf, 1)
+for _ in range(3):
+    h.ba_solve_visual_batch(cam, cfg, [w])
+L.orbx_debug_solve_stamps(buf, 0)
+n = buf[15]
+names = ["assemble S, b, |g|", "wait at the panel's top barrier (= trailing update)", "diagonal block factor (wave 0)", "row solves + right-hand side",
+         "last update + exit", "backward substitution", "dp, norms"]
+tot = sum(buf[i] for i in range(7))
+print("solves %d, ticks per solve %.0f" % (n, tot / n))
+for i in range(7):
+    print("  %-52s %8.0f  %5.1f %%" % (names[i], buf[i] / n, 100.0 * buf[i] / tot))
