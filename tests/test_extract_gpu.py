@@ -51,7 +51,8 @@ def test_blur_levels_bit_exact(h2000, oracle, frame0):
         assert np.array_equal(got, want), "blur level %d: %d pixels differ" % (l, (got != want).sum())
 
 
-@pytest.mark.parametrize("w,h", [(101, 77), (249, 131), (250, 300), (333, 258), (501, 97), (641, 481), (753, 261), (997, 64), (1241, 376)])
+@pytest.mark.parametrize("w,h", [(101, 77), (249, 131), (250, 300), (333, 258), (501, 97), (641, 481), (753, 261), (997, 64), (1241, 376),
+                                 (756, 140), (1004, 90), (260, 200)])   # rows 4- but not 16-byte aligned: the resize staging's clamped last column
 def test_pyramid_and_blur_levels_odd_sizes(pkg, oracle, w, h):
     """Whole levels (not only the patches keypoints sample) at widths whose last dword holds 1, 2, 3 or 4 pixels and whose
     remainder after the 248-px blur strips exercises the full, half and quarter strip modes; heights below, at and above
