@@ -106,16 +106,19 @@ __device__ __forceinline__ unsigned resize_h(unsigned long long win, int o, unsi
 // stages its source rectangle — at most 73 rows x 128 bytes for scale factors up to 1.5 — with aligned 16-byte loads (a quarter of
 // the lane requests) and the windows come from LDS as three aligned dwords + two v_alignbyte_b32 (unaligned LDS reads are slow).
 constexpr int RZ_LP = 128;                                               // LDS row pitch: 8 x 16 bytes (60 * 1.5 + 8 + 15 = 113)
-constexpr int RZ_SRC_ROWS = (16 * RESIZE_ROWS - 1) * 3 / 2 + 3;          // source rows under 16*RESIZE_ROWS output rows at scale 1.5
+constexpr int rz_src_rows(int rows) { return (16 * rows - 1) * 3 / 2 + 3; }   // source rows under 16*rows output rows at scale 1.5
+constexpr int RESIZE_ROWS_SMALL = 2;     // small batches (a pair): more, shorter blocks — latency, not throughput
 #ifndef ORBX_RESIZE_CHAIN
 #define ORBX_RESIZE_CHAIN 1
 #endif
 // consecutive tiles per block with the next one's source loads in flight under the current one's arithmetic: 1 / 2 / 3 tiles
 // 0.260 / 0.304 / 0.334 ms per 256 pairs — the upper levels have too few tiles to give any away (level 7: 8 per image)
 constexpr int RESIZE_CHAIN = ORBX_RESIZE_CHAIN;
+template <int RESIZE_ROWS>
 __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l, int n_img, XcdMap xm, int tiles_x, int n_tiles,
                                                      const unsigned* __restrict__ xtab,
                                                      const unsigned* __restrict__ ytab) {
+  constexpr int RZ_SRC_ROWS = rz_src_rows(RESIZE_ROWS);
   __shared__ __attribute__((aligned(16))) uint8_t st[RZ_SRC_ROWS * RZ_LP + 16];
   int img, chain;
   if (!xcd_decode(xm, n_img, img, chain)) return;
@@ -552,7 +555,7 @@ template <bool SWAR>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
                                                    unsigned* __restrict__ cand, unsigned* __restrict__ cand_count,
-                                                   unsigned* __restrict__ hist, int n_tiles) {
+                                                   unsigned* __restrict__ hist, int n_tiles, int chain_len) {
   __shared__ __attribute__((aligned(16))) uint8_t sp[FP_ROWS][FP_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t ss[FS_H][FS_W];
   __shared__ __attribute__((aligned(4))) unsigned short s_pos[FS_W * FS_H];
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   };
   int img0, chain;
   if (!xcd_decode(xm, n_img, img0, chain)) return;
-  const int tile0 = chain * FAST_CHAIN, tile_end = min(tile0 + FAST_CHAIN, n_tiles);
+  const int tile0 = chain * chain_len, tile_end = min(tile0 + chain_len, n_tiles);
   fetch(img0, tile0, cur);
   // The append of a tile's corners to its level's list needs a returning global atomic (about 2 us); it is issued when the tile's
   // NMS is done and consumed one phase into the NEXT tile, so only the last tile of a chain waits for it.
@@ -1507,10 +1510,16 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     {
       ProfScope ps(h, "resize_kernel");
       for (int l = 1; l < nl; ++l) {
-        const int tx = (g.lv[l].w + 63) / 64, ty = (g.lv[l].h + 16 * RESIZE_ROWS - 1) / (16 * RESIZE_ROWS);
+        const bool small = n < 16;                       // a pair or a few: latency counts, keep the blocks short and many
+        const int rows = small ? RESIZE_ROWS_SMALL : RESIZE_ROWS;
+        const int tx = (g.lv[l].w + 63) / 64, ty = (g.lv[l].h + 16 * rows - 1) / (16 * rows);
         const int chains = (tx * ty + RESIZE_CHAIN - 1) / RESIZE_CHAIN;
-        hipLaunchKernelGGL(resize_kernel, xcd_grid(chains, n), dim3(256), 0, st, s, g, l, n, xcd_map(chains), tx, tx * ty,
-                           tab + h->resize_tab_off[2 * l], tab + h->resize_tab_off[2 * l + 1]);
+        if (small)
+          hipLaunchKernelGGL(resize_kernel<RESIZE_ROWS_SMALL>, xcd_grid(chains, n), dim3(256), 0, st, s, g, l, n, xcd_map(chains), tx, tx * ty,
+                             tab + h->resize_tab_off[2 * l], tab + h->resize_tab_off[2 * l + 1]);
+        else
+          hipLaunchKernelGGL(resize_kernel<RESIZE_ROWS>, xcd_grid(chains, n), dim3(256), 0, st, s, g, l, n, xcd_map(chains), tx, tx * ty,
+                             tab + h->resize_tab_off[2 * l], tab + h->resize_tab_off[2 * l + 1]);
       }
     }
     // blur (latency-bound, ~50 % VALU-busy) and the FAST -> Harris -> ordering chain (issue-bound) both depend only on the
@@ -1536,11 +1545,13 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     if (fork) ORBX_HIP(h, hipEventRecord(h->ev_join, h->s_aux));
     if (g.ftiles_total > 0) {
       ProfScope ps(h, "fast_kernel", nullptr, true);
-      const int chains = (g.ftiles_total + FAST_CHAIN - 1) / FAST_CHAIN;
+      // chains of FAST_CHAIN tiles per block once there are blocks to spare (each CU holds 8): for a pair one tile per block
+      const int chain_len = (size_t)g.ftiles_total * n >= (size_t)4 * 8 * h->n_cu ? FAST_CHAIN : 1;
+      const int chains = (g.ftiles_total + chain_len - 1) / chain_len;
       if (g.fast_threshold < 128)
-        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(chains, n), dim3(256), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total);
+        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(chains, n), dim3(256), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len);
       else
-        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(chains, n), dim3(256), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total);
+        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(chains, n), dim3(256), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len);
     }
     {
       ProfScope ps(h, "harris_select_kernel", nullptr, true);
