@@ -398,7 +398,7 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaDims& d, const int* _
 // D[(l>>4)+4r][l&15], r = 0..3.  The dense [3M][6K] operands never exist in memory: per iteration the Schur product reads
 // 144 B per observation instead of 2 x 8 B x 3M x 6K (393 MB at 32 windows of 20 keyframes / 2000 points).
 constexpr int SCH_R = 24;                 // rows per LDS tile (8 points, 6 MFMA k-steps)
-constexpr int SCH_PITCH = 144;            // doubles per LDS row: 128 + 16 — the two 16-lane row groups of a ds_read_b64 half-wave land 32 banks apart
+constexpr int SCH_PITCH = 136;            // doubles per LDS row: 128 + 16 — the two 16-lane row groups of a ds_read_b64 half-wave land 32 banks apart
 __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, double* __restrict__ sY, double* __restrict__ sW) {
   const BaDims& d = win.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void ba_kf_kernel(const BaWin* __restrict__ wi
 
 // DIAG: every window of the launch has a reduced system of at most 128 columns (host-checked)
 template <bool DIAG>
-__global__ __launch_bounds__(256, 2) void ba_schur_kernel(const BaWin* __restrict__ wins) {
+__global__ __launch_bounds__(256, 3) void ba_schur_kernel(const BaWin* __restrict__ wins) {
   __shared__ double s_tiles[2 * SCH_R * SCH_PITCH];                 // Y and W operand tiles (51 KB)
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done) return;
