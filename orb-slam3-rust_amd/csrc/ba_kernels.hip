@@ -244,9 +244,15 @@ __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, co
   }
 }
 
-__device__ __forceinline__ double group_sum32(double v) {
+#ifndef ORBX_BA_PT_LANES
+#define ORBX_BA_PT_LANES 32
+#endif
+constexpr int BA_PT_LANES = ORBX_BA_PT_LANES;   // lanes per map point in the per-observation kernels.  16 instead of 32 (points average 16 observations): 32-window batch +4 % (39.6 -> 41.1 k it/s), single window -3.5 % (6.50 -> 6.29 k: half as many blocks for its latency chains); one value for both, since the group size fixes the summation order
+constexpr int BA_PT_SHIFT = BA_PT_LANES == 32 ? 5 : 4;
+static_assert(BA_PT_LANES == 32 || BA_PT_LANES == 16, "a power of two dividing the wave");
+__device__ __forceinline__ double group_sum32(double v) {   // sum over the point's lane group, fixed tree
 #pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  for (int off = BA_PT_LANES / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
 
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
   BaState* S = win.S;
-  if (S->done || (int)blockIdx.x * 8 >= max(d.M, 1)) return;   // (block 0 of a window without points still counts the iteration)
+  if (S->done || (int)blockIdx.x * (256 / BA_PT_LANES) >= max(d.M, 1)) return;   // (block 0 of a window without points still counts the iteration)
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ Rt_fix = win.Rt_fix;
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
@@ -269,15 +275,15 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
   const double* params = ba_cur(S, P0, P1);
   if (blockIdx.x == 0 && threadIdx.x == 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
   block_poses(params, d.K, cam.inertial, sRt);
-  const int lane32 = threadIdx.x & 31;
-  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> BA_PT_SHIFT;
   if (j >= d.M) return;   // whole 32-lane group leaves together
   const double X[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1],
                        params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   const int s = pt_start[j], e = pt_start[j + 1];
   double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, chi = 0.0;
   // pass 1: residual + Jacobian, accumulate V, g_l (lane-strided, then a fixed shuffle tree)
-  for (int i = s + lane32; i < e; i += 32) {
+  for (int i = s + lane32; i < e; i += BA_PT_LANES) {
     const int k = o_kf[i];
     double Rt[12];
     if (k >= 0) {
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
     pt_glsq[j] = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
   }
   // pass 2: W = A^T B, Y = W V*^-1 -> dense k-major operands; Y g_l per observation
-  for (int i = s + lane32; i < e; i += 32) {
+  for (int i = s + lane32; i < e; i += BA_PT_LANES) {
     const int k = o_kf[i];
     if (k < 0) continue;
     const double* Rt = sRt + 12 * k;
@@ -1212,7 +1218,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
   const BaState* S = win.S;
-  if (S->done || (int)blockIdx.x * 256 >= max(32 * d.M, 6 * d.K)) return;
+  if (S->done || (int)blockIdx.x * 256 >= max(BA_PT_LANES * d.M, 6 * d.K)) return;
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ dp = dp_override ? dp_override : win.dp;     // (inertial: the 6-d pose steps scattered out of the 15-d solve)
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
@@ -1230,11 +1236,11 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     pose_to_Rt(p6, cam.inertial, sRt + 12 * k);
   }
   __syncthreads();
-  const int lane32 = threadIdx.x & 31;
-  const int j = gtid >> 5;
+  const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
+  const int j = gtid >> BA_PT_SHIFT;
   if (j >= d.M) return;     // whole 32-lane group
   double acc[3] = {0.0, 0.0, 0.0};
-  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) {
+  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += BA_PT_LANES) {
     const int k = o_kf[i];
     if (k < 0) continue;
     double dk[6];
@@ -1263,7 +1269,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     dsq += dl * dl; psq += p * p;
   }
   double chi = 0.0;
-  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) {
+  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += BA_PT_LANES) {
     const int k = o_kf[i];
     double Rt[12];
     if (k >= 0) {
@@ -1297,7 +1303,7 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
   const BaState* S = win.S;
-  if (S->done || (int)blockIdx.x * 8 >= d.M) return;
+  if (S->done || (int)blockIdx.x * (256 / BA_PT_LANES) >= d.M) return;
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ Rt_fix = win.Rt_fix;
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
@@ -1306,13 +1312,13 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
   const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
   block_poses(params, d.K, cam.inertial, sRt);
   // one 32-lane group per point (as ba_build_kernel): 2000 points alone would fill 8 blocks
-  const int lane32 = threadIdx.x & 31;
-  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> BA_PT_SHIFT;
   if (j >= d.M) return;   // whole 32-lane group leaves together
   const double X[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1],
                        params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   double chi = 0.0;
-  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) {
+  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += BA_PT_LANES) {
     const int k = o_kf[i];
     double Rt[12];
     if (k >= 0) {
@@ -1970,7 +1976,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     max_schur_blocks = std::max(max_schur_blocks, pl.d.ncb * (pl.d.ncb + 1) / 2 * pl.d.ksplit);
     if (pl.d.ncb != 1) all_diag = 0;
     max_gather = std::max(max_gather, std::min(256, (4 * pl.n * pl.n + 255) / 256));
-    max_back = std::max(max_back, (std::max(32 * pl.d.M, pl.n) + 255) / 256);
+    max_back = std::max(max_back, (std::max(BA_PT_LANES * pl.d.M, pl.n) + 255) / 256);
     max_asm = std::max(max_asm, std::min(512, (pl.n * pl.n + 255) / 256));
   }
   BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, inertial ? inr->cfg->huber_threshold_mono : cfg->huber_threshold, global_mode ? 1 : 0,
@@ -2054,7 +2060,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // initial error (:1000-1001) -> res[12]
   {
     ProfScope ps(h, "ba_chi2");
-    if (maxM > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((maxM * 32 + 255) / 256, W), dim3(256), 0, st, d_wins, bc, 0);
+    if (maxM > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((maxM * BA_PT_LANES + 255) / 256, W), dim3(256), 0, st, d_wins, bc, 0);
     chi2_sum(0, 0);
   }
   if (int rc = allreduce(res0 + 12, 1)) return rc;
@@ -2065,7 +2071,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if (!dist && should_stop && should_stop(user)) { stopped = true; break; }                           // :1013
     {
       ProfScope ps(h, "ba_build_kernel");
-      if (maxM > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((maxM * 32 + 255) / 256, W), dim3(256), 0, st, d_wins, bc, iter);
+      if (maxM > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((maxM * BA_PT_LANES + 255) / 256, W), dim3(256), 0, st, d_wins, bc, iter);
       else hipLaunchKernelGGL(ba_iter_kernel, gW1, dim3(1), 0, st, d_wins, iter);
     }
     if (maxK > 0 && W == 1) {
