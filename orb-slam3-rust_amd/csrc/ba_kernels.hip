@@ -35,6 +35,7 @@
 #include <cmath>
 #include <mutex>
 #include <numeric>
+#include <chrono>
 #include <thread>
 
 #include "orbx_internal.hpp"
@@ -1828,6 +1829,12 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     return orbx_fail(h, ORBX_ERR_INVALID, "the inertial mode and the all-reduce hook take one window per call");
   for (int w = 0; w < W; ++w) { *win[w].iterations = 0; *win[w].initial_error = 0.0; *win[w].final_error = 0.0; win[w].status = ORBX_OK; }
   hipStream_t st = h->stream;
+  // ORBX_BA_TIMING=1: host-side phase times of this call on stderr (plan, preprocessing, descriptors + upload enqueue, launch
+  // enqueue, drain, unpack)
+  static const bool timing = getenv("ORBX_BA_TIMING") != nullptr;
+  double t_mark[8] = {0};
+  auto mark = [&](int i) { if (timing) t_mark[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  mark(0);
 
   // ---- plan: dimensions and the layout of the four buffers
   std::vector<WinPlan> plan(W);
@@ -1914,6 +1921,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   uint8_t* dar = (uint8_t*)h->ws_ba[B_ARENA].p;
   double* dout = (double*)h->ws_ba[B_OUT].p;
 
+  mark(1);
   // ---- host preprocessing, one window per task (threads when the batch is large enough to pay for them)
   std::vector<int> bad(W, -1);
   {
@@ -1929,6 +1937,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       for (auto& t : th) t.join();
     }
   }
+  mark(2);
   int first_bad = -1;
   for (int w = 0; w < W && first_bad < 0; ++w) if (bad[w] >= 0) first_bad = w;
   if (first_bad >= 0 && !dist) {
@@ -2011,6 +2020,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     gfull = b15.ginv + n15;
   }
   ORBX_HIP(h, hipMemcpyAsync(din, hin, cin.off, hipMemcpyHostToDevice, st));         // ONE upload for the whole batch
+  mark(3);
   {
     static std::once_flag once[64];                                    // process-wide function attribute: set once per device to
     hipError_t e_attr = hipSuccess;                                    // the largest size any window may ask for
@@ -2157,6 +2167,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   }
   double* hout = (double*)h->h_ba_out;
   ORBX_HIP(h, hipMemcpyAsync(hout, dout, cout.off, hipMemcpyDeviceToHost, st));   // ONE download
+  mark(4);
   // While the enqueued iterations drain, keep asking should_stop: a stop requested now (the local mapper's "new keyframe
   // arrived") ends the solve at the next iteration boundary, as in the reference, instead of being seen only by the polls
   // at enqueue time, which are all over within the first few hundred microseconds.
@@ -2166,6 +2177,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   }
   ORBX_HIP(h, hipStreamSynchronize(st));
   ORBX_HIP(h, hipGetLastError());
+  mark(5);
 
   for (int w = 0; w < W; ++w) {
     if (plan[w].skip) continue;
@@ -2218,6 +2230,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       for (int k = 0; k < K; ++k) host_params_to_pose_wc(&params[6 * (size_t)k], ww.poses_wc_out + 7 * (size_t)k);
     }
     for (int j = 0; j < 3 * M; ++j) ww.points[j] = params[6 * (size_t)K + j];
+  }
+  if (timing) {
+    mark(6);
+    fprintf(stderr, "[orbx ba] W=%d in=%.1f MB: plan %.3f | prep %.3f | descriptors+upload enqueue %.3f | iteration enqueue %.3f | drain %.3f | unpack %.3f ms\n",
+            W, cin.off / 1e6, t_mark[1] - t_mark[0], t_mark[2] - t_mark[1], t_mark[3] - t_mark[2], t_mark[4] - t_mark[3], t_mark[5] - t_mark[4], t_mark[6] - t_mark[5]);
   }
   return ORBX_OK;
 }
