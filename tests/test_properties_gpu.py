@@ -40,6 +40,32 @@ def test_rerun_is_bitwise_identical(full_batch):
             assert torch.equal(out["matches"][b, :nm[b]], snap["matches"][b, :nm[b]])
 
 
+def test_large_batch_launch_shapes_equal_small_batch_ones(full_batch, pkg, oracle):
+    """A 128-pair batch runs FAST with three tiles per block and the resize with six rows per thread; a single pair runs one tile per
+    block and two rows (launch_orb_extract picks by batch size).  Same pair, both ways, bit for bit — and one of them against the oracle."""
+    import torch
+    h, imgs, out, snap, B, cap = full_batch
+    h1 = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 2000, device=0, max_w=752, max_h=480, max_batch=1)
+    try:
+        o1 = h1.alloc_batch_outputs(1, cap)
+        for b in (0, 41, 127):
+            h1.process_stereo_batch_device(imgs[b:b + 1].contiguous(), o1)
+            h1.check_status()
+            big = h.unpack_batch_outputs(snap, b)
+            one = h1.unpack_batch_outputs(o1, 0)
+            for x, y in zip(big[:2], one[:2]):
+                assert np.array_equal(x.keypoints.view(np.uint8), y.keypoints.view(np.uint8)) and np.array_equal(x.descriptors, y.descriptors)
+            assert np.array_equal(big[2].view(np.uint8), one[2].view(np.uint8))
+            assert np.array_equal(big[4], one[4]) and np.array_equal(big[3][big[4] == 1], one[3][one[4] == 1])
+        p = oracle.orb_params(2000)
+        img = imgs[41, 0].cpu().numpy()
+        ok, od = oracle.orb_extract(img, p)
+        fl = h.unpack_batch_outputs(snap, 41)[0]
+        assert np.array_equal(fl.descriptors, od) and len(fl.keypoints) == len(ok)
+    finally:
+        h1.close()
+
+
 def test_optional_blur_fork_gives_identical_results(full_batch):
     """ORBX_FORK_BLUR=1 runs the blur on a second stream beside the FAST chain (read at launch time): same bytes out."""
     import os
