@@ -28,6 +28,8 @@ def algo_bytes_per_frame(w, h, n):
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_4CYC = 585.0  # G wave-instr/s, measured (profiles/r02_valu_issue_probe.txt): packed-i16 / perm / dot4 / cmp / ... class
 VALU_PEAK_2CYC = 960.0  # same file: v_add_u32 / v_and_b32 / v_lshrrev_b32 / v_bitop3_b32 / f32 fma class
+# share of a kernel's VALU instructions that belong to the 2-cycle class (ISA listing weighted by loop trip counts)
+TWO_CYCLE_SHARE = {"fast_kernel": 0.49}
 
 
 def make_batches(P, torch, dev, seed, batch, n_batches, w, h):
@@ -261,25 +263,24 @@ def main():
             kd = pmc["kernels"].get(dom_name, {})
             traffic = kd.get("hbm_bytes_per_launch")
             # what actually binds these byte/integer kernels: VALU issue.  Wave-instructions per launch from the SQ pass
-            # (same file), priced with the launch time measured live against the issue rate MEASURED on this chip by
-            # scripts/valu_issue_probe (profiles/r02_valu_issue_probe.txt): the opcodes these kernels are made of —
-            # v_pk_min/max/sub/mad_i16, v_perm_b32, v_alignbyte_b32, v_dot4/dot2, 24-bit multiplies, v_cmp, v_mbcnt, DPP
-            # moves, v_min/max_i32 — issue once per 4 cycles per SIMD at any occupancy (560-590 G wave-instr/s chip-wide:
-            # VALU_PEAK_4CYC); only v_add/sub_u32, v_and/or/xor, v_lshrrev, v_mov, v_bitop3, f32 add/mul/fma and v_min_u16
-            # reach the 2-cycle rate the guide quotes (950-1080 G/s: VALU_PEAK_2CYC).  frac is against the 4-cycle class.
+            # (same file), priced with the launch time measured live against the issue rates MEASURED on this chip by
+            # scripts/valu_issue_probe (profiles/r02_valu_issue_probe.txt): packed i16 / f16, v_perm_b32, v_alignbyte_b32,
+            # v_dot4/dot2, 24-bit multiplies, v_cmp, v_cndmask, v_mbcnt, DPP moves, v_min/max_i32, shifts left issue once per
+            # 4 cycles per SIMD at any occupancy (560-590 G wave-instr/s chip-wide: VALU_PEAK_4CYC); v_add/sub_u32,
+            # v_and/or/xor, v_lshrrev, v_mov, v_bitop3, f32 add/mul/fma and v_min_u16 once per 2 (950-1080 G/s: VALU_PEAK_2CYC).
+            # No hardware counter gives VALU busy time here — SQ_ACTIVE_INST_VALU and SQ_THREAD_CYCLES_VALU both count
+            # instructions (profiles/r02_pmc_counter_calibration.txt) — so a kernel that mixes the classes is priced by its mix:
+            # frac = rate x (share_2cycle / peak_2cycle + (1 - share_2cycle) / peak_4cycle), the share from the ISA listing
+            # weighted by loop trip counts (FAST after round 2: 0.49; every other kernel is 4-cycle class throughout).
             if kd.get("valu_wave_instr_per_launch") and dom_ms > 0:
                 rate = kd["valu_wave_instr_per_launch"] / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9
-                busy = kd.get("valu_busy_frac")
+                share2 = TWO_CYCLE_SHARE.get(dom_name, 0.0)
                 valu = dict(wave_instr_per_launch=kd["valu_wave_instr_per_launch"], achieved=round(rate, 1), peak=VALU_PEAK_4CYC,
-                            peak_simple_ops=VALU_PEAK_2CYC, unit="G wave-instr/s",
-                            # the counter's busy fraction where the pass has it; else the instruction rate against the 4-cycle class
-                            frac=(busy if busy is not None else round(rate / VALU_PEAK_4CYC, 4)),
+                            peak_simple_ops=VALU_PEAK_2CYC, unit="G wave-instr/s", two_cycle_share_est=share2,
+                            frac=round(rate * (share2 / VALU_PEAK_2CYC + (1.0 - share2) / VALU_PEAK_4CYC), 4),
                             frac_of_4cycle_class_rate=round(rate / VALU_PEAK_4CYC, 4),
-                            source="profiles/r02_valu_issue_probe.txt, profiles/pmc_traffic.json",
-                            # fraction of all SIMD cycles the VALU was issuing, from SQ_ACTIVE_INST_VALU of the counter pass (the
-                            # kernels now mix 2- and 4-cycle opcodes, which an instruction count alone no longer prices)
-                            busy_frac_pmc=kd.get("valu_busy_frac"), lds_busy_frac_pmc=kd.get("lds_busy_frac"),
-                            lds_bank_conflict_share_pmc=kd.get("lds_bank_conflict_share"))
+                            source="profiles/r02_valu_issue_probe.txt, profiles/pmc_traffic.json, profiles/r02_pmc_counter_calibration.txt",
+                            lds_busy_frac_pmc=kd.get("lds_busy_frac"), lds_bank_conflict_share_pmc=kd.get("lds_bank_conflict_share"))
     except Exception:
         traffic = None
     # the >= 60 % HBM goal is assessed on the streaming kernels — algorithmic bytes / measured time / 8 TB/s each

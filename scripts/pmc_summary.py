@@ -40,9 +40,10 @@ if len(sys.argv) > 6:
             if k in out["kernels"]:
                 out["kernels"][k][key + "_per_launch"] = int(sum(c[k]) / len(c[k]))
 if len(sys.argv) > 7:
-    # second SQ pass: SQ_ACTIVE_INST_VALU counts quad-cycles the VALU is issuing (one per 4-cycle-class instruction, half of one per
-    # 2-cycle-class instruction), GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs -> fraction of all SIMD cycles spent issuing
-    # VALU work, measured (no per-opcode price list needed); LDS pipe activity and its bank-conflict share beside it
+    # second SQ pass.  SQ_ACTIVE_INST_VALU turned out to count issued VALU instructions, not cycles (calibrated with the issue probe:
+    # profiles/r02_pmc_counter_calibration.txt), so "valu_instr_x4_over_cycles" = instructions x 4 / SIMD cycles is an instruction rate in
+    # units of the 4-cycle opcode class — the busy fraction of a kernel made of 4-cycle opcodes only, and up to 2.0 for 2-cycle opcodes.
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs.  LDS pipe activity and its bank-conflict share beside it
     extra = {t: load(sys.argv[7], t) for t in ("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT")}
     for k in out["kernels"]:
         if k in extra["SQ_ACTIVE_INST_VALU"] and k in extra["GRBM_GUI_ACTIVE"]:
@@ -51,7 +52,7 @@ if len(sys.argv) > 7:
             d = out["kernels"][k]
             d["valu_active_quadcycles_per_launch"] = int(act)
             d["gui_active_cycles_per_launch"] = int(gui)
-            d["valu_busy_frac"] = round(act * 4 / (gui / 8 * 1024), 4) if gui > 0 else None
+            d["valu_instr_x4_over_cycles"] = round(act * 4 / (gui / 8 * 1024), 4) if gui > 0 else None
             if k in extra["SQ_LDS_IDX_ACTIVE"]:
                 la = sum(extra["SQ_LDS_IDX_ACTIVE"][k]) / len(extra["SQ_LDS_IDX_ACTIVE"][k])
                 lc = sum(extra["SQ_LDS_BANK_CONFLICT"].get(k, [0])) / max(len(extra["SQ_LDS_BANK_CONFLICT"].get(k, [0])), 1)
@@ -65,9 +66,9 @@ for k in sorted(f):
     print("%-28s %8d %14.1f %14.2f %14.2f" % (k, len(f[k]), fm, 2 * fm * 1024 / 1e6, wm * 1024 / 1e6))
 if len(sys.argv) > 7:
     print()
-    print("%-28s %14s %14s %10s %10s %12s" % ("kernel", "VALU instr", "VALU active x4", "VALU busy", "LDS busy", "LDS conflict"))
+    print("%-28s %14s %14s %10s %10s %12s" % ("kernel", "VALU instr", "VALU active x4", "instr x4/cyc", "LDS busy", "LDS conflict"))
     for k in sorted(out["kernels"]):
         d = out["kernels"][k]
-        if "valu_busy_frac" in d:
+        if "valu_instr_x4_over_cycles" in d:
             print("%-28s %14.3e %14.3e %9.1f%% %9.1f%% %11.1f%%" % (k, d.get("valu_wave_instr_per_launch", 0), 4.0 * d["valu_active_quadcycles_per_launch"],
-                  100 * (d["valu_busy_frac"] or 0), 100 * (d.get("lds_busy_frac") or 0), 100 * (d.get("lds_bank_conflict_share") or 0)))
+                  100 * (d["valu_instr_x4_over_cycles"] or 0), 100 * (d.get("lds_busy_frac") or 0), 100 * (d.get("lds_bank_conflict_share") or 0)))
