@@ -495,7 +495,12 @@ __device__ __forceinline__ int fast_arc_score_h(unsigned v, const unsigned (&P)[
 //      level's candidates.
 constexpr int FT_W = 62, FT_H = 46;          // inner tile (heights 30 / 46 / 62: 0.837 / 0.821 / 0.835 ms per 256 pairs)
 constexpr int FS_W = 64, FS_H = 48;          // score region
-constexpr int FP_PITCH = 72, FP_ROWS = FS_H + 6;
+#ifndef ORBX_FP_PITCH
+#define ORBX_FP_PITCH 72
+#endif
+// (pixel-tile row pitch 72 / 76 / 80 / 88 / 104 bytes: 0.537 / 0.540 / 0.538 / 0.537 / 0.538 ms per 256 pairs — the 31 % bank-conflict share of
+// the LDS pipe's cycles does not bind the kernel)
+constexpr int FP_PITCH = ORBX_FP_PITCH, FP_ROWS = FS_H + 6;
 #ifndef ORBX_FAST_CHAIN
 #define ORBX_FAST_CHAIN 3
 #endif
