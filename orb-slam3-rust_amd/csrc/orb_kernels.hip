@@ -9,7 +9,7 @@
 //                         8-byte source windows, v_dot4 taps                                  (A.4)
 //   blur_kernel           7x7 sigma-2 fixed-point Gaussian of every level: register window walking down
 //                         column strips (no LDS), DPP neighbours, v_dot4 / v_dot2 taps       (A.8)
-//   fast_kernel           FAST-9/16 score + 3x3 NMS + border filter on 62x46 LDS tiles, 3 tiles per block with the next
+//   fast_kernel           FAST-9/16 score + 3x3 NMS + border filter on 62x62 LDS tiles, 3 tiles per block with the next
 //                         tile's pixels prefetched: byte-parallel compass pre-test (v_bitop3_b32), compacted survivors,
 //                         arc score on f16 denormals (v_pk_minimum3/maximum3_f16), deferred append; per-level
 //                         candidate lists + score histograms                                  (A.5)
@@ -485,16 +485,26 @@ __device__ __forceinline__ int fast_arc_score_h(unsigned v, const unsigned (&P)[
   return (int)__builtin_bit_cast(short, b);
 }
 
-// Two-phase per tile.  Score region 64 x 48 positions (inner 62 x 46 + 1-position NMS frame), pixel tile
-// 72 x 54 bytes staged so that position i sits at byte i+4 of its LDS row (dword aligned):
+// Two-phase per tile.  Score region 64 x (FT_H + 2) positions (inner 62 x FT_H + 1-position NMS frame), pixel tile
+// 72 x (FT_H + 8) bytes staged so that position i sits at byte i+4 of its LDS row (dword aligned):
 //   1. every position, 4 per thread from 5 dword LDS reads: compass pre-test — a 9-arc always contains
 //      two adjacent compass points (0,4,8,12), so a corner needs two adjacent ones both brighter than
 //      v+t or both darker than v-t; survivors (~10 %) are compacted into an LDS list;
 //   2. full arc score only for the listed positions, written into the LDS score tile;
 //   3. 3x3 NMS over the corners phase 2 found (second, much shorter list), block-aggregated append to the
 //      level's candidates.
-constexpr int FT_W = 62, FT_H = 46;          // inner tile (heights 30 / 46 / 62: 0.837 / 0.821 / 0.835 ms per 256 pairs)
-constexpr int FS_W = 64, FS_H = 48;          // score region
+#ifndef ORBX_FT_H
+#define ORBX_FT_H 62
+#endif
+#ifndef ORBX_FT_THREADS
+#define ORBX_FT_THREADS 256
+#endif
+constexpr int FT_THREADS = ORBX_FT_THREADS;
+// inner tile 62 x FT_H.  Round 1 (packed-i16 kernel): heights 30 / 46 / 62: 0.837 / 0.821 / 0.835 ms per 256 pairs.  After the round-2 work
+// (chains, deferred append) with 256 threads: 46 / 54 / 58 / 62 / 66 / 70 / 78: 0.537 / 0.528 / 0.503 / 0.498 / 0.526 / 0.527 / 0.540 — fewer tile
+// prologues and halo rows per pixel until the LDS footprint (21 KB at 62) takes a block away from the CU; 512 threads on 62 x 94: 0.568
+constexpr int FT_W = 62, FT_H = ORBX_FT_H;
+constexpr int FS_W = 64, FS_H = FT_H + 2;          // score region
 #ifndef ORBX_FP_PITCH
 #define ORBX_FP_PITCH 72
 #endif
@@ -505,8 +515,8 @@ constexpr int FP_PITCH = ORBX_FP_PITCH, FP_ROWS = FS_H + 6;
 #define ORBX_FAST_CHAIN 3
 #endif
 constexpr int FAST_CHAIN = ORBX_FAST_CHAIN;   // tiles per block
-static_assert(FP_ROWS <= 84, "the staging loop covers up to 3 x 28 rows");
-static_assert((FT_W / 2) * (FT_H / 2) <= 1024, "s_list holds the NMS survivors of a tile");
+
+
 
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
 
@@ -558,7 +568,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // SWAR: phase 1 in the byte-parallel form, eight positions per task (fast_threshold < 128; launch_orb_extract picks the variant)
 template <bool SWAR>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
-__global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
+__global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
                                                    unsigned* __restrict__ cand, unsigned* __restrict__ cand_count,
                                                    unsigned* __restrict__ hist, int n_tiles, int chain_len) {
   __shared__ __attribute__((aligned(16))) uint8_t sp[FP_ROWS][FP_PITCH];
@@ -574,8 +584,9 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   // fully persistent blocks measured worse both ways — a fixed stride 0.71 ms (tile costs differ, the slowest of 2048 fixed shares
   // sets the time) and tickets from 8 per-XCD queues 2.0 ms (170k same-address device atomics serialise at ~100 ns each).
   const int tid = threadIdx.x, lane = tid & 63;
-  const int st_r0 = tid / 9, st_c = tid - 9 * st_r0;               // staging: 9 lanes x 8 bytes per 72-byte row, 28 rows per pass
-  constexpr int ST_PASS = (FP_ROWS + 27) / 28;
+  const int st_r0 = tid / 9, st_c = tid - 9 * st_r0;               // staging: 9 lanes x 8 bytes per 72-byte row, FT_THREADS / 9 rows per pass
+  constexpr int ST_RPP = FT_THREADS / 9;
+  constexpr int ST_PASS = (FP_ROWS + ST_RPP - 1) / ST_RPP;
   unsigned long long pf[ST_PASS];
   struct Tile { int img, l, x0, y0, w, h, aw, ah; };
   Tile cur, nxt;
@@ -594,8 +605,8 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     // pixel tile: LDS row r = image row y0-4+r, byte b = image column x0-5+b
 #pragma unroll
     for (int k = 0; k < ST_PASS; ++k) {
-      const int r = st_r0 + 28 * k;
-      if (st_r0 < 28 && r < c.ah + 6) {
+      const int r = st_r0 + ST_RPP * k;
+      if (st_r0 < ST_RPP && r < c.ah + 6) {
         const int gy = min(c.y0 - 4 + r, c.h - 1), gx = min(c.x0 - 5 + 8 * st_c, pitch - 8);
         __builtin_memcpy(&pf[k], src + (size_t)gy * pitch + gx, 8);
       }
@@ -610,7 +621,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   int pend_cnt = 0, pend_il = 0;
   unsigned pend_off = 0, pend_base = 0;
   auto flush = [&]() {
-    for (int q = tid; q < pend_cnt; q += 256) {
+    for (int q = tid; q < pend_cnt; q += FT_THREADS) {
       const unsigned c = s_list[q];
       cand[(size_t)img0 * g.cand_total + pend_off + s_base + q] = c;
       atomicAdd(&hist[(size_t)pend_il * 256 + (c >> 24)], 1u);
@@ -625,11 +636,11 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   const unsigned inv = (unsigned)(65536.f / (float)qpr) + 1u;      // task / qpr = (task * inv) >> 16, exact for task < 512
 #pragma unroll
   for (int k = 0; k < ST_PASS; ++k) {
-    const int r = st_r0 + 28 * k;
-    if (st_r0 < 28 && r < ah + 6) *reinterpret_cast<unsigned long long*>(&sp[r][8 * st_c]) = pf[k];
+    const int r = st_r0 + ST_RPP * k;
+    if (st_r0 < ST_RPP && r < ah + 6) *reinterpret_cast<unsigned long long*>(&sp[r][8 * st_c]) = pf[k];
   }
-  static_assert(FS_W * FS_H / 16 <= 256, "one 16-byte store per thread clears the score tile");
-  if (tid < FS_W * FS_H / 16) reinterpret_cast<uint4*>(&ss[0][0])[tid] = uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = tid; i < FS_W * FS_H / 16; i += FT_THREADS) reinterpret_cast<uint4*>(&ss[0][0])[i] = uint4{0u, 0u, 0u, 0u};   // 16-byte stores clear the score tile
   __syncthreads();
   // the next tile's pixels travel while this one is processed (the barriers below wait for LDS only, not for these loads)
   if (tile + 1 < tile_end) fetch(img0, tile + 1, nxt);
@@ -642,7 +653,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     const int ntask8 = qpr8 * ah;
     const unsigned inv8 = (unsigned)(65536.f * __builtin_amdgcn_rcpf((float)qpr8)) + 1u;   // (v_rcp_f32 is within 1 ulp: the floor is the quotient's for 1..8)
     const unsigned T = (unsigned)t * 0x01010101u;
-    for (int task0 = 0; task0 < ntask8; task0 += 256) {
+    for (int task0 = 0; task0 < ntask8; task0 += FT_THREADS) {
       const int task = task0 + tid;
       unsigned m8 = 0;
       int j = 0, gq = 0;
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
     }
   } else
   // phase 1: compass pre-test, 4 positions per task
-  for (int task = tid; task < ntask; task += 256) {
+  for (int task = tid; task < ntask; task += FT_THREADS) {
     const int j = (int)(__umul24((unsigned)task, inv) >> 16), tq = task - (int)__umul24((unsigned)j, (unsigned)qpr);   // (v_mul_lo_u32 is quarter rate)
     const unsigned* rowc = reinterpret_cast<const unsigned*>(&sp[j + 3][0]) + tq;
     const unsigned c0 = rowc[0], c1 = rowc[1], c2 = rowc[2];
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   const int npos = s_npos;
   flush();                                                           // previous tile's corners; phase 3 below rewrites s_list
   // phase 2: full score of the pre-test survivors
-  for (int q = tid; q < npos; q += 256) {
+  for (int q = tid; q < npos; q += FT_THREADS) {
     const int p = s_pos[q], j = p >> 6, i = p & 63;
     const int cy = j + 3, cx = i + 4;
     const unsigned v = sp[cy][cx];
@@ -749,7 +760,7 @@ __global__ __launch_bounds__(256) void fast_kernel(OrbSrc s, OrbGeom g, int n_im
   __syncthreads();
   // phase 3: NMS (strictly greater than the 8 neighbours) + runByImageBorder, over the same list: corners inside the tile and the
   // border-filtered region (a few per cent of the survivors — the pre-test also passes every straight edge)
-  for (int q = tid; q < npos; q += 256) {
+  for (int q = tid; q < npos; q += FT_THREADS) {
     const int p = s_pos[q];
     const int j = p >> 6, i = p & 63;
     const int x = x0 + i - 1, y = y0 + j - 1;
@@ -1561,9 +1572,9 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
       const int chain_len = (size_t)g.ftiles_total * n >= (size_t)4 * 8 * h->n_cu ? FAST_CHAIN : 1;
       const int chains = (g.ftiles_total + chain_len - 1) / chain_len;
       if (g.fast_threshold < 128)
-        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(chains, n), dim3(256), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len);
+        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(chains, n), dim3(FT_THREADS), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len);
       else
-        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(chains, n), dim3(256), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len);
+        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(chains, n), dim3(FT_THREADS), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len);
     }
     {
       ProfScope ps(h, "harris_select_kernel", nullptr, true);
