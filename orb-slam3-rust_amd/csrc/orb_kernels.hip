@@ -237,7 +237,10 @@ __device__ __forceinline__ void decode_tile(const unsigned* __restrict__ tab, in
 #define ORBX_BLUR_PF 2
 #endif
 constexpr int BLUR_PF = ORBX_BLUR_PF;   // input rows in flight per lane
-constexpr int BLUR_W = 248, BLUR_STRIP = 32, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo;
+#ifndef ORBX_BLUR_STRIP
+#define ORBX_BLUR_STRIP 32
+#endif
+constexpr int BLUR_W = 248, BLUR_STRIP = ORBX_BLUR_STRIP, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo;
 // rows per wave 16 / 32 / 48 / 64 / 96 / 128: 0.307 / 0.300 / 0.302 / 0.315 / 0.366 / 0.369 ms per 256 pairs
 
 __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2, unsigned (&hs)[4]) {
