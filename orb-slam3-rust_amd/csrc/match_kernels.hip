@@ -21,7 +21,10 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int SM_THREADS = 256;
-constexpr int SM_LEFT_PER_WAVE = 8;   // multiple of 4: four left keypoints share a wave
+#ifndef ORBX_SM_LPW
+#define ORBX_SM_LPW 8
+#endif
+constexpr int SM_LEFT_PER_WAVE = ORBX_SM_LPW;   // multiple of 4: four left keypoints share a wave
 constexpr int SM_LEFT_PER_BLOCK = SM_LEFT_PER_WAVE * (SM_THREADS / kWave);
 constexpr unsigned TH_HIGH = 100;  // stereo.rs:10
 
