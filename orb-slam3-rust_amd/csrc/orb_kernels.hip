@@ -1188,6 +1188,10 @@ __device__ __forceinline__ int row16_sum(int v) {
   return v;
 }
 
+// (round 2 re-check of the occupancy: 4 / 5 / 6 waves per SIMD — 5 is what the 95 VGPRs give — 0.546 / 0.490 / 0.540 ms per 256 pairs)
+#ifdef ORBX_DESC_WAVES
+__attribute__((amdgpu_waves_per_eu(ORBX_DESC_WAVES, ORBX_DESC_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, int blocks_per_img,
                                                        const unsigned long long* __restrict__ sel2,
                                                        const unsigned long long* __restrict__ spatial,
