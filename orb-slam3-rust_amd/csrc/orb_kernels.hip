@@ -569,6 +569,9 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 }
 
 // SWAR: phase 1 in the byte-parallel form, eight positions per task (fast_threshold < 128; launch_orb_extract picks the variant)
+// (waves_per_eu(8, 8) keeps the register allocator at 64 VGPRs although 21 KB of LDS admit 7 blocks per CU: with (7, 8) it takes
+// more registers and the kernel runs 0.512 instead of 0.498 ms.  The per-(image, level) retainBest thresholds precomputed by a small
+// kernel instead of in each of harris_select_kernel's eight blocks: 0.149 -> 0.146 ms, not kept.)
 template <bool SWAR>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
