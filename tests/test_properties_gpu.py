@@ -66,6 +66,37 @@ def test_large_batch_launch_shapes_equal_small_batch_ones(full_batch, pkg, oracl
         h1.close()
 
 
+@pytest.mark.parametrize("w,hh,B", [(640, 480, 32), (1241, 376, 24), (333, 257, 16), (1920, 1080, 8)])
+def test_large_batch_equals_single_pair_other_sizes(pkg, w, hh, B):
+    """the batch-size dependent launch shapes (FAST chains, resize rows per thread) at other image sizes: pairs of a batch equal the
+    same pairs processed alone, bit for bit"""
+    import torch
+    rng = np.random.default_rng(w * 7 + hh)
+    base = pkg.synth.stereo_batch(91, 0, 4)                                   # 4 pairs of 752x480 scenes, resampled by cropping / tiling
+    reps_y, reps_x = (hh + 479) // 480, (w + 751) // 752
+    big = np.tile(base, (1, 1, reps_y, reps_x))[:, :, :hh, :w]
+    imgs_np = np.concatenate([big] * ((B + 3) // 4))[:B].copy()
+    imgs_np[1::2] = imgs_np[1::2, :, ::-1, :]                                 # vary the content a little across the batch
+    imgs_np = np.clip(imgs_np.astype(np.int16) + rng.integers(-3, 4, (B, 1, 1, 1)), 0, 255).astype(np.uint8)
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA)
+    hb = pkg.Handle(cam, 1500, device=0, max_w=w, max_h=hh, max_batch=B)
+    h1 = pkg.Handle(cam, 1500, device=0, max_w=w, max_h=hh, max_batch=1)
+    try:
+        imgs = torch.from_numpy(imgs_np).cuda()
+        ob = hb.alloc_batch_outputs(B, 2048)
+        hb.process_stereo_batch_device(imgs, ob); hb.check_status()
+        o1 = h1.alloc_batch_outputs(1, 2048)
+        for b in (0, B // 2 + 1, B - 1):
+            h1.process_stereo_batch_device(imgs[b:b + 1].contiguous(), o1); h1.check_status()
+            big_r = hb.unpack_batch_outputs(ob, b); one = h1.unpack_batch_outputs(o1, 0)
+            assert len(big_r[0].keypoints) > 100
+            for x, y in zip(big_r[:2], one[:2]):
+                assert np.array_equal(x.keypoints.view(np.uint8), y.keypoints.view(np.uint8)) and np.array_equal(x.descriptors, y.descriptors)
+            assert np.array_equal(big_r[2].view(np.uint8), one[2].view(np.uint8)) and np.array_equal(big_r[4], one[4])
+    finally:
+        hb.close(); h1.close()
+
+
 def test_optional_blur_fork_gives_identical_results(full_batch):
     """ORBX_FORK_BLUR=1 runs the blur on a second stream beside the FAST chain (read at launch time): same bytes out."""
     import os
