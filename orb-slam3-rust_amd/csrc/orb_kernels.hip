@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void resize_kernel(OrbSrc s, OrbGeom g, int l,
   constexpr int NP = (RZ_SRC_ROWS + 31) / 32;          // staging passes: every pass's load is issued before the first store waits for one
   struct Tile { int X0, Y0, ax, ncol, sy_lo, nrow, off; };
   uint4 v[NP];
+  // (the rectangle's bounds from the scale in f32 with margins instead of the four scalar table loads: 0.264 -> 0.274 ms)
   // a tile's source rectangle (block-uniform): columns from the first pixel's left tap (16-byte aligned, inside the row) to the
   // last active thread's window end, rows from the first output row's upper tap to the last one's lower tap; and its loads
   auto fetch = [&](int tb, Tile& t) {
