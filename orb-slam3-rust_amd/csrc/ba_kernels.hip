@@ -356,7 +356,10 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
   }
 }
 
-constexpr int BA_KFSPLIT = 8;
+#ifndef ORBX_BA_KFSPLIT
+#define ORBX_BA_KFSPLIT 2
+#endif
+constexpr int BA_KFSPLIT = ORBX_BA_KFSPLIT;   // 16 / 8 / 4 / 2 blocks per keyframe: 32-window batch 36.2 / 39.0 / 40.2 / 40.4 k LM it/s, single window unchanged (6.4-6.5 k): the 33 shuffle-tree reductions per block outweigh the observations a block adds up
 // BA_KFSPLIT blocks per optimised keyframe: partial U_k (21 unique), g_p (6), b_red (6) over a slice of its
 // observations; the gather kernel adds the partials in a fixed order.
 __device__ __forceinline__ void ba_kf_body(int bx, const BaDims& d, const int* __restrict__ kf_start, const int* __restrict__ kf_obs,
