@@ -356,6 +356,10 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
   }
 }
 
+#ifndef ORBX_BA_PPS
+#define ORBX_BA_PPS 32
+#endif
+constexpr int BA_PPS_TARGET = ORBX_BA_PPS;   // map points per k-split of the Schur product (multiple of 8).  24 / 32 / 48 / 64: single window 6.41 / 6.36 / 6.10 / 5.83 k LM it/s, 32-window batch 38.6 / 41.3 / 41.3 / 41.4 k
 #ifndef ORBX_BA_KFSPLIT
 #define ORBX_BA_KFSPLIT 2
 #endif
@@ -1861,11 +1865,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     d.P = std::max(16, (6 * K + 15) & ~15);
     d.ntile = d.P / 16;
     d.ncb = (d.ntile + 7) / 8;
-    // k-splits of the Schur product: ~24 map points each, at most 128 of them; a function of the window alone (never of the
+    // k-splits of the Schur product: ~32 map points each, at most 128 of them; a function of the window alone (never of the
     // batch it travels in: the split fixes the summation order of S_red)
     // (24 points per split measured best for one window of 20 keyframes / 2000 points — 8, 16, 24, 32, 48, 96, 192 tried: the
     // Schur blocks take 8.5 us + 3.6 us per 8 points, the reduction of the partials grows with the number of splits)
-    d.ksplit = std::max(1, std::min(128, (M + 23) / 24));
+    d.ksplit = std::max(1, std::min(128, (M + BA_PPS_TARGET - 1) / BA_PPS_TARGET));
     d.pps = std::max(8, (((M + d.ksplit - 1) / d.ksplit) + 7) & ~7);
     d.rows = 3 * d.pps * d.ksplit;
     pl.n = 6 * K;
