@@ -592,7 +592,7 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         K, M = 19, 2000
         P_ = (6 * K + 15) // 16 * 16
         nt = P_ // 16
-        ksplit = max(1, min(128, (M + 23) // 24))                     # as ba_solve_batch plans it
+        ksplit = max(1, min(128, (M + 31) // 32))                     # as ba_solve_batch plans it (BA_PPS_TARGET = 32)
         pps = max(8, ((M + ksplit - 1) // ksplit + 7) // 8 * 8)
         rows = 3 * pps * ksplit
         flop = nt * (nt + 1) // 2 * (rows // 4) * 2048.0 * nb        # one v_mfma_f64_16x16x4_f64 = 2*16*16*4 flop
