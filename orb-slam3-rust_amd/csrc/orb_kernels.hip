@@ -1178,6 +1178,8 @@ __constant__ unsigned c_ic_col[256];
 // loads (unaligned wide accesses split: 0.31 -> 0.36 ms), the test pattern as floats in LDS (ds_read_b128: slower),
 // 8-byte loads at aligned addresses with the misalignment undone in the arithmetic (24 loads instead of 29, bit-exact,
 // 0.31 -> 0.32 ms; per-lane task constants must then be kept from being hoisted out of the keypoint loop, ~50 VGPRs).
+// Round 2: not requesting the tenth of the patch / disc bytes that can never be read (rows |dy| >= 13 need fewer 8-byte columns)
+// — as predicated loads 0.485 -> 0.62 ms (the branches break the load schedule), as loads redirected to a needed neighbour address 0.54.
 // Four keypoints per wave, 16 lanes each: the per-keypoint work that every lane would otherwise repeat (slot and
 // key decode, the three centroid reductions, fastAtan2, the f64 sin/cos) is shared by 4 keypoints per instruction.
 // Lane li of a group owns centroid tasks t = it*16 + li and descriptor bits r*16 + li (it, r = 0..15); a ballot
