@@ -1547,6 +1547,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
       ProfScope ps(h, "resize_kernel");
       for (int l = 1; l < nl; ++l) {
         const bool small = n < 64;                       // up to 32 pairs: latency counts, keep the blocks short and many (4 / 8 / 16 pairs: 1-2 % over the 6-row form)
+        // (rows chosen per level to waste least of its last tile row, among 3..6: 0.262 against 0.258 ms with 6 everywhere)
         const int rows = small ? RESIZE_ROWS_SMALL : RESIZE_ROWS;
         const int tx = (g.lv[l].w + 63) / 64, ty = (g.lv[l].h + 16 * rows - 1) / (16 * rows);
         const int chains = (tx * ty + RESIZE_CHAIN - 1) / RESIZE_CHAIN;
