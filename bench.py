@@ -606,6 +606,28 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
                               mfma_frac=round(flop / (sch_ms * 1e-3) / 78.6e12, 4) if sch_ms > 0 else None,
                               note="orbx_ba_solve_visual_batch: host preprocessing + one upload + 10 LM iterations of all windows + one download per call; "
                                    "every window equals its single-window result bit for bit (tests/test_ba_gpu.py)")
+        # two such batches in flight (two handles = two HIP streams, one host thread each): the host preprocessing, upload and
+        # download of one batch run under the kernels of the other
+        h2 = [P.Handle(cam, 100, device=dev.index if dev is not None else 0) for _ in range(2)]
+        for x in h2:
+            x.ba_solve_visual_batch(cam, cfg, bw)
+        cnt2 = [0, 0]
+
+        def work2(i):
+            for _ in range(nrep + 1):
+                cnt2[i] += sum(r_["iterations"] for r_ in h2[i].ba_solve_visual_batch(cam, cfg, bw))
+
+        th2 = [threading.Thread(target=work2, args=(i,)) for i in range(2)]
+        t0 = time.perf_counter()
+        for t in th2:
+            t.start()
+        for t in th2:
+            t.join()
+        dt2 = time.perf_counter() - t0
+        for x in h2:
+            x.close()
+        out["batched"]["two_batches_in_flight"] = dict(lm_iters_per_s=round(sum(cnt2) / dt2, 1), vs_single_window=round(sum(cnt2) / dt2 / out["lm_iters_per_s"], 2),
+                                                       note="2 handles x 32 windows, one host thread each, no per-kernel events")
     else:
         # the other natural sharding: every stream has its own map, so rank r solves ITS OWN window — no
         # collective in the data path; aggregate LM iterations/s over the ranks
