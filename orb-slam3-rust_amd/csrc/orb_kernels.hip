@@ -1614,7 +1614,8 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     }
     return ORBX_OK;
   };
-  // (Two half-batches on two streams were measured: +0.3 % — every kernel already fills the chip — so one stream.)
+  // (Two half-batches on two streams were measured: +0.3 % in round 1; again at the end of round 2, when FAST's 7 blocks per CU leave wave
+  // slots free: 2 / 3 / 4 / 6 / 8 chunks alternating over two streams: +0.5 ... +2 % / -3 % / 0 / -3 % / -5 % without per-kernel events — so one stream.)
   if (int rc = run(h->stream, 0, n_images)) return rc;
   ORBX_HIP(h, hipGetLastError());
   return ORBX_OK;
