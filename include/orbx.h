@@ -420,7 +420,11 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
  * whole batch (and while the work drains); a window that converges early simply stops taking part.
  *   status: ORBX_OK, or ORBX_ERR_EMPTY for a window the reference answers None for (:923-925) — the call still returns
  *   ORBX_OK and solves the others.  An observation index out of range fails the whole call (ORBX_ERR_INVALID).
- * The all-reduce hook / RCCL communicator is not used here (independent windows need no collective). */
+ * The all-reduce hook / RCCL communicator is not used here (independent windows need no collective).
+ * A batch of 16 or more windows without a should_stop callback runs as two halves at once: the second half on an internal second
+ * stream with its own workspaces, driven by a helper thread for the duration of the call, so that one half's host preprocessing and
+ * transfers run under the other half's kernels (+12 % LM iterations/s at 32 windows).  Results do not depend on it.  With a callback
+ * (which would otherwise be called from two threads), or with per-kernel profiling on, the call keeps to one stream. */
 typedef struct {
   int K;                        /* in: optimised keyframes                         */
   const double* poses_cw;       /* in: [K][7]                                      */

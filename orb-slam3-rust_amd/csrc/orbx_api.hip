@@ -8,6 +8,7 @@
 #include <vector>
 
 #include <rccl/rccl.h>
+#include <thread>
 
 #include "orbx_internal.hpp"
 
@@ -143,6 +144,7 @@ int orbx_create(const orbx_camera* cam, const orbx_orb_params* orb, int device, 
 
 void orbx_destroy(orbx_handle* h) {
   if (!h) return;
+  if (h->ba_aux) { orbx_destroy(h->ba_aux); h->ba_aux = nullptr; }
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->resize_tab, &h->ws_pyr, &h->ws_blur, &h->ws_cand, &h->ws_counters,
@@ -902,7 +904,28 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
   orbx_allreduce_fn saved = h->allreduce;          // independent windows: no collective
   void* saved_comm = h->rccl_comm;
   h->allreduce = nullptr; h->rccl_comm = nullptr;
-  const int rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), should_stop, user);
+  // A large batch runs as two halves at once — this handle and a second, internal one (its own stream, workspaces and pinned blobs), the
+  // second half driven by a helper thread — so that one half's host preprocessing, upload and download run under the other half's kernels
+  // and the latency-bound launches of one fill the gaps of the other.  Windows are independent and a window's arithmetic never depends on
+  // the batch it travels in, so the results are the same bit for bit.  Not with a should_stop callback (it would be called from two
+  // threads), not while per-kernel profiling is on (the kernel times belong to one handle).
+  static const bool no_split = getenv("ORBX_BA_NO_SPLIT") != nullptr;
+  int rc;
+  if (!no_split && n_windows >= 16 && !should_stop && !h->profiling) {
+    if (!h->ba_aux) {
+      const int rc_aux = orbx_create(&h->cam, &h->orb, h->device, h->max_w, h->max_h, 1, &h->ba_aux);
+      if (rc_aux != ORBX_OK) { h->allreduce = saved; h->rccl_comm = saved_comm; return orbx_fail(h, rc_aux, "orbx_ba_solve_visual_batch: second stream: %s", orbx_last_error(nullptr)); }
+    }
+    const int n0 = n_windows / 2;
+    int rc1 = ORBX_OK;
+    std::thread helper([&] {
+      hipSetDevice(h->device);
+      rc1 = ba_solve_batch(h->ba_aux, cam, cfg, n_windows - n0, w.data() + n0, nullptr, nullptr);
+    });
+    rc = ba_solve_batch(h, cam, cfg, n0, w.data(), nullptr, nullptr);
+    helper.join();
+    if (rc == ORBX_OK && rc1 != ORBX_OK) rc = orbx_fail(h, rc1, "(windows %d..%d, numbered from %d) %s", n0, n_windows - 1, n0, orbx_last_error(h->ba_aux));
+  } else rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), should_stop, user);
   h->allreduce = saved; h->rccl_comm = saved_comm;
   for (int i = 0; i < n_windows; ++i) windows[i].status = rc == ORBX_OK ? w[i].status : rc;
   return rc;

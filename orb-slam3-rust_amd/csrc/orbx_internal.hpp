@@ -98,6 +98,7 @@ struct orbx_handle {
   orbx_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   void* rccl_comm = nullptr;                               // ncclComm_t of the point-partitioned solve (orbx_ba_init_rccl / orbx_ba_set_rccl_comm)
+  orbx_handle* ba_aux = nullptr;                           // second stream + workspaces of orbx_ba_solve_visual_batch (half of a large batch runs there)
   bool rccl_owned = false;
   void* h_ba_in = nullptr;   size_t h_ba_in_bytes = 0;    // pinned mirrors of the batch input / output blobs (ba_solve_batch)
   void* h_ba_out = nullptr;  size_t h_ba_out_bytes = 0;
