@@ -236,6 +236,33 @@ def test_ba_batch_32_windows_config3(gpu_handle, oracle, pkg):
     assert np.array_equal(one["poses_wc"], res[31]["poses_wc"]) and np.array_equal(one["points"], res[31]["points"])
 
 
+def test_ba_batch_two_streams_path(gpu_handle, pkg):
+    """16 or more windows without a callback run as two halves on two streams inside the call (orbx.h): windows of mixed sizes
+    across both halves, a window the reference answers None for in the second half, equality with the single-window solves, and an
+    observation index out of range in the second half failing the whole call with its window named."""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
+    shapes = [(5, 90, 0), (12, 400, 1), (20, 900, 0), (3, 40, 0), (8, 250, 2), (25, 600, 0)]
+    wins = [pkg.synth.ba_window(700 + i, *shapes[i % len(shapes)][:2], pkg.BA_OBS, n_fixed_extra=shapes[i % len(shapes)][2]) for i in range(18)]
+    empty = dict(wins[13]); empty["obs"] = wins[13]["obs"][:0]
+    wins[13] = empty
+    batch = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
+    assert batch[13] is None
+    for i in (0, 4, 8, 9, 12, 17):
+        w = wins[i]
+        s = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+        assert batch[i]["iterations"] == s["iterations"] and np.array_equal(batch[i]["poses_wc"], s["poses_wc"]) and \
+            np.array_equal(batch[i]["points"], s["points"]), i
+    bad = [dict(w) for w in wins]
+    o = bad[15]["obs"].copy(); o["mp_idx"][7] = len(bad[15]["points"]) + 3
+    bad[15]["obs"] = o
+    with pytest.raises(pkg.OrbxError) as e:
+        gpu_handle.ba_solve_visual_batch(cam, cfg, bad)
+    assert "out of range" in str(e.value) and "numbered from 9" in str(e.value)
+    # and the handle still works afterwards
+    again = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
+    assert np.array_equal(again[17]["poses_wc"], batch[17]["poses_wc"])
+
+
 def test_ba_batch_abort(gpu_handle, pkg):
     cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
     wins = [pkg.synth.ba_window(400 + i, 5, 80, pkg.BA_OBS) for i in range(3)]
