@@ -394,6 +394,12 @@ int orbx_ba_set_allreduce(orbx_handle* h, orbx_allreduce_fn fn, void* user);
 int orbx_rccl_unique_id(uint8_t* out, size_t cap);
 int orbx_ba_init_rccl(orbx_handle* h, const uint8_t* unique_id, size_t id_bytes, int rank, int world);
 int orbx_ba_set_rccl_comm(orbx_handle* h, void* nccl_comm);
+/* What would carry the all-reduces of a partitioned solve on this handle right now: bit 0 = an RCCL communicator
+ * (orbx_ba_init_rccl / orbx_ba_set_rccl_comm), bit 1 = the orbx_ba_set_allreduce hook; 0 = none — orbx_ba_solve_visual then
+ * treats the observations it is given as the WHOLE problem, so a host that partitions must check before it calls.
+ * librccl is bound on first use of the three calls above (dlopen by soname: a process that already mapped a librccl.so.1,
+ * e.g. PyTorch's, gets that copy); a single-GPU process never loads it. */
+int orbx_ba_has_collective(orbx_handle* h);
 
 /* Replaces solve_visual_ba (local_ba_lm.rs:912-1098).
  *   poses_cw [K][7]  (qw,qx,qy,qz,tx,ty,tz) T_cw of the optimised keyframes (:966-977)

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "orbx_keyframe_create", "orbx_keyframe_destroy", "orbx_keyframe_info", "orbx_keyframe_set_pose", "orbx_keyframe_set_map_points",
     "orbx_keyframe_get_map_points", "orbx_keyframe_download", "orbx_keyframe_device_keypoints", "orbx_keyframe_device_descriptors",
     "orbx_keyframe_guided_match", "orbx_keyframe_search_for_triangulation", "orbx_keyframe_fuse_search",
-    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_has_collective", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
     "orbx_fuse_search", "orbx_fuse_search_device",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
@@ -600,6 +600,12 @@ class Handle:
         """Use an existing ncclComm_t (integer address), e.g. torch's; None / 0 clears."""
         self._L.orbx_ba_set_rccl_comm.argtypes = [C.c_void_p, C.c_void_p]
         self._check(self._L.orbx_ba_set_rccl_comm(self._h, C.c_void_p(comm_ptr or None)))
+
+    def has_collective(self):
+        """Bit 0: an RCCL communicator is installed on the handle; bit 1: the all-reduce hook is (orbx_ba_has_collective)."""
+        self._L.orbx_ba_has_collective.argtypes = [C.c_void_p]
+        self._L.orbx_ba_has_collective.restype = C.c_int
+        return int(self._L.orbx_ba_has_collective(self._h))
 
     def ba_solve_visual(self, camera, cfg, poses_cw, fixed_cw, points, obs, should_stop=None):
         poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)

@@ -1824,7 +1824,10 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
 // W windows at once (W = 1: orbx_ba_solve_visual / global / inertial).  The all-reduce hook and the inertial mode apply to a
 // single window only.
 int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int W, BaWinHost* win,
-                   orbx_should_stop_fn should_stop, void* user, bool global_mode, const BaInertialHost* inr) {
+                   orbx_should_stop_fn should_stop, void* user, bool global_mode, const BaInertialHost* inr, bool single_call) {
+  // single_call: the one-window entry points (orbx_ba_solve_visual / global / inertial) answer ORBX_ERR_EMPTY as their return
+  // value where the reference returns None; the batch entry point reports it in the window's status and returns ORBX_OK,
+  // also for a batch of one (orbx.h)
   // inr != nullptr: solve_inertial_ba (local_inertial_ba.rs:1074-1275).  `poses_cw` then holds the T_wc poses of the window
   // and cfg carries max_iterations only; the point elimination, the per-keyframe 6x6 blocks and the Schur product are the
   // visual solver's kernels, the 15-d keyframe states are assembled and solved on top of them.
@@ -1903,7 +1906,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.o_out = cout.take(8 * (8 + pl.np));
   }
   if (live == 0) {
-    if (W == 1) return orbx_fail(h, ORBX_ERR_EMPTY, "no parameters or no residuals");
+    if (single_call) return orbx_fail(h, ORBX_ERR_EMPTY, "no parameters or no residuals");
     return ORBX_OK;                                                      // every window reports ORBX_ERR_EMPTY in its status
   }
   enum { B_IN, B_ARENA, B_OUT, B_IMU, B_S15 };
@@ -2251,7 +2254,7 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
                     const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
                     int* iterations, double* initial_error, double* final_error, bool global_mode, const BaInertialHost* inr) {
   BaWinHost w{K, F, M, N, poses_cw, fixed_poses_cw, points, obs, poses_wc_out, iterations, initial_error, final_error, ORBX_OK};
-  return ba_solve_batch(h, cam, cfg, 1, &w, should_stop, user, global_mode, inr);
+  return ba_solve_batch(h, cam, cfg, 1, &w, should_stop, user, global_mode, inr, true);
 }
 
 // residual / Jacobian blocks of every observation at the given parameters (input order): out [N][20] = r (2) | A (12) | B (6)

@@ -519,8 +519,23 @@ constexpr int FP_PITCH = ORBX_FP_PITCH, FP_ROWS = FS_H + 6;
 #define ORBX_FAST_CHAIN 3
 #endif
 constexpr int FAST_CHAIN = ORBX_FAST_CHAIN;   // tiles per block
-
-
+// The envelope of (ORBX_FT_H, ORBX_FT_THREADS, ORBX_FP_PITCH, ORBX_FAST_CHAIN) the kernel's index arithmetic is written for; a -D outside it
+// fails to compile instead of running.  (Round 2 swept these macros with the guards removed and one run of the 62-row / 512-thread
+// build ended in a GPU memory fault — DESIGN.md §4 "the f62t512 fault".)
+constexpr int FAST_ST_RPP = FT_THREADS / 9;                                   // rows staged per pass: 9 lanes x 8 bytes per 72-byte row
+constexpr int FAST_ST_PASS = (FP_ROWS + FAST_ST_RPP - 1) / FAST_ST_RPP;       // passes (one 8-byte register per pass and thread)
+constexpr int FAST_LIST_CAP = ((FT_W + 1) / 2) * ((FT_H + 1) / 2);            // 3x3-NMS survivors of a tile: at most one per 2x2 positions
+constexpr int FAST_LDS_BYTES = FP_ROWS * FP_PITCH + FS_H * FS_W + 2 * FS_W * FS_H + 4 * (FAST_LIST_CAP + 1) + 12;
+static_assert(FT_W == 62 && FS_W == 64, "a position is stored as j * 64 + i and split by >> 6 / & 63; a task is 8 positions of a 64-wide row");
+static_assert(FT_THREADS % 64 == 0 && FT_THREADS >= 128 && FT_THREADS <= 1024, "whole waves; the wave-level scans and ballots assume full waves");
+static_assert(FT_H >= 8 && FT_H % 2 == 0 && FT_H <= 126, "tile height: even (2x2 NMS bound), score rows j < 128 so that j * 64 + i fits the 16-bit list");
+static_assert(FP_PITCH >= 72 && FP_PITCH % 8 == 0, "a pixel row holds 9 aligned 8-byte chunks (positions 0..63 at bytes 4..67, ring reach +-3)");
+static_assert(FAST_ST_RPP >= 1 && FAST_ST_RPP * FAST_ST_PASS >= FP_ROWS && FAST_ST_PASS <= 4, "the staging passes cover every pixel row with at most 4 prefetch registers");
+static_assert(8 * ((FS_W + 7) / 8) * FS_H <= FS_W * FS_H && FS_W * FS_H <= 65536, "s_pos holds every position of the score region; entries are 16 bits");
+static_assert(8 * FS_H < 65536 / 8 && 16 * FS_H < 65536 / 16, "task / tasks-per-row by the 16.16 reciprocal is exact below 65536 / tasks-per-row tasks");
+static_assert((FS_W * FS_H) % 16 == 0, "the score tile is cleared with 16-byte stores");
+static_assert(FAST_LDS_BYTES <= 65536, "LDS per block (160 KB per CU / this = resident blocks: 7 at the shipped 62 x 62, 256 threads)");
+static_assert(FAST_CHAIN >= 1 && FAST_CHAIN <= 16, "tiles per block");
 
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p);
 
@@ -577,11 +592,11 @@ template <bool SWAR>
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
                                                    unsigned* __restrict__ cand, unsigned* __restrict__ cand_count,
-                                                   unsigned* __restrict__ hist, int n_tiles, int chain_len) {
+                                                   unsigned* __restrict__ hist, int n_tiles, int chain_len, unsigned* __restrict__ status) {
   __shared__ __attribute__((aligned(16))) uint8_t sp[FP_ROWS][FP_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t ss[FS_H][FS_W];
   __shared__ __attribute__((aligned(4))) unsigned short s_pos[FS_W * FS_H];
-  __shared__ unsigned s_list[(FT_W / 2) * (FT_H / 2) + 1];   // NMS survivors: at most one per 2x2 positions
+  __shared__ unsigned s_list[FAST_LIST_CAP + 1];   // NMS survivors: at most one per 2x2 positions
   __shared__ int s_npos, s_cnt;
   __shared__ unsigned s_base;
   // A block works through FAST_CHAIN consecutive tiles of one image and loads the NEXT tile's pixels into registers while it works
@@ -592,8 +607,7 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
   // sets the time) and tickets from 8 per-XCD queues 2.0 ms (170k same-address device atomics serialise at ~100 ns each).
   const int tid = threadIdx.x, lane = tid & 63;
   const int st_r0 = tid / 9, st_c = tid - 9 * st_r0;               // staging: 9 lanes x 8 bytes per 72-byte row, FT_THREADS / 9 rows per pass
-  constexpr int ST_RPP = FT_THREADS / 9;
-  constexpr int ST_PASS = (FP_ROWS + ST_RPP - 1) / ST_RPP;
+  constexpr int ST_RPP = FAST_ST_RPP, ST_PASS = FAST_ST_PASS;
   unsigned long long pf[ST_PASS];
   struct Tile { int img, l, x0, y0, w, h, aw, ah; };
   Tile cur, nxt;
@@ -626,11 +640,14 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
   // The append of a tile's corners to its level's list needs a returning global atomic (about 2 us); it is issued when the tile's
   // NMS is done and consumed one phase into the NEXT tile, so only the last tile of a chain waits for it.
   int pend_cnt = 0, pend_il = 0;
-  unsigned pend_off = 0, pend_base = 0;
+  unsigned pend_off = 0, pend_base = 0, pend_cap = 0;
   auto flush = [&]() {
     for (int q = tid; q < pend_cnt; q += FT_THREADS) {
       const unsigned c = s_list[q];
-      cand[(size_t)img0 * g.cand_total + pend_off + s_base + q] = c;
+      const unsigned slot = s_base + (unsigned)q;
+      // (cannot happen: a level's list is sized for the worst case of 3x3-NMS survivors — a slot beyond it is reported, never written)
+      if (slot >= pend_cap) { atomicOr(status, ORBX_ST_INTERNAL); continue; }
+      cand[(size_t)img0 * g.cand_total + pend_off + slot] = c;
       atomicAdd(&hist[(size_t)pend_il * 256 + (c >> 24)], 1u);
     }
   };
@@ -778,14 +795,16 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
                         max(max((int)ss[j][i + 1], (int)ss[j + 1][i - 1]), max((int)ss[j + 1][i], (int)ss[j + 1][i + 1])));
       if (sc > m) {
         const int pos = atomicAdd(&s_cnt, 1);
-        s_list[pos] = ((unsigned)sc << 24) | ((unsigned)y << 12) | (unsigned)x;
+        if (pos < FAST_LIST_CAP) s_list[pos] = ((unsigned)sc << 24) | ((unsigned)y << 12) | (unsigned)x;
+        else atomicOr(status, ORBX_ST_INTERNAL);    // (cannot happen: strict maxima of a 62 x FT_H tile are at most one per 2x2)
       }
     }
   }
   __syncthreads();
-  pend_cnt = s_cnt;
+  pend_cnt = min(s_cnt, FAST_LIST_CAP);
   pend_il = img * g.n_levels + l;
   pend_off = g.lv[l].cand_off;
+  pend_cap = g.lv[l].cand_cap;
   if (tid == 0 && pend_cnt > 0) pend_base = atomicAdd(&cand_count[pend_il], (unsigned)pend_cnt);
   // (no barrier here: the next round writes pixels, scores and s_npos before its first barrier, the position list after it, and
   // s_cnt / s_base / s_list only after the flush above)
@@ -871,7 +890,7 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
   const int l = bb >> chunk_shift, chunk = bb & ((1 << chunk_shift) - 1), n_chunks = 1 << chunk_shift;
   const int il = img * g.n_levels + l;
   const int tid = threadIdx.x;
-  const unsigned count = cand_count[il];
+  const unsigned count = min(cand_count[il], g.lv[l].cand_cap);   // (fast_kernel never writes beyond the level's list)
   const unsigned want = 2u * (unsigned)g.lv[l].quota;
   // threshold = largest score sc with #(score >= sc) >= want (the n-th best score; ties with it are kept), by a
   // parallel suffix sum over the 256 histogram bins (thread = bin)
@@ -1586,9 +1605,9 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
       const int chain_len = (size_t)g.ftiles_total * n >= (size_t)4 * 8 * h->n_cu ? FAST_CHAIN : 1;
       const int chains = (g.ftiles_total + chain_len - 1) / chain_len;
       if (g.fast_threshold < 128)
-        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(chains, n), dim3(FT_THREADS), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len);
+        hipLaunchKernelGGL(fast_kernel<true>, xcd_grid(chains, n), dim3(FT_THREADS), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len, h->d_status);
       else
-        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(chains, n), dim3(FT_THREADS), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len);
+        hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(chains, n), dim3(FT_THREADS), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len, h->d_status);
     }
     {
       ProfScope ps(h, "harris_select_kernel", nullptr, true);

@@ -7,10 +7,14 @@
 #include <algorithm>
 #include <vector>
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types only: the entry points are bound with dlopen on first use (rccl_api below)
+#include <dlfcn.h>
 #include <thread>
+#include <system_error>
+#include <new>
 
 #include "orbx_internal.hpp"
+
 
 static thread_local std::string g_create_error;
 
@@ -161,7 +165,7 @@ void orbx_destroy(orbx_handle* h) {
   if (h->s_out) hipStreamDestroy(h->s_out);
   for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
   if (h->pair_graph) hipGraphExecDestroy(h->pair_graph);
-  if (h->rccl_comm && h->rccl_owned) ncclCommDestroy((ncclComm_t)h->rccl_comm);
+  orbx_rccl_drop(h);
   if (h->h_stage) hipHostFree(h->h_stage);
   if (h->h_ba_in) hipHostFree(h->h_ba_in);
   if (h->h_ba_out) hipHostFree(h->h_ba_out);
@@ -825,45 +829,100 @@ int orbx_ba_set_allreduce(orbx_handle* h, orbx_allreduce_fn fn, void* user) {
 }
 
 // ---- native collective of the point-partitioned solve: RCCL over xGMI -------------------------
+// librccl is bound on first use (dlopen by soname), not at load time: a single-GPU user of this library never needs it, and a
+// process in which PyTorch already mapped a librccl.so.1 gets THAT copy back from the loader — one RCCL per process, so a
+// ncclComm_t handed over by orbx_ba_set_rccl_comm belongs to the library that will use it.
+}  // extern "C"
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  char err[256] = {0};
+};
+RcclApi g_rccl_api;
+RcclApi* rccl_api() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    RcclApi& api = g_rccl_api;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) { snprintf(api.err, sizeof(api.err), "librccl.so.1 not found (%s)", dlerror()); return; }
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+      snprintf(api.err, sizeof(api.err), "librccl: a collective entry point is missing");
+      api.lib = nullptr;
+    }
+  });
+  return g_rccl_api.lib ? &g_rccl_api : nullptr;
+}
+const char* rccl_why() { rccl_api(); return g_rccl_api.err[0] ? g_rccl_api.err : "RCCL is not available in this process"; }
+}  // namespace
+extern "C" {
+
 int orbx_rccl_unique_id(uint8_t* out, size_t cap) {
   if (!out || cap < sizeof(ncclUniqueId)) return ORBX_ERR_INVALID;
+  RcclApi* R = rccl_api();
+  if (!R) return ORBX_ERR_HIP;
   ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) return ORBX_ERR_HIP;
+  if (R->GetUniqueId(&id) != ncclSuccess) return ORBX_ERR_HIP;
   memcpy(out, &id, sizeof(id));
   return (int)sizeof(id);
 }
 
-static void rccl_drop(orbx_handle* h) {
-  if (h->rccl_comm && h->rccl_owned) ncclCommDestroy((ncclComm_t)h->rccl_comm);
+}  // extern "C"
+void orbx_rccl_drop(orbx_handle* h) {
+  if (h->rccl_comm && h->rccl_owned) { RcclApi* R = rccl_api(); if (R) R->CommDestroy((ncclComm_t)h->rccl_comm); }
   h->rccl_comm = nullptr; h->rccl_owned = false;
 }
+extern "C" {
 
 int orbx_ba_init_rccl(orbx_handle* h, const uint8_t* unique_id, size_t id_bytes, int rank, int world) {
   if (!h) return ORBX_ERR_INVALID;
   if (!unique_id || id_bytes != sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world)
     return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_init_rccl: bad argument (the id is %zu bytes)", sizeof(ncclUniqueId));
+  RcclApi* R = rccl_api();
+  if (!R) return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_init_rccl: %s", rccl_why());
   ORBX_HIP(h, hipSetDevice(h->device));
-  rccl_drop(h);
+  orbx_rccl_drop(h);
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof(id));
   ncclComm_t comm = nullptr;
-  const ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
-  if (r != ncclSuccess) return orbx_fail(h, ORBX_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+  const ncclResult_t r = R->CommInitRank(&comm, world, id, rank);
+  if (r != ncclSuccess) return orbx_fail(h, ORBX_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString(r));
   h->rccl_comm = comm; h->rccl_owned = true;
   return ORBX_OK;
 }
 
 int orbx_ba_set_rccl_comm(orbx_handle* h, void* nccl_comm) {
   if (!h) return ORBX_ERR_INVALID;
-  rccl_drop(h);
+  if (nccl_comm && !rccl_api()) return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_set_rccl_comm: %s", rccl_why());
+  orbx_rccl_drop(h);
   h->rccl_comm = nccl_comm; h->rccl_owned = false;
   return ORBX_OK;
 }
 
+int orbx_ba_has_collective(orbx_handle* h) {
+  if (!h) return 0;
+  return (h->rccl_comm ? 1 : 0) | (h->allreduce ? 2 : 0);
+}
+
 }  // extern "C"
 int orbx_rccl_allreduce_sum(orbx_handle* h, double* d_buf, size_t n, hipStream_t st) {
-  const ncclResult_t r = ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, (ncclComm_t)h->rccl_comm, st);
-  if (r != ncclSuccess) return orbx_fail(h, ORBX_ERR_HIP, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+  RcclApi* R = rccl_api();
+  if (!R) return orbx_fail(h, ORBX_ERR_HIP, "ncclAllReduce: %s", rccl_why());
+  const ncclResult_t r = R->AllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, (ncclComm_t)h->rccl_comm, st);
+  if (r != ncclSuccess) return orbx_fail(h, ORBX_ERR_HIP, "ncclAllReduce failed: %s", R->GetErrorString(r));
   return ORBX_OK;
 }
 extern "C" {
@@ -890,46 +949,70 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
   if (!cam || !cfg || n_windows < 0 || (n_windows > 0 && !windows))
     return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_batch: bad argument");
   if (n_windows > 65535) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_batch: at most 65535 windows per call");
-  std::vector<BaWinHost> w((size_t)n_windows);
-  for (int i = 0; i < n_windows; ++i) {
-    orbx_ba_window& q = windows[i];
-    if (q.K < 0 || q.F < 0 || q.M < 0 || q.N < 0 || (q.K > 0 && (!q.poses_cw || !q.poses_wc_out)) || (q.F > 0 && !q.fixed_poses_cw) ||
-        (q.M > 0 && !q.points) || (q.N > 0 && !q.obs))
-      return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_batch: window %d: bad argument", i);
-    w[i] = BaWinHost{q.K, q.F, q.M, q.N, q.poses_cw, q.fixed_poses_cw, q.points, q.obs, q.poses_wc_out, &q.iterations,
-                     &q.initial_error, &q.final_error, ORBX_OK};
-  }
-  ORBX_HIP(h, hipSetDevice(h->device));
-  orbx_prof_begin_call(h);
-  orbx_allreduce_fn saved = h->allreduce;          // independent windows: no collective
-  void* saved_comm = h->rccl_comm;
-  h->allreduce = nullptr; h->rccl_comm = nullptr;
-  // A large batch runs as two halves at once — this handle and a second, internal one (its own stream, workspaces and pinned blobs), the
-  // second half driven by a helper thread — so that one half's host preprocessing, upload and download run under the other half's kernels
-  // and the latency-bound launches of one fill the gaps of the other.  Windows are independent and a window's arithmetic never depends on
-  // the batch it travels in, so the results are the same bit for bit.  Not with a should_stop callback (it would be called from two
-  // threads), not while per-kernel profiling is on (the kernel times belong to one handle).  (Three / four parts on three / four
-  // streams: 39 / 37 k LM iterations/s against 46 k with two and 41 k with one, at 32 windows.)
-  static const bool no_split = getenv("ORBX_BA_NO_SPLIT") != nullptr;
-  int rc;
-  if (!no_split && n_windows >= 16 && !should_stop && !h->profiling) {
-    if (!h->ba_aux) {
-      const int rc_aux = orbx_create(&h->cam, &h->orb, h->device, h->max_w, h->max_h, 1, &h->ba_aux);
-      if (rc_aux != ORBX_OK) { h->allreduce = saved; h->rccl_comm = saved_comm; return orbx_fail(h, rc_aux, "orbx_ba_solve_visual_batch: second stream: %s", orbx_last_error(nullptr)); }
+  // (no C++ exception may cross this C boundary: allocation or thread-creation failure is reported as an error code)
+  try {
+    std::vector<BaWinHost> w((size_t)n_windows);
+    for (int i = 0; i < n_windows; ++i) {
+      orbx_ba_window& q = windows[i];
+      if (q.K < 0 || q.F < 0 || q.M < 0 || q.N < 0 || (q.K > 0 && (!q.poses_cw || !q.poses_wc_out)) || (q.F > 0 && !q.fixed_poses_cw) ||
+          (q.M > 0 && !q.points) || (q.N > 0 && !q.obs))
+        return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_batch: window %d: bad argument", i);
+      w[i] = BaWinHost{q.K, q.F, q.M, q.N, q.poses_cw, q.fixed_poses_cw, q.points, q.obs, q.poses_wc_out, &q.iterations,
+                       &q.initial_error, &q.final_error, ORBX_OK};
     }
-    const int n0 = n_windows / 2;
-    int rc1 = ORBX_OK;
-    std::thread helper([&] {
-      hipSetDevice(h->device);
-      rc1 = ba_solve_batch(h->ba_aux, cam, cfg, n_windows - n0, w.data() + n0, nullptr, nullptr);
-    });
-    rc = ba_solve_batch(h, cam, cfg, n0, w.data(), nullptr, nullptr);
-    helper.join();
-    if (rc == ORBX_OK && rc1 != ORBX_OK) rc = orbx_fail(h, rc1, "(windows %d..%d, numbered from %d) %s", n0, n_windows - 1, n0, orbx_last_error(h->ba_aux));
-  } else rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), should_stop, user);
-  h->allreduce = saved; h->rccl_comm = saved_comm;
-  for (int i = 0; i < n_windows; ++i) windows[i].status = rc == ORBX_OK ? w[i].status : rc;
-  return rc;
+    ORBX_HIP(h, hipSetDevice(h->device));
+    orbx_prof_begin_call(h);
+    orbx_allreduce_fn saved = h->allreduce;          // independent windows: no collective
+    void* saved_comm = h->rccl_comm;
+    h->allreduce = nullptr; h->rccl_comm = nullptr;
+    struct Restore { orbx_handle* h; orbx_allreduce_fn f; void* c; ~Restore() { h->allreduce = f; h->rccl_comm = c; } } restore{h, saved, saved_comm};
+    // A large batch runs as two halves at once — this handle and a second, internal one (its own stream, workspaces and pinned blobs), the
+    // second half driven by a helper thread — so that one half's host preprocessing, upload and download run under the other half's kernels
+    // and the latency-bound launches of one fill the gaps of the other.  Windows are independent and a window's arithmetic never depends on
+    // the batch it travels in, so the results are the same bit for bit.  Not with a should_stop callback (it would be called from two
+    // threads), not while per-kernel profiling is on (the kernel times belong to one handle).  (Three / four parts on three / four
+    // streams: 39 / 37 k LM iterations/s against 46 k with two and 41 k with one, at 32 windows.)  The halves are cut where the
+    // OBSERVATION count is halved, not the window count: the streaming kernels' time follows the observations.
+    // If a half fails the call fails as a whole (every window's status = the error) — the in/out `points` and `poses_wc_out` of windows in
+    // the half that did finish then already hold its results; a caller that retries must hand in the original points again (orbx.h).
+    static const bool no_split = getenv("ORBX_BA_NO_SPLIT") != nullptr;
+    int rc;
+    bool split = !no_split && n_windows >= 16 && !should_stop && !h->profiling;
+    if (split && !h->ba_aux) {
+      const int rc_aux = orbx_create(&h->cam, &h->orb, h->device, h->max_w, h->max_h, 1, &h->ba_aux);
+      if (rc_aux != ORBX_OK) { h->ba_aux = nullptr; split = false; }      // no second stream: the whole batch on this one
+    }
+    if (split) {
+      size_t total = 0, run = 0;
+      for (int i = 0; i < n_windows; ++i) total += (size_t)w[i].N;
+      int n0 = 0;
+      while (n0 < n_windows - 1 && 2 * (run + (size_t)w[n0].N) <= total + (size_t)w[n0].N) run += (size_t)w[n0++].N;
+      n0 = std::max(1, std::min(n_windows - 1, n0));
+      int rc1 = ORBX_OK;
+      bool helper_ran = false;
+      try {
+        std::thread helper([&] {
+          hipSetDevice(h->device);
+          try { rc1 = ba_solve_batch(h->ba_aux, cam, cfg, n_windows - n0, w.data() + n0, nullptr, nullptr); }
+          catch (...) { rc1 = ORBX_ERR_HIP; }
+        });
+        helper_ran = true;
+        try { rc = ba_solve_batch(h, cam, cfg, n0, w.data(), nullptr, nullptr); }
+        catch (...) { rc = orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_batch: out of host memory"); }
+        helper.join();
+      } catch (const std::system_error&) {                                  // no thread: both halves here, one after the other
+        if (!helper_ran) rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), nullptr, nullptr);
+        else rc = orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_batch: helper thread failed");
+      }
+      if (rc == ORBX_OK && rc1 != ORBX_OK) rc = orbx_fail(h, rc1, "(windows %d..%d, numbered from %d) %s", n0, n_windows - 1, n0, orbx_last_error(h->ba_aux));
+    } else rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), should_stop, user);
+    for (int i = 0; i < n_windows; ++i) windows[i].status = rc == ORBX_OK ? w[i].status : rc;
+    return rc;
+  } catch (const std::bad_alloc&) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_batch: out of host memory");
+  } catch (...) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_batch: unexpected C++ exception");
+  }
 }
 
 int orbx_debug_ba_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,

@@ -175,9 +175,12 @@ struct BaWinHost {
   int status;
 };
 int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int W, BaWinHost* win,
-                   orbx_should_stop_fn should_stop, void* user, bool global_mode = false, const struct BaInertialHost* inr = nullptr);
+                   orbx_should_stop_fn should_stop, void* user, bool global_mode = false, const struct BaInertialHost* inr = nullptr,
+                   bool single_call = false);
 // in-place sum of `n` doubles over the ranks of the handle's communicator, ordered on `st` (ncclAllReduce, orbx_api.hip)
 int orbx_rccl_allreduce_sum(orbx_handle* h, double* d_buf, size_t n, hipStream_t st);
+// destroys the handle's communicator if the library owns it, and clears it
+void orbx_rccl_drop(orbx_handle* h);
 int ba_debug_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw, int F,
                     const double* fixed_poses_cw, int M, const double* points, int N, const orbx_ba_obs* obs, int global_mode,
                     double* out);

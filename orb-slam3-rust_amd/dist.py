@@ -74,6 +74,10 @@ def ba_solve_partitioned(handle, camera, cfg, poses_cw, fixed_cw, points, obs, r
     hook (any transport: the CPU tests run gloo).  should_stop may answer differently on different ranks: the stop votes
     are all-reduced with the data, one rank asking stops every rank before the same iteration."""
     if hook is None:
+        # No transport = every rank would silently solve its own partition as if it were the whole problem (ADVICE r2): refuse.
+        if world > 1 and not (handle.has_collective() & 1):
+            raise RuntimeError("ba_solve_partitioned: world = %d but the handle has no RCCL communicator (call init_native_rccl / "
+                               "Handle.set_rccl_comm on every rank first) and no hook was given" % world)
         return handle.ba_solve_visual(camera, cfg, poses_cw, fixed_cw, points,
                                       partition_observations(obs, rank, world), should_stop)
     handle.set_allreduce(hook)

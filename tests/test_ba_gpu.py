@@ -413,3 +413,37 @@ def test_ba_point_seen_twice_by_one_keyframe(gpu_handle, oracle, pkg):
     o = oracle.ba_solve_dense(ocam, oracle.ba_config(), w["poses_cw"], w["fixed_cw"], w["points"], obs)
     assert g["iterations"] == o["iterations"] and abs(g["final_error"] - o["final_error"]) < 1e-8 * o["final_error"]
     assert_ba_close(g, o, POSE_TOL)
+
+
+@pytest.mark.gpu
+def test_ba_batch_of_one_empty_window(gpu_handle, pkg):
+    """A batch holding exactly one window the reference answers None for (local_ba_lm.rs:923-925): the call returns ORBX_OK with
+    ORBX_ERR_EMPTY in the window's status — [None] — as include/orbx.h says, not an error for the whole call; the
+    single-window entry point keeps returning ORBX_ERR_EMPTY (None) for the same window."""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
+    w = pkg.synth.ba_window(5, 4, 60, pkg.BA_OBS)
+    empty = dict(w); empty["obs"] = w["obs"][:0]
+    assert gpu_handle.ba_solve_visual_batch(cam, cfg, [empty]) == [None]
+    assert gpu_handle.ba_solve_visual_batch(cam, cfg, [empty, empty]) == [None, None]
+    assert gpu_handle.ba_solve_visual(cam, cfg, empty["poses_cw"], empty["fixed_cw"], empty["points"], empty["obs"]) is None
+    one = gpu_handle.ba_solve_visual_batch(cam, cfg, [w])
+    s = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+    assert np.array_equal(one[0]["poses_wc"], s["poses_wc"]) and np.array_equal(one[0]["points"], s["points"])
+
+
+@pytest.mark.gpu
+def test_ba_partitioned_without_transport_refuses(gpu_handle, pkg):
+    """dist.ba_solve_partitioned(world > 1, hook=None) on a handle without an RCCL communicator must raise instead of letting every
+    rank solve its own partition as if it were the whole problem; orbx_ba_has_collective reports what is installed."""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
+    w = pkg.synth.ba_window(5, 4, 60, pkg.BA_OBS)
+    assert gpu_handle.has_collective() == 0
+    with pytest.raises(RuntimeError, match="no RCCL communicator"):
+        pkg.dist.ba_solve_partitioned(gpu_handle, cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"], 0, 2)
+    gpu_handle.set_allreduce(lambda ptr, n, stream: None)
+    assert gpu_handle.has_collective() == 2
+    gpu_handle.set_allreduce(None)
+    assert gpu_handle.has_collective() == 0
+    # world == 1 needs no transport
+    r = pkg.dist.ba_solve_partitioned(gpu_handle, cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"], 0, 1)
+    assert r["iterations"] > 0

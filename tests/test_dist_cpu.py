@@ -91,3 +91,24 @@ def test_partition_properties():
     sizes = [len(p) for p in parts]
     assert max(sizes) < 1.3 * min(sizes)        # balanced
     assert P.dist.shard_streams(8, 3, 8) == [3] and P.dist.shard_streams(3, 1, 2) == [1]
+
+
+def test_partitioned_solve_refuses_without_transport():
+    """dist.ba_solve_partitioned with world > 1, no hook and no communicator on the handle raises before any solve is issued
+    (host logic only: a stub handle stands in for the GPU one)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import orb_slam3_rust_amd as P
+
+    class Stub:
+        calls = 0
+        coll = 0
+        def has_collective(self): return self.coll
+        def ba_solve_visual(self, *a, **k): Stub.calls += 1; return "solved"
+    obs = np.zeros(4, P.BA_OBS); obs["mp_idx"] = [0, 1, 2, 3]
+    with pytest.raises(RuntimeError, match="no RCCL communicator"):
+        P.dist.ba_solve_partitioned(Stub(), None, None, None, None, None, obs, 0, 2)
+    assert Stub.calls == 0
+    s = Stub(); s.coll = 1
+    assert P.dist.ba_solve_partitioned(s, None, None, None, None, None, obs, 1, 2) == "solved" and Stub.calls == 1
+    assert P.dist.ba_solve_partitioned(Stub(), None, None, None, None, None, obs, 0, 1) == "solved"
