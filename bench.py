@@ -28,8 +28,17 @@ def algo_bytes_per_frame(w, h, n):
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_4CYC = 585.0  # G wave-instr/s, measured (profiles/r02_valu_issue_probe.txt): packed-i16 / perm / dot4 / cmp / ... class
 VALU_PEAK_2CYC = 960.0  # same file: v_add_u32 / v_and_b32 / v_lshrrev_b32 / v_bitop3_b32 / f32 fma class
-# share of a kernel's VALU instructions that belong to the 2-cycle class (ISA listing weighted by loop trip counts)
-TWO_CYCLE_SHARE = {"fast_kernel": 0.49}
+
+
+def two_cycle_share(kernel):
+    """Share of a kernel's VALU instructions in the 2-cycle issue class: profiles/valu_class_mix.json, written by
+    scripts/valu_class_mix.py from the disassembly of liborbx_hip.so's gfx950 code objects (opcode classes from the issue probes,
+    loop trip counts stated in profiles/valu_loop_weights.json).  None when the file or the kernel is missing."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "valu_class_mix.json")))["kernels"][kernel]
+        return d["share_2cycle"], d.get("share_2cycle_bounds"), d.get("model_vs_pmc")
+    except Exception:
+        return None, None, None
 
 
 def make_batches(P, torch, dev, seed, batch, n_batches, w, h):
@@ -162,7 +171,10 @@ def main():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-files", action="store_true", help="skip the EuRoC-directory (PNG decode inclusive) leg")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / PCIe-inclusive / latency / config0 legs")
-    ap.add_argument("--small-gen", action="store_true", help="profiler passes: 32 numpy pairs expanded instead of the GPU scene generator")
+    ap.add_argument("--small-gen", action="store_true", help="32 numpy pairs expanded instead of the GPU scene generator (no longer used by the profiler passes)")
+    ap.add_argument("--save-batches", default=None, help="write the generated input batches (uint8 [n_batches, batch, 2, H, W]) to this .npy file")
+    ap.add_argument("--load-batches", default=None, help="read the input batches from a file --save-batches wrote instead of generating them: the profiler's "
+                                                         "counter passes run on the bench's own 768 unique pairs without the generator's ~50 000 torch launches in the profiled process")
     args = ap.parse_args()
 
     import torch
@@ -198,9 +210,17 @@ def main():
     cap = args.features + 304
     out = h.alloc_batch_outputs(args.batch, cap)
     # rank r owns stream r (seed 1000*r+1): frames shard across ranks, no collective
-    batches = (make_batches_small if args.small_gen else make_batches)(P, torch, dev, 1000 * P.dist.shard_streams(world, rank, world)[0] + 1,
-                                                                        args.batch, args.n_batches, W, H)
+    if args.load_batches:
+        arr = np.load(args.load_batches, mmap_mode="r")
+        if arr.shape != (args.n_batches, args.batch, 2, H, W) or arr.dtype != np.uint8:
+            sys.exit("bench.py: %s holds %s %s, expected uint8 %s" % (args.load_batches, arr.dtype, arr.shape, (args.n_batches, args.batch, 2, H, W)))
+        batches = [torch.from_numpy(np.ascontiguousarray(arr[i])).to(dev) for i in range(args.n_batches)]
+    else:
+        batches = (make_batches_small if args.small_gen else make_batches)(P, torch, dev, 1000 * P.dist.shard_streams(world, rank, world)[0] + 1,
+                                                                            args.batch, args.n_batches, W, H)
     torch.cuda.synchronize()
+    if args.save_batches and rank == 0:
+        np.save(args.save_batches, np.stack([b.cpu().numpy() for b in batches]))
 
     def barrier():
         if world > 1:
@@ -270,16 +290,21 @@ def main():
             # v_and/or/xor, v_lshrrev, v_mov, v_bitop3, f32 add/mul/fma and v_min_u16 once per 2 (950-1080 G/s: VALU_PEAK_2CYC).
             # No hardware counter gives VALU busy time here — SQ_ACTIVE_INST_VALU and SQ_THREAD_CYCLES_VALU both count
             # instructions (profiles/r02_pmc_counter_calibration.txt) — so a kernel that mixes the classes is priced by its mix:
-            # frac = rate x (share_2cycle / peak_2cycle + (1 - share_2cycle) / peak_4cycle), the share from the ISA listing
-            # weighted by loop trip counts (FAST after round 2: 0.49; every other kernel is 4-cycle class throughout).
+            # frac = rate x (share_2cycle / peak_2cycle + (1 - share_2cycle) / peak_4cycle), the share from scripts/valu_class_mix.py
+            # (disassembly of the shipped code object, loop trip counts stated in profiles/valu_loop_weights.json).
             if kd.get("valu_wave_instr_per_launch") and dom_ms > 0:
                 rate = kd["valu_wave_instr_per_launch"] / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9
-                share2 = TWO_CYCLE_SHARE.get(dom_name, 0.0)
+                share2, share2_bounds, model_vs_pmc = two_cycle_share(dom_name)
+                sh = share2 if share2 is not None else 0.0
                 valu = dict(wave_instr_per_launch=kd["valu_wave_instr_per_launch"], achieved=round(rate, 1), peak=VALU_PEAK_4CYC,
-                            peak_simple_ops=VALU_PEAK_2CYC, unit="G wave-instr/s", two_cycle_share_est=share2,
-                            frac=round(rate * (share2 / VALU_PEAK_2CYC + (1.0 - share2) / VALU_PEAK_4CYC), 4),
+                            peak_simple_ops=VALU_PEAK_2CYC, unit="G wave-instr/s", two_cycle_share=share2, two_cycle_share_bounds=share2_bounds,
+                            class_mix_model_vs_pmc=model_vs_pmc,
+                            frac=round(rate * (sh / VALU_PEAK_2CYC + (1.0 - sh) / VALU_PEAK_4CYC), 4),
                             frac_of_4cycle_class_rate=round(rate / VALU_PEAK_4CYC, 4),
-                            source="profiles/r02_valu_issue_probe.txt, profiles/pmc_traffic.json, profiles/r02_pmc_counter_calibration.txt",
+                            source="scripts/valu_class_mix.py -> profiles/valu_class_mix.json (class mix from the code object); "
+                                   "profiles/r02_valu_issue_probe.txt + profiles/r03_valu_issue_probe2.txt (class rates); profiles/pmc_traffic.json "
+                                   "(instructions per launch); profiles/r02_pmc_counter_calibration.txt (what the counters count)",
+                            counters_taken_on=pmc.get("input", "32 numpy pairs expanded (--small-gen)"), counters_unique_pairs=pmc.get("unique_pairs", 32),
                             lds_busy_frac_pmc=kd.get("lds_busy_frac"), lds_bank_conflict_share_pmc=kd.get("lds_bank_conflict_share"))
     except Exception:
         traffic = None
@@ -499,6 +524,91 @@ def bench_from_files(P, h, torch, n_features, n_distinct=12, repeats=32, chunk=1
         shutil.rmtree(root, ignore_errors=True)
 
 
+def schur_executed_flop(K_opt, M):
+    """f64 flop the Schur launch EXECUTES for one window (upper 16x16 tiles of the padded 6K x 6K product, k dimension padded to the
+    k-split plan of ba_solve_batch: BA_PPS_TARGET = 32 points per split, at most 128 splits): one v_mfma_f64_16x16x4_f64 = 2048 flop."""
+    P_ = max(16, (6 * K_opt + 15) // 16 * 16)
+    nt = P_ // 16
+    ksplit = max(1, min(128, (M + 31) // 32))
+    pps = max(8, ((M + ksplit - 1) // ksplit + 7) // 8 * 8)
+    rows = 3 * pps * ksplit
+    return nt * (nt + 1) // 2 * (rows // 4) * 2048.0
+
+
+def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
+    win = P.synth.ba_window(seed, K, M, P.BA_OBS)
+    args = (cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
+    r = h.ba_solve_visual(*args)
+    reps = 5
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(reps):
+        its += h.ba_solve_visual(*args)["iterations"]
+    dt = time.perf_counter() - t0
+    h.set_profiling(True)
+    h.ba_solve_visual(*args)
+    kt = h.kernel_times()
+    h.set_profiling(False)
+    n_it = max(r["iterations"], 1)
+    k_opt = len(win["poses_cw"])
+    flop = schur_executed_flop(k_opt, M)
+    fused = kt.get("ba_kf_schur_kernel", (0.0, 1))
+    fused_ms = fused[0] / max(fused[1], 1)
+    res = dict(workload="synth_ba(seed=%d, K=%d, M=%d), %d observations, %d optimised keyframes (reduced system n = %d, multi-kernel Cholesky)"
+                        % (seed, K, M, len(win["obs"]), k_opt, 6 * k_opt),
+               lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3), iterations=r["iterations"],
+               initial_error_px=round(r["initial_error"], 4), final_error_px=round(r["final_error"], 4),
+               kernel_ms_per_iteration={k: round(v[0] / n_it, 4) for k, v in sorted(kt.items()) if k.startswith("ba_")},
+               algorithmic_GFLOP_per_iteration=4.3,
+               schur=dict(executed_GFLOP_per_launch=round(flop / 1e9, 3), fused_launch_ms=round(fused_ms, 4),
+                          executed_TFLOPs_fused_launch=round(flop / (fused_ms * 1e-3) / 1e12, 2) if fused_ms > 0 else None,
+                          mfma_frac_fused_launch=round(flop / (fused_ms * 1e-3) / 78.6e12, 4) if fused_ms > 0 else None,
+                          note="one window: the keyframe partials share the Schur launch, so this fraction is a lower bound for the MFMA part"))
+    # the Schur product alone: 4 such windows through the batch call, where it is its own launch
+    wins = [win] + [P.synth.ba_window(seed + 1 + i, K, M, P.BA_OBS) for i in range(3)]
+    h.ba_solve_visual_batch(cam, cfg, wins)
+    h.set_profiling(True)
+    rb = h.ba_solve_visual_batch(cam, cfg, wins)
+    kb = h.kernel_times()
+    h.set_profiling(False)
+    sch = kb.get("ba_schur_kernel", (0.0, 1))
+    sch_ms = sch[0] / max(sch[1], 1)
+    fl4 = sum(schur_executed_flop(len(w["poses_cw"]), M) for w in wins)
+    res["schur"].update(batch_of_4=dict(schur_launch_ms=round(sch_ms, 4), executed_TFLOPs=round(fl4 / (sch_ms * 1e-3) / 1e12, 2) if sch_ms > 0 else None,
+                                        mfma_frac=round(fl4 / (sch_ms * 1e-3) / 78.6e12, 4) if sch_ms > 0 else None,
+                                        kernel_ms_per_iteration={k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(kb.items()) if k.startswith("ba_")},
+                                        iterations=[x["iterations"] for x in rb]))
+    return res
+
+
+def bench_ba_cpu(P):
+    """The oracle's two LM solvers timed on one host core: ba_solve_dense = the reference's literal formulation (dense J, J^T J,
+    LU of all 6K+3M unknowns, local_ba_lm.rs:1012-1056) at K=8 / M=400 where it fits; ba_solve_schur = the structured variant at
+    configs[2] and configs[4] sizes.  A bounded sample (about 10-20 s), kind "port"."""
+    from oracle import oracle as O
+    flags = "-O2 (portable build)"
+    try:
+        O.use_native_build()
+        flags = "-O3 -march=native"
+    except Exception:
+        O.lib()
+    ocam = O.Camera(**P.synth.EUROC_CAMERA)
+    out = dict(kind="port", threads=1, cores=1, unit="LM iterations/s", build="g++ " + flags)
+    for key, fn, seed, K, M, reps in (("dense_K8_M400", O.ba_solve_dense, 42, 8, 400, 1), ("schur_K20_M2000", O.ba_solve_schur, 42, 20, 2000, 6),
+                                      ("schur_K50_M8000", O.ba_solve_schur, 43, 50, 8000, 1)):
+        w = P.synth.ba_window(seed, K, M, P.BA_OBS)
+        t0 = time.perf_counter()
+        its = 0
+        for _ in range(reps):
+            its += fn(ocam, O.ba_config(), w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])["iterations"]
+        dt = time.perf_counter() - t0
+        out[key] = dict(lm_iters_per_s=round(its / dt, 3), ms_per_iteration=round(dt / max(its, 1) * 1e3, 3), observations=len(w["obs"]),
+                        unknowns=6 * len(w["poses_cw"]) + 3 * M, solves=reps)
+    out["sample"] = ("oracle.ba_solve_dense (the reference's literal dense LM, local_ba_lm.rs:1012-1056) on synth_ba(42, 8, 400): 1 solve; "
+                     "oracle.ba_solve_schur (structured) on synth_ba(42, 20, 2000): 6 solves and synth_ba(43, 50, 8000): 1 solve; 10 LM iterations each")
+    return out
+
+
 def bench_ba(P, h, cam, rank=0, world=1, dev=None):
     import torch
     """configs[2]: local BA, 20 keyframes / 2000 map points, LM iterations per second.  One GPU: the
@@ -593,13 +703,7 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         h.set_profiling(False)
         dev_ms = sum(v[0] for k, v in kt.items() if k.startswith("ba_")) / nrep
         # f64 MFMA share: executed flops of the Schur launch (upper 16x16 tiles, padded) / its measured time / 78.6 TFLOP/s
-        K, M = 19, 2000
-        P_ = (6 * K + 15) // 16 * 16
-        nt = P_ // 16
-        ksplit = max(1, min(128, (M + 31) // 32))                     # as ba_solve_batch plans it (BA_PPS_TARGET = 32)
-        pps = max(8, ((M + ksplit - 1) // ksplit + 7) // 8 * 8)
-        rows = 3 * pps * ksplit
-        flop = nt * (nt + 1) // 2 * (rows // 4) * 2048.0 * nb        # one v_mfma_f64_16x16x4_f64 = 2*16*16*4 flop
+        flop = schur_executed_flop(len(bw[0]["poses_cw"]), 2000) * nb
         sch = kt.get("ba_schur_kernel", (0.0, 1))
         sch_ms = sch[0] / max(sch[1], 1)
         out["batched"] = dict(windows=nb, lm_iters_per_s=round(itb / dtb, 1), ms_per_call=round(dtb / nrep * 1e3, 3),
@@ -633,6 +737,18 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
             x.close()
         out["batched"]["two_batches_in_flight"] = dict(lm_iters_per_s=round(sum(cnt2) / dt2, 1), vs_single_window=round(sum(cnt2) / dt2 / out["lm_iters_per_s"], 2),
                                                        note="2 handles x 32 windows, one host thread each, no per-kernel events")
+        # configs[4]'s BA: 50 keyframes / 8000 map points (synth_ba(seed=43, K=50, M=8000)); the reduced system (n = 294)
+        # no longer fits LDS, so the factorisation is the multi-kernel form
+        try:
+            out["config5"] = bench_ba_config5(P, h, cam, cfg)
+        except Exception as e:
+            out["config5"] = dict(error=repr(e))
+        # the CPU side of the BA half of the metric: the reference's literal dense-LM formulation at a size where it
+        # fits, and the structured (Schur) variant at the GPU's sizes — the oracle, one thread, same run
+        try:
+            out["cpu_baseline"] = bench_ba_cpu(P)
+        except Exception as e:
+            out["cpu_baseline"] = dict(error=repr(e))
     else:
         # the other natural sharding: every stream has its own map, so rank r solves ITS OWN window — no
         # collective in the data path; aggregate LM iterations/s over the ranks

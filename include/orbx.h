@@ -526,6 +526,15 @@ int orbx_debug_ba_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          int F, const double* fixed_poses_cw, int M, const double* points, int N, const orbx_ba_obs* obs,
                          int global_mode, double* out);
 
+/* compute_imu_residual (src/optimizer/imu_factors.rs:66-103) of every IMU edge at the given keyframe states, from the device
+ * function the inertial solver's ba_imu_kernel calls.
+ *   poses_wc [K][7] (qw,qx,qy,qz,tx,ty,tz) T_wc, velocities [K][3], edge_kf [E][2] = (i, j), preint [E][11] as orbx_ba_solve_inertial
+ *   (delta_rot qw,qx,qy,qz | delta_vel | delta_pos | dt);  out [E][9] = rotation | velocity | position residual.
+ * This is how the reference's own known answer for this factor (test_imu_residual_zero_motion, imu_factors.rs:264-276: identical
+ * states and an identity preintegration give a zero residual) is checked on the GPU. */
+int orbx_debug_imu_residual(orbx_handle* h, int K, const double* poses_wc, const double* velocities, int E, const int* edge_kf,
+                            const double* preint, double* out);
+
 #ifdef __cplusplus
 }
 #endif

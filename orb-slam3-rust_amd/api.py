@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "orbx_keyframe_create", "orbx_keyframe_destroy", "orbx_keyframe_info", "orbx_keyframe_set_pose", "orbx_keyframe_set_map_points",
     "orbx_keyframe_get_map_points", "orbx_keyframe_download", "orbx_keyframe_device_keypoints", "orbx_keyframe_device_descriptors",
     "orbx_keyframe_guided_match", "orbx_keyframe_search_for_triangulation", "orbx_keyframe_fuse_search",
-    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_has_collective", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_has_collective", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_debug_imu_residual", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
     "orbx_fuse_search", "orbx_fuse_search_device",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
@@ -668,6 +668,17 @@ class Handle:
                                                  C.c_int(1 if global_mode else 0), _vp(out)))
         out = out[:len(obs)]
         return out[:, 0:2].copy(), out[:, 2:14].reshape(-1, 2, 6).copy(), out[:, 14:20].reshape(-1, 2, 3).copy()
+
+    def debug_imu_residual(self, poses_wc, velocities, edge_kf, preint):
+        """orbx_debug_imu_residual: compute_imu_residual (imu_factors.rs:66-103) of every edge, [E, 9], from the solver's device function."""
+        poses_wc = np.ascontiguousarray(poses_wc, np.float64).reshape(-1, 7)
+        vel = np.ascontiguousarray(velocities, np.float64).reshape(-1, 3)
+        ek = np.ascontiguousarray(edge_kf, np.int32).reshape(-1, 2); pre = np.ascontiguousarray(preint, np.float64).reshape(-1, 11)
+        if len(vel) != len(poses_wc) or len(pre) != len(ek):
+            raise ValueError("debug_imu_residual: one velocity per pose and one preintegration per edge")
+        out = np.zeros((max(len(ek), 1), 9))
+        self._check(self._L.orbx_debug_imu_residual(self._h, C.c_int(len(poses_wc)), _vp(poses_wc), _vp(vel), C.c_int(len(ek)), _vp(ek), _vp(pre), _vp(out)))
+        return out[:len(ek)]
 
     def ba_solve_inertial(self, camera, cfg, poses_wc, velocities, biases, fixed_cw, points, obs, edge_kf, preint, should_stop=None):
         """solve_inertial_ba (local_inertial_ba.rs:1074-1275) on flat arrays; every keyframe of the window is returned."""

@@ -1529,6 +1529,19 @@ __global__ __launch_bounds__(64) void ba_imu_kernel(const BaState* S, double* P0
   }
 }
 
+// The 9-d preintegration residual of every edge at the given states, from the device function ba_imu_kernel calls (orbx_debug_imu_residual)
+__global__ __launch_bounds__(64) void ba_debug_imu_kernel(int E, const int* __restrict__ edge_kf, const double* __restrict__ states9,
+                                                          const double* __restrict__ preint, double* __restrict__ out) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= E) return;
+  double a[9], b[9], rr[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { a[j] = states9[9 * (size_t)edge_kf[2 * e] + j]; b[j] = states9[9 * (size_t)edge_kf[2 * e + 1] + j]; }
+  imu_residual_dev(a, b, preint + 11 * (size_t)e, rr);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) out[9 * (size_t)e + k] = rr[k];
+}
+
 // res[slot] += sum over the edges of their chi2 (fixed order)
 __global__ void ba_imu_addchi_kernel(const BaState* S, int E, const double* __restrict__ imu_buf, double* __restrict__ res, int slot) {
   if (S->done) return;
@@ -2255,6 +2268,34 @@ int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config
                     int* iterations, double* initial_error, double* final_error, bool global_mode, const BaInertialHost* inr) {
   BaWinHost w{K, F, M, N, poses_cw, fixed_poses_cw, points, obs, poses_wc_out, iterations, initial_error, final_error, ORBX_OK};
   return ba_solve_batch(h, cam, cfg, 1, &w, should_stop, user, global_mode, inr, true);
+}
+
+// compute_imu_residual (imu_factors.rs:66-103) of every edge: out [E][9] = rotation | velocity | position residual
+int ba_debug_imu_residual(orbx_handle* h, int K, const double* poses_wc, const double* velocities, int E, const int* edge_kf,
+                          const double* preint, double* out) {
+  if (E == 0) return ORBX_OK;
+  for (int e = 0; e < E; ++e)
+    if (edge_kf[2 * e] < 0 || edge_kf[2 * e] >= K || edge_kf[2 * e + 1] < 0 || edge_kf[2 * e + 1] >= K)
+      return orbx_fail(h, ORBX_ERR_INVALID, "IMU edge %d: keyframe index out of range", e);
+  std::vector<double> st(9 * (size_t)K);
+  for (int k = 0; k < K; ++k) {
+    host_se3_to_params(poses_wc + 7 * (size_t)k, &st[9 * (size_t)k]);      // scaled axis + translation of T_wc, as the solver's parameters
+    for (int i = 0; i < 3; ++i) st[9 * (size_t)k + 6 + i] = velocities[3 * (size_t)k + i];
+  }
+  Carve c;
+  const size_t o_s = c.take(8 * st.size()), o_e = c.take(8 * (size_t)E), o_p = c.take(88 * (size_t)E), o_o = c.take(72 * (size_t)E);
+  if (int rc = orbx_reserve(h, h->ws_ba[6], c.off)) return rc;
+  uint8_t* d = (uint8_t*)h->ws_ba[6].p;
+  hipStream_t s = h->stream;
+  ORBX_HIP(h, hipMemcpyAsync(d + o_s, st.data(), 8 * st.size(), hipMemcpyHostToDevice, s));
+  ORBX_HIP(h, hipMemcpyAsync(d + o_e, edge_kf, 8 * (size_t)E, hipMemcpyHostToDevice, s));
+  ORBX_HIP(h, hipMemcpyAsync(d + o_p, preint, 88 * (size_t)E, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(ba_debug_imu_kernel, dim3((E + 63) / 64), dim3(64), 0, s, E, (const int*)(d + o_e), (const double*)(d + o_s),
+                     (const double*)(d + o_p), (double*)(d + o_o));
+  ORBX_HIP(h, hipMemcpyAsync(out, d + o_o, 72 * (size_t)E, hipMemcpyDeviceToHost, s));
+  ORBX_HIP(h, hipStreamSynchronize(s));
+  ORBX_HIP(h, hipGetLastError());
+  return ORBX_OK;
 }
 
 // residual / Jacobian blocks of every observation at the given parameters (input order): out [N][20] = r (2) | A (12) | B (6)

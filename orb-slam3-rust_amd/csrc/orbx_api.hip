@@ -1027,6 +1027,15 @@ int orbx_debug_ba_blocks(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
   return ba_debug_blocks(h, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, global_mode, out);
 }
 
+int orbx_debug_imu_residual(orbx_handle* h, int K, const double* poses_wc, const double* velocities, int E, const int* edge_kf,
+                            const double* preint, double* out) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (K < 0 || E < 0 || (K > 0 && (!poses_wc || !velocities)) || (E > 0 && (!edge_kf || !preint || !out)))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_debug_imu_residual: bad argument");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  return ba_debug_imu_residual(h, K, poses_wc, velocities, E, edge_kf, preint, out);
+}
+
 void orbx_default_inertial_ba_config(orbx_inertial_ba_config* c) {       // local_inertial_ba.rs:126-141
   if (!c) return;
   c->max_iterations = 10; c->window_size = 10;

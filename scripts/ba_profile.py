@@ -8,7 +8,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 cam = P.CameraModel(**P.synth.EUROC_CAMERA)
 h = P.Handle(cam, 100)
-w = P.synth.ba_window(42, K, M, P.BA_OBS)
+w = P.synth.ba_window(43 if K == 50 else 42, K, M, P.BA_OBS)       # configs[4] = synth_ba(seed=43, K=50, M=8000)
 cfg = P.LocalBAConfigLM()
 for _ in range(3):
     r = h.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
@@ -24,6 +24,9 @@ for k, (ms, n) in sorted(kt.items(), key=lambda kv: -kv[1][0]):
     print("  %-22s %8.3f ms  %3d scopes  %7.1f us each" % (k, ms, n, ms / n * 1e3)); tot += ms
 print("sum of kernel scopes: %.3f ms" % tot)
 
+if len(sys.argv) > 3 and sys.argv[3] == "visual-only":     # profiler passes: the visual solve alone
+    h.close()
+    sys.exit(0)
 # local inertial BA (local_inertial_ba.rs:1074-1275): window of 10 keyframes, 2000 points
 from oracle import oracle as O
 iw = P.synth.inertial_window(42, 10, 2000, P.BA_OBS)

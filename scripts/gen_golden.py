@@ -74,6 +74,27 @@ G["level_sizes"] = {"752x480": [[752, 480], [627, 400], [522, 333], [435, 278], 
                     "1920x1080": [[1920, 1080], [1600, 900], [1333, 750], [1111, 625], [926, 521], [772, 434], [643, 362], [536, 301]]}
 G["umax"] = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
 
+# D13/D14: the reference's known answers for the preintegration factor, imu_factors.rs:264-321 (compute_imu_residual :68-103,
+# GRAVITY = (0, 0, -9.81) imu/sample.rs:6, PreintegratedState::identity imu/preintegration.rs:101-111).
+#   zero motion (:264-276): identity pose, zero velocity, both keyframes the same, identity preintegration (dt = 0) -> every
+#   component < 1e-10;
+#   free fall (:278-321): identity poses, v_i = 0, v_j = g * dt, dt = 0.1; with delta_vel = 0 the velocity residual is
+#   R_i^T (v_j - v_i - g dt) - 0 = 0 (< 0.01 in the reference's assert) and, from the formulas at :85-99, the rotation residual
+#   is 0 and the position residual R_i^T (p_j - p_i - v_i dt - g dt^2 / 2) - 0 = (0, 0, +0.04905); with delta_vel = g * dt
+#   (the first half of that test) the velocity residual is -g * dt = (0, 0, +0.981).
+g = [0.0, 0.0, -9.81]; dt = 0.1
+ident7 = [1.0, 0, 0, 0, 0, 0, 0]
+G["imu_residual"] = [
+    dict(name="zero_motion", poses_wc=[ident7, ident7], velocities=[[0, 0, 0], [0, 0, 0]], preint=[1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0],
+         expect=[0.0] * 9, tol=1e-10, cite="imu_factors.rs:264-276"),
+    dict(name="free_fall_consistent", poses_wc=[ident7, ident7], velocities=[[0, 0, 0], [g[0] * dt, g[1] * dt, g[2] * dt]],
+         preint=[1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, dt], expect=[0, 0, 0, 0, 0, 0, 0, 0, -0.5 * g[2] * dt * dt], tol=1e-12,
+         cite="imu_factors.rs:303-320 (velocity residual < 0.01); position component from :93-96"),
+    dict(name="free_fall_delta_vel_g_dt", poses_wc=[ident7, ident7], velocities=[[0, 0, 0], [g[0] * dt, g[1] * dt, g[2] * dt]],
+         preint=[1.0, 0, 0, 0, g[0] * dt, g[1] * dt, g[2] * dt, 0, 0, 0, dt], expect=[0, 0, 0, 0, 0, -g[2] * dt, 0, 0, -0.5 * g[2] * dt * dt],
+         tol=1e-12, cite="imu_factors.rs:290-302 (the residual the comment derives: -g * dt)"),
+]
+
 with open(os.path.join(root, "tests", "golden", "reference_known_answers.json"), "w") as f:
     json.dump(G, f, indent=1)
 print("written")

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/g$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files --no-extras --small-gen > /dev/null 2> $O/g$i.err
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/g$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ba --no-files --no-extras ${ORBX_BENCH_INPUT:---small-gen} > /dev/null 2> $O/g$i.err
 done
 cd $R
 python scripts/pmc_sq_summary.py $(ls $O/g*/*/*counter_collection.csv) > $O/summary.txt

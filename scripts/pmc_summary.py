@@ -58,6 +58,10 @@ if len(sys.argv) > 7:
                 lc = sum(extra["SQ_LDS_BANK_CONFLICT"].get(k, [0])) / max(len(extra["SQ_LDS_BANK_CONFLICT"].get(k, [0])), 1)
                 d["lds_busy_frac"] = round(la / (gui / 8 * 256), 4) if gui > 0 else None
                 d["lds_bank_conflict_share"] = round(lc / la, 4) if la > 0 else None
+import os
+if os.environ.get("ORBX_PMC_UNIQUE_PAIRS"):
+    out["unique_pairs"] = int(os.environ["ORBX_PMC_UNIQUE_PAIRS"])        # the input the counter passes ran on (refresh_profiles.sh)
+    out["input"] = os.environ.get("ORBX_PMC_INPUT", "")
 if len(sys.argv) > 5:
     json.dump(out, open(sys.argv[5], "w"), indent=1)
 print("%-28s %8s %14s %14s %14s" % ("kernel", "launches", "FETCH KiB", "FETCHx2 MB", "WRITE MB"))

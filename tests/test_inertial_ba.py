@@ -129,3 +129,40 @@ def test_gpu_solve_inertial_ba_keyed_by_ids(gpu_handle):
     assert _rel(np.array([r.optimized_points[m] for m in mp_ids]), o["points"]) < TOL
     prob.opt_kf_ids = kf_ids[:1]
     assert P.solve_inertial_ba(prob, P.CameraModel(**w["camera"]), P.LocalInertialBAConfig(), lambda: False, handle=gpu_handle) is None
+
+
+def _imu_case_states(case):
+    poses = np.array(case["poses_wc"], np.float64); vel = np.array(case["velocities"], np.float64)
+    st = [np.concatenate([_scaled_axis(poses[k, :4]), poses[k, 4:], vel[k]]) for k in (0, 1)]
+    return poses, vel, st
+
+
+def test_oracle_imu_residual_reference_known_answers(golden):
+    """The reference's own known answers for compute_imu_residual (imu_factors.rs:264-321: test_imu_residual_zero_motion,
+    test_imu_residual_pure_gravity) on the oracle."""
+    for case in golden["imu_residual"]:
+        _, _, st = _imu_case_states(case)
+        r = O.inertial_imu_residual(st[0], st[1], np.array(case["preint"], np.float64))
+        assert np.abs(r - np.array(case["expect"])).max() < case["tol"], case["name"]
+
+
+@pytest.mark.gpu
+def test_gpu_imu_residual_reference_known_answers(gpu_handle, golden):
+    """The same known answers read back from the device function ba_imu_kernel calls (orbx_debug_imu_residual), and that function
+    against the oracle's on the edges of a synthetic window (ground-truth and perturbed states)."""
+    for case in golden["imu_residual"]:
+        poses, vel, _ = _imu_case_states(case)
+        r = gpu_handle.debug_imu_residual(poses, vel, [[0, 1]], [case["preint"]])[0]
+        assert np.abs(r - np.array(case["expect"])).max() < case["tol"], case["name"]
+        if case["name"] == "zero_motion":                        # imu_factors.rs:273-275: the three norms
+            assert np.linalg.norm(r[:3]) < 1e-10 and np.linalg.norm(r[3:6]) < 1e-10 and np.linalg.norm(r[6:]) < 1e-10
+    w = P.synth.inertial_window(3, 6, 40, P.BA_OBS)
+    for poses, vel in ((w["gt_poses_wc"], w["gt_velocities"]), (w["poses_wc"], w["velocities"])):
+        got = gpu_handle.debug_imu_residual(poses, vel, w["edge_kf"], w["preint"])
+        for e, (i, j) in enumerate(w["edge_kf"]):
+            si = np.concatenate([_scaled_axis(poses[i, :4]), poses[i, 4:], vel[i]])
+            sj = np.concatenate([_scaled_axis(poses[j, :4]), poses[j, 4:], vel[j]])
+            want = O.inertial_imu_residual(si, sj, w["preint"][e])
+            assert np.abs(got[e] - want).max() < 1e-12 * max(1.0, np.abs(want).max()), e
+    with pytest.raises(P.OrbxError):
+        gpu_handle.debug_imu_residual(w["poses_wc"], w["velocities"], [[0, 99]], w["preint"][:1])
