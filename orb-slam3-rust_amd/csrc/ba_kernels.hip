@@ -88,8 +88,8 @@ struct BaWin {
   const double* Rt_fix;  // [F+1][12]
   const int *pt_start, *o_kf, *o_fix;
   const double* o_uv;
-  const int *kf_start, *kf_obs;
-  double *oA, *oR, *oYg, *Vinv, *gl;
+  const int *kf_start, *kf_obs, *kf_pt;   // keyframe CSR over the point-major order: observation index and its map point
+  double *Vinv, *gl, *vg;           // per point: V*^-1 (9), g_l (3), V*^-1 g_l (3)
   double *pt_chi2, *pt_glsq, *pt_dsq, *pt_psq;
   double *oW;            // [N][18] W = A^T B of every observation of an optimised keyframe, w[c][a] (point coordinate major)
   const int *slot_first; // [M][K] first observation (point-major index) of point j in optimised keyframe k, or -1
@@ -268,8 +268,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
   const double* __restrict__ Rt_fix = win.Rt_fix;
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
   const double* __restrict__ o_uv = win.o_uv;
-  double* __restrict__ oA = win.oA /*N*12*/; double* __restrict__ oR = win.oR /*N*2*/; double* __restrict__ oYg = win.oYg /*N*6*/;
-  double* __restrict__ Vinv = win.Vinv /*M*9*/; double* __restrict__ gl = win.gl /*M*3*/;
+  double* __restrict__ Vinv = win.Vinv /*M*9*/; double* __restrict__ gl = win.gl /*M*3*/; double* __restrict__ vg = win.vg /*M*3*/;
   double* __restrict__ pt_chi2 = win.pt_chi2 /*M*/; double* __restrict__ pt_glsq = win.pt_glsq /*M*/;
   double* __restrict__ oW = win.oW;
   const double lambda = S->lambda;
@@ -283,6 +282,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
                        params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   const int s = pt_start[j], e = pt_start[j + 1];
   double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, chi = 0.0;
+  ObsOut o;                 // (after pass 1: the blocks of this lane's LAST observation — its only one when the point has <= BA_PT_LANES)
   // pass 1: residual + Jacobian, accumulate V, g_l (lane-strided, then a fixed shuffle tree)
   for (int i = s + lane32; i < e; i += BA_PT_LANES) {
     const int k = o_kf[i];
@@ -294,7 +294,6 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
 #pragma unroll
       for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
     }
-    ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
     chi += o.r0 * o.r0 + o.r1 * o.r1;
     V[0] += o.B[0] * o.B[0] + o.B[3] * o.B[3];
@@ -306,9 +305,6 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
     g[0] += o.B[0] * o.r0 + o.B[3] * o.r1;
     g[1] += o.B[1] * o.r0 + o.B[4] * o.r1;
     g[2] += o.B[2] * o.r0 + o.B[5] * o.r1;
-    oR[2 * (size_t)i] = o.r0; oR[2 * (size_t)i + 1] = o.r1;
-#pragma unroll
-    for (int a = 0; a < 12; ++a) oA[12 * (size_t)i + a] = o.A[a];
   }
 #pragma unroll
   for (int a = 0; a < 6; ++a) V[a] = group_sum32(V[a]);
@@ -329,30 +325,27 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
 #pragma unroll
     for (int a = 0; a < 9; ++a) Vinv[9 * (size_t)j + a] = I[a];
     gl[3 * (size_t)j] = g[0]; gl[3 * (size_t)j + 1] = g[1]; gl[3 * (size_t)j + 2] = g[2];
+    // V*^-1 g_l: what the keyframe partials need of this point for b_red = sum W V*^-1 g_l = sum A^T (B V*^-1 g_l)
+    vg[3 * (size_t)j] = I[0] * g[0] + I[1] * g[1] + I[2] * g[2];
+    vg[3 * (size_t)j + 1] = I[3] * g[0] + I[4] * g[1] + I[5] * g[2];
+    vg[3 * (size_t)j + 2] = I[6] * g[0] + I[7] * g[1] + I[8] * g[2];
     pt_chi2[j] = chi;
     pt_glsq[j] = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
   }
-  // pass 2: W = A^T B, Y = W V*^-1 -> dense k-major operands; Y g_l per observation
+  // pass 2: W = A^T B per observation of an optimised keyframe: the operand of the Schur product (its tiles are filled from
+  // oW).  Nothing else is stored per observation: the keyframe partials and the back-substitution recompute the 2x6 / 2x3
+  // blocks from (point, pose, uv) — 44-72 B per observation instead of the 164 B / 144 B of stored blocks.
+  const bool one_pass = e - s <= BA_PT_LANES;           // group-uniform: every lane still holds the blocks of its one observation
   for (int i = s + lane32; i < e; i += BA_PT_LANES) {
     const int k = o_kf[i];
     if (k < 0) continue;
-    const double* Rt = sRt + 12 * k;
-    ObsOut o;
-    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
-    double yg[6];
+    if (!one_pass) obs_terms(cam, sRt + 12 * k, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const double w0 = o.A[a] * o.B[0] + o.A[6 + a] * o.B[3];
-      const double w1 = o.A[a] * o.B[1] + o.A[6 + a] * o.B[4];
-      const double w2 = o.A[a] * o.B[2] + o.A[6 + a] * o.B[5];
-      const double y0 = w0 * I[0] + w1 * I[3] + w2 * I[6];
-      const double y1 = w0 * I[1] + w1 * I[4] + w2 * I[7];
-      const double y2 = w0 * I[2] + w1 * I[5] + w2 * I[8];
-      oW[18 * (size_t)i + a] = w0; oW[18 * (size_t)i + 6 + a] = w1; oW[18 * (size_t)i + 12 + a] = w2;
-      yg[a] = y0 * g[0] + y1 * g[1] + y2 * g[2];
+      oW[18 * (size_t)i + a] = o.A[a] * o.B[0] + o.A[6 + a] * o.B[3];
+      oW[18 * (size_t)i + 6 + a] = o.A[a] * o.B[1] + o.A[6 + a] * o.B[4];
+      oW[18 * (size_t)i + 12 + a] = o.A[a] * o.B[2] + o.A[6 + a] * o.B[5];
     }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) oYg[6 * (size_t)i + a] = yg[a];
   }
 }
 
@@ -366,22 +359,33 @@ constexpr int BA_PPS_TARGET = ORBX_BA_PPS;   // map points per k-split of the Sc
 constexpr int BA_KFSPLIT = ORBX_BA_KFSPLIT;   // 16 / 8 / 4 / 2 blocks per keyframe: 32-window batch 36.2 / 39.0 / 40.2 / 40.4 k LM it/s, single window unchanged (6.4-6.5 k): the 33 shuffle-tree reductions per block outweigh the observations a block adds up
 // BA_KFSPLIT blocks per optimised keyframe: partial U_k (21 unique), g_p (6), b_red (6) over a slice of its
 // observations; the gather kernel adds the partials in a fixed order.
-__device__ __forceinline__ void ba_kf_body(int bx, const BaDims& d, const int* __restrict__ kf_start, const int* __restrict__ kf_obs,
-                                           const double* __restrict__ oA, const double* __restrict__ oR,
-                                           const double* __restrict__ oYg, double* __restrict__ kfpart /*[K][BA_KFSPLIT][33]*/) {
+__device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam& cam) {
   __shared__ double red[4][33];
+  __shared__ double sRtk[12];
+  const BaDims& d = win.d;
+  const int* __restrict__ kf_start = win.kf_start; const int* __restrict__ kf_obs = win.kf_obs; const int* __restrict__ kf_pt = win.kf_pt;
+  const double* __restrict__ o_uv = win.o_uv; const double* __restrict__ vg = win.vg;
+  double* __restrict__ kfpart = win.kfpart;   /*[K][BA_KFSPLIT][33]*/
+  const double* params = ba_cur(win.S, win.P0, win.P1);
+  const double* __restrict__ pts = params + 6 * (size_t)d.K;
   const int k = bx / BA_KFSPLIT, sp = bx % BA_KFSPLIT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) pose_to_Rt(params + 6 * (size_t)k, cam.inertial, sRtk);     // this block's keyframe (the build kernel's expression)
+  __syncthreads();
+  double Rt[12];
+#pragma unroll
+  for (int a = 0; a < 12; ++a) Rt[a] = sRtk[a];
   const int s0 = kf_start[k], len = kf_start[k + 1] - s0;
   const int s = s0 + (int)((long long)len * sp / BA_KFSPLIT), e = s0 + (int)((long long)len * (sp + 1) / BA_KFSPLIT);
   double acc[33];   // 21 unique U entries, 6 g_p, 6 b_red
 #pragma unroll
   for (int a = 0; a < 33; ++a) acc[a] = 0.0;
   for (int t = s + tid; t < e; t += 256) {
-    const int i = kf_obs[t];
-    double A[12];
-#pragma unroll
-    for (int a = 0; a < 12; ++a) A[a] = oA[12 * (size_t)i + a];
-    const double r0 = oR[2 * (size_t)i], r1 = oR[2 * (size_t)i + 1];
+    const int i = kf_obs[t], j = kf_pt[t];
+    const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
+    ObsOut o;
+    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
+    const double* A = o.A;
+    const double r0 = o.r0, r1 = o.r1;
     int q = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -389,8 +393,11 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaDims& d, const int* _
       for (int b = a; b < 6; ++b) acc[q++] += A[a] * A[b] + A[6 + a] * A[6 + b];
 #pragma unroll
     for (int a = 0; a < 6; ++a) acc[21 + a] += A[a] * r0 + A[6 + a] * r1;
+    // W V*^-1 g_l = A^T (B (V*^-1 g_l)): the 2-vector B vg, then A^T of it
+    const double v0 = vg[3 * (size_t)j], v1 = vg[3 * (size_t)j + 1], v2 = vg[3 * (size_t)j + 2];
+    const double t0 = o.B[0] * v0 + o.B[1] * v1 + o.B[2] * v2, t1 = o.B[3] * v0 + o.B[4] * v1 + o.B[5] * v2;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) acc[27 + a] += oYg[6 * (size_t)i + a];
+    for (int a = 0; a < 6; ++a) acc[27 + a] += A[a] * t0 + A[6 + a] * t1;
   }
 #pragma unroll
   for (int a = 0; a < 33; ++a) {
@@ -616,21 +623,21 @@ __device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, dou
 // One window: keyframe partials and Schur blocks in ONE launch (both consume the build kernel's output and feed the solve;
 // a launch less on a latency-bound chain, and ~200 blocks do not compete for LDS or registers).  Same block bodies: same results.
 template <bool DIAG>
-__global__ __launch_bounds__(256, 2) void ba_kf_schur_kernel(const BaWin* __restrict__ wins) {
+__global__ __launch_bounds__(256, 2) void ba_kf_schur_kernel(const BaWin* __restrict__ wins, BaCam cam) {
   __shared__ double s_tiles[2 * SCH_R * SCH_PITCH];
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done) return;
   const int nkf = win.d.K * BA_KFSPLIT;
-  if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, win.d, win.kf_start, win.kf_obs, win.oA, win.oR, win.oYg, win.kfpart);
+  if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, win, cam);
   else if (DIAG) ba_schur_diag_body((int)blockIdx.x - nkf, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);
   else ba_schur_body((int)blockIdx.x - nkf, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);
 }
 
 // (their own launches in a batch: 51 KB of LDS and ~200 VGPRs per block would otherwise throttle the thousands of small keyframe blocks too)
-__global__ __launch_bounds__(256) void ba_kf_kernel(const BaWin* __restrict__ wins) {
+__global__ __launch_bounds__(256) void ba_kf_kernel(const BaWin* __restrict__ wins, BaCam cam) {
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done || (int)blockIdx.x >= win.d.K * BA_KFSPLIT) return;
-  ba_kf_body((int)blockIdx.x, win.d, win.kf_start, win.kf_obs, win.oA, win.oR, win.oYg, win.kfpart);
+  ba_kf_body((int)blockIdx.x, win, cam);
 }
 
 // DIAG: every window of the launch has a reduced system of at most 128 columns (host-checked)
@@ -748,6 +755,24 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return y;
 }
 
+// Lane broadcasts inside a row of 16 lanes by DPP row_newbcast (gfx90a+): the f64 forms v_mov_b64_dpp / v_fmac_f64_dpp take the
+// value of lane L of the reader's own 16-lane row as source 0 — one instruction where a v_readlane pair through SGPRs plus the fma
+// took three (and their SGPR hazards).  The leading s_nop covers the "VALU write -> DPP read of that VGPR" wait states, which the
+// compiler's hazard recogniser does not see inside inline assembly.  All 64 lanes must be active.
+template <int L> __device__ __forceinline__ double row_bcast_f64(double v) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(L));
+  return r;
+}
+// acc - (bsrc of lane L of this lane's row) * m, one rounding (the same value as fma(-m, that, acc))
+template <int L> __device__ __forceinline__ double fnma_row_bcast_f64(double acc, double bsrc, double m) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(L));
+  return acc;
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
 // force-inlined into both kernels so that the address space of S (LDS vs global) is known: as an
 // out-of-line function it took a generic pointer and every access became a slow flat_load/flat_store.
 //
@@ -783,9 +808,9 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   const double* U = rb + nn;
   const double* gp = U + 36 * (size_t)K;
   const double* bred = gp + n;
-  // S = blockdiag(U*) - S_red ; b = -g_p + b_red
+  // S = blockdiag(U*) - S_red ; b = -g_p + b_red.  Only the lower triangle (j <= i) is ever read below.
   for (int i = tid / BA_TG; i < n; i += nth / BA_TG)
-    for (int j = tid % BA_TG; j < n; j += BA_TG) {
+    for (int j = tid % BA_TG; j <= i; j += BA_TG) {
       double v = -rb[(size_t)i * n + j];
       if (i / 6 == j / 6) {
         double u = U[36 * (size_t)(i / 6) + (i % 6) * 6 + (j % 6)];
@@ -810,37 +835,41 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   SOLVE_STAMP(0);
   if (tid == 0) s_ok = 1;
   int ok = 1;
-  for (int c0 = 0; c0 < n; c0 += 16) {
-    const int nb = min(16, n - c0);
-    __syncthreads();
-    SOLVE_STAMP(1);
-    ok = s_ok;
-    if (!ok) break;
-    if (tid < 64) {
+  // the 16x16 diagonal block at c0_ (nb_ live columns), by wave 0 alone: reads and writes only that block of S, s_rv and s_ok
+  auto factor_diag = [&](int c0_, int nb_) {
       const int j = tid & 15;
       double Lr[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) Lr[i] = (j < nb && i <= j) ? S[(size_t)(c0 + j) * n + c0 + i] : (i == j ? 1.0 : 0.0);
+      for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? S[(size_t)(c0_ + j) * n + c0_ + i] : (i == j ? 1.0 : 0.0);
       int good = 1;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[jj]), jj), __builtin_amdgcn_readlane(__double2loint(Lr[jj]), jj));
-        if (jj < nb && !(d > 0.0)) good = 0;                                  // uniform
+      // lane j (of every 16-lane row: the four rows of the wave carry the same block) owns row j; step jj: the pivot and then, for
+      // every later column kk, the entry L[kk][jj] reach all lanes of the row by DPP row_newbcast — 1 + (15 - jj) instructions
+      // where readlane pairs through SGPRs took 2 + 3 (15 - jj)
+      static_for<16>([&](auto jj_) {
+        constexpr int jj = decltype(jj_)::value;
+        const double d = row_bcast_f64<jj>(Lr[jj]);
+        if (jj < nb_ && !(d > 0.0)) good = 0;                                    // uniform
         const double ri = rsqrt_nr(good ? d : 1.0);
         if (tid == jj) s_rv[jj] = ri;
-        Lr[jj] = (j == jj) ? d * ri : Lr[jj] * ri;                            // column jj of L (rows >= jj matter)
-#pragma unroll
-        for (int kk = jj + 1; kk < 16; ++kk) {
-          const double lk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Lr[jj]), kk), __builtin_amdgcn_readlane(__double2loint(Lr[jj]), kk));
-          Lr[kk] = fma(-Lr[jj], lk, Lr[kk]);                                  // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk)
-        }
-      }
+        Lr[jj] = (j == jj) ? d * ri : Lr[jj] * ri;                              // column jj of L (rows >= jj matter)
+        static_for<16>([&](auto kk_) {
+          constexpr int kk = decltype(kk_)::value;
+          if constexpr (kk > jj) Lr[kk] = fnma_row_bcast_f64<kk>(Lr[kk], Lr[jj], Lr[jj]);   // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk)
+        });
+      });
       if (tid == 0 && !good) s_ok = 0;
-      if (good && tid < nb) {
+      if (good && tid < nb_) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) if (i <= j) S[(size_t)(c0 + j) * n + c0 + i] = Lr[i];
+        for (int i = 0; i < 16; ++i) if (i <= j) S[(size_t)(c0_ + j) * n + c0_ + i] = Lr[i];
       }
-    }
+  };
+  // Look-ahead: the diagonal block of panel p + 1 is factored by wave 0 inside the update phase of panel p, right after wave 0 has
+  // brought that one tile up to date, while the other 15 waves finish the trailing update — the longest phase of a panel (the
+  // serial 16-step factor) leaves the critical path and a panel costs two block barriers instead of three.
+  __syncthreads();
+  if (tid < 64) factor_diag(0, min(16, n));
+  for (int c0 = 0; c0 < n; c0 += 16) {
+    const int nb = min(16, n - c0);
     __syncthreads();
     SOLVE_STAMP(2);
     ok = s_ok;
@@ -894,8 +923,9 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         for (int k = 0; k < 16; ++k) acc = fma(S[(size_t)(c1 + tid) * n + c0 + k], sb[c0 + k], acc);
         sb[c1 + tid] -= acc;
       }
-      const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2, nw = nth >> 6;
-      for (int unit = tid >> 6; unit < units; unit += nw) {                    // wave-uniform
+      const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2, nw = (nth >> 6) - 1;
+      // wave 0: tile (c1, c1) only, then the factor of that block; waves 1..15: the other lower tiles
+      for (int unit = (tid < 64) ? 0 : (tid >> 6); unit < units; unit += (tid < 64) ? units : nw) {   // wave-uniform
         int ti = 0, rem = unit;
         while (rem > ti) { rem -= ti + 1; ++ti; }                              // unit = ti (ti + 1) / 2 + tj, tj <= ti
         const int tj = rem;
@@ -913,12 +943,17 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
           if (row < n && col <= row) S[(size_t)row * n + col] -= acc[q];
         }
       }
+      if (tid < 64) factor_diag(c1, min(16, n - c1));                          // (same wave wrote the tile: no barrier in between)
     }
   }
   __syncthreads();
   SOLVE_STAMP(4);
   ok = s_ok;
   __syncthreads();
+  // (A panel-blocked backward substitution — the panel's 16 unknowns by DPP row_newbcast steps in wave 0, the rows above it one
+  // thread each, same operations in the same order, bit-identical — was built and measured: 15.0 us against the 12.2 us of the
+  // single wave below at n = 114; its 16 block barriers and LDS round trips cost more than the readlane pairs they replace.
+  // v_fmac_f64_dpp / v_mov_b64_dpp issue every 16 cycles, a v_readlane_b32 every 4: profiles/r03_valu_issue_probe2.txt.)
   if (ok && tid < 64 && n <= 128) {
     // backward L^T x = y (y is already in sb: the forward substitution ran inside the factorisation), column oriented:
     // lane holds rows `lane` and `lane+64` of the right-hand side in registers, each step broadcasts one solved entry
@@ -1222,7 +1257,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
                                                          int owned_only) {
   // + the trial residuals of the point (local_ba_lm.rs:1047-1048): the group that back-substitutes a point already holds
   // its trial position, and the trial rotations follow from the pose step alone, so chi2(trial) needs no launch of its own
-  __shared__ double sRt[12 * BA_MAX_K];
+  __shared__ double sRt[12 * BA_MAX_K];      // trial poses
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
   const BaState* S = win.S;
@@ -1247,7 +1282,11 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
   const int j = gtid >> BA_PT_SHIFT;
   if (j >= d.M) return;     // whole 32-lane group
+  const double X0[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1], params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   double acc[3] = {0.0, 0.0, 0.0};
+  // sum_k W_kj^T delta_p_k from the stored W blocks.  (Recomputing A and B here instead — B^T (A delta_p), no 144-byte read —
+  // was built and measured: 68 -> 88 us per iteration of a 32-window batch; the kernel is bound by its dependent chains, not by
+  // the bytes, and the extra divisions and square roots of obs_terms lengthen them.)
   for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += BA_PT_LANES) {
     const int k = o_kf[i];
     if (k < 0) continue;
@@ -1272,7 +1311,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const double dl = I[a * 3] * rhs[0] + I[a * 3 + 1] * rhs[1] + I[a * 3 + 2] * rhs[2];
-    const double p = params[6 * (size_t)d.K + 3 * (size_t)j + a];
+    const double p = X0[a];
     X[a] = p + dl;
     dsq += dl * dl; psq += p * p;
   }
@@ -1742,8 +1781,8 @@ struct WinPlan {
   int n = 0, use_lds = 0, skip = 0;
   size_t np = 0, n_upper = 0, rb_len = 0, lds_need = 0;
   // byte offsets: input blob (host-prepared arrays), scratch arena, output blob
-  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_oflag, i_slot, i_next;
-  size_t a_p1, a_oA, a_oR, a_oYg, a_oW, a_vinv, a_gl, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
+  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_kfpt, i_oflag, i_slot, i_next;
+  size_t a_p1, a_oW, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
   size_t o_out;
   int n_kfobs = 0;
   double n_res = 0.0;
@@ -1775,6 +1814,7 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
   int* o_fix = (int*)(blob + pl.i_ofix);
   double* o_uv = (double*)(blob + pl.i_ouv);
   int* kf_obs = (int*)(blob + pl.i_kfobs);
+  int* kf_pt = (int*)(blob + pl.i_kfpt);
   int* o_flag = inertial ? (int*)(blob + pl.i_oflag) : nullptr;
   for (int j = 0; j <= M; ++j) pt_start[j] = 0;
   for (int i = 0; i < N; ++i) pt_start[obs[i].mp_idx + 1]++;
@@ -1795,7 +1835,11 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
   for (int k = 0; k < K; ++k) kf_start[k + 1] += kf_start[k];
   {
     std::vector<int> fill(kf_start, kf_start + K);
-    for (int t = 0; t < N; ++t) if (o_kf[t] >= 0) kf_obs[fill[o_kf[t]]++] = t;
+    int j = 0;
+    for (int t = 0; t < N; ++t) {
+      while (t >= pt_start[j + 1]) ++j;                                  // the map point of observation t (point-major order)
+      if (o_kf[t] >= 0) { const int q = fill[o_kf[t]]++; kf_obs[q] = t; kf_pt[q] = j; }
+    }
   }
   // (point, keyframe) -> its observation(s): what fills the operand tiles of the Schur product.  A point seen twice by one
   // keyframe (two features of it carry the same map point) has its W blocks chained; the tile slot holds their sum, as J^T J does.
@@ -1905,12 +1949,13 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.i_ofix = cin.take(4 * n1);
     pl.i_ouv = cin.take(16 * n1);
     pl.i_kfobs = cin.take(4 * n1);
+    pl.i_kfpt = cin.take(4 * n1);
     pl.i_oflag = inertial ? cin.take(4 * n1) : 0;
     pl.i_slot = cin.take(4 * m1 * k1);
     pl.i_next = cin.take(4 * n1);
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
-    pl.a_oA = car.take(96 * n1); pl.a_oR = car.take(16 * n1); pl.a_oYg = car.take(48 * n1); pl.a_oW = car.take(144 * n1);
-    pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
+    pl.a_oW = car.take(144 * n1);
+    pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_vg = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
     pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
     pl.a_part = car.take(8 * pl.n_upper * d.ksplit * 256);
     pl.a_rb = car.take(8 * (pl.rb_len + 8));
@@ -1983,9 +2028,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.Rt_fix = (const double*)(din + pl.i_rtfix);
     b.pt_start = (const int*)(din + pl.i_ptstart); b.o_kf = (const int*)(din + pl.i_okf); b.o_fix = (const int*)(din + pl.i_ofix);
     b.o_uv = (const double*)(din + pl.i_ouv);
-    b.kf_start = (const int*)(din + pl.i_kfstart); b.kf_obs = (const int*)(din + pl.i_kfobs);
-    b.oA = (double*)(dar + pl.a_oA); b.oR = (double*)(dar + pl.a_oR); b.oYg = (double*)(dar + pl.a_oYg);
-    b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl);
+    b.kf_start = (const int*)(din + pl.i_kfstart); b.kf_obs = (const int*)(din + pl.i_kfobs); b.kf_pt = (const int*)(din + pl.i_kfpt);
+    b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl); b.vg = (double*)(dar + pl.a_vg);
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
     b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
     b.oW = (double*)(dar + pl.a_oW);
@@ -2110,12 +2154,12 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if (maxK > 0 && W == 1) {
       ProfScope ps(h, "ba_kf_schur_kernel");
       const dim3 g(maxK * BA_KFSPLIT + max_schur_blocks, 1);
-      if (all_diag) hipLaunchKernelGGL(ba_kf_schur_kernel<true>, g, dim3(256), 0, st, d_wins);
-      else hipLaunchKernelGGL(ba_kf_schur_kernel<false>, g, dim3(256), 0, st, d_wins);
+      if (all_diag) hipLaunchKernelGGL(ba_kf_schur_kernel<true>, g, dim3(256), 0, st, d_wins, bc);
+      else hipLaunchKernelGGL(ba_kf_schur_kernel<false>, g, dim3(256), 0, st, d_wins, bc);
     } else if (maxK > 0) {
       {
         ProfScope ps(h, "ba_kf_kernel");
-        hipLaunchKernelGGL(ba_kf_kernel, dim3(maxK * BA_KFSPLIT, W), dim3(256), 0, st, d_wins);
+        hipLaunchKernelGGL(ba_kf_kernel, dim3(maxK * BA_KFSPLIT, W), dim3(256), 0, st, d_wins, bc);
       }
       ProfScope ps(h, "ba_schur_kernel", nullptr, true);
       if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins);

@@ -20,3 +20,13 @@ for _ in range(reps):
     its += sum(r["iterations"] for r in h.ba_solve_visual_batch(cam, cfg, wins))
 dt = time.perf_counter() - t0
 print("%d windows (K=%d, M=%d, %d observations each): %.3f ms per call, %.0f LM iterations/s" % (W, K, M, len(wins[0]["obs"]), dt / reps * 1e3, its / dt))
+if len(sys.argv) > 4 and sys.argv[4] == "kernels":     # per-kernel HIP-event times of one more call (one stream)
+    h.set_profiling(True)
+    h.ba_solve_visual_batch(cam, cfg, wins)
+    kt = h.kernel_times()
+    h.set_profiling(False)
+    tot = sum(v[0] for k, v in kt.items() if k.startswith("ba_"))
+    for k, (ms, n) in sorted(kt.items(), key=lambda kv: -kv[1][0]):
+        if k.startswith("ba_"):
+            print("  %-22s %8.3f ms  %3d scopes  %7.1f us each" % (k, ms, n, ms / n * 1e3))
+    print("device ms per call %.3f -> %.0f LM iterations/s device-only" % (tot, its / reps / (tot * 1e-3)))

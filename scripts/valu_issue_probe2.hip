@@ -28,6 +28,11 @@
   asm volatile(S : "+v"(q4) : "v"(k0), "v"(c0), "v"(c1) : "vcc"); asm volatile(S : "+v"(q5) : "v"(k0), "v"(c0), "v"(c1) : "vcc"); \
   asm volatile(S : "+v"(q6) : "v"(k0), "v"(c0), "v"(c1) : "vcc"); asm volatile(S : "+v"(q7) : "v"(k0), "v"(c0), "v"(c1) : "vcc");
 #define Q64(S) Q8(S) Q8(S) Q8(S) Q8(S) Q8(S) Q8(S) Q8(S) Q8(S)
+// dependent chains: ONE accumulator, every instruction waits for the one before it (latency, not issue rate)
+#define D8Q(S) asm volatile(S "\n" S "\n" S "\n" S "\n" S "\n" S "\n" S "\n" S : "+v"(q0) : "v"(k0), "v"(c0), "v"(c1) : "vcc");
+#define D64(S) D8Q(S) D8Q(S) D8Q(S) D8Q(S) D8Q(S) D8Q(S) D8Q(S) D8Q(S)
+#define D8R(S) asm volatile(S "\n" S "\n" S "\n" S "\n" S "\n" S "\n" S "\n" S : "+v"(a0) : "v"(c0), "v"(c1) : "vcc", "s20");
+#define D32(S) D8R(S) D8R(S) D8R(S) D8R(S) D8R(S) D8R(S) D8R(S) D8R(S)
 
 // X(index, printed name, R64 | Q64, asm)
 #define OPS(X)                                                                         \
@@ -77,8 +82,17 @@
   X(43, "v_rcp_f64", Q64, "v_rcp_f64 %0, %0")                                          \
   X(44, "v_cvt_f64_i32 (pair <- lo dword)", Q64, "v_cvt_f64_i32 %0, %2")               \
   X(45, "v_add_u32 (control row)", R64, "v_add_u32 %0, %0, %1")                        \
-  X(46, "v_pk_min_i16 (control row)", R64, "v_pk_min_i16 %0, %0, %1")
-constexpr int OP_COUNT = 47;
+  X(46, "v_pk_min_i16 (control row)", R64, "v_pk_min_i16 %0, %0, %1")                  \
+  X(47, "v_fmac_f64_dpp row_newbcast:3 (8 accumulators)", Q64, "s_nop 1\n v_fmac_f64_dpp %0, %1, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf") \
+  X(48, "v_mov_b64_dpp row_newbcast:3", Q64, "s_nop 1\n v_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf") \
+  X(49, "v_fma_f64 (8 accumulators)", Q64, "v_fma_f64 %0, %0, %1, %1")                 \
+  X(50, "v_fma_f64 DEPENDENT chain (1 accumulator)", D64, "v_fma_f64 %0, %0, %1, %1")  \
+  X(51, "v_fmac_f64_dpp DEPENDENT chain", D64, "s_nop 1\n v_fmac_f64_dpp %0, %1, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf") \
+  X(52, "v_rsq_f64", Q64, "v_rsq_f64 %0, %0")                                          \
+  X(53, "v_rsq_f64 DEPENDENT chain", D64, "v_rsq_f64 %0, %0")                          \
+  X(54, "v_add_u32 DEPENDENT chain", D32, "v_add_u32 %0, %0, %1")                      \
+  X(55, "v_fma_f32 DEPENDENT chain", D32, "v_fma_f32 %0, %0, %1, %2")
+constexpr int OP_COUNT = 56;
 #define NAME_ROW(i, n, k, s) n,
 static const char* kOpName[OP_COUNT] = {OPS(NAME_ROW)};
 
