@@ -65,6 +65,17 @@ ABI_SYMBOLS = [
 ]
 
 
+BOW_VECTORS_MAX = 8192      # descriptors per orbx_bow_vectors call (bow_kernels.hip: BOWV_MAX)
+
+
+def _seq_sum(a):
+    """left-to-right f64 sum (the order the device kernel adds a run in)"""
+    t = 0.0
+    for x in a:
+        t += float(x)
+    return t
+
+
 class OrbxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("orbx error %d: %s" % (code, msg))
@@ -1206,9 +1217,25 @@ class OrbVocabulary:
 
     def vectors_arrays(self, descriptors, levels_up=4):
         """orbx_bow_vectors: the two maps of OrbVocabulary::transform accumulated ON THE DEVICE ->
-        (bow_word [nb] ascending, bow_weight [nb] L1-normalised, fv_node [nf] ascending, fv_start [nf+1], fv_index [n])."""
+        (bow_word [nb] ascending, bow_weight [nb] L1-normalised, fv_node [nf] ascending, fv_start [nf+1], fv_index [n]).
+        Up to BOW_VECTORS_MAX = 8192 descriptors per call on the device; more: device descent + host accumulation, same result."""
         d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
         n = len(d)
+        if n > BOW_VECTORS_MAX:
+            # orbx_bow_vectors sorts one call's descriptors in one workgroup's LDS (at most 8192 of them: four frames' worth).  Beyond
+            # that the tree descent still runs on the GPU (orbx_bow_transform) and the two maps are accumulated here with the device
+            # kernel's own orders: weights of a word added in feature order, the L1 norm in ascending word id.
+            word, _leaf, node, w = self.transform_arrays(d, levels_up)
+            order = np.argsort(word, kind="stable")
+            bw, first = np.unique(word[order], return_index=True)
+            bv = np.array([_seq_sum(w[order[a:b]]) for a, b in zip(first, list(first[1:]) + [n])], np.float64)
+            norm = _seq_sum(bv)
+            if norm > 0.0:
+                bv = bv / norm
+            forder = np.argsort(node, kind="stable")
+            fn, ffirst = np.unique(node[forder], return_index=True)
+            fs = np.concatenate([ffirst, [n]]).astype(np.int32)
+            return bw.astype(np.uint32), bv, fn.astype(np.uint32), fs, forder.astype(np.int32)
         bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64); fn = np.zeros(max(n, 1), np.uint32)
         fs = np.zeros(n + 1, np.int32); fi = np.zeros(max(n, 1), np.int32); nb = C.c_int(); nf = C.c_int()
         h = self._handle

@@ -773,6 +773,29 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
 
+// Cholesky of a 16x16 block in one wave.  Lane j of every 16-lane row (the four rows of the wave carry the same block) owns row j:
+// Lr[i] = a[j][i] for i <= j (rows >= nb: the identity).  Step jj: the pivot and then, for every later column kk, the entry
+// L[kk][jj] reach all lanes of the row by DPP row_newbcast — 1 + (15 - jj) instructions where readlane pairs through SGPRs took
+// 2 + 3 (15 - jj).  On return Lr holds row j of L; rv[jj] = 1 / L[jj][jj] (written by thread jj).  Returns 0 when a live pivot is
+// not positive (uniform).
+__device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid, double* __restrict__ rv) {
+  const int j = tid & 15;
+  int good = 1;
+  static_for<16>([&](auto jj_) {
+    constexpr int jj = decltype(jj_)::value;
+    const double d = row_bcast_f64<jj>(Lr[jj]);
+    if (jj < nb && !(d > 0.0)) good = 0;                                    // uniform
+    const double ri = rsqrt_nr(good ? d : 1.0);
+    if (tid == jj) rv[jj] = ri;
+    Lr[jj] = (j == jj) ? d * ri : Lr[jj] * ri;                              // column jj of L (rows >= jj matter)
+    static_for<16>([&](auto kk_) {
+      constexpr int kk = decltype(kk_)::value;
+      if constexpr (kk > jj) Lr[kk] = fnma_row_bcast_f64<kk>(Lr[kk], Lr[jj], Lr[jj]);   // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk)
+    });
+  });
+  return good;
+}
+
 // force-inlined into both kernels so that the address space of S (LDS vs global) is known: as an
 // out-of-line function it took a generic pointer and every access became a slow flat_load/flat_store.
 //
@@ -841,22 +864,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       double Lr[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? S[(size_t)(c0_ + j) * n + c0_ + i] : (i == j ? 1.0 : 0.0);
-      int good = 1;
-      // lane j (of every 16-lane row: the four rows of the wave carry the same block) owns row j; step jj: the pivot and then, for
-      // every later column kk, the entry L[kk][jj] reach all lanes of the row by DPP row_newbcast — 1 + (15 - jj) instructions
-      // where readlane pairs through SGPRs took 2 + 3 (15 - jj)
-      static_for<16>([&](auto jj_) {
-        constexpr int jj = decltype(jj_)::value;
-        const double d = row_bcast_f64<jj>(Lr[jj]);
-        if (jj < nb_ && !(d > 0.0)) good = 0;                                    // uniform
-        const double ri = rsqrt_nr(good ? d : 1.0);
-        if (tid == jj) s_rv[jj] = ri;
-        Lr[jj] = (j == jj) ? d * ri : Lr[jj] * ri;                              // column jj of L (rows >= jj matter)
-        static_for<16>([&](auto kk_) {
-          constexpr int kk = decltype(kk_)::value;
-          if constexpr (kk > jj) Lr[kk] = fnma_row_bcast_f64<kk>(Lr[kk], Lr[jj], Lr[jj]);   // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk)
-        });
-      });
+      const int good = chol16_rows_dpp(Lr, nb_, tid, s_rv);
       if (tid == 0 && !good) s_ok = 0;
       if (good && tid < nb_) {
 #pragma unroll
@@ -1023,10 +1031,9 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(const Ba
 // ---- large reduced systems (n > ~135: S does not fit LDS) -------------------------------------------------------
 // Right-looking blocked Cholesky over several launches, panels of 16 columns, S in global memory (L2 resident):
 //   ba_big_assemble_kernel   S = blockdiag(U*) - S_red, b, |g|                                   (many blocks)
-//   per panel:  ba_big_panel_kernel   16x16 diagonal block in LDS, rows below solved against it   (1 block)
-//               ba_big_update_kernel  trailing  S22 -= L21 L21^T : one wave per lower 16x16 tile, four
-//                                     v_mfma_f64_16x16x4_f64 (rank-16 update)                     (many waves)
-//   ba_big_subst_kernel      panel-blocked forward / backward substitution, |dp|^2, |p|^2         (1 block)
+//   per panel:  ba_big_step_kernel    trailing update of the previous panel (one wave per lower 16x16 tile, four
+//                                     v_mfma_f64_16x16x4_f64) + this panel: diagonal block, rows below it, its part of L y = b
+//   ba_big_back_kernel       panel-blocked backward substitution, |dp|^2, |p|^2                   (1 block)
 constexpr int BB_NB = 16;
 
 __global__ __launch_bounds__(256) void ba_big_assemble_kernel(const BaWin* __restrict__ wins) {
@@ -1064,92 +1071,177 @@ __global__ __launch_bounds__(256) void ba_big_assemble_kernel(const BaWin* __res
   }
 }
 
-__global__ __launch_bounds__(256) void ba_big_panel_kernel(const BaWin* __restrict__ wins, int c0) {
+// One launch per panel (c0 = first column of the panel).  Block 0 = the panel block: it first brings the panel's own column block
+// up to date with the rank-16 update of the PREVIOUS panel (the tiles (ti, 0) of the trailing matrix) and the right-hand side below
+// it (forward substitution rides along: b_r -= L[r][prev..] y_prev), then factors the 16x16 diagonal block (wave 0, DPP), solves
+// the rows below against it and the panel's 16 entries of the right-hand side.  The other blocks apply the previous panel's update
+// to the rest of the trailing matrix, one wave per lower 16x16 tile (ti, tj), tj >= 1.  Both read only the previous panel's
+// columns, which nobody writes in this launch, and write disjoint tiles.  (Round 2: a panel kernel, an update kernel per panel and
+// forward AND backward substitution in a one-block kernel afterwards — 38 + 1 dependent launches at n = 294, 381 us per solve; now
+// 19 + 1.)
+// (1024-thread blocks — the panel block's column tiles in two rounds, every row below in one — measured slower: 327 -> 438 us per solve.)
+constexpr int BB_STEP_THREADS = 256;
+constexpr int BB_COL_TILES = (BA_MAX_N / 16 + 3) / 4;      // column tiles per wave of the panel block, all in flight at once
+__global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWin* __restrict__ wins, int c0) {
   __shared__ double D[BB_NB][BB_NB + 1];
-  __shared__ double rinv[BB_NB];
+  __shared__ double rinv[BB_NB], ys[BB_NB];
   __shared__ int s_ok;
   const BaWin& win = wins[blockIdx.y];
   const int n = win.n;
-  double* __restrict__ Sg = win.Sg; double* __restrict__ ginv = win.ginv; double* __restrict__ res = win.res;
+  double* __restrict__ Sg = win.Sg; double* __restrict__ ginv = win.ginv; double* __restrict__ bvec = win.bvec; double* __restrict__ res = win.res;
   if (win.use_lds || c0 >= n || win.S->done || res[2] == 0.0) return;
-  const int tid = threadIdx.x, nb = min(BB_NB, n - c0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prev = c0 - BB_NB;                                            // the finished panel whose update is applied here (none at c0 = 0)
+  const int nt = (n - c0 + 15) / 16;                                      // tile rows of the trailing matrix [c0, n)
+  if (blockIdx.x > 0) {
+    if (prev < 0) return;
+    const int unit = ((int)blockIdx.x - 1) * 4 + wave;                     // tiles (ti, tj) with 1 <= tj <= ti < nt: unit = ti (ti - 1) / 2 + tj - 1
+    if (unit >= nt * (nt - 1) / 2) return;
+    int ti = 1, rem = unit;
+    while (rem >= ti) { rem -= ti; ++ti; }
+    const int tj = rem + 1;
+    // S[ti][tj] -= L[ti][prev] L[tj][prev]^T, lower part, one wave
+    const int ra = min(c0 + 16 * ti + (lane & 15), n - 1), rb_ = min(c0 + 16 * tj + (lane & 15), n - 1);
+    const double* pa = Sg + (size_t)ra * n + prev + (lane >> 4);
+    const double* pb = Sg + (size_t)rb_ * n + prev + (lane >> 4);
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { av[q] = pa[4 * q]; bv[q] = pb[4 * q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+    const int col = c0 + 16 * tj + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = c0 + 16 * ti + (lane >> 4) + 4 * q;
+      if (row < n && col <= row) Sg[(size_t)row * n + col] -= acc[q];
+    }
+    return;
+  }
+  // ---- the panel block
+  const int nb = min(BB_NB, n - c0);
   if (tid == 0) s_ok = 1;
   {
     const int i = tid / BB_NB, j = tid % BB_NB;
-    D[i][j] = (i < nb && j <= i) ? Sg[(size_t)(c0 + i) * n + c0 + j] : (i == j ? 1.0 : 0.0);
+    D[i][j] = i == j ? 1.0 : 0.0;                                           // rows / columns beyond nb: the identity
   }
-  __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    const double d = D[j][j];
-    if (!(d > 0.0)) { if (tid == 0) s_ok = 0; break; }   // uniform
-    const double ri = rsqrt_nr(d);
-    __syncthreads();
-    if (tid == 0) { rinv[j] = ri; D[j][j] = d * ri; }
-    if (tid > j && tid < nb) D[tid][j] *= ri;
-    __syncthreads();
-    const int i = tid / BB_NB, k = tid % BB_NB;
-    if (k > j && k <= i && i < nb) D[i][k] = fma(-D[i][j], D[k][j], D[i][k]);
-    __syncthreads();
+  if (prev >= 0) {
+    // Column tiles (ti, 0), ti = wave, wave + 4, ...: EVERY operand of all of a wave's tiles (the shared tile-0 rows of the previous
+    // panel, each tile's own rows, each tile's current values) and the right-hand side's rows are requested before the first is
+    // used — one L2 round trip for the whole phase instead of two per tile, five tiles deep.
+    if (tid < BB_NB) ys[tid] = bvec[prev + tid];
+    const int rb_ = min(c0 + (lane & 15), n - 1);
+    double bv[4], av[BB_COL_TILES][4], cv[BB_COL_TILES][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = Sg[(size_t)rb_ * n + prev + (lane >> 4) + 4 * q];
+    const int col = c0 + (lane & 15);
+#pragma unroll
+    for (int t = 0; t < BB_COL_TILES; ++t) {
+      const int ti = wave + 4 * t;
+      if (ti < nt) {                                                       // wave-uniform
+        const int ra = min(c0 + 16 * ti + (lane & 15), n - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[t][q] = Sg[(size_t)ra * n + prev + (lane >> 4) + 4 * q];
+          const int row = c0 + 16 * ti + (lane >> 4) + 4 * q;
+          cv[t][q] = (row < n && col <= row) ? Sg[(size_t)row * n + col] : 0.0;
+        }
+      }
+    }
+    __syncthreads();                                                       // ys
+    // right-hand side below the previous panel: b_r -= L[r][prev ..] y_prev
+    for (int r = c0 + tid; r < n; r += BB_STEP_THREADS) {
+      const double* row = Sg + (size_t)r * n + prev;
+      double v = bvec[r];
+#pragma unroll
+      for (int j = 0; j < BB_NB; ++j) v = fma(-row[j], ys[j], v);
+      bvec[r] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < BB_COL_TILES; ++t) {
+      const int ti = wave + 4 * t;
+      if (ti < nt) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t][q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = c0 + 16 * ti + (lane >> 4) + 4 * q;
+          if (row < n && col <= row) {
+            const double v = cv[t][q] - acc[q];
+            if (ti == 0) D[(lane >> 4) + 4 * q][lane & 15] = v;            // the diagonal tile goes to the factor through LDS
+            else Sg[(size_t)row * n + col] = v;
+          }
+        }
+      }
+    }
+  } else {
+    const int i = tid / BB_NB, j = tid % BB_NB;
+    if (i < nb && j <= i) D[i][j] = Sg[(size_t)(c0 + i) * n + c0 + j];
+  }
+  __syncthreads();                                                         // the column block and the right-hand side are up to date (block scope)
+  // rows below the block: their 16 entries are final now; request them before the factor so that they travel under it
+  const int r0 = c0 + BB_NB + tid;
+  double xr[BB_NB];
+  if (r0 < n) {
+#pragma unroll
+    for (int j = 0; j < BB_NB; ++j) xr[j] = Sg[(size_t)r0 * n + c0 + j];
+  }
+  if (tid < 64) {
+    const int j = tid & 15;
+    double Lr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Lr[i] = (j < nb && i <= j) ? D[j][i] : (i == j ? 1.0 : 0.0);
+    const int good = chol16_rows_dpp(Lr, nb, tid, rinv);
+    if (tid == 0 && !good) s_ok = 0;
+    if (good && tid < BB_NB) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        D[j][i] = i <= j ? Lr[i] : 0.0;
+        if (j < nb && i <= j) Sg[(size_t)(c0 + j) * n + c0 + i] = Lr[i];
+      }
+    }
   }
   __syncthreads();
   if (!s_ok) { if (tid == 0) res[2] = 0.0; return; }
-  // factored block and 1/L_jj back to global
-  {
-    const int i = tid / BB_NB, j = tid % BB_NB;
-    if (i < nb && j <= i) Sg[(size_t)(c0 + i) * n + c0 + j] = D[i][j];
-    if (tid < nb) ginv[c0 + tid] = rinv[tid];
-  }
-  // rows below the block: x = a L11^-T
-  for (int r = c0 + BB_NB + tid; r < n; r += 256) {
+  if (tid < nb) ginv[c0 + tid] = rinv[tid];
+  if (tid == BB_STEP_THREADS - 1) {                                        // y of this panel: L11 y = b, entry by entry
     double x[BB_NB];
-    double* row = Sg + (size_t)r * n + c0;
 #pragma unroll
-    for (int j = 0; j < BB_NB; ++j) x[j] = row[j];
+    for (int jx = 0; jx < BB_NB; ++jx) x[jx] = jx < nb ? bvec[c0 + jx] : 0.0;
 #pragma unroll
-    for (int j = 0; j < BB_NB; ++j) {
-      double v = x[j];
+    for (int jx = 0; jx < BB_NB; ++jx) {
+      if (jx < nb) {
+        double v = x[jx];
 #pragma unroll
-      for (int t = 0; t < j; ++t) v = fma(-x[t], D[j][t], v);
-      x[j] = v * rinv[j];
+        for (int t = 0; t < jx; ++t) v = fma(-D[jx][t], x[t], v);
+        x[jx] = v * rinv[jx];
+      }
     }
 #pragma unroll
-    for (int j = 0; j < BB_NB; ++j) row[j] = x[j];
+    for (int jx = 0; jx < BB_NB; ++jx) if (jx < nb) bvec[c0 + jx] = x[jx];
+  }
+  // rows below the block: x = a L11^-T
+  for (int r = r0; r < n; r += BB_STEP_THREADS) {
+    double* row = Sg + (size_t)r * n + c0;
+    if (r != r0) {
+#pragma unroll
+      for (int j = 0; j < BB_NB; ++j) xr[j] = row[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BB_NB; ++j) {
+      double v = xr[j];
+#pragma unroll
+      for (int t = 0; t < j; ++t) v = fma(-xr[t], D[j][t], v);
+      xr[j] = v * rinv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BB_NB; ++j) row[j] = xr[j];
   }
 }
 
-// one wave per lower 16x16 tile (ti >= tj) of the trailing matrix [c1, n) x [c1, n), c1 = c0 + 16
-__global__ __launch_bounds__(256) void ba_big_update_kernel(const BaWin* __restrict__ wins, int c0) {
-  const BaWin& win = wins[blockIdx.y];
-  const int n = win.n;
-  double* __restrict__ Sg = win.Sg;
-  if (win.use_lds || win.S->done || win.res[2] == 0.0) return;
-  const int lane = threadIdx.x & 63;
-  const int c1 = c0 + BB_NB, m = n - c1;
-  if (m <= 0) return;
-  const int nt = (m + 15) / 16;
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (unit >= nt * (nt + 1) / 2) return;
-  int ti = 0, rem = unit;
-  while (rem > ti) { rem -= ti + 1; ++ti; }      // unit = ti (ti + 1) / 2 + tj, tj <= ti
-  const int tj = rem;
-  const int ra = min(c1 + 16 * ti + (lane & 15), n - 1), rb_ = min(c1 + 16 * tj + (lane & 15), n - 1);
-  const double* pa = Sg + (size_t)ra * n + c0 + (lane >> 4);
-  const double* pb = Sg + (size_t)rb_ * n + c0 + (lane >> 4);
-  double4_t acc = {0.0, 0.0, 0.0, 0.0};
-  double av[4], bv[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { av[q] = pa[4 * q]; bv[q] = pb[4 * q]; }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
-  const int col = c1 + 16 * tj + (lane & 15);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = c1 + 16 * ti + (lane >> 4) + 4 * q;
-    if (row < n && col <= row) Sg[(size_t)row * n + col] -= acc[q];
-  }
-}
-
-__global__ __launch_bounds__(256) void ba_big_subst_kernel(const BaWin* __restrict__ wins) {
+// backward substitution L^T x = y (y = bvec after the last ba_big_step_kernel), |dp|^2, |p|^2: one block
+__global__ __launch_bounds__(256) void ba_big_back_kernel(const BaWin* __restrict__ wins) {
   __shared__ double sb[BA_MAX_N];
   __shared__ double y[BB_NB];
   __shared__ double red[256];
@@ -1169,45 +1261,29 @@ __global__ __launch_bounds__(256) void ba_big_subst_kernel(const BaWin* __restri
     // chain: read straight from global memory that chain was ~270 serial L2 round trips per panel (n = 300: 289 us)
     __shared__ double Dg[BB_NB][BB_NB + 1];
     __shared__ double gi[BB_NB];
-    for (int c0 = 0; c0 < n; c0 += BB_NB) {            // forward: L y = b
+    // Everything a panel needs from global memory — its diagonal block, 1 / L_jj, and for every row above it the 16 entries of L
+    // that couple it to the panel — is requested BEFORE the previous panel's dependent chain is waited for (the block element one
+    // panel ahead, the row entries ahead of the chain): one L2 round trip per panel on the critical path instead of three.
+    constexpr int BACK_ROWS = (BA_MAX_N + 255) / 256;                     // rows above a panel per thread
+    const int c_last = ((n - 1) / BB_NB) * BB_NB;
+    const int di = tid / BB_NB, dj = tid % BB_NB;
+    auto block_elem = [&](int c0) -> double { const int nb_ = min(BB_NB, n - c0); return (c0 >= 0 && di < nb_ && dj <= di) ? Sg[(size_t)(c0 + di) * n + c0 + dj] : 0.0; };
+    auto inv_elem = [&](int c0) -> double { return (c0 >= 0 && tid < min(BB_NB, n - c0)) ? ginv[c0 + tid] : 0.0; };
+    double d_next = block_elem(c_last), g_next = inv_elem(c_last);
+    for (int c0 = c_last; c0 >= 0; c0 -= BB_NB) {                         // backward: L^T x = y
       const int nb = min(BB_NB, n - c0);
-      {
-        const int i = tid / BB_NB, j = tid % BB_NB;   // 256 threads = one 16x16 block
-        if (i < nb && j <= i) Dg[i][j] = Sg[(size_t)(c0 + i) * n + c0 + j];
-        if (tid < nb) gi[tid] = ginv[c0 + tid];
-      }
-      __syncthreads();
-      if (tid < 64) {                                  // wave 0: lane j owns row j of the block, columns by v_readlane
-        const int j = tid & 15;
-        double Lr[BB_NB];
+      Dg[di][dj] = d_next;
+      if (tid < BB_NB) gi[tid] = g_next;
+      double Lrow[BACK_ROWS][BB_NB];
 #pragma unroll
-        for (int i = 0; i < BB_NB; ++i) Lr[i] = (j < nb && i < j) ? Dg[j][i] : 0.0;
-        double v = j < nb ? sb[c0 + j] : 0.0;
+      for (int q = 0; q < BACK_ROWS; ++q) {
+        const int i = tid + 256 * q;
+        if (i < c0) {
 #pragma unroll
-        for (int i = 0; i < BB_NB; ++i) {
-          if (i < nb) {                                // uniform
-            const double yi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i)) * gi[i];
-            if (j == i) v = yi; else if (j > i) v = fma(-Lr[i], yi, v);
-          }
+          for (int j = 0; j < BB_NB; ++j) Lrow[q][j] = j < nb ? Sg[(size_t)(c0 + j) * n + i] : 0.0;
         }
-        if (tid < nb) { y[tid] = v; sb[c0 + tid] = v; }
       }
-      __syncthreads();
-      for (int r = c0 + nb + tid; r < n; r += 256) {
-        const double* row = Sg + (size_t)r * n + c0;
-        double v = sb[r];
-        for (int j = 0; j < nb; ++j) v = fma(-row[j], y[j], v);
-        sb[r] = v;
-      }
-      __syncthreads();
-    }
-    for (int c0 = ((n - 1) / BB_NB) * BB_NB; c0 >= 0; c0 -= BB_NB) {   // backward: L^T x = y
-      const int nb = min(BB_NB, n - c0);
-      {
-        const int i = tid / BB_NB, j = tid % BB_NB;
-        if (i < nb && j <= i) Dg[i][j] = Sg[(size_t)(c0 + i) * n + c0 + j];
-        if (tid < nb) gi[tid] = ginv[c0 + tid];
-      }
+      d_next = block_elem(c0 - BB_NB); g_next = inv_elem(c0 - BB_NB);
       __syncthreads();
       if (tid < 64) {                                  // wave 0: lane j owns column j of the block (= row j of L^T)
         const int j = tid & 15;
@@ -1225,10 +1301,15 @@ __global__ __launch_bounds__(256) void ba_big_subst_kernel(const BaWin* __restri
         if (tid < nb) { y[tid] = v; sb[c0 + tid] = v; }
       }
       __syncthreads();
-      for (int i = tid; i < c0; i += 256) {
-        double v = sb[i];
-        for (int j = 0; j < nb; ++j) v = fma(-Sg[(size_t)(c0 + j) * n + i], y[j], v);
-        sb[i] = v;
+#pragma unroll
+      for (int q = 0; q < BACK_ROWS; ++q) {
+        const int i = tid + 256 * q;
+        if (i < c0) {
+          double v = sb[i];
+#pragma unroll
+          for (int j = 0; j < BB_NB; ++j) if (j < nb) v = fma(-Lrow[q][j], y[j], v);
+          sb[i] = v;
+        }
       }
       __syncthreads();
     }
@@ -2176,14 +2257,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       if (inr->E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, w0.S, w0.P0, w0.P1, 0, 1, ind, imu_buf);
       hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, ind, w0.rb, imu_buf, b15.Sg, b15.bvec, gfull, res0);
       for (int c0 = 0; c0 < n15; c0 += BB_NB) {
-        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15, c0);
-        const int m = n15 - c0 - BB_NB;
-        if (m > 0) {
-          const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2;
-          hipLaunchKernelGGL(ba_big_update_kernel, dim3((units + 3) / 4, 1), dim3(256), 0, st, d_wins15, c0);
-        }
+        const int nt = (n15 - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
+        hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + 3) / 4, 1), dim3(256), 0, st, d_wins15, c0);
       }
-      hipLaunchKernelGGL(ba_big_subst_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15);
+      hipLaunchKernelGGL(ba_big_back_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15);
       hipLaunchKernelGGL(ba_inertial_scatter_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, K0, M0, dp15, w0.dp);
     } else {
       ProfScope ps(h, "ba_solve_kernel");
@@ -2191,14 +2268,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       if (any_big) {
         hipLaunchKernelGGL(ba_big_assemble_kernel, dim3(max_asm, W), dim3(256), 0, st, d_wins);
         for (int c0 = 0; c0 < n_big_max; c0 += BB_NB) {
-          hipLaunchKernelGGL(ba_big_panel_kernel, gW1, dim3(256), 0, st, d_wins, c0);
-          const int m = n_big_max - c0 - BB_NB;
-          if (m > 0) {
-            const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2;
-            hipLaunchKernelGGL(ba_big_update_kernel, dim3((units + 3) / 4, W), dim3(256), 0, st, d_wins, c0);
-          }
+          const int nt = (n_big_max - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
+          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + 3) / 4, W), dim3(256), 0, st, d_wins, c0);
         }
-        hipLaunchKernelGGL(ba_big_subst_kernel, gW1, dim3(256), 0, st, d_wins);
+        hipLaunchKernelGGL(ba_big_back_kernel, gW1, dim3(256), 0, st, d_wins);
       }
     }
     {

@@ -338,7 +338,11 @@ __device__ __forceinline__ void blur_strip_e(const uint8_t* __restrict__ src, in
     for (int k = 0; k + 1 < BLUR_PF; ++k) pq[k] = pq[k + 1];
     pq[BLUR_PF - 1] = *reinterpret_cast<const unsigned*>(rowp(i + BLUR_PF));
     unsigned hs[4];
+#ifdef ORBX_BLUR_NOARITH   // measurement build only (scripts/build_variant.sh): the kernel's loads and stores without its arithmetic
+    hs[0] = hs[1] = hs[2] = hs[3] = cur;
+#else
     blur_row<EDGE>(cur, be, hs);
+#endif
     if (i > 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) pr[i - 1][k] = hprev[k] | (hs[k] << 16);
@@ -358,6 +362,10 @@ __device__ __forceinline__ void blur_strip_e(const uint8_t* __restrict__ src, in
         for (int k = 0; k + 1 < BLUR_PF; ++k) pq[k] = pq[k + 1];
         pq[BLUR_PF - 1] = *reinterpret_cast<const unsigned*>(rowp(y + 6 + BLUR_PF));
         unsigned hs[4];
+#ifdef ORBX_BLUR_NOARITH
+        const unsigned packed = cur ^ hprev[0];
+        hprev[0] = cur;
+#else
         blur_row<EDGE>(cur, be, hs);
         unsigned vv[4];
 #pragma unroll
@@ -370,6 +378,7 @@ __device__ __forceinline__ void blur_strip_e(const uint8_t* __restrict__ src, in
           vv[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(blur_us2, pr[(i + 4) % 6][k]), T2, v, false);
         }
         const unsigned packed = pack_byte2(vv[0], vv[1], vv[2], vv[3]);   // (v >> 16) of the four 16.16 sums
+#endif
         if (active && (M == 1 || y < nrows_l)) *reinterpret_cast<unsigned*>(dst + (unsigned)(__umul24((unsigned)(ys + y), (unsigned)dpitch) + (unsigned)x0)) = packed;
       }
     }
@@ -1183,7 +1192,10 @@ __device__ __forceinline__ void sincos_deg(float angle_deg, float& c_out, float&
   s_out = (float)sn;
 }
 
-constexpr int PB_ROWS = 37, PB_PITCH = 10;   // blurred 37x37 patch: 10 dwords per row (26.7 KB per block with the tables: 6 blocks per CU)
+#ifndef ORBX_PB_PITCH
+#define ORBX_PB_PITCH 10
+#endif
+constexpr int PB_ROWS = 37, PB_PITCH = ORBX_PB_PITCH;   // blurred 37x37 patch: 10 dwords per row (26.7 KB per block with the tables: 6 blocks per CU)
 
 // Intensity-centroid weights (Appendix A.7): the 31x31 patch as 31 rows x 8 dwords (task t = r*8 + c,
 // pixel column 4c+b); per task one dword of 0/1 disc-membership bytes and one of (column index)*membership

@@ -169,7 +169,8 @@ def test_gpu_bow_search_matches_oracle(gpu_handle, seed, n, k, depth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,depth,n,lu", [(10, 4, 6000, 2), (10, 3, 2000, 1), (6, 3, 700, 0), (4, 2, 64, 4)])
+@pytest.mark.parametrize("k,depth,n,lu", [(10, 4, 6000, 2), (10, 3, 2000, 1), (6, 3, 700, 0), (4, 2, 64, 4),
+                                          (10, 4, 8092, 2), (10, 4, 8093, 2), (10, 3, 12000, 1)])   # 8192 (device limit), 8193 and beyond: host accumulation
 def test_gpu_bow_vectors_match_restatement(gpu_handle, k, depth, n, lu):
     """BowVector / FeatureVector accumulated on the device (orbx_bow_vectors) against the literal loop of transform
     (mod.rs:296-325) over the ORACLE's per-descriptor results: weights summed per word in feature order, the L1 norm summed in
