@@ -425,11 +425,15 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
  * orbx_ba_solve_visual on it bit for bit.  Windows may differ in size.  should_stop is polled once per iteration for the
  * whole batch (and while the work drains); a window that converges early simply stops taking part.
  *   status: ORBX_OK, or ORBX_ERR_EMPTY for a window the reference answers None for (:923-925) — the call still returns
- *   ORBX_OK and solves the others.  An observation index out of range fails the whole call (ORBX_ERR_INVALID).
+ *   ORBX_OK and solves the others (also when that window is the only one of the batch).  An observation index out of range fails
+ *   the whole call (ORBX_ERR_INVALID): every window's status then carries the error, and the in/out `points` / `poses_wc_out` of
+ *   windows that had already finished (the other half of a two-stream batch) hold their results — hand in the original points
+ *   again when retrying.  No C++ exception leaves the call: allocation or thread-creation failure is an error code.
  * The all-reduce hook / RCCL communicator is not used here (independent windows need no collective).
  * A batch of 16 or more windows without a should_stop callback runs as two halves at once: the second half on an internal second
  * stream with its own workspaces, driven by a helper thread for the duration of the call, so that one half's host preprocessing and
- * transfers run under the other half's kernels (+12 % LM iterations/s at 32 windows).  Results do not depend on it.  With a callback
+ * transfers run under the other half's kernels (+12 % LM iterations/s at 32 windows); the halves are cut where the observation
+ * count is halved; if the second stream cannot be created the whole batch runs on the first.  Results do not depend on it.  With a callback
  * (which would otherwise be called from two threads), or with per-kernel profiling on, the call keeps to one stream. */
 typedef struct {
   int K;                        /* in: optimised keyframes                         */

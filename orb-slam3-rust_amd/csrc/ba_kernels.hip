@@ -641,8 +641,10 @@ __global__ __launch_bounds__(256) void ba_kf_kernel(const BaWin* __restrict__ wi
 }
 
 // DIAG: every window of the launch has a reduced system of at most 128 columns (host-checked)
+// (three blocks per CU for the one-column-block body; the general body holds 2 x 8 accumulator tiles = 256 VGPRs and would spill under
+// that cap: as (256, 3) its launch over four 50-keyframe windows ran 0.94 ms, 13 % of the f64 matrix peak)
 template <bool DIAG>
-__global__ __launch_bounds__(256, 3) void ba_schur_kernel(const BaWin* __restrict__ wins) {
+__global__ __launch_bounds__(256, DIAG ? 3 : 2) void ba_schur_kernel(const BaWin* __restrict__ wins) {
   __shared__ double s_tiles[2 * SCH_R * SCH_PITCH];                 // Y and W operand tiles (51 KB)
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done) return;
