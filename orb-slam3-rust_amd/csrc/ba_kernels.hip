@@ -258,7 +258,11 @@ __device__ __forceinline__ double group_sum32(double v) {   // sum over the poin
 }
 
 // One 32-lane group per point (2 points per wave).  Observations are stored point-major (CSR).
-__global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__ wins, BaCam cam, int iter) {
+// (115 VGPRs; caps for 3 / 5 blocks per CU: 103.3 -> 102.5 / 134 us per batch iteration)
+#ifndef ORBX_BUILD_MINBLOCKS
+#define ORBX_BUILD_MINBLOCKS 1
+#endif
+__global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(const BaWin* __restrict__ wins, BaCam cam, int iter) {
   __shared__ double sRt[12 * BA_MAX_K];
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
@@ -276,8 +280,11 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
   if (blockIdx.x == 0 && threadIdx.x == 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
   block_poses(params, d.K, cam.inertial, sRt);
   const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
-  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> BA_PT_SHIFT;
-  if (j >= d.M) return;   // whole 32-lane group leaves together
+  // a group takes the points g0, g0 + (groups of the launch), ...: one point per group for a single window (as many short blocks as
+  // possible for its latency chain), several in a large batch, where the block's prologue (K poses) is then paid once for all of
+  // them.  A point's arithmetic does not depend on which block or round handles it.
+  const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> BA_PT_SHIFT, gstride = (int)gridDim.x * (256 / BA_PT_LANES);
+  for (int j = g0; j < d.M; j += gstride) {   // group-uniform
   const double X[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1],
                        params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   const int s = pt_start[j], e = pt_start[j + 1];
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(256) void ba_build_kernel(const BaWin* __restrict__
       oW[18 * (size_t)i + 6 + a] = o.A[a] * o.B[1] + o.A[6 + a] * o.B[4];
       oW[18 * (size_t)i + 12 + a] = o.A[a] * o.B[2] + o.A[6 + a] * o.B[5];
     }
+  }
   }
 }
 
@@ -634,7 +642,12 @@ __global__ __launch_bounds__(256, 2) void ba_kf_schur_kernel(const BaWin* __rest
 }
 
 // (their own launches in a batch: 51 KB of LDS and ~200 VGPRs per block would otherwise throttle the thousands of small keyframe blocks too)
-__global__ __launch_bounds__(256) void ba_kf_kernel(const BaWin* __restrict__ wins, BaCam cam) {
+// (242 VGPRs, 2 waves per SIMD: a cap of 128 VGPRs / 4 waves per SIMD measured 61.1 -> 61.5 us per batch iteration, 64 VGPRs with spills 78 us:
+// the kernel is not occupancy-bound)
+#ifndef ORBX_KF_MINBLOCKS
+#define ORBX_KF_MINBLOCKS 1
+#endif
+__global__ __launch_bounds__(256, ORBX_KF_MINBLOCKS) void ba_kf_kernel(const BaWin* __restrict__ wins, BaCam cam) {
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done || (int)blockIdx.x >= win.d.K * BA_KFSPLIT) return;
   ba_kf_body((int)blockIdx.x, win, cam);
@@ -1363,8 +1376,8 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   }
   __syncthreads();
   const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
-  const int j = gtid >> BA_PT_SHIFT;
-  if (j >= d.M) return;     // whole 32-lane group
+  const int gstride = (int)gridDim.x * (256 / BA_PT_LANES);
+  for (int j = gtid >> BA_PT_SHIFT; j < d.M; j += gstride) {   // group-uniform (several points per group in a large batch, as ba_build_kernel)
   const double X0[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1], params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   double acc[3] = {0.0, 0.0, 0.0};
   // sum_k W_kj^T delta_p_k from the stored W blocks.  (Recomputing A and B here instead — B^T (A delta_p), no 144-byte read —
@@ -1414,12 +1427,13 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     chi += o.r0 * o.r0 + o.r1 * o.r1;
   }
   chi = group_sum32(chi);
-  if (lane32 != 0) return;
+  if (lane32 != 0) continue;
 #pragma unroll
   for (int a = 0; a < 3; ++a) trial[6 * (size_t)d.K + 3 * (size_t)j + a] = X[a];
   // partitioned over ranks: a point's |p|^2 is counted by the rank that holds its observations
   if (owned_only && pt_start[j + 1] == pt_start[j]) psq = 0.0;
   pt_dsq[j] = dsq; pt_psq[j] = psq; pt_chi2[j] = chi;
+  }
 }
 
 // out[i] = a[i] - b[i]  /  a[i] += b[i]   (merging point updates across ranks)
@@ -2100,6 +2114,9 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   BaWin* hw = (BaWin*)(hin + i_wins);
   size_t* hoff = (size_t*)(hin + i_outoff);
   size_t lds_max = 0;
+  // points per 32-lane group of the build / back-substitution launches: 1 for a few windows, 4 in a large batch (one block prologue —
+  // the K rotations — per 32 points instead of per 8; 32-window batch: build 0.103 -> 0.096, back-substitution 0.068 -> 0.064 ms per iteration)
+  const int ppg = W >= 8 ? 4 : 1;
   int any_lds = 0, any_big = 0, n_big_max = 0, maxM = 0, maxK = 0, max_schur_blocks = 1, all_diag = 1, max_gather = 1, max_back = 1, max_asm = 1;
   for (int w = 0; w < W; ++w) {
     const WinPlan& pl = plan[w];
@@ -2135,9 +2152,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     max_schur_blocks = std::max(max_schur_blocks, pl.d.ncb * (pl.d.ncb + 1) / 2 * pl.d.ksplit);
     if (pl.d.ncb != 1) all_diag = 0;
     max_gather = std::max(max_gather, std::min(256, (4 * pl.n * pl.n + 255) / 256));
-    max_back = std::max(max_back, (std::max(BA_PT_LANES * pl.d.M, pl.n) + 255) / 256);
+    max_back = std::max(max_back, (std::max(BA_PT_LANES * ((pl.d.M + ppg - 1) / ppg), pl.n) + 255) / 256);
     max_asm = std::max(max_asm, std::min(512, (pl.n * pl.n + 255) / 256));
   }
+  const int pt_groups = (maxM + ppg - 1) / ppg;
   BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, inertial ? inr->cfg->huber_threshold_mono : cfg->huber_threshold, global_mode ? 1 : 0,
            inertial ? 1 : 0, inertial ? inr->cfg->huber_threshold_stereo : 0.0, nullptr};
   BaInertialDev ind{};
@@ -2231,7 +2249,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if (!dist && should_stop && should_stop(user)) { stopped = true; break; }                           // :1013
     {
       ProfScope ps(h, "ba_build_kernel");
-      if (maxM > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((maxM * BA_PT_LANES + 255) / 256, W), dim3(256), 0, st, d_wins, bc, iter);
+      if (maxM > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((pt_groups * BA_PT_LANES + 255) / 256, W), dim3(256), 0, st, d_wins, bc, iter);
       else hipLaunchKernelGGL(ba_iter_kernel, gW1, dim3(1), 0, st, d_wins, iter);
     }
     if (maxK > 0 && W == 1) {

@@ -241,7 +241,12 @@ constexpr int BLUR_PF = ORBX_BLUR_PF;   // input rows in flight per lane
 #ifndef ORBX_BLUR_STRIP
 #define ORBX_BLUR_STRIP 32
 #endif
-constexpr int BLUR_W = 248, BLUR_STRIP = ORBX_BLUR_STRIP, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo;
+#if defined(ORBX_BLUR_NOARITH) && ORBX_BLUR_NOARITH == 2   // measurement build: 256-px strips on line boundaries, no halo lanes (results meaningless)
+constexpr int BLUR_W = 256, BLUR_HALO = 0;
+#else
+constexpr int BLUR_W = 248, BLUR_HALO = 1;
+#endif
+constexpr int BLUR_STRIP = ORBX_BLUR_STRIP, BLUR_H = 4 * BLUR_STRIP;   // lanes 1..62 produce output, 0 and 63 are halo;
 // rows per wave 16 / 32 / 48 / 64 / 96 / 128: 0.307 / 0.300 / 0.302 / 0.315 / 0.366 / 0.369 ms per 256 pairs
 
 __device__ __forceinline__ void blur_hsum(unsigned d0, unsigned d1, unsigned d2, unsigned (&hs)[4]) {
@@ -394,8 +399,8 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
   const int nrows = min(R, h - ys_wave);          // wave-uniform: group 0 has the most rows
   int nrows_l = min(R, h - ys);                    // this lane's group (M > 1: can be <= 0 below the image)
   if (M > 1 && nrows_l <= 0) { ys = ys_wave; nrows_l = 0; }   // idle group: walk group 0's rows, store nothing
-  const int x0 = xbase + (gl - 1) * 4;
-  const bool active = gl >= 1 && gl <= GL - 2 && x0 < w && nrows_l > 0;
+  const int x0 = xbase + (gl - BLUR_HALO) * 4;
+  const bool active = gl >= BLUR_HALO && gl <= GL - 1 - BLUR_HALO && x0 < w && nrows_l > 0;
   const BlurEdge be = blur_edge_setup(x0, w, active);
   // some lane of this wave sits on the image edge (wave-uniform)
   if (__ballot(be.left || !be.hi || be.s2 != 0x07060504u) != 0ull) blur_strip_e<M, true>(src, pitch, h, dst, dpitch, be, x0, active, ys, nrows, nrows_l);
@@ -1404,7 +1409,7 @@ std::vector<std::pair<int, int>> blur_strips(int w) {
   while (w - x >= BLUR_W) { out.push_back({x, 0}); x += BLUR_W; }
   const int rem = w - x;
   if (rem <= 0) return out;
-  const int wid[3] = {BLUR_W, 120, 56}, cost[3] = {BLUR_STRIP + 6, BLUR_STRIP / 2 + 6, BLUR_STRIP / 4 + 6};
+  const int wid[3] = {BLUR_W, BLUR_W / 2 - 4 * BLUR_HALO, BLUR_W / 4 - 6 * BLUR_HALO}, cost[3] = {BLUR_STRIP + 6, BLUR_STRIP / 2 + 6, BLUR_STRIP / 4 + 6};
   int best_cost = 1 << 30, best[3] = {1, 0, 0};
   for (int a = 0; a <= 1; ++a)
     for (int b = 0; b <= 2; ++b)
