@@ -33,6 +33,8 @@ CASES = [
     ("hd_1920x1080_n4000", 13, 1, 1920, 1080, 4000),     # configs[4] image side
     ("odd_613x389_n700", 14, 2, 613, 389, 700),          # odd width/height: unaligned rows, partial tiles
     ("small_quota_320x240_n150", 15, 0, 320, 240, 150),
+    ("kitti_1241x376_n2000", 16, 1, 1241, 376, 2000),   # round 3: wide, odd width, pitch not a multiple of 4 (level-0 copy path)
+    ("vga_640x480_n1000", 17, 2, 640, 480, 1000),       # round 3: rows of exactly 10 x 64 bytes
 ]
 PATH = os.path.join(ROOT, "tests", "golden", "extract_frozen.json")
 
@@ -104,7 +106,7 @@ def main():
     with open(PATH, "w") as f:
         json.dump(out, f, indent=1)
     # the smallest case's input images as data, so that one case does not depend on numpy's generator at all
-    name, seed, frame, w, h, n = CASES[-1]
+    name, seed, frame, w, h, n = next(c for c in CASES if c[0] == "small_quota_320x240_n150")
     L, R = synth.stereo_pair(seed, frame, w, h)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + "_images.npz"), left=L, right=R)
     print("written", PATH)
