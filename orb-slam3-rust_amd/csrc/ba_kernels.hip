@@ -9,17 +9,18 @@
 // Six launches per LM iteration (every block derives the keyframe rotations it needs itself):
 //
 //   ba_build_kernel      one 32-lane group per map point: residual + Jacobian blocks of its
-//                        observations, V_j = sum B^T B, g_l, damped inverse V*_j^-1, W = A^T B and
-//                        Y g_l; W stays per observation (oW [N][18]) — the dense operands of the Schur product exist only as
-//                        LDS tiles
-//   ba_kf_schur_kernel   keyframe partials (U_k = sum A^T A, g_p, b_red, fixed summation order) and, in the
+//                        observations, V_j = sum B^T B, g_l, damped inverse V*_j^-1, V*_j^-1 g_l, and W = A^T B per
+//                        observation (oW [N][18]: the only per-observation block that is stored — the dense operands of
+//                        the Schur product exist only as LDS tiles filled from it)
+//   ba_kf_schur_kernel   keyframe partials (U_k = sum A^T A, g_p, b_red = sum A^T (B V*^-1 g_l), fixed summation order; residual
+//                        and Jacobian blocks RECOMPUTED per observation from (point, the block's pose, uv)) and, in the
 //                        same launch, S_red = Y^T W ((6K x 3M) x (3M x 6K)) on v_mfma_f64_16x16x4_f64: a block owns a
 //                        (128-column block pair, k-split), fills 24-row operand tiles in LDS from oW and V*^-1 and
 //                        accumulates its upper 16x16 tiles in registers — the one dense contraction of the path
 //   ba_gather_kernel     fixed-order reduction of the split-K and keyframe-split partials
-//   ba_solve_lds_kernel  one workgroup: S = U* - S_red in LDS, blocked right-looking Cholesky (MFMA trailing
-//                        updates, forward substitution inside the panels), delta_p
-//                        (n > 135: ba_big_assemble / panel / update / subst kernels, S in global memory)
+//   ba_solve_lds_kernel  one workgroup: S = U* - S_red in LDS, blocked right-looking Cholesky (diagonal blocks by DPP row_newbcast
+//                        in wave 0, look-ahead inside the MFMA trailing update, forward substitution inside the panels), delta_p
+//                        (n > 135: ba_big_assemble + one ba_big_step_kernel per panel + ba_big_back_kernel, S in global memory)
 //   ba_backsub_kernel    delta_l = V*^-1 (-g_l - W^T delta_p), trial parameters and trial residuals
 //   ba_decide_kernel     sums, accept / reject, lambda, stop tests — the LM state lives on the device
 //
@@ -494,7 +495,7 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, double* 
           const int col = 6 * k + a - cb;
           if (col < 0 || col >= 128) continue;
           const double w0 = w[a], w1 = w[6 + a], w2 = w[12 + a];
-          sY[(3 * pj + 0) * SCH_PITCH + col] = w0 * I[0] + w1 * I[3] + w2 * I[6];       // Y = W V*^-1, as the build kernel forms it for Y g_l
+          sY[(3 * pj + 0) * SCH_PITCH + col] = w0 * I[0] + w1 * I[3] + w2 * I[6];       // Y = W V*^-1
           sY[(3 * pj + 1) * SCH_PITCH + col] = w0 * I[1] + w1 * I[4] + w2 * I[7];
           sY[(3 * pj + 2) * SCH_PITCH + col] = w0 * I[2] + w1 * I[5] + w2 * I[8];
           if (diag) { sW[(3 * pj + 0) * SCH_PITCH + col] = w0; sW[(3 * pj + 1) * SCH_PITCH + col] = w1; sW[(3 * pj + 2) * SCH_PITCH + col] = w2; }
