@@ -687,7 +687,7 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         nb = 32
         bw = [P.synth.ba_window(200 + i, 20, 2000, P.BA_OBS) for i in range(nb)]
         rb = h.ba_solve_visual_batch(cam, cfg, bw)
-        nrep = 3
+        nrep = 6
         # the rate: as a caller sees it (a batch of this size runs as two halves on two streams inside the call, see orbx.h)
         t0 = time.perf_counter()
         itb = 0

@@ -93,8 +93,8 @@ struct BaWin {
   double *Vinv, *gl, *vg;           // per point: V*^-1 (9), g_l (3), V*^-1 g_l (3)
   double *pt_chi2, *pt_glsq, *pt_dsq, *pt_psq;
   double *oW;            // [N][18] W = A^T B of every observation of an optimised keyframe, w[c][a] (point coordinate major)
-  const int *slot_first; // [M][K] first observation (point-major index) of point j in optimised keyframe k, or -1
-  const int *obs_next;   // [N] next observation of the same (point, keyframe), or -1 (a point seen twice by one keyframe)
+  int *slot_first;       // [M][K] first observation (point-major index) of point j in optimised keyframe k, or -1   } built on the device once
+  int *obs_next;         // [N] next observation of the same (point, keyframe), or -1 (a point seen twice by one keyframe) } per call: ba_slots_kernel
   double *kfpart, *part, *rb;
   double *dp;            // step of the reduced system [n pad 16]
   double *Sg, *bvec, *ginv;   // global-memory factorisation (n > ~135 and the inertial system)
@@ -175,6 +175,31 @@ __global__ void ba_iter_kernel(const BaWin* __restrict__ wins, int iter) {
   BaState* S = wins[blockIdx.y].S;
   if (S->done) return;
   S->iters = iter + 1;                                                  // local_ba_lm.rs:1017
+}
+
+// (point, keyframe) -> its observation(s): what fills the operand tiles of the Schur product.  One thread per map point walks the
+// point's observations in order (they are contiguous, point-major): slot (j, k) = the first observation of point j by optimised
+// keyframe k; a point seen twice by one keyframe (two features of it carry the same map point) has its observations chained in
+// order through obs_next — the tile slot then holds the sum of their W blocks, as J^T J does.  Built here once per call instead of
+// on the host: 4 (M K + N) bytes per window less to prepare and to upload (a fifth of the input blob at 20 keyframes / 2000 points).
+__global__ __launch_bounds__(256) void ba_slots_kernel(const BaWin* __restrict__ wins) {
+  const BaWin& win = wins[blockIdx.y];
+  const int K = win.d.K, M = win.d.M;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (win.S->done || j >= M || K <= 0) return;        // (a window the reference answers None for was never prepared: its index arrays hold nothing)
+  int* __restrict__ slot = win.slot_first + (size_t)j * K;
+  int* __restrict__ nxt = win.obs_next;
+  const int* __restrict__ o_kf = win.o_kf;
+  for (int k = 0; k < K; ++k) slot[k] = -1;
+  for (int t = win.pt_start[j]; t < win.pt_start[j + 1]; ++t) {
+    nxt[t] = -1;
+    const int k = o_kf[t];
+    if (k < 0) continue;
+    int i = slot[k];
+    if (i < 0) { slot[k] = t; continue; }
+    while (nxt[i] >= 0) i = nxt[i];                                      // (chains hold two, rarely three observations)
+    nxt[i] = t;
+  }
 }
 
 struct ObsOut { double r0, r1, A[12], B[6]; };
@@ -363,9 +388,9 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
 #endif
 constexpr int BA_PPS_TARGET = ORBX_BA_PPS;   // map points per k-split of the Schur product (multiple of 8).  24 / 32 / 48 / 64: single window 6.41 / 6.36 / 6.10 / 5.83 k LM it/s, 32-window batch 38.6 / 41.3 / 41.3 / 41.4 k
 #ifndef ORBX_BA_KFSPLIT
-#define ORBX_BA_KFSPLIT 2
+#define ORBX_BA_KFSPLIT 1
 #endif
-constexpr int BA_KFSPLIT = ORBX_BA_KFSPLIT;   // 16 / 8 / 4 / 2 blocks per keyframe: 32-window batch 36.2 / 39.0 / 40.2 / 40.4 k LM it/s, single window unchanged (6.4-6.5 k): the 33 shuffle-tree reductions per block outweigh the observations a block adds up
+constexpr int BA_KFSPLIT = ORBX_BA_KFSPLIT;   // round 2 (stored blocks): 16 / 8 / 4 / 2 blocks per keyframe: 32-window batch 36.2 / 39.0 / 40.2 / 40.4 k LM it/s, single window unchanged: the 33 shuffle-tree reductions per block outweigh the observations a block adds up.  Round 3 (recomputed blocks): 8 / 4 / 2 / 1 blocks: keyframe partials 134 / 82.5 / 61.7 / 55.7 us per 32-window iteration, one window 22.4 us throughout: 1
 // BA_KFSPLIT blocks per optimised keyframe: partial U_k (21 unique), g_p (6), b_red (6) over a slice of its
 // observations; the gather kernel adds the partials in a fixed order.
 __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam& cam) {
@@ -1879,8 +1904,8 @@ struct WinPlan {
   int n = 0, use_lds = 0, skip = 0;
   size_t np = 0, n_upper = 0, rb_len = 0, lds_need = 0;
   // byte offsets: input blob (host-prepared arrays), scratch arena, output blob
-  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_kfpt, i_oflag, i_slot, i_next;
-  size_t a_p1, a_oW, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
+  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_kfpt, i_oflag;
+  size_t a_p1, a_oW, a_slot, a_next, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
   size_t o_out;
   int n_kfobs = 0;
   double n_res = 0.0;
@@ -1937,24 +1962,6 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
     for (int t = 0; t < N; ++t) {
       while (t >= pt_start[j + 1]) ++j;                                  // the map point of observation t (point-major order)
       if (o_kf[t] >= 0) { const int q = fill[o_kf[t]]++; kf_obs[q] = t; kf_pt[q] = j; }
-    }
-  }
-  // (point, keyframe) -> its observation(s): what fills the operand tiles of the Schur product.  A point seen twice by one
-  // keyframe (two features of it carry the same map point) has its W blocks chained; the tile slot holds their sum, as J^T J does.
-  {
-    int* slot_first = (int*)(blob + pl.i_slot);
-    int* obs_next = (int*)(blob + pl.i_next);
-    for (size_t q = 0; q < (size_t)M * (size_t)std::max(K, 1); ++q) slot_first[q] = -1;
-    std::vector<int> last((size_t)std::max(K, 1), -1);
-    for (int j = 0; j < M; ++j) {
-      for (int t = pt_start[j]; t < pt_start[j + 1]; ++t) {
-        obs_next[t] = -1;
-        const int k = o_kf[t];
-        if (k < 0) continue;
-        int& head = slot_first[(size_t)j * K + k];
-        if (head < 0) head = t; else obs_next[last[(size_t)k]] = t;
-        last[(size_t)k] = t;
-      }
     }
   }
   for (int k = 0; k < K; ++k) host_se3_to_params(w.poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);   // scaled axis + translation
@@ -2049,10 +2056,9 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.i_kfobs = cin.take(4 * n1);
     pl.i_kfpt = cin.take(4 * n1);
     pl.i_oflag = inertial ? cin.take(4 * n1) : 0;
-    pl.i_slot = cin.take(4 * m1 * k1);
-    pl.i_next = cin.take(4 * n1);
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
     pl.a_oW = car.take(144 * n1);
+    pl.a_slot = car.take(4 * m1 * k1); pl.a_next = car.take(4 * n1);
     pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_vg = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
     pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
     pl.a_part = car.take(8 * pl.n_upper * d.ksplit * 256);
@@ -2134,7 +2140,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
     b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
     b.oW = (double*)(dar + pl.a_oW);
-    b.slot_first = (const int*)(din + pl.i_slot); b.obs_next = (const int*)(din + pl.i_next);
+    b.slot_first = (int*)(dar + pl.a_slot); b.obs_next = (int*)(dar + pl.a_next);
     b.kfpart = (double*)(dar + pl.a_kfpart); b.part = (double*)(dar + pl.a_part); b.rb = (double*)(dar + pl.a_rb);
     b.dp = (double*)(dar + pl.a_solve);
     b.Sg = b.dp + ((pl.n + 15) & ~15); b.bvec = b.Sg + (size_t)pl.n * pl.n; b.ginv = b.bvec + pl.n;
@@ -2236,6 +2242,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     my_stop = tot[1] > 0.0;                                              // the collective decision for iteration 0
   }
 
+  if (maxM > 0 && maxK > 0) hipLaunchKernelGGL(ba_slots_kernel, dim3((maxM + 255) / 256, W), dim3(256), 0, st, d_wins);
   // initial error (:1000-1001) -> res[12]
   {
     ProfScope ps(h, "ba_chi2");
