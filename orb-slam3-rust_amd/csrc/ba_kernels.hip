@@ -92,7 +92,8 @@ struct BaWin {
   const int *kf_start, *kf_obs, *kf_pt;   // keyframe CSR over the point-major order: observation index and its map point
   double *Vinv, *gl, *vg;           // per point: V*^-1 (9), g_l (3), V*^-1 g_l (3)
   double *pt_chi2, *pt_glsq, *pt_dsq, *pt_psq;
-  double *oW;            // [N][18] W = A^T B of every observation of an optimised keyframe, w[c][a] (point coordinate major)
+  double *oP;            // [N][6] per observation: x, y of the point in the camera frame, 1/z, sqrt(Huber weight), weighted residual (2) — what A, B, W are rebuilt from
+  double *Rt_cur;        // [K][12] R|t of the optimised keyframes at the current parameters (written by block 0 of ba_build_kernel)
   int *slot_first;       // [M][K] first observation (point-major index) of point j in optimised keyframe k, or -1   } built on the device once
   int *obs_next;         // [N] next observation of the same (point, keyframe), or -1 (a point seen twice by one keyframe) } per call: ba_slots_kernel
   double *kfpart, *part, *rb;
@@ -202,9 +203,67 @@ __global__ __launch_bounds__(256) void ba_slots_kernel(const BaWin* __restrict__
   }
 }
 
-struct ObsOut { double r0, r1, A[12], B[6]; };
+struct ObsOut { double r0, r1, A[12], B[6]; double px, py, piz, psw; };
 
-// error (:192-212), Huber (:291-297), J_pose (:239-254), J_point (:281-287), both * sqrt(w)
+// The 2x6 pose block A and the 2x3 point block B of one observation (both * sqrt(w)) from its four "projective" numbers —
+// x, y of the point in the camera frame, 1/z, and the square root of the Huber weight — and the keyframe's R|t: no division, no
+// square root.  piz == 0 marks an observation whose Jacobian rows are zero (|z| < 1e-6, or behind the camera in the global /
+// inertial forms).  obs_terms itself goes through this function, so every kernel that rebuilds the blocks from the stored
+// (x, y, 1/z, sqrt w) gets the same bits the build kernel used for V and g_l.
+// J_pose (:239-254), J_point (:281-287); inertial: local_inertial_ba.rs:735-804.
+__device__ __forceinline__ void obs_jac_from_proj(const BaCam& cam, const double* Rt, double x, double y, double piz, double sw,
+                                                  double* __restrict__ A, double* __restrict__ B) {
+  if (piz == 0.0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) A[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) B[i] = 0.0;
+    return;
+  }
+  const double fx = cam.fx, fy = cam.fy;
+  if (cam.inertial) {
+    const double zi = piz, zi2 = zi * zi;
+    const double du0 = fx * zi, du2 = -fx * x * zi2, dv1 = fy * zi, dv2 = -fy * y * zi2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                      // -(R_cw^T d(u,v)/dp_cam) (:760-771)
+      B[c] = -(Rt[c] * du0 + Rt[3 + c] * 0.0 + Rt[6 + c] * du2) * sw;
+      B[3 + c] = -(Rt[c] * 0.0 + Rt[3 + c] * dv1 + Rt[6 + c] * dv2) * sw;
+    }
+    const double xy = x * y, xs = x * x, ys = y * y;    // :774-803 (the caller drops A for a fixed keyframe)
+    A[0] = -fx * xy * zi2 * sw; A[1] = fx * (1.0 + xs * zi2) * sw; A[2] = -fx * y * zi * sw;
+    A[3] = fx * zi * sw; A[4] = 0.0; A[5] = -fx * x * zi2 * sw;
+    A[6] = -fy * (1.0 + ys * zi2) * sw; A[7] = fy * xy * zi2 * sw; A[8] = fy * x * zi * sw;
+    A[9] = 0.0; A[10] = fy * zi * sw; A[11] = -fy * y * zi2 * sw;
+    return;
+  }
+  const double invz = piz, invz2 = invz * invz;
+  A[0] = x * y * invz2 * fx * sw;         A[1] = -(1.0 + x * x * invz2) * fx * sw; A[2] = y * invz * fx * sw;
+  A[3] = -invz * fx * sw;                 A[4] = 0.0;                              A[5] = x * invz2 * fx * sw;
+  A[6] = (1.0 + y * y * invz2) * fy * sw; A[7] = -x * y * invz2 * fy * sw;         A[8] = -x * invz * fy * sw;
+  A[9] = 0.0;                             A[10] = -invz * fy * sw;                 A[11] = y * invz2 * fy * sw;
+  const double t0 = fx, t2 = -fx * x * invz, t4 = fy, t5 = -fy * y * invz;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    B[c] = (-invz) * (t0 * Rt[c] + t2 * Rt[6 + c]) * sw;
+    B[3 + c] = (-invz) * (t4 * Rt[3 + c] + t5 * Rt[6 + c]) * sw;
+  }
+}
+
+// W = A^T B (6x3, w[c * 6 + a]) of the observation stored at q = oP + 6 i, for the keyframe with R|t `Rt`
+// ACC: add to w (a point seen twice by one keyframe: the slot holds the sum of its observations' W blocks, first + second + ...)
+template <bool ACC>
+__device__ __forceinline__ void obs_w_from_stored(const BaCam& cam, const double* Rt, const double* __restrict__ q, double* __restrict__ w) {
+  double A[12], B[6];
+  obs_jac_from_proj(cam, Rt, q[0], q[1], q[2], q[3], A, B);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double w0 = A[a] * B[0] + A[6 + a] * B[3], w1 = A[a] * B[1] + A[6 + a] * B[4], w2 = A[a] * B[2] + A[6 + a] * B[5];
+    if (ACC) { w[a] += w0; w[6 + a] += w1; w[12 + a] += w2; }
+    else { w[a] = w0; w[6 + a] = w1; w[12 + a] = w2; }
+  }
+}
+
+// error (:192-212), Huber (:291-297), and with want_jac the Jacobian blocks and the four numbers they follow from
 __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, const double* X, double u, double v,
                                           bool want_jac, ObsOut& o, int flag = 0) {
   // X_c = R X + t.  (The reference rotates with the quaternion form v + w t + q x t; R X is the same
@@ -212,12 +271,13 @@ __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, co
   const double x = Rt[0] * X[0] + Rt[1] * X[1] + Rt[2] * X[2] + Rt[9];
   const double y = Rt[3] * X[0] + Rt[4] * X[1] + Rt[5] * X[2] + Rt[10];
   const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+  o.px = x; o.py = y; o.piz = 0.0; o.psw = 0.0;
   if (cam.inertial) {   // local_inertial_ba.rs:633-659 (residual), :735-804 (Jacobian rows)
-#pragma unroll
-    for (int i = 0; i < 12; ++i) o.A[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) o.B[i] = 0.0;
-    if (!(z > 0.001)) { o.r0 = 100.0; o.r1 = 100.0; return; }
+    if (!(z > 0.001)) {
+      o.r0 = 100.0; o.r1 = 100.0;
+      if (want_jac) obs_jac_from_proj(cam, Rt, x, y, 0.0, 0.0, o.A, o.B);
+      return;
+    }
     const double thr = (flag & 1) ? cam.huber_stereo : cam.huber, fx = cam.fx, fy = cam.fy;
     {
       const double e0 = u - (fx * x / z + cam.cx), e1 = v - (fy * y / z + cam.cy);
@@ -226,21 +286,12 @@ __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, co
       o.r0 = e0 * sw; o.r1 = e1 * sw;
     }
     if (!want_jac) return;
-    const double zi = 1.0 / z, zi2 = zi * zi;
+    const double zi = 1.0 / z;
     const double e0 = u - (fx * x * zi + cam.cx), e1 = v - (fy * y * zi + cam.cy);   // :743-745 (x * z_inv, not x / z)
     const double en = sqrt(e0 * e0 + e1 * e1);
     const double sw = en <= thr ? 1.0 : sqrt(thr / en);
-    const double du0 = fx * zi, du2 = -fx * x * zi2, dv1 = fy * zi, dv2 = -fy * y * zi2;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {                      // -(R_cw^T d(u,v)/dp_cam) (:760-771)
-      o.B[c] = -(Rt[c] * du0 + Rt[3 + c] * 0.0 + Rt[6 + c] * du2) * sw;
-      o.B[3 + c] = -(Rt[c] * 0.0 + Rt[3 + c] * dv1 + Rt[6 + c] * dv2) * sw;
-    }
-    const double xy = x * y, xs = x * x, ys = y * y;    // :774-803 (the caller drops A for a fixed keyframe)
-    o.A[0] = -fx * xy * zi2 * sw; o.A[1] = fx * (1.0 + xs * zi2) * sw; o.A[2] = -fx * y * zi * sw;
-    o.A[3] = fx * zi * sw; o.A[4] = 0.0; o.A[5] = -fx * x * zi2 * sw;
-    o.A[6] = -fy * (1.0 + ys * zi2) * sw; o.A[7] = fy * xy * zi2 * sw; o.A[8] = fy * x * zi * sw;
-    o.A[9] = 0.0; o.A[10] = fy * zi * sw; o.A[11] = -fy * y * zi2 * sw;
+    o.piz = zi; o.psw = sw;
+    obs_jac_from_proj(cam, Rt, x, y, zi, sw, o.A, o.B);
     return;
   }
   double e0, e1;
@@ -251,24 +302,8 @@ __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, co
   const double sw = sqrt(w);
   o.r0 = e0 * sw; o.r1 = e1 * sw;
   if (!want_jac) return;
-  if (fabs(z) < 1e-6 || (cam.zero_behind && z <= 0.001)) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) o.A[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) o.B[i] = 0.0;
-    return;
-  }
-  const double invz = 1.0 / z, invz2 = invz * invz, fx = cam.fx, fy = cam.fy;
-  o.A[0] = x * y * invz2 * fx * sw;         o.A[1] = -(1.0 + x * x * invz2) * fx * sw; o.A[2] = y * invz * fx * sw;
-  o.A[3] = -invz * fx * sw;                 o.A[4] = 0.0;                              o.A[5] = x * invz2 * fx * sw;
-  o.A[6] = (1.0 + y * y * invz2) * fy * sw; o.A[7] = -x * y * invz2 * fy * sw;         o.A[8] = -x * invz * fy * sw;
-  o.A[9] = 0.0;                             o.A[10] = -invz * fy * sw;                 o.A[11] = y * invz2 * fy * sw;
-  const double t0 = fx, t2 = -fx * x * invz, t4 = fy, t5 = -fy * y * invz;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    o.B[c] = (-invz) * (t0 * Rt[c] + t2 * Rt[6 + c]) * sw;
-    o.B[3 + c] = (-invz) * (t4 * Rt[3 + c] + t5 * Rt[6 + c]) * sw;
-  }
+  if (!(fabs(z) < 1e-6 || (cam.zero_behind && z <= 0.001))) { o.piz = 1.0 / z; o.psw = sw; }
+  obs_jac_from_proj(cam, Rt, x, y, o.piz, o.psw, o.A, o.B);
 }
 
 #ifndef ORBX_BA_PT_LANES
@@ -300,11 +335,12 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
   const double* __restrict__ o_uv = win.o_uv;
   double* __restrict__ Vinv = win.Vinv /*M*9*/; double* __restrict__ gl = win.gl /*M*3*/; double* __restrict__ vg = win.vg /*M*3*/;
   double* __restrict__ pt_chi2 = win.pt_chi2 /*M*/; double* __restrict__ pt_glsq = win.pt_glsq /*M*/;
-  double* __restrict__ oW = win.oW;
+  double* __restrict__ oP = win.oP;
   const double lambda = S->lambda;
   const double* params = ba_cur(S, P0, P1);
   if (blockIdx.x == 0 && threadIdx.x == 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
   block_poses(params, d.K, cam.inertial, sRt);
+  if (blockIdx.x == 0) for (int a = threadIdx.x; a < 12 * d.K; a += blockDim.x) win.Rt_cur[a] = sRt[a];   // for the kernels that rebuild the blocks
   const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
   // a group takes the points g0, g0 + (groups of the launch), ...: one point per group for a single window (as many short blocks as
   // possible for its latency chain), several in a large batch, where the block's prologue (K poses) is then paid once for all of
@@ -315,8 +351,8 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
                        params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   const int s = pt_start[j], e = pt_start[j + 1];
   double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, chi = 0.0;
-  ObsOut o;                 // (after pass 1: the blocks of this lane's LAST observation — its only one when the point has <= BA_PT_LANES)
-  // pass 1: residual + Jacobian, accumulate V, g_l (lane-strided, then a fixed shuffle tree)
+  // residual + Jacobian, accumulate V, g_l (lane-strided, then a fixed shuffle tree); per observation only the six numbers the
+  // consumers rebuild A, B and W = A^T B from are stored (48 B; until round 3: W itself, 144 B, written in a second pass)
   for (int i = s + lane32; i < e; i += BA_PT_LANES) {
     const int k = o_kf[i];
     double Rt[12];
@@ -327,7 +363,12 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
 #pragma unroll
       for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
     }
+    ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
+    {
+      double* q = oP + 6 * (size_t)i;
+      q[0] = o.px; q[1] = o.py; q[2] = o.piz; q[3] = o.psw; q[4] = o.r0; q[5] = o.r1;
+    }
     chi += o.r0 * o.r0 + o.r1 * o.r1;
     V[0] += o.B[0] * o.B[0] + o.B[3] * o.B[3];
     V[1] += o.B[0] * o.B[1] + o.B[3] * o.B[4];
@@ -365,21 +406,6 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
     pt_chi2[j] = chi;
     pt_glsq[j] = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
   }
-  // pass 2: W = A^T B per observation of an optimised keyframe: the operand of the Schur product (its tiles are filled from
-  // oW).  Nothing else is stored per observation: the keyframe partials and the back-substitution recompute the 2x6 / 2x3
-  // blocks from (point, pose, uv) — 44-72 B per observation instead of the 164 B / 144 B of stored blocks.
-  const bool one_pass = e - s <= BA_PT_LANES;           // group-uniform: every lane still holds the blocks of its one observation
-  for (int i = s + lane32; i < e; i += BA_PT_LANES) {
-    const int k = o_kf[i];
-    if (k < 0) continue;
-    if (!one_pass) obs_terms(cam, sRt + 12 * k, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      oW[18 * (size_t)i + a] = o.A[a] * o.B[0] + o.A[6 + a] * o.B[3];
-      oW[18 * (size_t)i + 6 + a] = o.A[a] * o.B[1] + o.A[6 + a] * o.B[4];
-      oW[18 * (size_t)i + 12 + a] = o.A[a] * o.B[2] + o.A[6 + a] * o.B[5];
-    }
-  }
   }
 }
 
@@ -395,19 +421,13 @@ constexpr int BA_KFSPLIT = ORBX_BA_KFSPLIT;   // round 2 (stored blocks): 16 / 8
 // observations; the gather kernel adds the partials in a fixed order.
 __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam& cam) {
   __shared__ double red[4][33];
-  __shared__ double sRtk[12];
-  const BaDims& d = win.d;
   const int* __restrict__ kf_start = win.kf_start; const int* __restrict__ kf_obs = win.kf_obs; const int* __restrict__ kf_pt = win.kf_pt;
-  const double* __restrict__ o_uv = win.o_uv; const double* __restrict__ vg = win.vg;
+  const double* __restrict__ oP = win.oP; const double* __restrict__ vg = win.vg;
   double* __restrict__ kfpart = win.kfpart;   /*[K][BA_KFSPLIT][33]*/
-  const double* params = ba_cur(win.S, win.P0, win.P1);
-  const double* __restrict__ pts = params + 6 * (size_t)d.K;
   const int k = bx / BA_KFSPLIT, sp = bx % BA_KFSPLIT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) pose_to_Rt(params + 6 * (size_t)k, cam.inertial, sRtk);     // this block's keyframe (the build kernel's expression)
-  __syncthreads();
-  double Rt[12];
+  double Rt[12];                                                          // this block's keyframe, as the build kernel derived it
 #pragma unroll
-  for (int a = 0; a < 12; ++a) Rt[a] = sRtk[a];
+  for (int a = 0; a < 12; ++a) Rt[a] = win.Rt_cur[12 * (size_t)k + a];
   const int s0 = kf_start[k], len = kf_start[k + 1] - s0;
   const int s = s0 + (int)((long long)len * sp / BA_KFSPLIT), e = s0 + (int)((long long)len * (sp + 1) / BA_KFSPLIT);
   double acc[33];   // 21 unique U entries, 6 g_p, 6 b_red
@@ -415,21 +435,20 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
   for (int a = 0; a < 33; ++a) acc[a] = 0.0;
   for (int t = s + tid; t < e; t += 256) {
     const int i = kf_obs[t], j = kf_pt[t];
-    const double X[3] = {pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2]};
-    ObsOut o;
-    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
-    const double* A = o.A;
-    const double r0 = o.r0, r1 = o.r1;
-    int q = 0;
+    const double* q = oP + 6 * (size_t)i;
+    double A[12], B[6];
+    obs_jac_from_proj(cam, Rt, q[0], q[1], q[2], q[3], A, B);           // no division, no square root: the build kernel stored what they gave
+    const double r0 = q[4], r1 = q[5];
+    int qi = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-      for (int b = a; b < 6; ++b) acc[q++] += A[a] * A[b] + A[6 + a] * A[6 + b];
+      for (int b = a; b < 6; ++b) acc[qi++] += A[a] * A[b] + A[6 + a] * A[6 + b];
 #pragma unroll
     for (int a = 0; a < 6; ++a) acc[21 + a] += A[a] * r0 + A[6 + a] * r1;
     // W V*^-1 g_l = A^T (B (V*^-1 g_l)): the 2-vector B vg, then A^T of it
     const double v0 = vg[3 * (size_t)j], v1 = vg[3 * (size_t)j + 1], v2 = vg[3 * (size_t)j + 2];
-    const double t0 = o.B[0] * v0 + o.B[1] * v1 + o.B[2] * v2, t1 = o.B[3] * v0 + o.B[4] * v1 + o.B[5] * v2;
+    const double t0 = B[0] * v0 + B[1] * v1 + B[2] * v2, t1 = B[3] * v0 + B[4] * v1 + B[5] * v2;
 #pragma unroll
     for (int a = 0; a < 6; ++a) acc[27 + a] += A[a] * t0 + A[6 + a] * t1;
   }
@@ -454,7 +473,7 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
 // 144 B per observation instead of 2 x 8 B x 3M x 6K (393 MB at 32 windows of 20 keyframes / 2000 points).
 constexpr int SCH_R = 24;                 // rows per LDS tile (8 points, 6 MFMA k-steps)
 constexpr int SCH_PITCH = 136;            // doubles per LDS row: 128 + 16 — the two 16-lane row groups of a ds_read_b64 half-wave land 32 banks apart
-__device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, double* __restrict__ sY, double* __restrict__ sW) {
+__device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const BaCam& cam, double* __restrict__ sY, double* __restrict__ sW) {
   const BaDims& d = win.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int npair = d.ncb * (d.ncb + 1) / 2;
@@ -465,7 +484,7 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, double* 
   const int bj = bi + rem;
   const bool diag = bi == bj;
   const int j_begin = ks * d.pps;                                   // first map point of this k-split
-  const double* __restrict__ oW = win.oW; const double* __restrict__ Vinv = win.Vinv;
+  const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv; const double* __restrict__ Rt_cur = win.Rt_cur;
   const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
   double4_t acc[2][8];
 #pragma unroll
@@ -507,10 +526,9 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, double* 
       double w[18];
 #pragma unroll
       for (int t = 0; t < 18; ++t) w[t] = 0.0;
-      for (int i = cur[q]; i >= 0; i = obs_next[i]) {               // usually once
-#pragma unroll
-        for (int t = 0; t < 18; ++t) w[t] += oW[18 * (size_t)i + t];
-      }
+      const double* Rk = Rt_cur + 12 * (size_t)k;                     // (read where used: 16 accumulator tiles leave no registers to park it in)
+      for (int i = cur[q]; i >= 0; i = obs_next[i])                 // usually once: W = A^T B rebuilt from the observation's stored numbers
+        obs_w_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, w);    // (0 + W for the first: the stored-W form summed the same way)
       if (side == 0) {
         double I[9];
 #pragma unroll
@@ -574,12 +592,12 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, double* 
 //     fetched before the MFMA phase of the current tile: the two dependent memory round trips of a fill (slot -> W) hide
 //     behind the matrix instructions instead of standing between them.
 // Same operands, same k order, same v_mfma_f64_16x16x4_f64 sequence per tile as ba_schur_body: bit-identical partials.
-__device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, double* __restrict__ sY, double* __restrict__ sW) {
+__device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, const BaCam& cam, double* __restrict__ sY, double* __restrict__ sW) {
   const BaDims& d = win.d;
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;       // wave q owns tile rows q and 7 - q
   if (bx >= d.ksplit) return;
   const int ks = bx, j_begin = ks * d.pps;
-  const double* __restrict__ oW = win.oW; const double* __restrict__ Vinv = win.Vinv;
+  const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv;
   const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
   constexpr int NPT = SCH_R / 3;
   const int pj = tid / 23, k = tid - pj * 23;                        // this thread's slot: point j0 + pj, keyframe k (columns 6k .. 6k+5)
@@ -588,16 +606,20 @@ __device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, dou
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
   for (int u = tid; u < 2 * SCH_R * SCH_PITCH; u += 256) sY[u] = 0.0;   // columns past 6K stay zero (sW follows sY)
-  double w[18], I[9];
+  double pq[4], I[9], Rk[12];                                       // the next tile's observation (x, y, 1/z, sqrt w) and V*^-1; this thread's keyframe
+  bool have = false;
+#pragma unroll
+  for (int t = 0; t < 12; ++t) Rk[t] = slot ? win.Rt_cur[12 * (size_t)k + t] : 0.0;
   int nxt_chain = -1;
   auto slot_of = [&](int j0) -> int {                               // first observation of (point j0 + pj, keyframe k), or -1
     const int j = j0 + pj;
     return (slot && j < d.M && j0 < j_begin + d.pps) ? slot_first[(size_t)j * d.K + k] : -1;
   };
-  auto fetch = [&](int j0, int i) {                                 // W block and V*^-1 of that slot -> registers
+  auto fetch = [&](int j0, int i) {                                 // the slot's stored numbers (32 B; until round 3 its W block, 144 B) and V*^-1 -> registers
     const int j = j0 + pj;
+    have = i >= 0;
 #pragma unroll
-    for (int t = 0; t < 18; ++t) w[t] = i >= 0 ? oW[18 * (size_t)i + t] : 0.0;
+    for (int t = 0; t < 4; ++t) pq[t] = i >= 0 ? oP[6 * (size_t)i + t] : 0.0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) I[t] = (slot && j < d.M) ? Vinv[9 * (size_t)j + t] : 0.0;
     nxt_chain = i >= 0 ? obs_next[i] : -1;
@@ -608,10 +630,14 @@ __device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, dou
   for (int j0 = j_begin; j0 < j_begin + d.pps; j0 += NPT) {
     __syncthreads();                                                // the previous tile has been consumed (first pass: zero fill done)
     if (slot) {
-      for (int i = nxt_chain; i >= 0; i = obs_next[i]) {            // a point seen twice by this keyframe: rare, fetched on the spot
+      double w[18];
+      if (have) obs_w_from_stored<false>(cam, Rk, pq, w);           // W = A^T B of the slot's observation: ~90 multiply-adds, no division
+      else {
 #pragma unroll
-        for (int t = 0; t < 18; ++t) w[t] += oW[18 * (size_t)i + t];
+        for (int t = 0; t < 18; ++t) w[t] = 0.0;
       }
+      for (int i = nxt_chain; i >= 0; i = obs_next[i])              // a point seen twice by this keyframe: rare, fetched on the spot
+        obs_w_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, w);
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const int col = 6 * k + a;
@@ -663,8 +689,8 @@ __global__ __launch_bounds__(256, 2) void ba_kf_schur_kernel(const BaWin* __rest
   if (win.S->done) return;
   const int nkf = win.d.K * BA_KFSPLIT;
   if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, win, cam);
-  else if (DIAG) ba_schur_diag_body((int)blockIdx.x - nkf, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);
-  else ba_schur_body((int)blockIdx.x - nkf, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+  else if (DIAG) ba_schur_diag_body((int)blockIdx.x - nkf, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+  else ba_schur_body((int)blockIdx.x - nkf, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);
 }
 
 // (their own launches in a batch: 51 KB of LDS and ~200 VGPRs per block would otherwise throttle the thousands of small keyframe blocks too)
@@ -683,12 +709,17 @@ __global__ __launch_bounds__(256, ORBX_KF_MINBLOCKS) void ba_kf_kernel(const BaW
 // (three blocks per CU for the one-column-block body; the general body holds 2 x 8 accumulator tiles = 256 VGPRs and would spill under
 // that cap: as (256, 3) its launch over four 50-keyframe windows ran 0.94 ms, 13 % of the f64 matrix peak)
 template <bool DIAG>
-__global__ __launch_bounds__(256, DIAG ? 3 : 2) void ba_schur_kernel(const BaWin* __restrict__ wins) {
+// (round 3: the fill rebuilds W = A^T B from 32 stored bytes per slot; with that arithmetic's temporaries the one-column-block body no longer fits the
+// 168 VGPRs of three blocks per CU — 324 B of scratch per lane, 241 us per 32-window launch — and runs two blocks per CU like the general body: 119 us)
+#ifndef ORBX_SCHUR_DIAG_BLOCKS
+#define ORBX_SCHUR_DIAG_BLOCKS 2
+#endif
+__global__ __launch_bounds__(256, DIAG ? ORBX_SCHUR_DIAG_BLOCKS : 2) void ba_schur_kernel(const BaWin* __restrict__ wins, BaCam cam) {
   __shared__ double s_tiles[2 * SCH_R * SCH_PITCH];                 // Y and W operand tiles (51 KB)
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done) return;
-  if (DIAG) ba_schur_diag_body((int)blockIdx.x, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);
-  else ba_schur_body((int)blockIdx.x, win, s_tiles, s_tiles + SCH_R * SCH_PITCH);   // (blocks beyond this window's need return inside)
+  if (DIAG) ba_schur_diag_body((int)blockIdx.x, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+  else ba_schur_body((int)blockIdx.x, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);   // (blocks beyond this window's need return inside)
 }
 
 // reduce-buffer layout (doubles): [Sred n*n | U 36K | gp n | bred n | chi2 | glsq], n = 6K
@@ -1380,6 +1411,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   // + the trial residuals of the point (local_ba_lm.rs:1047-1048): the group that back-substitutes a point already holds
   // its trial position, and the trial rotations follow from the pose step alone, so chi2(trial) needs no launch of its own
   __shared__ double sRt[12 * BA_MAX_K];      // trial poses
+  __shared__ double sRt0[12 * BA_MAX_K];     // current poses (the linearisation point: ba_build_kernel's, read back)
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
   const BaState* S = win.S;
@@ -1388,7 +1420,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   const double* __restrict__ dp = dp_override ? dp_override : win.dp;     // (inertial: the 6-d pose steps scattered out of the 15-d solve)
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
   const double* __restrict__ o_uv = win.o_uv; const double* __restrict__ Rt_fix = win.Rt_fix;
-  const double* __restrict__ oW = win.oW; const double* __restrict__ Vinv = win.Vinv; const double* __restrict__ gl = win.gl;
+  const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv; const double* __restrict__ gl = win.gl;
   double* __restrict__ pt_dsq = win.pt_dsq; double* __restrict__ pt_psq = win.pt_psq; double* __restrict__ pt_chi2 = win.pt_chi2;
   const double* params = ba_cur(S, P0, P1);
   double* trial = ba_trial(S, P0, P1);
@@ -1400,29 +1432,27 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     for (int a = 0; a < 6; ++a) p6[a] = params[6 * (size_t)k + a] + dp[6 * (size_t)k + a];   // = the trial pose written above
     pose_to_Rt(p6, cam.inertial, sRt + 12 * k);
   }
+  for (int a = threadIdx.x; a < 12 * d.K; a += blockDim.x) sRt0[a] = win.Rt_cur[a];
   __syncthreads();
   const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
   const int gstride = (int)gridDim.x * (256 / BA_PT_LANES);
   for (int j = gtid >> BA_PT_SHIFT; j < d.M; j += gstride) {   // group-uniform (several points per group in a large batch, as ba_build_kernel)
   const double X0[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1], params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   double acc[3] = {0.0, 0.0, 0.0};
-  // sum_k W_kj^T delta_p_k from the stored W blocks.  (Recomputing A and B here instead — B^T (A delta_p), no 144-byte read —
-  // was built and measured: 68 -> 88 us per iteration of a 32-window batch; the kernel is bound by its dependent chains, not by
-  // the bytes, and the extra divisions and square roots of obs_terms lengthen them.)
+  // sum_k W_kj^T delta_p_k = sum over the point's observations of B^T (A delta_p_k), with A and B rebuilt from the observation's
+  // stored (x, y, 1/z, sqrt w) and the keyframe's current R|t — 32 B read per observation where the W block was 144.  (Round 3's
+  // first attempt at this recomputed the projection itself, with its divisions and square roots: 68 -> 88 us per batch iteration.)
   for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += BA_PT_LANES) {
     const int k = o_kf[i];
     if (k < 0) continue;
-    double dk[6];
+    const double* q = oP + 6 * (size_t)i;
+    double A[12], B[6];
+    obs_jac_from_proj(cam, sRt0 + 12 * k, q[0], q[1], q[2], q[3], A, B);
+    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) dk[a] = dp[6 * (size_t)k + a];
+    for (int a = 0; a < 6; ++a) { const double dk = dp[6 * (size_t)k + a]; s0 += A[a] * dk; s1 += A[6 + a] * dk; }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double* w = oW + 18 * (size_t)i + 6 * c;
-      double sum = 0.0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) sum += w[a] * dk[a];
-      acc[c] += sum;
-    }
+    for (int c = 0; c < 3; ++c) acc[c] += B[c] * s0 + B[3 + c] * s1;
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) acc[c] = group_sum32(acc[c]);
@@ -1905,7 +1935,7 @@ struct WinPlan {
   size_t np = 0, n_upper = 0, rb_len = 0, lds_need = 0;
   // byte offsets: input blob (host-prepared arrays), scratch arena, output blob
   size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_kfpt, i_oflag;
-  size_t a_p1, a_oW, a_slot, a_next, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
+  size_t a_p1, a_oP, a_rtcur, a_slot, a_next, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
   size_t o_out;
   int n_kfobs = 0;
   double n_res = 0.0;
@@ -2057,7 +2087,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.i_kfpt = cin.take(4 * n1);
     pl.i_oflag = inertial ? cin.take(4 * n1) : 0;
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
-    pl.a_oW = car.take(144 * n1);
+    pl.a_oP = car.take(48 * n1); pl.a_rtcur = car.take(96 * k1);
     pl.a_slot = car.take(4 * m1 * k1); pl.a_next = car.take(4 * n1);
     pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_vg = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
     pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
@@ -2139,7 +2169,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl); b.vg = (double*)(dar + pl.a_vg);
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
     b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
-    b.oW = (double*)(dar + pl.a_oW);
+    b.oP = (double*)(dar + pl.a_oP); b.Rt_cur = (double*)(dar + pl.a_rtcur);
     b.slot_first = (int*)(dar + pl.a_slot); b.obs_next = (int*)(dar + pl.a_next);
     b.kfpart = (double*)(dar + pl.a_kfpart); b.part = (double*)(dar + pl.a_part); b.rb = (double*)(dar + pl.a_rb);
     b.dp = (double*)(dar + pl.a_solve);
@@ -2271,8 +2301,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
         hipLaunchKernelGGL(ba_kf_kernel, dim3(maxK * BA_KFSPLIT, W), dim3(256), 0, st, d_wins, bc);
       }
       ProfScope ps(h, "ba_schur_kernel", nullptr, true);
-      if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins);
-      else hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins);
+      if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins, bc);
+      else hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins, bc);
     }
     {
       ProfScope ps(h, "ba_gather_kernel");
