@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
 #ifndef ORBX_BA_PPS
 #define ORBX_BA_PPS 32
 #endif
-constexpr int BA_PPS_TARGET = ORBX_BA_PPS;   // map points per k-split of the Schur product (multiple of 8).  24 / 32 / 48 / 64: single window 6.41 / 6.36 / 6.10 / 5.83 k LM it/s, 32-window batch 38.6 / 41.3 / 41.3 / 41.4 k
+constexpr int BA_PPS_TARGET = ORBX_BA_PPS;   // map points per k-split of the Schur product (multiple of 8).  Round 3 (48-byte observations): 24 / 32 / 48 / 64 points: one window 1.417 / 1.443 / 1.483 / 1.569 ms per solve, 32-window batch 69.2 / 75.6 / 76.5 / 79.9 k LM it/s device-only — the batch wants few, long blocks (half the partials to write and gather), one window many short ones; 32 stays.  (Having it both ways — k-splits summed PAIRS FIRST, the batch's blocks owning a pair and parking the first partial in their own slot of the buffer, one window's gather forming the pairs: same bits either way — was built and passed every batch-equals-single test, but the parked partial's read-modify-write at the end of each block cost what the gather saved: Schur 117.7 -> 138.0, gather 38.9 -> 22.5 us per iteration; withdrawn.)  Earlier sweeps:  24 / 32 / 48 / 64: single window 6.41 / 6.36 / 6.10 / 5.83 k LM it/s, 32-window batch 38.6 / 41.3 / 41.3 / 41.4 k
 #ifndef ORBX_BA_KFSPLIT
 #define ORBX_BA_KFSPLIT 1
 #endif
