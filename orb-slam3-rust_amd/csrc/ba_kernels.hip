@@ -584,6 +584,18 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
   }
 }
 
+#ifdef ORBX_SCHUR_STAMPS
+// debug build only (-DORBX_SCHUR_STAMPS, scripts/ba_schur_stamps.py): s_memtime ticks per phase of ba_schur_diag_body, wave 0 of every block, summed
+__device__ unsigned long long g_schur_stamps[8];
+#define SCHUR_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_schur_stamps[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
+extern "C" int orbx_debug_schur_stamps(unsigned long long* out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_schur_stamps), 64) != hipSuccess) return -1;
+  if (reset) { const unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_schur_stamps), z, 64) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define SCHUR_STAMP(k) do { } while (0)
+#endif
 // The same product for windows whose reduced system fits ONE 128-column block (K <= 21 optimised keyframes: every local-BA
 // window of the reference, max_covisible_keyframes = 20): only the diagonal block pair exists, so
 //   - a wave's 9 upper tiles share 9 accumulators: slot c holds tile (q, c) for c >= q and tile (7-q, 7-c) for c < q, the ninth
@@ -596,6 +608,9 @@ __device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, con
   const BaDims& d = win.d;
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;       // wave q owns tile rows q and 7 - q
   if (bx >= d.ksplit) return;
+#ifdef ORBX_SCHUR_STAMPS
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   const int ks = bx, j_begin = ks * d.pps;
   const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv;
   const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
@@ -627,8 +642,10 @@ __device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, con
   // the slot index runs TWO tiles ahead, the W block one: neither of the two dependent loads is waited for where it is issued
   fetch(j_begin, slot_of(j_begin));
   int i_next = slot_of(j_begin + NPT);
+  SCHUR_STAMP(0);
   for (int j0 = j_begin; j0 < j_begin + d.pps; j0 += NPT) {
     __syncthreads();                                                // the previous tile has been consumed (first pass: zero fill done)
+    SCHUR_STAMP(1);
     if (slot) {
       double w[18];
       if (have) obs_w_from_stored<false>(cam, Rk, pq, w);           // W = A^T B of the slot's observation: ~90 multiply-adds, no division
@@ -649,8 +666,10 @@ __device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, con
         sW[(3 * pj + 0) * SCH_PITCH + col] = w0; sW[(3 * pj + 1) * SCH_PITCH + col] = w1; sW[(3 * pj + 2) * SCH_PITCH + col] = w2;
       }
     }
+    SCHUR_STAMP(2);
     if (j0 + NPT < j_begin + d.pps) { fetch(j0 + NPT, i_next); i_next = slot_of(j0 + 2 * NPT); }   // in flight during the MFMA phase below
     __syncthreads();
+    SCHUR_STAMP(3);
 #pragma unroll
     for (int kq = 0; kq < SCH_R / 4; ++kq) {
       const int row = 4 * kq + (lane >> 4);
@@ -664,6 +683,7 @@ __device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, con
         if (c == 7 - q) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accx, 0, 0, 0);              // tile (7-q, 7-q)
       }
     }
+    SCHUR_STAMP(4);
   }
   auto store = [&](int ti, int tj, const double4_t& v) {
     if (ti >= d.ntile || tj >= d.ntile) return;
@@ -678,6 +698,10 @@ __device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, con
     else store(7 - q, 7 - c, acc[c]);
   }
   store(7 - q, 7 - q, accx);
+  SCHUR_STAMP(5);
+#ifdef ORBX_SCHUR_STAMPS
+  if (threadIdx.x == 0) atomicAdd(&g_schur_stamps[7], 1ull);
+#endif
 }
 
 // One window: keyframe partials and Schur blocks in ONE launch (both consume the build kernel's output and feed the solve;
