@@ -8,7 +8,7 @@
 //
 // Six launches per LM iteration (every block derives the keyframe rotations it needs itself):
 //
-//   ba_build_kernel      one 32-lane group per map point: residual + Jacobian blocks of its
+//   ba_build_kernel      one 32- or 16-lane group per map point: residual + Jacobian blocks of its
 //                        observations, V_j = sum B^T B, g_l, damped inverse V*_j^-1, V*_j^-1 g_l, and W = A^T B per
 //                        observation (oW [N][18]: the only per-observation block that is stored — the dense operands of
 //                        the Schur product exist only as LDS tiles filled from it)
@@ -306,15 +306,18 @@ __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, co
   obs_jac_from_proj(cam, Rt, x, y, o.piz, o.psw, o.A, o.B);
 }
 
-#ifndef ORBX_BA_PT_LANES
-#define ORBX_BA_PT_LANES 32
-#endif
-constexpr int BA_PT_LANES = ORBX_BA_PT_LANES;   // lanes per map point in the per-observation kernels.  16 instead of 32 (points average 16 observations): 32-window batch +4 % (39.6 -> 41.1 k it/s), single window -3.5 % (6.50 -> 6.29 k: half as many blocks for its latency chains); one value for both, since the group size fixes the summation order
-constexpr int BA_PT_SHIFT = BA_PT_LANES == 32 ? 5 : 4;
-static_assert(BA_PT_LANES == 32 || BA_PT_LANES == 16, "a power of two dividing the wave");
-__device__ __forceinline__ double group_sum32(double v) {   // sum over the point's lane group, fixed tree
+// Lanes per map point in the per-observation kernels: 32 for one window (twice the blocks for its latency chains), 16 in a batch of
+// >= 8 windows (points average 16 observations: in a 32-lane group half the lanes idle through the Jacobian arithmetic, and these
+// kernels are f64-VALU-bound there).  The group size must not enter the sums, so the 16-lane form keeps TWO accumulators per sum —
+// a for the observations a 32-lane group's lane l would take (l, l + 32, ...), b for lane l + 16's (l + 16, l + 48, ...) — and starts
+// its shuffle tree with a + b, which is the 32-lane tree's first step; the remaining four steps are the same lanes in the same order.
+// (Round 2/3 tried 16 lanes as ONE compile-time value for both: batch +4 %, single window -3.5 %.)
+template <int LANES> __device__ __forceinline__ double group_sum(double a, double b) {   // sum over the point's lane group, fixed tree
+  static_assert(LANES == 32 || LANES == 16, "a power of two dividing the wave");
+  double v = a;
+  if (LANES == 32) v += __shfl_xor(v, 16); else v = a + b;
 #pragma unroll
-  for (int off = BA_PT_LANES / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
 
@@ -323,12 +326,13 @@ __device__ __forceinline__ double group_sum32(double v) {   // sum over the poin
 #ifndef ORBX_BUILD_MINBLOCKS
 #define ORBX_BUILD_MINBLOCKS 1
 #endif
+template <int LANES>
 __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(const BaWin* __restrict__ wins, BaCam cam, int iter) {
   __shared__ double sRt[12 * BA_MAX_K];
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
   BaState* S = win.S;
-  if (S->done || (int)blockIdx.x * (256 / BA_PT_LANES) >= max(d.M, 1)) return;   // (block 0 of a window without points still counts the iteration)
+  if (S->done || (int)blockIdx.x * (256 / LANES) >= max(d.M, 1)) return;   // (block 0 of a window without points still counts the iteration)
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ Rt_fix = win.Rt_fix;
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
@@ -341,19 +345,19 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
   if (blockIdx.x == 0 && threadIdx.x == 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
   block_poses(params, d.K, cam.inertial, sRt);
   if (blockIdx.x == 0) for (int a = threadIdx.x; a < 12 * d.K; a += blockDim.x) win.Rt_cur[a] = sRt[a];   // for the kernels that rebuild the blocks
-  const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
+  const int lane32 = threadIdx.x & (LANES - 1);
   // a group takes the points g0, g0 + (groups of the launch), ...: one point per group for a single window (as many short blocks as
   // possible for its latency chain), several in a large batch, where the block's prologue (K poses) is then paid once for all of
   // them.  A point's arithmetic does not depend on which block or round handles it.
-  const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) >> BA_PT_SHIFT, gstride = (int)gridDim.x * (256 / BA_PT_LANES);
+  const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) / LANES, gstride = (int)gridDim.x * (256 / LANES);
   for (int j = g0; j < d.M; j += gstride) {   // group-uniform
   const double X[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1],
                        params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
   const int s = pt_start[j], e = pt_start[j + 1];
-  double V[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, chi = 0.0;
+  double Va[6] = {0, 0, 0, 0, 0, 0}, ga[3] = {0, 0, 0}, chia = 0.0, Vb[6] = {0, 0, 0, 0, 0, 0}, gb[3] = {0, 0, 0}, chib = 0.0;
   // residual + Jacobian, accumulate V, g_l (lane-strided, then a fixed shuffle tree); per observation only the six numbers the
   // consumers rebuild A, B and W = A^T B from are stored (48 B; until round 3: W itself, 144 B, written in a second pass)
-  for (int i = s + lane32; i < e; i += BA_PT_LANES) {
+  auto one = [&](int i, double (&V)[6], double (&g)[3], double& chi) {
     const int k = o_kf[i];
     double Rt[12];
     if (k >= 0) {
@@ -379,12 +383,17 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
     g[0] += o.B[0] * o.r0 + o.B[3] * o.r1;
     g[1] += o.B[1] * o.r0 + o.B[4] * o.r1;
     g[2] += o.B[2] * o.r0 + o.B[5] * o.r1;
+  };
+  for (int i = s + lane32; i < e; i += 32) {
+    one(i, Va, ga, chia);
+    if (LANES == 16 && i + 16 < e) one(i + 16, Vb, gb, chib);
   }
+  double V[6], g[3];
 #pragma unroll
-  for (int a = 0; a < 6; ++a) V[a] = group_sum32(V[a]);
+  for (int a = 0; a < 6; ++a) V[a] = group_sum<LANES>(Va[a], Vb[a]);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) g[a] = group_sum32(g[a]);
-  chi = group_sum32(chi);
+  for (int a = 0; a < 3; ++a) g[a] = group_sum<LANES>(ga[a], gb[a]);
+  const double chi = group_sum<LANES>(chia, chib);
   // damped V* = V + lambda*max(diag,1e-6) (:1031-1034), closed-form symmetric inverse
   const double a_ = V[0] + lambda * fmax(V[0], 1e-6), b_ = V[1], c_ = V[2];
   const double d_ = V[3] + lambda * fmax(V[3], 1e-6), e_ = V[4], f_ = V[5] + lambda * fmax(V[5], 1e-6);
@@ -433,12 +442,36 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
   double acc[33];   // 21 unique U entries, 6 g_p, 6 b_red
 #pragma unroll
   for (int a = 0; a < 33; ++a) acc[a] = 0.0;
-  for (int t = s + tid; t < e; t += 256) {
-    const int i = kf_obs[t], j = kf_pt[t];
-    const double* q = oP + 6 * (size_t)i;
+  // Software pipeline over this thread's observations t = s + tid, + 256, ...: the indices run two rounds ahead, the observation's
+  // six numbers and its point's V*^-1 g_l one round — a round's two dependent gathers (index -> data) are in flight under the arithmetic
+  // of the rounds before it instead of standing in front of it (the loop was two exposed memory round trips per observation: 55.7 us
+  // per 32-window launch with 608 blocks that all run at once, i.e. the time of ONE block's seven rounds).
+  int t = s + tid;
+  int i1 = -1, j1 = 0, i2 = -1, j2 = 0;                                   // next round's / the round after's indices (-1: none)
+  double q0[6], v0[3], q1[6], v1[3];
+  bool have0 = t < e;
+  if (have0) {
+    const int i0 = kf_obs[t], j0 = kf_pt[t];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) q0[a] = oP[6 * (size_t)i0 + a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v0[a] = vg[3 * (size_t)j0 + a];
+  }
+  if (t + 256 < e) { i1 = kf_obs[t + 256]; j1 = kf_pt[t + 256]; }
+  if (t + 512 < e) { i2 = kf_obs[t + 512]; j2 = kf_pt[t + 512]; }
+  while (have0) {
+    const bool have1 = i1 >= 0;
+    if (have1) {                                                             // next round's data: issued before this round's arithmetic
+#pragma unroll
+      for (int a = 0; a < 6; ++a) q1[a] = oP[6 * (size_t)i1 + a];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) v1[a] = vg[3 * (size_t)j1 + a];
+    }
+    i1 = i2; j1 = j2;
+    if (t + 768 < e) { i2 = kf_obs[t + 768]; j2 = kf_pt[t + 768]; } else i2 = -1;
     double A[12], B[6];
-    obs_jac_from_proj(cam, Rt, q[0], q[1], q[2], q[3], A, B);           // no division, no square root: the build kernel stored what they gave
-    const double r0 = q[4], r1 = q[5];
+    obs_jac_from_proj(cam, Rt, q0[0], q0[1], q0[2], q0[3], A, B);         // no division, no square root: the build kernel stored what they gave
+    const double r0 = q0[4], r1 = q0[5];
     int qi = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -447,10 +480,15 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
 #pragma unroll
     for (int a = 0; a < 6; ++a) acc[21 + a] += A[a] * r0 + A[6 + a] * r1;
     // W V*^-1 g_l = A^T (B (V*^-1 g_l)): the 2-vector B vg, then A^T of it
-    const double v0 = vg[3 * (size_t)j], v1 = vg[3 * (size_t)j + 1], v2 = vg[3 * (size_t)j + 2];
-    const double t0 = B[0] * v0 + B[1] * v1 + B[2] * v2, t1 = B[3] * v0 + B[4] * v1 + B[5] * v2;
+    const double t0 = B[0] * v0[0] + B[1] * v0[1] + B[2] * v0[2], t1 = B[3] * v0[0] + B[4] * v0[1] + B[5] * v0[2];
 #pragma unroll
     for (int a = 0; a < 6; ++a) acc[27 + a] += A[a] * t0 + A[6 + a] * t1;
+    have0 = have1;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) q0[a] = q1[a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v0[a] = v1[a];
+    t += 256;
   }
 #pragma unroll
   for (int a = 0; a < 33; ++a) {
@@ -723,10 +761,24 @@ __global__ __launch_bounds__(256, 2) void ba_kf_schur_kernel(const BaWin* __rest
 #ifndef ORBX_KF_MINBLOCKS
 #define ORBX_KF_MINBLOCKS 1
 #endif
+// Workgroups go to the 8 XCDs round-robin in launch order, and a window's keyframe blocks share cache lines: consecutive observations
+// (48 B each) belong to the same point and to DIFFERENT keyframes, so a 128-byte line of the store is wanted by two or three blocks.  With
+// the plain (keyframe, window) grid those sit on different XCDs and every L2 fetches the line for itself; when the window count is a
+// multiple of 8 the launch order is re-read so that all blocks of a window land on XCD (window mod 8) and walk the store side by side under
+// one L2.  Which block computes a keyframe's partial does not enter its value.
+#ifndef ORBX_KF_XCD
+#define ORBX_KF_XCD 1
+#endif
 __global__ __launch_bounds__(256, ORBX_KF_MINBLOCKS) void ba_kf_kernel(const BaWin* __restrict__ wins, BaCam cam) {
-  const BaWin& win = wins[blockIdx.y];
-  if (win.S->done || (int)blockIdx.x >= win.d.K * BA_KFSPLIT) return;
-  ba_kf_body((int)blockIdx.x, win, cam);
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (ORBX_KF_XCD && (gridDim.y & 7) == 0) {
+    const int lin = by * (int)gridDim.x + bx, xcd = lin & 7, slot = lin >> 3;      // slot: this block's place in its XCD's queue
+    by = xcd + 8 * (slot / (int)gridDim.x);
+    bx = slot - (slot / (int)gridDim.x) * (int)gridDim.x;
+  }
+  const BaWin& win = wins[by];
+  if (win.S->done || bx >= win.d.K * BA_KFSPLIT) return;
+  ba_kf_body(bx, win, cam);
 }
 
 // DIAG: every window of the launch has a reduced system of at most 128 columns (host-checked)
@@ -1430,6 +1482,7 @@ __global__ __launch_bounds__(256) void ba_big_back_kernel(const BaWin* __restric
 
 // delta_l = V*^-1 (-g_l - sum_k W_kj^T delta_p_k); trial = params + delta; per-point |delta_l|^2, |p_l|^2.
 // One 32-lane group per point: lanes take the point's observations, fixed shuffle tree for the three sums.
+template <int LANES>
 __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict__ wins, BaCam cam, const double* __restrict__ dp_override,
                                                          int owned_only) {
   // + the trial residuals of the point (local_ba_lm.rs:1047-1048): the group that back-substitutes a point already holds
@@ -1439,7 +1492,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
   const BaState* S = win.S;
-  if (S->done || (int)blockIdx.x * 256 >= max(BA_PT_LANES * d.M, 6 * d.K)) return;
+  if (S->done || (int)blockIdx.x * 256 >= max(LANES * d.M, 6 * d.K)) return;
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ dp = dp_override ? dp_override : win.dp;     // (inertial: the 6-d pose steps scattered out of the 15-d solve)
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
@@ -1458,17 +1511,18 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   }
   for (int a = threadIdx.x; a < 12 * d.K; a += blockDim.x) sRt0[a] = win.Rt_cur[a];
   __syncthreads();
-  const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
-  const int gstride = (int)gridDim.x * (256 / BA_PT_LANES);
-  for (int j = gtid >> BA_PT_SHIFT; j < d.M; j += gstride) {   // group-uniform (several points per group in a large batch, as ba_build_kernel)
+  const int lane32 = threadIdx.x & (LANES - 1);
+  const int gstride = (int)gridDim.x * (256 / LANES);
+  for (int j = gtid / LANES; j < d.M; j += gstride) {   // group-uniform (several points per group in a large batch, as ba_build_kernel)
   const double X0[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1], params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
-  double acc[3] = {0.0, 0.0, 0.0};
+  const int s = pt_start[j], e = pt_start[j + 1];
+  double acca[3] = {0.0, 0.0, 0.0}, accb[3] = {0.0, 0.0, 0.0};
   // sum_k W_kj^T delta_p_k = sum over the point's observations of B^T (A delta_p_k), with A and B rebuilt from the observation's
   // stored (x, y, 1/z, sqrt w) and the keyframe's current R|t — 32 B read per observation where the W block was 144.  (Round 3's
   // first attempt at this recomputed the projection itself, with its divisions and square roots: 68 -> 88 us per batch iteration.)
-  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += BA_PT_LANES) {
+  auto wtdp = [&](int i, double (&acc)[3]) {
     const int k = o_kf[i];
-    if (k < 0) continue;
+    if (k < 0) return;
     const double* q = oP + 6 * (size_t)i;
     double A[12], B[6];
     obs_jac_from_proj(cam, sRt0 + 12 * k, q[0], q[1], q[2], q[3], A, B);
@@ -1477,9 +1531,14 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     for (int a = 0; a < 6; ++a) { const double dk = dp[6 * (size_t)k + a]; s0 += A[a] * dk; s1 += A[6 + a] * dk; }
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c] += B[c] * s0 + B[3 + c] * s1;
+  };
+  for (int i = s + lane32; i < e; i += 32) {
+    wtdp(i, acca);
+    if (LANES == 16 && i + 16 < e) wtdp(i + 16, accb);
   }
+  double acc[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) acc[c] = group_sum32(acc[c]);
+  for (int c = 0; c < 3; ++c) acc[c] = group_sum<LANES>(acca[c], accb[c]);
   // every lane of the group forms the trial position (same arithmetic, same value); lane 0 stores it
   const double rhs[3] = {-gl[3 * (size_t)j] - acc[0], -gl[3 * (size_t)j + 1] - acc[1], -gl[3 * (size_t)j + 2] - acc[2]};
   const double* I = Vinv + 9 * (size_t)j;
@@ -1491,8 +1550,8 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     X[a] = p + dl;
     dsq += dl * dl; psq += p * p;
   }
-  double chi = 0.0;
-  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += BA_PT_LANES) {
+  double chia = 0.0, chib = 0.0;
+  auto trial_chi = [&](int i, double& chi) {
     const int k = o_kf[i];
     double Rt[12];
     if (k >= 0) {
@@ -1505,8 +1564,12 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
     chi += o.r0 * o.r0 + o.r1 * o.r1;
+  };
+  for (int i = s + lane32; i < e; i += 32) {
+    trial_chi(i, chia);
+    if (LANES == 16 && i + 16 < e) trial_chi(i + 16, chib);
   }
-  chi = group_sum32(chi);
+  const double chi = group_sum<LANES>(chia, chib);
   if (lane32 != 0) continue;
 #pragma unroll
   for (int a = 0; a < 3; ++a) trial[6 * (size_t)d.K + 3 * (size_t)j + a] = X[a];
@@ -1527,7 +1590,7 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
   const BaWin& win = wins[blockIdx.y];
   const BaDims d = win.d;
   const BaState* S = win.S;
-  if (S->done || (int)blockIdx.x * (256 / BA_PT_LANES) >= d.M) return;
+  if (S->done || (int)blockIdx.x * (256 / 32) >= d.M) return;
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ Rt_fix = win.Rt_fix;
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
@@ -1536,13 +1599,13 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
   const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
   block_poses(params, d.K, cam.inertial, sRt);
   // one 32-lane group per point (as ba_build_kernel): 2000 points alone would fill 8 blocks
-  const int lane32 = threadIdx.x & (BA_PT_LANES - 1);
-  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> BA_PT_SHIFT;
+  const int lane32 = threadIdx.x & 31;
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
   if (j >= d.M) return;   // whole 32-lane group leaves together
   const double X[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1],
                        params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
-  double chi = 0.0;
-  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += BA_PT_LANES) {
+  double chia = 0.0, chib = 0.0;
+  auto trial_chi = [&](int i, double& chi) {
     const int k = o_kf[i];
     double Rt[12];
     if (k >= 0) {
@@ -1555,8 +1618,9 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
     chi += o.r0 * o.r0 + o.r1 * o.r1;
-  }
-  chi = group_sum32(chi);
+  };
+  for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) trial_chi(i, chia);
+  const double chi = group_sum<32>(chia, chib);
   if (lane32 == 0) pt_chi2[j] = chi;
 }
 
@@ -2178,6 +2242,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // points per 32-lane group of the build / back-substitution launches: 1 for a few windows, 4 in a large batch (one block prologue —
   // the K rotations — per 32 points instead of per 8; 32-window batch: build 0.103 -> 0.096, back-substitution 0.068 -> 0.064 ms per iteration)
   const int ppg = W >= 8 ? 4 : 1;
+  const int ptl = W >= 8 ? 16 : 32;   // lanes per point in those two kernels (group_sum<>: the sums do not depend on it)
   int any_lds = 0, any_big = 0, n_big_max = 0, maxM = 0, maxK = 0, max_schur_blocks = 1, all_diag = 1, max_gather = 1, max_back = 1, max_asm = 1;
   for (int w = 0; w < W; ++w) {
     const WinPlan& pl = plan[w];
@@ -2213,7 +2278,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     max_schur_blocks = std::max(max_schur_blocks, pl.d.ncb * (pl.d.ncb + 1) / 2 * pl.d.ksplit);
     if (pl.d.ncb != 1) all_diag = 0;
     max_gather = std::max(max_gather, std::min(256, (4 * pl.n * pl.n + 255) / 256));
-    max_back = std::max(max_back, (std::max(BA_PT_LANES * ((pl.d.M + ppg - 1) / ppg), pl.n) + 255) / 256);
+    max_back = std::max(max_back, (std::max(ptl * ((pl.d.M + ppg - 1) / ppg), pl.n) + 255) / 256);
     max_asm = std::max(max_asm, std::min(512, (pl.n * pl.n + 255) / 256));
   }
   const int pt_groups = (maxM + ppg - 1) / ppg;
@@ -2300,7 +2365,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // initial error (:1000-1001) -> res[12]
   {
     ProfScope ps(h, "ba_chi2");
-    if (maxM > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((maxM * BA_PT_LANES + 255) / 256, W), dim3(256), 0, st, d_wins, bc, 0);
+    if (maxM > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((maxM * 32 + 255) / 256, W), dim3(256), 0, st, d_wins, bc, 0);
     chi2_sum(0, 0);
   }
   if (int rc = allreduce(res0 + 12, 1)) return rc;
@@ -2311,7 +2376,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if (!dist && should_stop && should_stop(user)) { stopped = true; break; }                           // :1013
     {
       ProfScope ps(h, "ba_build_kernel");
-      if (maxM > 0) hipLaunchKernelGGL(ba_build_kernel, dim3((pt_groups * BA_PT_LANES + 255) / 256, W), dim3(256), 0, st, d_wins, bc, iter);
+      if (maxM > 0) {
+        const dim3 g((pt_groups * ptl + 255) / 256, W);
+        if (ptl == 16) hipLaunchKernelGGL(ba_build_kernel<16>, g, dim3(256), 0, st, d_wins, bc, iter);
+        else hipLaunchKernelGGL(ba_build_kernel<32>, g, dim3(256), 0, st, d_wins, bc, iter);
+      }
       else hipLaunchKernelGGL(ba_iter_kernel, gW1, dim3(1), 0, st, d_wins, iter);
     }
     if (maxK > 0 && W == 1) {
@@ -2358,7 +2427,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     }
     {
       ProfScope ps(h, "ba_backsub_kernel");
-      hipLaunchKernelGGL(ba_backsub_kernel, dim3(max_back, W), dim3(256), 0, st, d_wins, bc, (const double*)nullptr, dist ? 1 : 0);
+      if (ptl == 16) hipLaunchKernelGGL(ba_backsub_kernel<16>, dim3(max_back, W), dim3(256), 0, st, d_wins, bc, (const double*)nullptr, dist ? 1 : 0);
+      else hipLaunchKernelGGL(ba_backsub_kernel<32>, dim3(max_back, W), dim3(256), 0, st, d_wins, bc, (const double*)nullptr, dist ? 1 : 0);
     }
     // trial residuals (:1047-1048): res[5] = chi2(trial), res[6] = |delta_l|^2, res[7] = |p_l|^2 from the per-point parts the
     // back-substitution kernel left; then the accept / reject / stop decision (:1041-1055)

@@ -222,6 +222,22 @@ def test_ba_batch_equals_single_bit_for_bit(gpu_handle, pkg):
         assert np.array_equal(again[k]["poses_wc"], single[i]["poses_wc"]) and np.array_equal(again[k]["points"], single[i]["points"])
 
 
+def test_ba_batch_lane_groups_do_not_enter_the_sums(gpu_handle, pkg):
+    """A batch of 8 or more windows runs the per-point kernels with 16 lanes per point, one window with 32 (ba_kernels.hip group_sum):
+    points seen by 1..16, 17..32, 33..48 and more than 48 keyframes must come out bit for bit as in the single-window solve."""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
+    shapes = [(40, 300), (70, 200), (50, 400), (12, 500), (24, 350), (33, 260), (18, 640), (66, 120), (5, 80)]
+    wins = [pkg.synth.ba_window(900 + i, K, M, pkg.BA_OBS) for i, (K, M) in enumerate(shapes)]
+    counts = np.concatenate([np.bincount(w["obs"]["mp_idx"], minlength=len(w["points"])) for w in wins])
+    assert (counts <= 16).any() and ((counts > 16) & (counts <= 32)).any() and ((counts > 32) & (counts <= 48)).any() and (counts > 48).any()
+    batch = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
+    for i, w in enumerate(wins):
+        s = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+        assert batch[i]["iterations"] == s["iterations"], i
+        assert batch[i]["initial_error"] == s["initial_error"] and batch[i]["final_error"] == s["final_error"], i
+        assert np.array_equal(batch[i]["poses_wc"], s["poses_wc"]) and np.array_equal(batch[i]["points"], s["points"]), i
+
+
 def test_ba_batch_32_windows_config3(gpu_handle, oracle, pkg):
     """32 windows of BASELINE configs[2] size in one call (the bench's batched leg): all converge like the single solve,
     window 0 against the Schur oracle."""
