@@ -642,17 +642,25 @@ class Handle:
         Returns one result dict per window (None where the reference returns None)."""
         keep = []
         arr = (_BaWindow * max(len(windows), 1))()
+        # the in/out points and the output poses of ALL windows live in two arrays allocated once per call (a fresh 48 KB copy per
+        # window cost 19 us each in page faults: 0.6 ms of a 5.6 ms call at 32 windows); the per-window results are views of them
+        in_pts = [np.asarray(w["points"], np.float64).reshape(-1, 3) for w in windows]
+        in_poses = [np.ascontiguousarray(w["poses_cw"], np.float64).reshape(-1, 7) for w in windows]
+        all_pts = np.concatenate(in_pts) if in_pts else np.zeros((0, 3))
+        all_out = np.zeros((sum(max(len(p), 1) for p in in_poses), 7))
+        p_pts, p_out, o_pts, o_out = all_pts.ctypes.data, all_out.ctypes.data, 0, 0
         for i, w in enumerate(windows):
-            poses_cw = np.ascontiguousarray(w["poses_cw"], np.float64).reshape(-1, 7)
+            poses_cw = in_poses[i]
             fixed_cw = np.ascontiguousarray(w["fixed_cw"], np.float64).reshape(-1, 7)
-            pts = np.array(w["points"], np.float64, copy=True).reshape(-1, 3)
             obs = np.ascontiguousarray(w["obs"], BA_OBS)
-            out_wc = np.zeros((max(len(poses_cw), 1), 7))
+            M, Ko = len(in_pts[i]), max(len(poses_cw), 1)
+            pts = all_pts[o_pts:o_pts + M]; out_wc = all_out[o_out:o_out + Ko]
             keep.append((poses_cw, fixed_cw, pts, obs, out_wc))
             a = arr[i]
-            a.K, a.F, a.M, a.N = len(poses_cw), len(fixed_cw), len(pts), len(obs)
-            a.poses_cw = poses_cw.ctypes.data; a.fixed_poses_cw = fixed_cw.ctypes.data; a.points = pts.ctypes.data
-            a.obs = obs.ctypes.data; a.poses_wc_out = out_wc.ctypes.data
+            a.K, a.F, a.M, a.N = len(poses_cw), len(fixed_cw), M, len(obs)
+            a.poses_cw = poses_cw.ctypes.data; a.fixed_poses_cw = fixed_cw.ctypes.data; a.points = p_pts + 24 * o_pts
+            a.obs = obs.ctypes.data; a.poses_wc_out = p_out + 56 * o_out
+            o_pts += M; o_out += Ko
         cb = SHOULD_STOP_FN((lambda user: 1 if should_stop() else 0)) if should_stop else C.cast(None, SHOULD_STOP_FN)
         cam = camera._c(); c = cfg._c()
         self._check(self._L.orbx_ba_solve_visual_batch(self._h, C.byref(cam), C.byref(c), C.c_int(len(windows)), arr, cb, None))

@@ -2219,13 +2219,13 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     size_t total_obs = 0;
     for (int w = 0; w < W; ++w) total_obs += (size_t)win[w].N;
     int nthr = (int)std::min<size_t>({(size_t)W, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, total_obs / 20000 + 1});
-    if (nthr <= 1) { for (int w = 0; w < W; ++w) work(w); }
-    else {
-      std::atomic<int> next{0};
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthr; ++t) th.emplace_back([&] { for (int w; (w = next.fetch_add(1)) < W;) work(w); });
-      for (auto& t : th) t.join();
+    if (h->ba_pool_cap > 0) nthr = std::min(nthr, h->ba_pool_cap);
+    if (nthr > 1 && !h->ba_pool) {
+      try { h->ba_pool = new OrbxWorkPool((int)std::min<size_t>(15, std::max(1u, std::thread::hardware_concurrency()) - 1)); }
+      catch (...) { h->ba_pool = nullptr; }                              // no workers: this thread does it all
     }
+    if (nthr <= 1 || !h->ba_pool) { for (int w = 0; w < W; ++w) work(w); }
+    else if (!h->ba_pool->run(W, nthr - 1, work)) return orbx_fail(h, ORBX_ERR_HIP, "batch preprocessing: out of host memory");
   }
   mark(2);
   int first_bad = -1;

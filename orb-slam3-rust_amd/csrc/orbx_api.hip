@@ -149,6 +149,7 @@ int orbx_create(const orbx_camera* cam, const orbx_orb_params* orb, int device, 
 void orbx_destroy(orbx_handle* h) {
   if (!h) return;
   if (h->ba_aux) { orbx_destroy(h->ba_aux); h->ba_aux = nullptr; }
+  delete h->ba_pool; h->ba_pool = nullptr;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->resize_tab, &h->ws_pyr, &h->ws_blur, &h->ws_cand, &h->ws_counters,
@@ -990,6 +991,10 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
       n0 = std::max(1, std::min(n_windows - 1, n0));
       int rc1 = ORBX_OK;
       bool helper_ran = false;
+      // the two halves preprocess at the same time: half the cores each
+      const int half_cores = std::max(1, (int)std::thread::hardware_concurrency() / 2);
+      h->ba_pool_cap = half_cores; h->ba_aux->ba_pool_cap = half_cores;
+      struct Uncap { orbx_handle* h; ~Uncap() { h->ba_pool_cap = 0; h->ba_aux->ba_pool_cap = 0; } } uncap{h};
       try {
         std::thread helper([&] {
           hipSetDevice(h->device);

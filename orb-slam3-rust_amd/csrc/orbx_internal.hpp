@@ -2,15 +2,80 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbx.h"
 
 #define ORBX_MAX_LEVELS 8
+
+// Persistent host workers of a handle (the batch BA call's per-window preprocessing: creating and joining 16 threads per call cost
+// more than the 0.4 ms of work each of them then did).  run(items, want, f) calls f(0..items-1), each index once, on the calling thread
+// and up to `want` workers, and returns when all are done; an exception inside f is reported by the return value (false), never thrown
+// across the workers.  Not reentrant: one run() at a time per pool (a handle is used by one thread at a time, orbx.h).
+class OrbxWorkPool {
+ public:
+  explicit OrbxWorkPool(int workers) {
+    for (int i = 0; i < workers; ++i) th_.emplace_back([this, i] { loop(i); });      // std::system_error if a thread cannot be created
+  }
+  ~OrbxWorkPool() {
+    { std::lock_guard<std::mutex> g(m_); quit_ = true; ++gen_; }
+    go_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int workers() const { return (int)th_.size(); }
+  bool run(int items, int want, const std::function<void(int)>& f) {
+    want = want < 0 ? 0 : (want > (int)th_.size() ? (int)th_.size() : want);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      job_ = &f; items_ = items; want_ = want; active_ = want; failed_ = false;
+      next_.store(0, std::memory_order_relaxed);
+      ++gen_;
+    }
+    if (want > 0) go_.notify_all();
+    take();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [&] { return active_ == 0; });
+    job_ = nullptr;
+    return !failed_;
+  }
+
+ private:
+  void take() {
+    try { for (int i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < items_;) (*job_)(i); }
+    catch (...) { std::lock_guard<std::mutex> g(m_); failed_ = true; }
+  }
+  void loop(int idx) {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        go_.wait(g, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (quit_) return;
+        if (idx >= want_) continue;                                     // this round runs on fewer workers
+      }
+      take();
+      { std::lock_guard<std::mutex> g(m_); if (--active_ == 0) done_.notify_one(); }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable go_, done_;
+  const std::function<void(int)>* job_ = nullptr;
+  std::atomic<int> next_{0};
+  int items_ = 0, want_ = 0, active_ = 0;
+  unsigned long long gen_ = 0;
+  bool quit_ = false, failed_ = false;
+};
 
 // ---- launch descriptors shared by host code and kernels ------------------------------------------
 // Geometry of one pyramid level inside the per-image pyramid / blur slots (identical layout).
@@ -103,6 +168,8 @@ struct orbx_handle {
   void* h_ba_in = nullptr;   size_t h_ba_in_bytes = 0;    // pinned mirrors of the batch input / output blobs (ba_solve_batch)
   void* h_ba_out = nullptr;  size_t h_ba_out_bytes = 0;
   int* h_abort = nullptr;    int* d_abort = nullptr;       // pinned, device-visible: should_stop() seen while the iterations drain
+  OrbxWorkPool* ba_pool = nullptr;                         // host workers of the batch preprocessing (created by the first large batch)
+  int ba_pool_cap = 0;                                     // > 0: at most this many threads for the next preprocessing (two halves share the cores)
   // profiling
   bool profiling = false;
   std::vector<KernelTimer> timers;
