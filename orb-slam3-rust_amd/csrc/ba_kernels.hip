@@ -872,7 +872,6 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict_
 // side always in LDS.  Right-looking Cholesky: 2 barriers per column, trailing update on a 16x16 thread grid; the two
 // triangular solves run in wave 0 alone as row dot products with shuffle reductions (no block barriers).
 constexpr int BA_SOLVE_THREADS = 1024;
-constexpr int BA_TG = 32;                 // trailing update runs on a BA_TG x BA_TG thread grid
 constexpr int BA_MAX_N = 768;
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -931,6 +930,7 @@ __device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid
   int good = 1;
   static_for<16>([&](auto jj_) {
     constexpr int jj = decltype(jj_)::value;
+    if (jj >= nb) return;                                                     // (uniform) the identity rows of a short last block: nothing to do
     const double d = row_bcast_f64<jj>(Lr[jj]);
     if (jj < nb && !(d > 0.0)) good = 0;                                    // uniform
     const double ri = rsqrt_nr(good ? d : 1.0);
@@ -979,17 +979,42 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   const double* U = rb + nn;
   const double* gp = U + 36 * (size_t)K;
   const double* bred = gp + n;
-  // S = blockdiag(U*) - S_red ; b = -g_p + b_red.  Only the lower triangle (j <= i) is ever read below.
-  for (int i = tid / BA_TG; i < n; i += nth / BA_TG)
-    for (int j = tid % BA_TG; j <= i; j += BA_TG) {
-      double v = -rb[(size_t)i * n + j];
-      if (i / 6 == j / 6) {
-        double u = U[36 * (size_t)(i / 6) + (i % 6) * 6 + (j % 6)];
-        if (i == j) u += lambda * fmax(u, 1e-6);
-        v += u;
+  // S = blockdiag(U*) - S_red ; b = -g_p + b_red.  The factorisation reads and writes the lower triangle (j <= i) only; the upper
+  // triangle is written as ZERO here and stays zero, which the backward substitution relies on.  Thread (ty, tx) of a 32 x 32 grid
+  // takes the entries (ty + 32 a, tx + 32 b): all of its loads are issued before the first is used (the nested loops with their
+  // run-time bounds waited for each global load in turn: 6 us of a 63 us solve at n = 114).
+  {
+    constexpr int AS = (135 + 31) / 32;                                         // the LDS path ends at n = 135
+    const int ty = tid >> 5, tx = tid & 31;
+    double rv_[AS][AS], uv_[AS][AS];
+#pragma unroll
+    for (int a = 0; a < AS; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < AS; ++b2) {
+        const int i = ty + 32 * a, j = tx + 32 * b2;
+        const bool low = i < n && j <= i;
+        rv_[a][b2] = low ? rb[(size_t)i * n + j] : 0.0;
+        uv_[a][b2] = (low && i / 6 == j / 6) ? U[36 * (size_t)(i / 6) + (i % 6) * 6 + (j % 6)] : 0.0;
       }
-      S[(size_t)i * n + j] = v;
-    }
+#pragma unroll
+    for (int a = 0; a < AS; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < AS; ++b2) {
+        const int i = ty + 32 * a, j = tx + 32 * b2;
+        if (i < n && j < n) {
+          double v = 0.0;
+          if (j <= i) {
+            v = -rv_[a][b2];
+            if (i / 6 == j / 6) {
+              double u = uv_[a][b2];
+              if (i == j) u += lambda * fmax(u, 1e-6);
+              v += u;
+            }
+          }
+          S[(size_t)i * n + j] = v;
+        }
+      }
+  }
   double gs = 0.0;
   for (int i = tid; i < n; i += nth) { sb[i] = -gp[i] + bred[i]; gs += gp[i] * gp[i]; }
   gs = block_sum_fixed(gs, s_red);
@@ -1105,42 +1130,73 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   __syncthreads();
   SOLVE_STAMP(4);
   ok = s_ok;
+  if (tid < n) S[(size_t)tid * n + tid] = 0.0;                                    // L_cc itself is not read again (1 / L_cc is in srinv): see the backward substitution
   __syncthreads();
   // (A panel-blocked backward substitution — the panel's 16 unknowns by DPP row_newbcast steps in wave 0, the rows above it one
   // thread each, same operations in the same order, bit-identical — was built and measured: 15.0 us against the 12.2 us of the
   // single wave below at n = 114; its 16 block barriers and LDS round trips cost more than the readlane pairs they replace.
   // v_fmac_f64_dpp / v_mov_b64_dpp issue every 16 cycles, a v_readlane_b32 every 4: profiles/r03_valu_issue_probe2.txt.)
   if (ok && tid < 64 && n <= 128) {
-    // backward L^T x = y (y is already in sb: the forward substitution ran inside the factorisation), column oriented:
-    // lane holds rows `lane` and `lane+64` of the right-hand side in registers, each step broadcasts one solved entry
-    // with v_readlane; columns are fetched in chunks of 8 one chunk ahead
+    // backward L^T x = y (y is already in sb: the forward substitution ran inside the factorisation), column oriented: lane holds
+    // rows `lane` and `lane + 64` of the right-hand side in registers; step c: x_c = b_c / L_cc reaches all lanes by a v_readlane
+    // pair, b_r -= L_cr x_c for r < c.  ONE wave issues an instruction every ~8.4 cycles whatever the instruction
+    // (profiles/r03_valu_issue_probe2.txt, 1 wave/SIMD), so what counts here is the instruction count of a step — now address add,
+    // ds_read, multiply, two readlanes, fma:
+    //   - rows r >= c need no mask: they read the upper triangle and the diagonal of S, which hold zeros (above), so the fma leaves
+    //     them alone — lane c keeps b_c and is scaled once at the end (the same product that was broadcast);
+    //   - 1 / L_cc is not fetched per step: every lane multiplies its own entry by its own 1 / L_rr and the readlane picks lane c's;
+    //   - columns >= 64 (both registers, pivot in the second) and < 64 run as two loops, chunks of 8 columns fetched one chunk ahead,
+    //     registers alternating (no copies); what does not fill a pair of chunks goes first, step by step.
+    // Until round 3 a step was 22 instructions with two exec-mask regions and a uniform branch: 11.8 us of a 68.7 us solve at n = 114.
+    // Same operations on the same operands in the same order: same bits.
     const int r0 = min(lane, n - 1), r1 = min(lane + 64, n - 1);
     double b0 = lane < n ? sb[lane] : 0.0, b1 = lane + 64 < n ? sb[lane + 64] : 0.0;
+    const double ri0 = srinv[r0], ri1 = srinv[r1];
     constexpr int CH = 8;
-    double l0[CH], l1[CH], rc[CH], l0n[CH], l1n[CH], rcn[CH];
-    // backward: row c of L, chunks run downwards from n-1
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { const int c = max(n - 1 - j, 0); l0[j] = S[(size_t)c * n + r0]; l1[j] = S[(size_t)c * n + r1]; rc[j] = srinv[c]; }
-    for (int c0 = n - 1; c0 >= 0; c0 -= CH) {
-#pragma unroll
-      for (int j = 0; j < CH; ++j) { const int c = max(c0 - CH - j, 0); l0n[j] = S[(size_t)c * n + r0]; l1n[j] = S[(size_t)c * n + r1]; rcn[j] = srinv[c]; }
+    double l0a[CH], l1a[CH], l0b[CH], l1b[CH];
+    auto bcast = [&](double t, int src) -> double {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(t), src), hi = __builtin_amdgcn_readlane(__double2hiint(t), src);
+      return __hiloint2double(hi, lo);
+    };
+    auto fetch = [&](auto hi_, int ctop, double (&l0)[CH], double (&l1)[CH]) {
+      constexpr bool HI = decltype(hi_)::value;
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
-        const int c = c0 - j;
-        if (c >= 0) {   // uniform
-          const double own = (c < 64) ? b0 : b1;
-          const int src = c & 63;
-          const int lo = __builtin_amdgcn_readlane(__double2loint(own), src), hi = __builtin_amdgcn_readlane(__double2hiint(own), src);
-          const double xc = __hiloint2double(hi, lo) * rc[j];
-          if (lane < c) b0 = fma(-l0[j], xc, b0); else if (lane == c) b0 = xc;
-          if (lane + 64 < c) b1 = fma(-l1[j], xc, b1); else if (lane + 64 == c) b1 = xc;
-        }
+        const int cc = max(ctop - j, 0);                                          // (the prefetch past the last chunk: any row will do)
+        l0[j] = S[(size_t)cc * n + r0];
+        if (HI) l1[j] = S[(size_t)cc * n + r1];
       }
+    };
+    auto chunk = [&](auto hi_, int ctop, const double (&l0)[CH], const double (&l1)[CH]) {
+      constexpr bool HI = decltype(hi_)::value;
 #pragma unroll
-      for (int j = 0; j < CH; ++j) { l0[j] = l0n[j]; l1[j] = l1n[j]; rc[j] = rcn[j]; }
-    }
-    if (lane < n) sb[lane] = b0;
-    if (lane + 64 < n) sb[lane + 64] = b1;
+      for (int j = 0; j < CH; ++j) {
+        const double xc = bcast(HI ? b1 * ri1 : b0 * ri0, (ctop - j) & 63);        // column c lives in lane c mod 64
+        b0 = fma(-l0[j], xc, b0);
+        if (HI) b1 = fma(-l1[j], xc, b1);
+      }
+    };
+    auto run = [&](auto hi_, int c_hi, int c_lo) {                                // columns c_hi .. c_lo, downwards
+      constexpr bool HI = decltype(hi_)::value;
+      const int cnt = c_hi - c_lo + 1, pairs = cnt / (2 * CH);
+      int c = c_hi;
+      for (; c >= c_lo + pairs * 2 * CH; --c) {                                   // the odd part first, one column at a time
+        const double xc = bcast(HI ? b1 * ri1 : b0 * ri0, c & 63);
+        b0 = fma(-S[(size_t)c * n + r0], xc, b0);
+        if (HI) b1 = fma(-S[(size_t)c * n + r1], xc, b1);
+      }
+      if (pairs > 0) fetch(hi_, c, l0a, l1a);
+      for (int q = 0; q < pairs; ++q, c -= 2 * CH) {
+        fetch(hi_, c - CH, l0b, l1b);
+        chunk(hi_, c, l0a, l1a);
+        fetch(hi_, c - 2 * CH, l0a, l1a);
+        chunk(hi_, c - CH, l0b, l1b);
+      }
+    };
+    if (n > 64) run(std::true_type{}, n - 1, 64);
+    run(std::false_type{}, min(n, 64) - 1, 0);
+    if (lane < n) sb[lane] = b0 * ri0;
+    if (lane + 64 < n) sb[lane + 64] = b1 * ri1;
   } else if (ok && tid < 64) {
     // general n: row dot products with shuffle reductions
     for (int r = n - 1; r >= 0; --r) {
