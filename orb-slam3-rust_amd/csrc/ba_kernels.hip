@@ -44,6 +44,7 @@
 namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 struct BaDims {
   int K, F, M, N;
@@ -896,8 +897,12 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    // y <- y + y (e / 2), e = 1 - x y^2.  Written with h = y / 2 (exact) as fma(h, e, y): the same real product h e = y (e / 2) under the
+    // same single rounding as fma(y, 0.5 * e, y), but h does not wait for e — three dependent operations per step instead of four on the
+    // factorisation's pivot chain.
+    const double h = 0.5 * y;
     const double e = fma(-x * y, y, 1.0);
-    y = fma(y, 0.5 * e, y);
+    y = fma(h, e, y);
   }
   return y;
 }
@@ -923,24 +928,26 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // Cholesky of a 16x16 block in one wave.  Lane j of every 16-lane row (the four rows of the wave carry the same block) owns row j:
 // Lr[i] = a[j][i] for i <= j (rows >= nb: the identity).  Step jj: the pivot and then, for every later column kk, the entry
 // L[kk][jj] reach all lanes of the row by DPP row_newbcast — 1 + (15 - jj) instructions where readlane pairs through SGPRs took
-// 2 + 3 (15 - jj).  On return Lr holds row j of L; rv[jj] = 1 / L[jj][jj] (written by thread jj).  Returns 0 when a live pivot is
-// not positive (uniform).
+// 2 + 3 (15 - jj).  On return Lr holds row j of L; rv[jj] = 1 / L[jj][jj] (written by thread jj; 1.0 past nb).  Returns 0 when a live
+// pivot is not positive (uniform).
 __device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid, double* __restrict__ rv) {
   const int j = tid & 15;
   int good = 1;
+  double myri = 1.0;
   static_for<16>([&](auto jj_) {
     constexpr int jj = decltype(jj_)::value;
     if (jj >= nb) return;                                                     // (uniform) the identity rows of a short last block: nothing to do
     const double d = row_bcast_f64<jj>(Lr[jj]);
     if (jj < nb && !(d > 0.0)) good = 0;                                    // uniform
     const double ri = rsqrt_nr(good ? d : 1.0);
-    if (tid == jj) rv[jj] = ri;
-    Lr[jj] = (j == jj) ? d * ri : Lr[jj] * ri;                              // column jj of L (rows >= jj matter)
+    myri = (j == jj) ? ri : myri;                                             // (stored once, after the last step)
+    Lr[jj] = Lr[jj] * ri;                                                     // column jj of L (rows >= jj matter; row jj itself holds d: d / sqrt d)
     static_for<16>([&](auto kk_) {
       constexpr int kk = decltype(kk_)::value;
       if constexpr (kk > jj) Lr[kk] = fnma_row_bcast_f64<kk>(Lr[kk], Lr[jj], Lr[jj]);   // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk)
     });
   });
+  if (tid < 16) rv[tid] = myri;
   return good;
 }
 
@@ -971,7 +978,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
 #endif
   const double lambda = St->lambda;
   const double* params = ba_cur(St, P0, P1);
-  __shared__ double sb[BA_MAX_N];
+  __shared__ __align__(16) double sb[BA_MAX_N];
   __shared__ double srinv[BA_MAX_N];
   __shared__ double s_red[BA_SOLVE_THREADS];
   const int tid = threadIdx.x, nth = BA_SOLVE_THREADS, lane = tid & 63;
@@ -1027,7 +1034,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   // (The left-looking form it replaces spent 22 us in scalar panel updates and 31 us in 8x8 diagonal blocks that every
   // row thread factored redundantly, at n = 114.)
   __shared__ int s_ok;
-  __shared__ double s_rv[16];
+  __shared__ __align__(16) double s_rv[16];
   SOLVE_STAMP(0);
   if (tid == 0) s_ok = 1;
   int ok = 1;
@@ -1036,7 +1043,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       const int j = tid & 15;
       double Lr[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? S[(size_t)(c0_ + j) * n + c0_ + i] : (i == j ? 1.0 : 0.0);
+      for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? S[(size_t)(c0_ + j) * n + c0_ + i] : 0.0;   // (rows >= nb_ take no pivot step: chol16_rows_dpp; a 1.0 on their diagonal was 16 loop-invariant constants held in — and spilled from — registers)
       const int good = chol16_rows_dpp(Lr, nb_, tid, s_rv);
       if (tid == 0 && !good) s_ok = 0;
       if (good && tid < nb_) {
@@ -1056,10 +1063,45 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     ok = s_ok;
     if (!ok) break;
     if (tid < nb) srinv[c0 + tid] = s_rv[tid];
-    if (tid == nth - 1) {
-      // the right-hand side is one more row solved against the panel: forward substitution L y = b rides along with the
-      // factorisation (y of this panel here, its effect on the entries below in the update phase), instead of 114
-      // dependent steps in one wave afterwards
+    if (nb == 16) {
+      // Rows below the panel, and the right-hand side as one more row (thread m, the first without a row of S: forward substitution
+      // L y = b rides along with the factorisation — y of this panel here, its effect on the entries below in the update phase —
+      // instead of 114 dependent steps in one wave afterwards; in the same wave as the last rows it costs no instruction stream of its
+      // own).  Column oriented: once x_t is final every later entry takes its term -x_t L[jx][t] — per entry the same fma sequence in
+      // the same order as a row-oriented loop (same bits), but the 15 - t updates of a step are independent, so the dependent chain
+      // through a row is 16 x (multiply, fma) instead of 136 fmas, and L11 comes in pairs (ds_read_b128 of L[jx][t], L[jx][t+1]: n = 6K
+      // is even and c0 a multiple of 16) — 64 + 8 reads instead of 120 + 16 in a wave that issues one instruction every ~8 cycles.
+      const int r = c0 + 16 + tid;
+      if (r <= n) {
+        double* row = r < n ? &S[(size_t)r * n + c0] : &sb[c0];
+        double x[16];
+#pragma unroll
+        for (int jx = 0; jx < 16; jx += 2) {
+          const double2_t p2 = *(const double2_t*)&row[jx];
+          x[jx] = p2[0]; x[jx + 1] = p2[1];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+          double la[16], lb[16];                                                   // L[jx][t], L[jx][t + 1] for jx > t
+#pragma unroll
+          for (int jx = t + 1; jx < 16; ++jx) {
+            const double2_t p2 = *(const double2_t*)&S[(size_t)(c0 + jx) * n + c0 + t];
+            la[jx] = p2[0]; lb[jx] = p2[1];
+          }
+          const double2_t q = *(const double2_t*)&s_rv[t];
+          x[t] = x[t] * q[0];
+#pragma unroll
+          for (int jx = t + 1; jx < 16; ++jx) x[jx] = fma(-x[t], la[jx], x[jx]);
+          x[t + 1] = x[t + 1] * q[1];
+#pragma unroll
+          for (int jx = t + 2; jx < 16; ++jx) x[jx] = fma(-x[t + 1], lb[jx], x[jx]);
+          __builtin_amdgcn_sched_barrier(0);                                       // (hoisting every step's reads to the top spilled 39 VGPRs)
+        }
+#pragma unroll
+        for (int jx = 0; jx < 16; jx += 2) *(double2_t*)&row[jx] = double2_t{x[jx], x[jx + 1]};
+      }
+    } else if (tid == nth - 1) {
+      // the short last panel has no rows below it: only the right-hand side, entry by entry
       double x[16];
 #pragma unroll
       for (int jx = 0; jx < 16; ++jx) x[jx] = (jx < nb) ? sb[c0 + jx] : 0.0;
@@ -1075,34 +1117,16 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
 #pragma unroll
       for (int jx = 0; jx < 16; ++jx) if (jx < nb) sb[c0 + jx] = x[jx];
     }
-    {
-      const int r = c0 + nb + tid;                                             // rows below the panel
-      if (r < n) {
-        double x[16];
-#pragma unroll
-        for (int jx = 0; jx < 16; ++jx) x[jx] = (jx < nb) ? S[(size_t)r * n + c0 + jx] : 0.0;
-#pragma unroll
-        for (int jx = 0; jx < 16; ++jx) {
-          if (jx < nb) {                                                       // uniform
-            double v = x[jx];
-#pragma unroll
-            for (int t = 0; t < jx; ++t) v = fma(-x[t], S[(size_t)(c0 + jx) * n + c0 + t], v);
-            x[jx] = v * s_rv[jx];
-          }
-        }
-#pragma unroll
-        for (int jx = 0; jx < 16; ++jx) if (jx < nb) S[(size_t)r * n + c0 + jx] = x[jx];
-      }
-    }
     __syncthreads();
     SOLVE_STAMP(3);
     const int c1 = c0 + 16, m = n - c1;
     if (m > 0) {
-      if (tid < m) {                                                           // b_below -= L21 y_panel
+      if (tid >= nth - 128 && tid - (nth - 128) < m) {                         // b_below -= L21 y_panel (the last two waves: not in wave 0's way)
+        const int rr = c1 + tid - (nth - 128);
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc = fma(S[(size_t)(c1 + tid) * n + c0 + k], sb[c0 + k], acc);
-        sb[c1 + tid] -= acc;
+        for (int k = 0; k < 16; ++k) acc = fma(S[(size_t)rr * n + c0 + k], sb[c0 + k], acc);
+        sb[rr] -= acc;
       }
       const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2, nw = (nth >> 6) - 1;
       // wave 0: tile (c1, c1) only, then the factor of that block; waves 1..15: the other lower tiles
@@ -2216,7 +2240,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.n_upper = (size_t)d.ntile * (d.ntile + 1) / 2;
     pl.rb_len = (size_t)pl.n * pl.n + 36 * (size_t)K + 2 * (size_t)pl.n + 2;
     pl.lds_need = 8 * ((size_t)pl.n * pl.n + BA_SOLVE_THREADS);
-    pl.use_lds = pl.lds_need <= BA_LDS_DYN_MAX ? 1 : 0;
+    pl.use_lds = (pl.lds_need <= BA_LDS_DYN_MAX && pl.n % 2 == 0) ? 1 : 0;   // (the LDS solve reads pairs of entries: even n, which 6K is)
     pl.n_res = 2.0 * (double)N;
     const size_t n1 = (size_t)std::max(N, 1), m1 = (size_t)std::max(M, 1), k1 = (size_t)std::max(K, 1);
     pl.i_state = cin.take(sizeof(BaState));
