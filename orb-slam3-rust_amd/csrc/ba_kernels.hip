@@ -921,6 +921,13 @@ template <int L> __device__ __forceinline__ double fnma_row_bcast_f64(double acc
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(L));
   return acc;
 }
+// the same without the wait states: for a caller whose `bsrc` was written at least two instructions ago — the second and later updates of
+// a pivot step, which all read the column the first one read (an s_nop is an instruction like any other to a wave that issues one every
+// ~8 cycles: 105 of them were a fifth of the 16 x 16 factorisation)
+template <int L> __device__ __forceinline__ double fnma_row_bcast_f64_settled(double acc, double bsrc, double m) {
+  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(L));
+  return acc;
+}
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
@@ -939,12 +946,14 @@ __device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid
     if (jj >= nb) return;                                                     // (uniform) the identity rows of a short last block: nothing to do
     const double d = row_bcast_f64<jj>(Lr[jj]);
     if (jj < nb && !(d > 0.0)) good = 0;                                    // uniform
-    const double ri = rsqrt_nr(good ? d : 1.0);
+    const double ri = rsqrt_nr(d);                                            // (after a bad pivot: NaNs, which nobody stores)
     myri = (j == jj) ? ri : myri;                                             // (stored once, after the last step)
     Lr[jj] = Lr[jj] * ri;                                                     // column jj of L (rows >= jj matter; row jj itself holds d: d / sqrt d)
     static_for<16>([&](auto kk_) {
       constexpr int kk = decltype(kk_)::value;
-      if constexpr (kk > jj) Lr[kk] = fnma_row_bcast_f64<kk>(Lr[kk], Lr[jj], Lr[jj]);   // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk)
+      // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk); Lr[jj] was written just above: the first update waits for it, the others need not
+      if constexpr (kk == jj + 1) Lr[kk] = fnma_row_bcast_f64<kk>(Lr[kk], Lr[jj], Lr[jj]);
+      else if constexpr (kk > jj + 1) Lr[kk] = fnma_row_bcast_f64_settled<kk>(Lr[kk], Lr[jj], Lr[jj]);
     });
   });
   if (tid < 16) rv[tid] = myri;
@@ -1042,11 +1051,30 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   auto factor_diag = [&](int c0_, int nb_) {
       const int j = tid & 15;
       double Lr[16];
+      if (nb_ == 16) {
+        // a full block: whole rows as eight ds_read_b128 — no masks, the entries right of the diagonal are the zeros the assembly wrote
+        // (rows 912 bytes apart land on distinct banks; the wave's four 16-lane rows read the same addresses)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? S[(size_t)(c0_ + j) * n + c0_ + i] : 0.0;   // (rows >= nb_ take no pivot step: chol16_rows_dpp; a 1.0 on their diagonal was 16 loop-invariant constants held in — and spilled from — registers)
+        for (int i = 0; i < 16; i += 2) {
+          const double2_t p2 = *(const double2_t*)&S[(size_t)(c0_ + j) * n + c0_ + i];
+          Lr[i] = p2[0]; Lr[i + 1] = p2[1];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? S[(size_t)(c0_ + j) * n + c0_ + i] : 0.0;   // (rows >= nb_ take no pivot step: chol16_rows_dpp; a 1.0 on their diagonal was 16 loop-invariant constants held in — and spilled from — registers)
+      }
+      SOLVE_STAMP(8);
       const int good = chol16_rows_dpp(Lr, nb_, tid, s_rv);
+      SOLVE_STAMP(9);
       if (tid == 0 && !good) s_ok = 0;
-      if (good && tid < nb_) {
+      if (good && nb_ == 16) {
+        // (the registers right of the diagonal hold the mirror entries' updates by now: zeros go back, the backward substitution counts on them)
+        if (tid < 16) {
+#pragma unroll
+          for (int i = 0; i < 16; i += 2)
+            *(double2_t*)&S[(size_t)(c0_ + j) * n + c0_ + i] = double2_t{i <= j ? Lr[i] : 0.0, i + 1 <= j ? Lr[i + 1] : 0.0};
+        }
+      } else if (good && tid < nb_) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) if (i <= j) S[(size_t)(c0_ + j) * n + c0_ + i] = Lr[i];
       }
@@ -1148,7 +1176,9 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
           if (row < n && col <= row) S[(size_t)row * n + col] -= acc[q];
         }
       }
+      SOLVE_STAMP(7);
       if (tid < 64) factor_diag(c1, min(16, n - c1));                          // (same wave wrote the tile: no barrier in between)
+      SOLVE_STAMP(10);
     }
   }
   __syncthreads();

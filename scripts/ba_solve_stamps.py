@@ -17,8 +17,9 @@ for _ in range(3):
 L.orbx_debug_solve_stamps(buf, 0)
 n = buf[15]
 names = ["assemble S, b, |g|", "wait at the panel's top barrier (= trailing update)", "diagonal block factor (wave 0)", "row solves + right-hand side",
-         "last update + exit", "backward substitution", "dp, norms"]
-tot = sum(buf[i] for i in range(7))
+         "last update + exit", "backward substitution", "dp, norms", "  wave 0: b_below + its tile of the update", "  wave 0: diagonal block from LDS",
+         "  wave 0: the 16 pivot steps", "  wave 0: diagonal block to LDS"]
+tot = sum(buf[i] for i in range(11))
 print("solves %d, ticks per solve %.0f" % (n, tot / n))
-for i in range(7):
+for i in range(11):
     print("  %-52s %8.0f  %5.1f %%" % (names[i], buf[i] / n, 100.0 * buf[i] / tot))
