@@ -9,17 +9,18 @@
 // Six launches per LM iteration (every block derives the keyframe rotations it needs itself):
 //
 //   ba_build_kernel      one 32- or 16-lane group per map point: residual + Jacobian blocks of its
-//                        observations, V_j = sum B^T B, g_l, damped inverse V*_j^-1, V*_j^-1 g_l, and W = A^T B per
-//                        observation (oW [N][18]: the only per-observation block that is stored — the dense operands of
-//                        the Schur product exist only as LDS tiles filled from it)
-//   ba_kf_schur_kernel   keyframe partials (U_k = sum A^T A, g_p, b_red = sum A^T (B V*^-1 g_l), fixed summation order; residual
-//                        and Jacobian blocks RECOMPUTED per observation from (point, the block's pose, uv)) and, in the
-//                        same launch, S_red = Y^T W ((6K x 3M) x (3M x 6K)) on v_mfma_f64_16x16x4_f64: a block owns a
-//                        (128-column block pair, k-split), fills 24-row operand tiles in LDS from oW and V*^-1 and
+//                        observations, V_j = sum B^T B, g_l, damped inverse V*_j^-1, V*_j^-1 g_l; per observation only six
+//                        numbers are stored (oP [N][6] = x, y, 1/z, sqrt w, r0, r1: 48 B) — A, B and W = A^T B are rebuilt
+//                        from them where they are needed, without a division or a square root
+//   ba_kf_schur_kernel   keyframe partials (U_k = sum A^T A, g_p, b_red = sum A^T (B V*^-1 g_l), fixed summation order) and, in
+//                        the same launch, S_red = Y^T W ((6K x 3M) x (3M x 6K)) on v_mfma_f64_16x16x4_f64: a block owns a
+//                        (128-column block pair, k-split), fills 24-row operand tiles in LDS (W from oP, Y = W V*^-1) and
 //                        accumulates its upper 16x16 tiles in registers — the one dense contraction of the path
+//                        (in a batch: ba_kf_kernel and ba_schur_kernel, their own launches)
 //   ba_gather_kernel     fixed-order reduction of the split-K and keyframe-split partials
 //   ba_solve_lds_kernel  one workgroup: S = U* - S_red in LDS, blocked right-looking Cholesky (diagonal blocks by DPP row_newbcast
-//                        in wave 0, look-ahead inside the MFMA trailing update, forward substitution inside the panels), delta_p
+//                        in wave 0, look-ahead inside the MFMA trailing update, column-oriented row solves with the right-hand
+//                        side as one more row), branch-free backward substitution over the zeroed upper triangle, delta_p
 //                        (n > 135: ba_big_assemble + one ba_big_step_kernel per panel + ba_big_back_kernel, S in global memory)
 //   ba_backsub_kernel    delta_l = V*^-1 (-g_l - W^T delta_p), trial parameters and trial residuals
 //   ba_decide_kernel     sums, accept / reject, lambda, stop tests — the LM state lives on the device
