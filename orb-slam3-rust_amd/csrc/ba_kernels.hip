@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict_
   const size_t nn = (size_t)n * n;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   // S_red = sum of the k-split partials, upper triangle computed, mirrored on store.  Four lanes per element: each adds a
-  // quarter of the k-splits in order (eight loads in flight), then ((q0 + q1) + (q2 + q3)) — a fixed tree, the same for every
+  // quarter of the k-splits in order (sixteen or eight loads in flight), then ((q0 + q1) + (q2 + q3)) — a fixed tree, the same for every
   // launch shape.  (One lane per element walked 40-80 dependent-latency loads: a quarter of a batch's iteration.)
   const int ksq = (d.ksplit + 3) >> 2;
   const int qd = threadIdx.x & 3;
@@ -827,6 +827,13 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict_
       const int tile = ti * d.ntile - ti * (ti - 1) / 2 + (tj - ti);
       const double* p = part + (size_t)tile * d.ksplit * 256 + (i & 15) * 16 + (j & 15);
       int ks = k_lo;
+      for (; ks + 16 <= k_hi; ks += 16) {                                  // (a 2000-point window: 16 k-splits per lane — one round trip, not two)
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = p[(size_t)(ks + q) * 256];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += v[q];
+      }
       for (; ks + 8 <= k_hi; ks += 8) {
         double v[8];
 #pragma unroll
@@ -1342,8 +1349,9 @@ __global__ __launch_bounds__(256) void ba_big_assemble_kernel(const BaWin* __res
 constexpr int BB_STEP_THREADS = 256;
 constexpr int BB_COL_TILES = (BA_MAX_N / 16 + 3) / 4;      // column tiles per wave of the panel block, all in flight at once
 __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWin* __restrict__ wins, int c0) {
-  __shared__ double D[BB_NB][BB_NB + 1];
-  __shared__ double rinv[BB_NB], ys[BB_NB];
+  __shared__ __align__(16) double D[BB_NB][BB_NB + 2];                    // (even pitch: the row solves read L11 in pairs)
+  __shared__ __align__(16) double rinv[BB_NB];
+  __shared__ double ys[BB_NB];
   __shared__ int s_ok;
   const BaWin& win = wins[blockIdx.y];
   const int n = win.n;
@@ -1439,12 +1447,16 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
     if (i < nb && j <= i) D[i][j] = Sg[(size_t)(c0 + i) * n + c0 + j];
   }
   __syncthreads();                                                         // the column block and the right-hand side are up to date (block scope)
-  // rows below the block: their 16 entries are final now; request them before the factor so that they travel under it
+  // rows below the block: their 16 entries are final now; request them before the factor so that they travel under it.  Row n = the
+  // right-hand side (its 16 entries of this panel): one more row of the same solve (a full panel; the short last one has no rows below
+  // and solves its right-hand side on its own further down)
   const int r0 = c0 + BB_NB + tid;
+  const bool rows_here = nb == BB_NB;
   double xr[BB_NB];
-  if (r0 < n) {
+  if (rows_here && r0 <= n) {
+    const double* src = r0 < n ? Sg + (size_t)r0 * n + c0 : bvec + c0;
 #pragma unroll
-    for (int j = 0; j < BB_NB; ++j) xr[j] = Sg[(size_t)r0 * n + c0 + j];
+    for (int j = 0; j < BB_NB; ++j) xr[j] = src[j];
   }
   if (tid < 64) {
     const int j = tid & 15;
@@ -1464,35 +1476,49 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
   __syncthreads();
   if (!s_ok) { if (tid == 0) res[2] = 0.0; return; }
   if (tid < nb) ginv[c0 + tid] = rinv[tid];
-  if (tid == BB_STEP_THREADS - 1) {                                        // y of this panel: L11 y = b, entry by entry
-    double x[BB_NB];
+  if (!rows_here) {
+    if (tid == BB_STEP_THREADS - 1) {                                      // the short last panel: y of this panel, L11 y = b, entry by entry
+      double x[BB_NB];
 #pragma unroll
-    for (int jx = 0; jx < BB_NB; ++jx) x[jx] = jx < nb ? bvec[c0 + jx] : 0.0;
+      for (int jx = 0; jx < BB_NB; ++jx) x[jx] = jx < nb ? bvec[c0 + jx] : 0.0;
 #pragma unroll
-    for (int jx = 0; jx < BB_NB; ++jx) {
-      if (jx < nb) {
-        double v = x[jx];
+      for (int jx = 0; jx < BB_NB; ++jx) {
+        if (jx < nb) {
+          double v = x[jx];
 #pragma unroll
-        for (int t = 0; t < jx; ++t) v = fma(-D[jx][t], x[t], v);
-        x[jx] = v * rinv[jx];
+          for (int t = 0; t < jx; ++t) v = fma(-D[jx][t], x[t], v);
+          x[jx] = v * rinv[jx];
+        }
       }
-    }
 #pragma unroll
-    for (int jx = 0; jx < BB_NB; ++jx) if (jx < nb) bvec[c0 + jx] = x[jx];
+      for (int jx = 0; jx < BB_NB; ++jx) if (jx < nb) bvec[c0 + jx] = x[jx];
+    }
+    return;
   }
-  // rows below the block: x = a L11^-T
-  for (int r = r0; r < n; r += BB_STEP_THREADS) {
-    double* row = Sg + (size_t)r * n + c0;
+  // rows below the block (and the right-hand side): x = a L11^-T, column oriented as in ba_solve_lds_kernel — once x_t is final every
+  // later entry takes its term, per entry the same fma sequence as a row-oriented substitution; L11 in pairs from LDS
+  for (int r = r0; r <= n; r += BB_STEP_THREADS) {
+    double* row = r < n ? Sg + (size_t)r * n + c0 : bvec + c0;
     if (r != r0) {
 #pragma unroll
       for (int j = 0; j < BB_NB; ++j) xr[j] = row[j];
     }
 #pragma unroll
-    for (int j = 0; j < BB_NB; ++j) {
-      double v = xr[j];
+    for (int t = 0; t < BB_NB; t += 2) {
+      double la[BB_NB], lb[BB_NB];                                           // L[jx][t], L[jx][t + 1] for jx > t
 #pragma unroll
-      for (int t = 0; t < j; ++t) v = fma(-xr[t], D[j][t], v);
-      xr[j] = v * rinv[j];
+      for (int jx = t + 1; jx < BB_NB; ++jx) {
+        const double2_t p2 = *(const double2_t*)&D[jx][t];
+        la[jx] = p2[0]; lb[jx] = p2[1];
+      }
+      const double2_t q2 = *(const double2_t*)&rinv[t];
+      xr[t] = xr[t] * q2[0];
+#pragma unroll
+      for (int jx = t + 1; jx < BB_NB; ++jx) xr[jx] = fma(-xr[t], la[jx], xr[jx]);
+      xr[t + 1] = xr[t + 1] * q2[1];
+#pragma unroll
+      for (int jx = t + 2; jx < BB_NB; ++jx) xr[jx] = fma(-xr[t + 1], lb[jx], xr[jx]);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < BB_NB; ++j) row[j] = xr[j];
@@ -1545,18 +1571,23 @@ __global__ __launch_bounds__(256) void ba_big_back_kernel(const BaWin* __restric
       d_next = block_elem(c0 - BB_NB); g_next = inv_elem(c0 - BB_NB);
       __syncthreads();
       if (tid < 64) {                                  // wave 0: lane j owns column j of the block (= row j of L^T)
+        // step i: x_i = v_i / L_ii reaches every lane by a readlane pair, v_j -= L_ij x_i for j < i.  As in ba_solve_lds_kernel the step is
+        // multiply, two readlanes, fma and nothing else: entries with j >= i are zeros in Lc (so the fma leaves those lanes alone), lane i
+        // keeps v_i and is scaled once at the end by the same 1 / L_ii, which every lane applies to its own entry before the readlane
+        // picks lane i's (until round 3: a select, two exec-mask regions and an LDS read of 1 / L_ii per step).
         const int j = tid & 15;
         double Lc[BB_NB];
 #pragma unroll
         for (int i = 0; i < BB_NB; ++i) Lc[i] = (i < nb && i > j) ? Dg[i][j] : 0.0;
         double v = j < nb ? sb[c0 + j] : 0.0;
+        const double gj = j < nb ? gi[j] : 0.0;
 #pragma unroll
         for (int i = BB_NB - 1; i >= 0; --i) {
-          if (i < nb) {                                // uniform
-            const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i)) * gi[i];
-            if (j == i) v = xi; else if (j < i) v = fma(-Lc[i], xi, v);
-          }
+          const double t = v * gj;
+          const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), i), __builtin_amdgcn_readlane(__double2loint(t), i));
+          v = fma(-Lc[i], xi, v);                      // (steps i >= nb: Lc = 0 and t = 0)
         }
+        v = v * gj;
         if (tid < nb) { y[tid] = v; sb[c0 + tid] = v; }
       }
       __syncthreads();
@@ -1759,6 +1790,10 @@ __global__ __launch_bounds__(256) void ba_sum3_kernel(const BaWin* __restrict__ 
   if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
 }
 
+// (Taking this decision in the LAST block of the back-substitution launch — every block counts itself on a device-scope atomic, the one that
+// sees all others counted reads their per-point sums — was built and passed every test, and cost 25 us per launch for one window, 117 us for
+// 32: the results of the other blocks sit in the L2s of other XCDs, and the __threadfence() that makes them visible device-wide is an L2
+// write-back per block.  A kernel boundary does that once.  7.5 us for this launch it is.)
 // The tail of one LM iteration, local_ba_lm.rs:1022-1055, on the device.  res: [0] chi2(cur) [1] |g| [2] chol ok
 // [3] |dp|^2 [4] |p_pose|^2 [5] chi2(trial) [6] |dl|^2 [7] |p_points|^2.
 // With M >= 0 the kernel first forms res[5..7] itself — the fixed-order sums of the per-point chi2(trial), |delta_l|^2 and
