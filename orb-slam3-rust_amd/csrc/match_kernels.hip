@@ -131,27 +131,55 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
   const int* bs = bstart + (size_t)pair * (SB_ROWS + 1);
   const int* si = sidx + (size_t)pair * cap;
   const float2* sx = sxy + (size_t)pair * cap;
-#pragma unroll 1
-  for (int q = 0; q < SM_LEFT_PER_WAVE; q += 4) {
-    const int li = blockIdx.x * SM_LEFT_PER_BLOCK + wave * SM_LEFT_PER_WAVE + q + grp;
-    if (li >= nL) return;                                                    // uniform over the 16-lane group
-    const float ul = kpL[li].x, vl = kpL[li].y;
+  // The kernel is a chain of dependent memory round trips per left keypoint (keypoint -> row buckets -> candidate position -> its index
+  // -> its descriptor), a few dozen waves per SIMD living through it one after the other: what it costs is the LENGTH of that chain.
+  // So: the keypoints, descriptors and bucket bounds of ALL of a wave's rounds are requested before the first is used; a candidate's
+  // index travels with its position (both are functions of t), not after the gates; and two candidates per lane (t, t + 16) are in
+  // flight at a time, their descriptors requested together.  (Round 2's form took 8 round trips per round of 4 keypoints, two rounds
+  // per wave in turn: 0.130 ms per 256 pairs.)
+  constexpr int NR = SM_LEFT_PER_WAVE / 4;
+  if (nL <= 0) return;
+  int li_[NR]; bool live[NR]; float ul_[NR], vl_[NR]; Desc256 dl_[NR]; int lo_[NR], hi_[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    li_[r] = blockIdx.x * SM_LEFT_PER_BLOCK + wave * SM_LEFT_PER_WAVE + 4 * r + grp;
+    live[r] = li_[r] < nL;                                                   // uniform over the 16-lane group
+    const int lc = live[r] ? li_[r] : 0;
+    ul_[r] = kpL[lc].x; vl_[r] = kpL[lc].y;
+    dl_[r] = load_desc(dL + (size_t)lc * 32);
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int rb = row_bucket(vl_[r]);
+    lo_[r] = bs[max(rb - 3, 0)]; hi_[r] = live[r] ? bs[min(rb + 3, SB_ROWS - 1) + 1] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const float ul = ul_[r], vl = vl_[r];
     const float min_u = fmaxf(ul - max_disp, 0.0f);                          // stereo.rs:100
     const float lim = ((float)nR * ul) / (float)nL;                          // stereo.rs:102
     const float max_u = fminf(ul - min_disp, lim);                           // stereo.rs:101
-    const Desc256 dl = load_desc(dL + (size_t)li * 32);
-    const int rb = row_bucket(vl);
-    const int lo = bs[max(rb - 3, 0)], hi = bs[min(rb + 3, SB_ROWS - 1) + 1];
+    const int hi = hi_[r];
     unsigned b = TH_HIGH, s = TH_HIGH;
     int bi = 0x7fffffff;
-    for (int t = lo + gl; t < hi; t += 16) {
-      const float2 r = sx[t];
-      if (fabsf(vl - r.y) > 2.0f) continue;                                  // stereo.rs:117
-      if (r.x < min_u || r.x > max_u) continue;                              // stereo.rs:122
-      if (ul <= r.x) continue;                                               // stereo.rs:127
-      const int ri = si[t];
-      const unsigned d = hamming(dl, load_desc(dR + (size_t)ri * 32));      // stereo.rs:132-133
-      if (d < TH_HIGH) push_top2(b, bi, s, d, ri);                           // :135-141 (d >= 100 never enters)
+    auto gates = [&](const float2& rr) -> bool {
+      return !(fabsf(vl - rr.y) > 2.0f) &&                                   // stereo.rs:117
+             !(rr.x < min_u || rr.x > max_u) &&                              // stereo.rs:122
+             !(ul <= rr.x);                                                  // stereo.rs:127
+    };
+    for (int t = lo_[r] + gl; t < hi; t += 32) {
+      const int t2 = t + 16;
+      const bool in2 = t2 < hi;
+      const float2 r1 = sx[t];
+      const int i1 = si[t];
+      const float2 r2 = sx[in2 ? t2 : t];
+      const int i2 = si[in2 ? t2 : t];
+      const bool p1 = gates(r1), p2 = in2 && gates(r2);
+      Desc256 d1, d2;
+      if (p1) d1 = load_desc(dR + (size_t)i1 * 32);
+      if (p2) d2 = load_desc(dR + (size_t)i2 * 32);
+      if (p1) { const unsigned d = hamming(dl_[r], d1); if (d < TH_HIGH) push_top2(b, bi, s, d, i1); }   // stereo.rs:132-141 (d >= 100 never enters)
+      if (p2) { const unsigned d = hamming(dl_[r], d2); if (d < TH_HIGH) push_top2(b, bi, s, d, i2); }
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {                                 // xor < 16 stays inside the group
@@ -160,10 +188,10 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
       const unsigned os = __shfl_xor(s, off);
       merge_top2(b, bi, s, ob, obi, os);
     }
-    if (gl == 0) {
+    if (gl == 0 && live[r]) {
       const bool has = bi != 0x7fffffff;
       const bool emit = has && (((float)b < 0.9f * (float)s) || s == TH_HIGH);   // stereo.rs:145-148
-      tmp[(size_t)pair * cap + li] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
+      tmp[(size_t)pair * cap + li_[r]] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
     }
   }
 }
