@@ -2360,8 +2360,28 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   mark(1);
   // ---- host preprocessing, one window per task (threads when the batch is large enough to pay for them)
   std::vector<int> bad(W, -1);
+  std::atomic<int> up_failed{0};
+  bool piecewise = false;                                                  // windows uploaded one by one by the preprocessing workers
   {
-    auto work = [&](int w) { if (!plan[w].skip) bad[w] = prep_window(win[w], plan[w], hin, inertial, inr); };
+    // A window's task: its LM state and its preprocessed arrays into its own region of the pinned blob and — when the tasks run on the
+    // handle's workers — that region's upload enqueued by the worker itself the moment it is written, so that the copy engine works
+    // through the first windows while the last are still being sorted (the single 34 MB copy of a 32-window batch used to start only
+    // after all preprocessing: 0.4 ms of a 4.7 ms call with the GPU idle).  The stream takes the copies in whatever order they arrive;
+    // everything that reads them is enqueued by this thread after the workers are done.
+    auto work = [&](int w) {
+      const WinPlan& pl = plan[w];
+      BaState& s0 = *(BaState*)(hin + pl.i_state);
+      memset(&s0, 0, sizeof(s0));
+      s0.lambda = inertial ? inr->cfg->initial_lambda : 1e-3;            // :1006-1010 / local_inertial_ba.rs:1195
+      s0.gtol = inertial ? 1e-8 : cfg->gradient_tolerance;              // local_inertial_ba.rs:1213
+      s0.ptol = inertial ? 0.0 : cfg->param_tolerance;                  // the inertial loop has no step-size test
+      s0.done = pl.skip;                                                 // a window the reference answers None for (:923-925) never runs
+      if (!pl.skip) bad[w] = prep_window(win[w], pl, hin, inertial, inr);
+      if (piecewise) {
+        const size_t lo = pl.i_state, hi = w + 1 < W ? plan[w + 1].i_state : cin.off;
+        if (hipSetDevice(h->device) != hipSuccess || hipMemcpyAsync(din + lo, hin + lo, hi - lo, hipMemcpyHostToDevice, st) != hipSuccess) up_failed.store(1);
+      }
+    };
     size_t total_obs = 0;
     for (int w = 0; w < W; ++w) total_obs += (size_t)win[w].N;
     int nthr = (int)std::min<size_t>({(size_t)W, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, total_obs / 20000 + 1});
@@ -2370,8 +2390,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       try { h->ba_pool = new OrbxWorkPool((int)std::min<size_t>(15, std::max(1u, std::thread::hardware_concurrency()) - 1)); }
       catch (...) { h->ba_pool = nullptr; }                              // no workers: this thread does it all
     }
-    if (nthr <= 1 || !h->ba_pool) { for (int w = 0; w < W; ++w) work(w); }
+    piecewise = nthr > 1 && h->ba_pool != nullptr;
+    if (!piecewise) { for (int w = 0; w < W; ++w) work(w); }
     else if (!h->ba_pool->run(W, nthr - 1, work)) return orbx_fail(h, ORBX_ERR_HIP, "batch preprocessing: out of host memory");
+    if (up_failed.load()) return orbx_fail(h, ORBX_ERR_HIP, "batch upload failed: %s", hipGetErrorString(hipGetLastError()));
   }
   mark(2);
   int first_bad = -1;
@@ -2411,13 +2433,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.Sg = b.dp + ((pl.n + 15) & ~15); b.bvec = b.Sg + (size_t)pl.n * pl.n; b.ginv = b.bvec + pl.n;
     b.res = (double*)(dar + pl.a_res);
     hoff[w] = pl.o_out / 8;
-    BaState& s0 = *(BaState*)(hin + pl.i_state);
-    memset(&s0, 0, sizeof(s0));
-    s0.lambda = inertial ? inr->cfg->initial_lambda : 1e-3;            // :1006-1010 / local_inertial_ba.rs:1195
-    s0.gtol = inertial ? 1e-8 : cfg->gradient_tolerance;              // local_inertial_ba.rs:1213
-    s0.ptol = inertial ? 0.0 : cfg->param_tolerance;                  // the inertial loop has no step-size test
-    s0.done = pl.skip;                                                 // a window the reference answers None for (:923-925) never runs
-    if (pl.skip) continue;
+    if (pl.skip) continue;                                             // (its LM state says done: set with the window's preprocessing)
     if (pl.use_lds && !inertial) { any_lds = 1; lds_max = std::max(lds_max, pl.lds_need); }
     else if (!inertial) { any_big = 1; n_big_max = std::max(n_big_max, pl.n); }
     maxM = std::max(maxM, pl.d.M); maxK = std::max(maxK, pl.d.K);
@@ -2459,7 +2475,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b15.Sg = dp15 + ((n15 + 15) & ~15); b15.bvec = b15.Sg + (size_t)n15 * n15; b15.ginv = b15.bvec + n15;
     gfull = b15.ginv + n15;
   }
-  ORBX_HIP(h, hipMemcpyAsync(din, hin, cin.off, hipMemcpyHostToDevice, st));         // ONE upload for the whole batch
+  // the window descriptors (and, unless the workers already sent them, the windows): one upload
+  ORBX_HIP(h, hipMemcpyAsync(din, hin, piecewise ? plan[0].i_state : cin.off, hipMemcpyHostToDevice, st));
   mark(3);
   {
     static std::once_flag once[64];                                    // process-wide function attribute: set once per device to

@@ -279,6 +279,35 @@ def test_ba_batch_two_streams_path(gpu_handle, pkg):
     assert np.array_equal(again[17]["poses_wc"], batch[17]["poses_wc"])
 
 
+def test_ba_two_handles_two_host_threads(gpu_handle, pkg):
+    """Two handles driven by two host threads at once (each a batch of 16 windows: its own stream, workspaces, persistent
+    preprocessing workers and internal two-stream split), three rounds: every window equals the result of the same batch solved alone."""
+    import threading
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
+    shapes = [(20, 700), (9, 300), (14, 520), (6, 150)]
+    batches = [[pkg.synth.ba_window(1200 + 40 * b + i, *shapes[(i + b) % 4], pkg.BA_OBS) for i in range(16)] for b in range(2)]
+    want = [gpu_handle.ba_solve_visual_batch(cam, cfg, ws) for ws in batches]
+    handles = [pkg.Handle(cam, 100) for _ in range(2)]
+    try:
+        for _ in range(3):
+            got = [None, None]; err = []
+
+            def run(k):
+                try:
+                    got[k] = handles[k].ba_solve_visual_batch(cam, cfg, batches[k])
+                except Exception as e:       # noqa: BLE001 - reported below
+                    err.append(e)
+            th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+            [t.start() for t in th]; [t.join() for t in th]
+            assert not err, err
+            for k in range(2):
+                for a, b in zip(got[k], want[k]):
+                    assert a["iterations"] == b["iterations"] and np.array_equal(a["poses_wc"], b["poses_wc"]) and np.array_equal(a["points"], b["points"])
+    finally:
+        for h in handles:
+            h.close()
+
+
 def test_ba_batch_abort(gpu_handle, pkg):
     cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
     wins = [pkg.synth.ba_window(400 + i, 5, 80, pkg.BA_OBS) for i in range(3)]
