@@ -625,135 +625,219 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
 }
 
 #ifdef ORBX_SCHUR_STAMPS
-// debug build only (-DORBX_SCHUR_STAMPS, scripts/ba_schur_stamps.py): s_memtime ticks per phase of ba_schur_diag_body, wave 0 of every block, summed
-__device__ unsigned long long g_schur_stamps[8];
-#define SCHUR_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_schur_stamps[k], now_ - t_prev_); t_prev_ = now_; } } while (0)
-extern "C" int orbx_debug_schur_stamps(unsigned long long* out8, int reset) {
-  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_schur_stamps), 64) != hipSuccess) return -1;
-  if (reset) { const unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_schur_stamps), z, 64) != hipSuccess) return -1; }
+// debug build only (-DORBX_SCHUR_STAMPS, scripts/ba_schur_stamps.py): s_memtime ticks per phase of the consumer wave 0 of every ba_schur_diag_ws_body workgroup, summed; [6] = the same span in s_memrealtime ticks (100 MHz), [7] = workgroups
+__device__ unsigned long long g_schur_stamps[16];
+#define SCHUR_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc_[k] += now_ - t_prev_; t_prev_ = now_; } while (0)   /* per-thread sums, flushed once at the end: an atomic per stamp distorted what it measured */
+#define SCHUR_STAMP_FLUSH(a, b) do { if (threadIdx.x == 0 || threadIdx.x == 256) for (int k_ = (a); k_ < (b); ++k_) atomicAdd(&g_schur_stamps[k_], st_acc_[k_]); } while (0)
+extern "C" int orbx_debug_schur_stamps(unsigned long long* out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_schur_stamps), 128) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; z[2] = ~0ull; if (hipMemcpyToSymbol(HIP_SYMBOL(g_schur_stamps), z, 128) != hipSuccess) return -1; }
   return 0;
 }
 #else
 #define SCHUR_STAMP(k) do { } while (0)
+#define SCHUR_STAMP_FLUSH(a, b) do { } while (0)
 #endif
-// The same product for windows whose reduced system fits ONE 128-column block (K <= 21 optimised keyframes: every local-BA
-// window of the reference, max_covisible_keyframes = 20): only the diagonal block pair exists, so
-//   - a wave's 9 upper tiles share 9 accumulators: slot c holds tile (q, c) for c >= q and tile (7-q, 7-c) for c < q, the ninth
-//     the diagonal tile (7-q, 7-q) — 72 registers instead of the 128 of the general body;
-//   - every thread fills at most one (point, keyframe) slot, and the registers saved hold the NEXT tile's W block and V*^-1,
-//     fetched before the MFMA phase of the current tile: the two dependent memory round trips of a fill (slot -> W) hide
-//     behind the matrix instructions instead of standing between them.
-// Same operands, same k order, same v_mfma_f64_16x16x4_f64 sequence per tile as ba_schur_body: bit-identical partials.
-__device__ __forceinline__ void ba_schur_diag_body(int bx, const BaWin& win, const BaCam& cam, double* __restrict__ sY, double* __restrict__ sW) {
+// The same product for windows whose reduced system fits ONE 128-column block (K <= 21 optimised keyframes: every local-BA window of
+// the reference, max_covisible_keyframes = 20): only the diagonal block pair exists, so a wave's 9 upper tiles share 9 accumulators —
+// slot c holds tile (q, c) for c >= q and tile (7-q, 7-c) for c < q, the ninth the diagonal tile (7-q, 7-q): 72 registers instead of the
+// 128 of the general body — and every slot thread fills at most one (point, keyframe) slot per tile.
+// PRODUCER and CONSUMER waves of one 512-thread workgroup per CU: waves 4-7 build tile T + 1 (the slot's W = A^T B from its 32 stored
+// bytes, Y = W V*^-1; the slot index fetched two tiles ahead, the stored numbers one) into the second of two LDS buffers while waves 0-3
+// run the 54 MFMAs of tile T out of the first — one barrier per tile — and a workgroup walks `spb` consecutive k-splits (one for a
+// single window, enough in a batch that the launch is one workgroup per CU), writing each split's partial in its own slot.  Same slots,
+// same operands, same k order, same v_mfma_f64_16x16x4_f64 sequence per tile as ba_schur_body: bit-identical partials.
+// What it bought and what it showed (phase stamps of a consumer and a producer wave, scripts/ba_schur_stamps.py): one window 23.5 ->
+// 18.3 us per fused launch (its 63 workgroups own a CU each either way; the prologue and the fill left the consumers' path).  The
+// 32-window launch stayed at 117-118 us, and the stamps say why: per tile a consumer wave spends 3.56 k cycles in its 54 MFMAs — 64
+// cycles each: the matrix pipe is saturated for the length of the phase — and then waits 3.1 k cycles at the barrier for its SIMD's
+// producer wave, which needed 5.6 k cycles for a tile of ~280 instructions: 3.5 k of them standing still while the MFMAs ran, the rest
+// once they had finished.  f64 VALU instructions and f64 MFMAs do not execute side by side on a SIMD — MI355X quotes the same 78.6
+// TFLOP/s for vector and matrix f64: one double-precision datapath — so the fill's arithmetic serialises with the matrix instructions
+// whichever wave issues it, and a tile costs the SIMD 3.5 k (MFMA) + ~2 k (fill) + barrier and store ≈ 9 k cycles in this body and in
+// its predecessor (fill -> barrier -> MFMA -> barrier in the same four waves, two workgroups per CU) alike.  The clock stays at
+// 2.25 GHz throughout (s_memtime against s_memrealtime inside the kernel).  Neither a second register set of slot data (numbers two
+// tiles ahead) nor halving the producers' instruction stream moved the launch: 39 % of the f64 MFMA peak is what a product whose
+// operands take a third as much f64 arithmetic to BUILD as to multiply can reach on this datapath; the remaining lever is the
+// arithmetic of the fill itself.
+template <int Q>
+__device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const double* __restrict__ lds, int ks0, int nT, int tps) {
   const BaDims& d = win.d;
-  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;       // wave q owns tile rows q and 7 - q
-  if (bx >= d.ksplit) return;
+  constexpr int TILE = SCH_R * SCH_PITCH;
+  const int lane = threadIdx.x & 63;
 #ifdef ORBX_SCHUR_STAMPS
-  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0};
+  const unsigned long long t_real0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int ks = bx, j_begin = ks * d.pps;
-  const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv;
-  const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
-  constexpr int NPT = SCH_R / 3;
-  const int pj = tid / 23, k = tid - pj * 23;                        // this thread's slot: point j0 + pj, keyframe k (columns 6k .. 6k+5)
-  const bool slot = pj < NPT && k < d.K && 6 * k < 128;
   double4_t acc[8], accx = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
-  for (int u = tid; u < 2 * SCH_R * SCH_PITCH; u += 256) sY[u] = 0.0;   // columns past 6K stay zero (sW follows sY)
-  double pq[4], I[9], Rk[12];                                       // the next tile's observation (x, y, 1/z, sqrt w) and V*^-1; this thread's keyframe
-  bool have = false;
-#pragma unroll
-  for (int t = 0; t < 12; ++t) Rk[t] = slot ? win.Rt_cur[12 * (size_t)k + t] : 0.0;
-  int nxt_chain = -1;
-  auto slot_of = [&](int j0) -> int {                               // first observation of (point j0 + pj, keyframe k), or -1
-    const int j = j0 + pj;
-    return (slot && j < d.M && j0 < j_begin + d.pps) ? slot_first[(size_t)j * d.K + k] : -1;
+  // this wave's nine partial tiles: element offsets inside a k-split's 256-double tile slots (tile index x ksplit x 256), or -1
+  const int lofs = ((lane >> 4)) * 16 + (lane & 15);
+  auto tile_of = [&](int ti, int tj) -> long long {
+    if (ti >= d.ntile || tj >= d.ntile) return -1;
+    return (long long)(ti * d.ntile - ti * (ti - 1) / 2 + (tj - ti)) * d.ksplit * 256 + lofs;
   };
-  auto fetch = [&](int j0, int i) {                                 // the slot's stored numbers (32 B; until round 3 its W block, 144 B) and V*^-1 -> registers
-    const int j = j0 + pj;
-    have = i >= 0;
+  long long tofs[9];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) pq[t] = i >= 0 ? oP[6 * (size_t)i + t] : 0.0;
+  for (int c = 0; c < 8; ++c) tofs[c] = c >= Q ? tile_of(Q, c) : tile_of(7 - Q, 7 - c);
+  tofs[8] = tile_of(7 - Q, 7 - Q);
+  auto store = [&](int ks, long long o, const double4_t& v) {
+    if (o < 0) return;
+    double* p = win.part + o + (size_t)ks * 256;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) I[t] = (slot && j < d.M) ? Vinv[9 * (size_t)j + t] : 0.0;
-    nxt_chain = i >= 0 ? obs_next[i] : -1;
+    for (int r = 0; r < 4; ++r) p[64 * r] = v[r];                    // rows (lane >> 4) + 4 r of the tile
   };
-  // the slot index runs TWO tiles ahead, the W block one: neither of the two dependent loads is waited for where it is issued
-  fetch(j_begin, slot_of(j_begin));
-  int i_next = slot_of(j_begin + NPT);
+  __syncthreads();                                                    // zero fill done
+  __syncthreads();                                                    // tile 0 is in buffer 0
   SCHUR_STAMP(0);
-  for (int j0 = j_begin; j0 < j_begin + d.pps; j0 += NPT) {
-    __syncthreads();                                                // the previous tile has been consumed (first pass: zero fill done)
+  for (int T = 0; T < nT; ++T) {
+    const double* __restrict__ sY = lds + (size_t)(T & 1) * 2 * TILE;
+    const double* __restrict__ sW = sY + TILE;
+#pragma unroll
+    for (int kq = 0; kq < SCH_R / 4; ++kq) {
+      const int row = 4 * kq + (lane >> 4);
+      const double a0 = sY[row * SCH_PITCH + Q * 16 + (lane & 15)];
+      const double a1 = sY[row * SCH_PITCH + (7 - Q) * 16 + (lane & 15)];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
+        if (c >= Q) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[c], 0, 0, 0);              // tile (Q, c)
+        if (c > 7 - Q) acc[7 - c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[7 - c], 0, 0, 0);  // tile (7-Q, c) in slot 7-c < Q
+        if (c == 7 - Q) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accx, 0, 0, 0);              // tile (7-Q, 7-Q)
+      }
+    }
+    SCHUR_STAMP(4);
+    if ((T + 1) % tps == 0) {                                         // the k-split is complete: its partial out, accumulators cleared
+      const int ks = ks0 + T / tps;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { store(ks, tofs[c], acc[c]); acc[c] = double4_t{0.0, 0.0, 0.0, 0.0}; }
+      store(ks, tofs[8], accx);
+      accx = double4_t{0.0, 0.0, 0.0, 0.0};
+      SCHUR_STAMP(5);
+    }
+    __syncthreads();
     SCHUR_STAMP(1);
-    if (slot) {
+  }
+#ifdef ORBX_SCHUR_STAMPS
+  SCHUR_STAMP_FLUSH(0, 6);
+  if (threadIdx.x == 0) { const unsigned long long t_real1_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_schur_stamps[6], t_real1_ - t_real0_); atomicAdd(&g_schur_stamps[7], 1ull);
+    atomicMin(&g_schur_stamps[2], t_real0_); atomicMax(&g_schur_stamps[3], t_real1_); }   // ([2], [3]: first start / last end of the launches since the reset, 100 MHz)
+#endif
+}
+
+constexpr int SCHW_THREADS = 512;      // 4 consumer + 4 producer waves
+constexpr size_t SCHW_LDS_BYTES = 4 * (size_t)SCH_R * SCH_PITCH * sizeof(double);      // two buffers x (Y, W): 104 448 B
+__device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaWin& win, const BaCam& cam, double* __restrict__ lds) {
+  const BaDims& d = win.d;
+  const int ks0 = bx * spb, ks1 = min(ks0 + spb, d.ksplit);
+  if (ks0 >= d.ksplit) return;                                        // (the whole workgroup, before any barrier)
+  const int tid = threadIdx.x;
+  constexpr int NPT = SCH_R / 3, TILE = SCH_R * SCH_PITCH;
+  const int tps = d.pps / NPT;                                        // tiles per k-split (pps is a multiple of 8)
+  const int nT = (ks1 - ks0) * tps;
+  const int j_begin = ks0 * d.pps;
+  for (int u = tid; u < 4 * TILE; u += SCHW_THREADS) lds[u] = 0.0;    // columns past 6K and slots of absent keyframes stay zero in both buffers
+  if (tid >= 256) {
+#ifdef ORBX_SCHUR_STAMPS
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0};
+#endif
+    // ---- producers: thread f fills slot (point j0 + pj, keyframe k) of every tile.  (Two threads of different waves per slot, one per
+    // half of the keyframe's six columns — 768-thread workgroups, 8 producer waves — measured the same 117 us per 32-window launch as
+    // this form: the producers do not wait for their instruction stream, see the note at the top.)
+    const int f = tid - 256, pj = f / 23, k = f - pj * 23;
+    const bool slot = pj < NPT && k < d.K && 6 * k < 128;
+    const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv;
+    const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
+    // (the slot index runs two tiles ahead, the stored numbers one; a second register set — numbers two tiles ahead — measured no
+    // difference: the producers wait for the double-precision pipe, not for memory)
+    struct SlotData { double pq[4], I[9]; bool have; int chain, idx; } sd;
+    double Rk[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) Rk[t] = slot ? win.Rt_cur[12 * (size_t)k + t] : 0.0;
+    auto slot_of = [&](int T) -> int {                                // first observation of (point of tile T, keyframe k), or -1
+      const int j0 = j_begin + T * NPT, j = j0 + pj;
+      return (slot && T < nT && j < d.M) ? slot_first[(size_t)j * d.K + k] : -1;
+    };
+    auto fetch = [&](SlotData& q, int T) {                             // tile T's stored numbers (32 B) and V*^-1 -> registers, by q.idx
+      const int j = j_begin + T * NPT + pj, i = q.idx;
+      q.have = i >= 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) q.pq[t] = i >= 0 ? oP[6 * (size_t)i + t] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) q.I[t] = (slot && T < nT && j < d.M) ? Vinv[9 * (size_t)j + t] : 0.0;
+      q.chain = i >= 0 ? obs_next[i] : -1;
+    };
+    auto fill = [&](const SlotData& q, double* __restrict__ sY, double* __restrict__ sW) {
+      if (!slot) return;
       double w[18];
-      if (have) obs_w_from_stored<false>(cam, Rk, pq, w);           // W = A^T B of the slot's observation: ~90 multiply-adds, no division
+      if (q.have) obs_w_from_stored<false>(cam, Rk, q.pq, w);         // W = A^T B of the slot's observation: ~90 multiply-adds, no division
       else {
 #pragma unroll
         for (int t = 0; t < 18; ++t) w[t] = 0.0;
       }
-      for (int i = nxt_chain; i >= 0; i = obs_next[i])              // a point seen twice by this keyframe: rare, fetched on the spot
+      for (int i = q.chain; i >= 0; i = obs_next[i])                  // a point seen twice by this keyframe: rare, fetched on the spot
         obs_w_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, w);
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const int col = 6 * k + a;
         if (col >= 128) continue;
         const double w0 = w[a], w1 = w[6 + a], w2 = w[12 + a];
-        sY[(3 * pj + 0) * SCH_PITCH + col] = w0 * I[0] + w1 * I[3] + w2 * I[6];
-        sY[(3 * pj + 1) * SCH_PITCH + col] = w0 * I[1] + w1 * I[4] + w2 * I[7];
-        sY[(3 * pj + 2) * SCH_PITCH + col] = w0 * I[2] + w1 * I[5] + w2 * I[8];
+        sY[(3 * pj + 0) * SCH_PITCH + col] = w0 * q.I[0] + w1 * q.I[3] + w2 * q.I[6];
+        sY[(3 * pj + 1) * SCH_PITCH + col] = w0 * q.I[1] + w1 * q.I[4] + w2 * q.I[7];
+        sY[(3 * pj + 2) * SCH_PITCH + col] = w0 * q.I[2] + w1 * q.I[5] + w2 * q.I[8];
         sW[(3 * pj + 0) * SCH_PITCH + col] = w0; sW[(3 * pj + 1) * SCH_PITCH + col] = w1; sW[(3 * pj + 2) * SCH_PITCH + col] = w2;
       }
-    }
-    SCHUR_STAMP(2);
-    if (j0 + NPT < j_begin + d.pps) { fetch(j0 + NPT, i_next); i_next = slot_of(j0 + 2 * NPT); }   // in flight during the MFMA phase below
+    };
+    // build tile T into buffer T & 1, then request tile T + 1's numbers and tile T + 2's slot index
+    auto step = [&](int T) {
+      double* b = lds + (size_t)(T & 1) * 2 * TILE;
+      fill(sd, b, b + TILE);
+      SCHUR_STAMP(8);
+      fetch(sd, T + 1);                                                // (by the index loaded a step ago; past the last tile: zeros)
+      sd.idx = slot_of(T + 2);
+      SCHUR_STAMP(9);
+    };
+    sd.idx = slot_of(0);
+    fetch(sd, 0);
+    sd.idx = slot_of(1);
+    __syncthreads();                                                  // zero fill done
+    step(0);                                                          // tile 0 -> buffer 0
     __syncthreads();
-    SCHUR_STAMP(3);
-#pragma unroll
-    for (int kq = 0; kq < SCH_R / 4; ++kq) {
-      const int row = 4 * kq + (lane >> 4);
-      const double a0 = sY[row * SCH_PITCH + q * 16 + (lane & 15)];
-      const double a1 = sY[row * SCH_PITCH + (7 - q) * 16 + (lane & 15)];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
-        if (c >= q) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[c], 0, 0, 0);              // tile (q, c)
-        if (c > 7 - q) acc[7 - c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[7 - c], 0, 0, 0);  // tile (7-q, c) in slot 7-c < q
-        if (c == 7 - q) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accx, 0, 0, 0);              // tile (7-q, 7-q)
-      }
+    SCHUR_STAMP(11);
+    for (int T = 0; T < nT; ++T) {                                    // (the consumers work on tile T)
+      if (T + 1 < nT) step(T + 1);
+      __syncthreads();
+      SCHUR_STAMP(10);
     }
-    SCHUR_STAMP(4);
+    SCHUR_STAMP_FLUSH(8, 12);
+    return;
   }
-  auto store = [&](int ti, int tj, const double4_t& v) {
-    if (ti >= d.ntile || tj >= d.ntile) return;
-    const int tile = ti * d.ntile - ti * (ti - 1) / 2 + (tj - ti);
-    double* o = win.part + ((size_t)tile * d.ksplit + ks) * 256;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = v[r];
-  };
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    if (c >= q) store(q, c, acc[c]);
-    else store(7 - q, 7 - c, acc[c]);
+  // ---- consumers: wave q owns tile rows q and 7 - q (slot c: tile (q, c) for c >= q, tile (7-q, 7-c) for c < q; the ninth: (7-q, 7-q)).
+  // The wave index is a template argument of the loop: with q a run-time value every `if (c >= q)` around an MFMA was a branch, a tile
+  // step was some forty basic blocks, and no ds_read of the next k-step could be scheduled above the MFMAs of this one (the matrix pipe
+  // ran 3456 of a step's ~6000 cycles).
+  switch (tid >> 6) {
+    case 0: ba_schur_ws_consume<0>(win, lds, ks0, nT, tps); break;
+    case 1: ba_schur_ws_consume<1>(win, lds, ks0, nT, tps); break;
+    case 2: ba_schur_ws_consume<2>(win, lds, ks0, nT, tps); break;
+    default: ba_schur_ws_consume<3>(win, lds, ks0, nT, tps); break;
   }
-  store(7 - q, 7 - q, accx);
-  SCHUR_STAMP(5);
-#ifdef ORBX_SCHUR_STAMPS
-  if (threadIdx.x == 0) atomicAdd(&g_schur_stamps[7], 1ull);
-#endif
 }
 
 // One window: keyframe partials and Schur blocks in ONE launch (both consume the build kernel's output and feed the solve;
 // a launch less on a latency-bound chain, and ~200 blocks do not compete for LDS or registers).  Same block bodies: same results.
+// (DIAG: 512-thread workgroups with 102 KB of dynamic LDS for the producer / consumer Schur body; the keyframe blocks use the first 256
+// threads; the general body keeps 256-thread workgroups and its static tiles)
 template <bool DIAG>
-__global__ __launch_bounds__(256, 2) void ba_kf_schur_kernel(const BaWin* __restrict__ wins, BaCam cam) {
-  __shared__ double s_tiles[2 * SCH_R * SCH_PITCH];
+__global__ __launch_bounds__(DIAG ? SCHW_THREADS : 256, DIAG ? 1 : 2) void ba_kf_schur_kernel(const BaWin* __restrict__ wins, BaCam cam) {
+  extern __shared__ __align__(16) double s_dyn[];
+  __shared__ double s_tiles[DIAG ? 1 : 2 * SCH_R * SCH_PITCH];
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done) return;
   const int nkf = win.d.K * BA_KFSPLIT;
-  if ((int)blockIdx.x < nkf) ba_kf_body((int)blockIdx.x, win, cam);
-  else if (DIAG) ba_schur_diag_body((int)blockIdx.x - nkf, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+  if ((int)blockIdx.x < nkf) { if (threadIdx.x < 256) ba_kf_body((int)blockIdx.x, win, cam); }
+  else if (DIAG) ba_schur_diag_ws_body((int)blockIdx.x - nkf, 1, win, cam, s_dyn);
   else ba_schur_body((int)blockIdx.x - nkf, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);
 }
 
@@ -786,17 +870,16 @@ __global__ __launch_bounds__(256, ORBX_KF_MINBLOCKS) void ba_kf_kernel(const BaW
 // DIAG: every window of the launch has a reduced system of at most 128 columns (host-checked)
 // (three blocks per CU for the one-column-block body; the general body holds 2 x 8 accumulator tiles = 256 VGPRs and would spill under
 // that cap: as (256, 3) its launch over four 50-keyframe windows ran 0.94 ms, 13 % of the f64 matrix peak)
+// (their own launch in a batch.  DIAG — every window one column block —: the producer / consumer body, `spb` consecutive k-splits per
+// workgroup, one 512-thread workgroup per CU; until round 3's second half: ba_schur_diag_body, two 256-thread workgroups per CU, 118 us
+// per 32-window launch.  Otherwise the general body.)
 template <bool DIAG>
-// (round 3: the fill rebuilds W = A^T B from 32 stored bytes per slot; with that arithmetic's temporaries the one-column-block body no longer fits the
-// 168 VGPRs of three blocks per CU — 324 B of scratch per lane, 241 us per 32-window launch — and runs two blocks per CU like the general body: 119 us)
-#ifndef ORBX_SCHUR_DIAG_BLOCKS
-#define ORBX_SCHUR_DIAG_BLOCKS 2
-#endif
-__global__ __launch_bounds__(256, DIAG ? ORBX_SCHUR_DIAG_BLOCKS : 2) void ba_schur_kernel(const BaWin* __restrict__ wins, BaCam cam) {
-  __shared__ double s_tiles[2 * SCH_R * SCH_PITCH];                 // Y and W operand tiles (51 KB)
+__global__ __launch_bounds__(DIAG ? SCHW_THREADS : 256, DIAG ? 1 : 2) void ba_schur_kernel(const BaWin* __restrict__ wins, BaCam cam, int spb) {
+  extern __shared__ __align__(16) double s_dyn[];
+  __shared__ double s_tiles[DIAG ? 1 : 2 * SCH_R * SCH_PITCH];     // Y and W operand tiles of the general body (51 KB)
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done) return;
-  if (DIAG) ba_schur_diag_body((int)blockIdx.x, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+  if (DIAG) ba_schur_diag_ws_body((int)blockIdx.x, spb, win, cam, s_dyn);
   else ba_schur_body((int)blockIdx.x, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);   // (blocks beyond this window's need return inside)
 }
 
@@ -2483,9 +2566,14 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     hipError_t e_attr = hipSuccess;                                    // the largest size any window may ask for
     std::call_once(once[h->device & 63], [&] {
       e_attr = hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_LDS_DYN_MAX);
+      if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_kf_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
+      if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
     });
     ORBX_HIP(h, e_attr);
   }
+  // k-splits per workgroup of the batch's one-column-block Schur launch: as many as make the launch about one workgroup per CU (a
+  // workgroup owns its CU: 102 KB of LDS); the partials do not depend on it
+  const int schur_spb = all_diag ? std::max(1, std::min(16, (int)(((size_t)W * max_schur_blocks + h->n_cu - 1) / std::max(1, h->n_cu)))) : 1;
   const BaWin& w0 = hw[0];                                              // host copies of the device pointers of window 0
   double* res0 = w0.res;
   const dim3 gW1(1, W);
@@ -2549,7 +2637,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if (maxK > 0 && W == 1) {
       ProfScope ps(h, "ba_kf_schur_kernel");
       const dim3 g(maxK * BA_KFSPLIT + max_schur_blocks, 1);
-      if (all_diag) hipLaunchKernelGGL(ba_kf_schur_kernel<true>, g, dim3(256), 0, st, d_wins, bc);
+      if (all_diag) hipLaunchKernelGGL(ba_kf_schur_kernel<true>, g, dim3(SCHW_THREADS), SCHW_LDS_BYTES, st, d_wins, bc);
       else hipLaunchKernelGGL(ba_kf_schur_kernel<false>, g, dim3(256), 0, st, d_wins, bc);
     } else if (maxK > 0) {
       {
@@ -2557,8 +2645,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
         hipLaunchKernelGGL(ba_kf_kernel, dim3(maxK * BA_KFSPLIT, W), dim3(256), 0, st, d_wins, bc);
       }
       ProfScope ps(h, "ba_schur_kernel", nullptr, true);
-      if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins, bc);
-      else hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins, bc);
+      if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3((max_schur_blocks + schur_spb - 1) / schur_spb, W), dim3(SCHW_THREADS), SCHW_LDS_BYTES, st, d_wins, bc, schur_spb);
+      else hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins, bc, 1);
     }
     {
       ProfScope ps(h, "ba_gather_kernel");
