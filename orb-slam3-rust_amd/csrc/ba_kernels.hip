@@ -625,7 +625,7 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
 }
 
 #ifdef ORBX_SCHUR_STAMPS
-// debug build only (-DORBX_SCHUR_STAMPS, scripts/ba_schur_stamps.py): s_memtime ticks per phase of the consumer wave 0 of every ba_schur_diag_ws_body workgroup, summed; [6] = the same span in s_memrealtime ticks (100 MHz), [7] = workgroups
+// debug build only (-DORBX_SCHUR_STAMPS, scripts/ba_schur_stamps.py): s_memtime ticks per phase of the consumer wave 0 of every ba_schur_diag_ws_body workgroup, summed; [6] / [12] = the wave's life in s_memrealtime ticks (100 MHz) / s_memtime ticks (shader clock), [7] = workgroups, [8..11] = producer wave 4
 __device__ unsigned long long g_schur_stamps[16];
 #define SCHUR_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc_[k] += now_ - t_prev_; t_prev_ = now_; } while (0)   /* per-thread sums, flushed once at the end: an atomic per stamp distorted what it measured */
 #define SCHUR_STAMP_FLUSH(a, b) do { if (threadIdx.x == 0 || threadIdx.x == 256) for (int k_ = (a); k_ < (b); ++k_) atomicAdd(&g_schur_stamps[k_], st_acc_[k_]); } while (0)
@@ -667,7 +667,7 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
   const int lane = threadIdx.x & 63;
 #ifdef ORBX_SCHUR_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0};
-  const unsigned long long t_real0_ = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t_real0_ = __builtin_amdgcn_s_memrealtime(), t_clk0_ = t_prev_;
 #endif
   double4_t acc[8], accx = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -721,7 +721,7 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
   }
 #ifdef ORBX_SCHUR_STAMPS
   SCHUR_STAMP_FLUSH(0, 6);
-  if (threadIdx.x == 0) { const unsigned long long t_real1_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_schur_stamps[6], t_real1_ - t_real0_); atomicAdd(&g_schur_stamps[7], 1ull);
+  if (threadIdx.x == 0) { const unsigned long long t_real1_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_schur_stamps[12], __builtin_amdgcn_s_memtime() - t_clk0_); atomicAdd(&g_schur_stamps[6], t_real1_ - t_real0_); atomicAdd(&g_schur_stamps[7], 1ull);
     atomicMin(&g_schur_stamps[2], t_real0_); atomicMax(&g_schur_stamps[3], t_real1_); }   // ([2], [3]: first start / last end of the launches since the reset, 100 MHz)
 #endif
 }

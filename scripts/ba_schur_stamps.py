@@ -22,7 +22,7 @@ names = ["from the start of the consumer wave to the first tile (zero fill, tile
          "-", "-", "the tile's 54 MFMAs (operands from LDS)", "a k-split's nine partial tiles out"]
 tot = sum(buf[i] for i in (0, 1, 4, 5))
 print("%d windows: workgroups %d, cycles (s_memtime) per workgroup %.0f; shader clock over the consumer wave's life %.3f GHz" %
-      (W, n, tot / max(n, 1), tot / max(buf[6], 1) * 0.1))
+      (W, n, tot / max(n, 1), buf[12] / max(buf[6], 1) * 0.1))
 for i in (0, 1, 4, 5):
     print("  %-100s %9.0f  %5.1f %%" % (names[i], buf[i] / max(n, 1), 100.0 * buf[i] / max(tot, 1)))
 ptot = buf[8] + buf[9] + buf[10] + buf[11]
