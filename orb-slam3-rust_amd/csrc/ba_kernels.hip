@@ -86,6 +86,7 @@ struct BaWin {
   BaDims d;
   int n;                 // size of the reduced system the solve kernels see (6K; 15K for the inertial window)
   int use_lds;           // reduced system factored in LDS by ba_solve_lds_kernel (else the ba_big_* kernels)
+  int part_sums;         // the Schur launch leaves one partial tile set per gather share (its k-splits already added in the gather's order) instead of one per k-split
   BaState* S;
   double *P0, *P1;       // the two parameter buffers [6K | 3M (| 9K)]
   const double* Rt_fix;  // [F+1][12]
@@ -661,7 +662,7 @@ extern "C" int orbx_debug_schur_stamps(unsigned long long* out16, int reset) {
 // operands take a third as much f64 arithmetic to BUILD as to multiply can reach on this datapath; the remaining lever is the
 // arithmetic of the fill itself.
 template <int Q>
-__device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const double* __restrict__ lds, int ks0, int nT, int tps) {
+__device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const double* __restrict__ lds, int ks0, int nT, int tps, bool sums) {
   const BaDims& d = win.d;
   constexpr int TILE = SCH_R * SCH_PITCH;
   const int lane = threadIdx.x & 63;
@@ -669,9 +670,11 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0};
   const unsigned long long t_real0_ = __builtin_amdgcn_s_memrealtime(), t_clk0_ = t_prev_;
 #endif
-  double4_t acc[8], accx = double4_t{0.0, 0.0, 0.0, 0.0};
+  double4_t acc[8], accx = double4_t{0.0, 0.0, 0.0, 0.0}, run[9];
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 9; ++c) run[c] = double4_t{0.0, 0.0, 0.0, 0.0};
   // this wave's nine partial tiles: element offsets inside a k-split's 256-double tile slots (tile index x ksplit x 256), or -1
   const int lofs = ((lane >> 4)) * 16 + (lane & 15);
   auto tile_of = [&](int ti, int tj) -> long long {
@@ -708,12 +711,27 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
       }
     }
     SCHUR_STAMP(4);
-    if ((T + 1) % tps == 0) {                                         // the k-split is complete: its partial out, accumulators cleared
+    if ((T + 1) % tps == 0) {                                         // the k-split is complete
       const int ks = ks0 + T / tps;
+      if (!sums) {                                                    // its partial out, accumulators cleared
 #pragma unroll
-      for (int c = 0; c < 8; ++c) { store(ks, tofs[c], acc[c]); acc[c] = double4_t{0.0, 0.0, 0.0, 0.0}; }
-      store(ks, tofs[8], accx);
-      accx = double4_t{0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < 8; ++c) { store(ks, tofs[c], acc[c]); acc[c] = double4_t{0.0, 0.0, 0.0, 0.0}; }
+        store(ks, tofs[8], accx);
+        accx = double4_t{0.0, 0.0, 0.0, 0.0};
+      } else {
+        // this workgroup owns one of the gather's shares: it adds the share's partials itself, in the order the gather would (running
+        // sum + next partial, starting from the first), and leaves the ONE sum in the first k-split's slot — 1/spb of the bytes
+        const bool first = T + 1 == tps, last = T + 1 == nT;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+          double4_t& a = c < 8 ? acc[c] : accx;
+          double4_t& r = run[c];
+          if (first) r = a;
+          else { r[0] = r[0] + a[0]; r[1] = r[1] + a[1]; r[2] = r[2] + a[2]; r[3] = r[3] + a[3]; }
+          a = double4_t{0.0, 0.0, 0.0, 0.0};
+          if (last) store(ks0, tofs[c], r);
+        }
+      }
       SCHUR_STAMP(5);
     }
     __syncthreads();
@@ -727,9 +745,11 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
 }
 
 constexpr int SCHW_THREADS = 512;      // 4 consumer + 4 producer waves
+constexpr int BA_GATHER_LANES = 8;     // shares of a window's k-splits (ba_gather_kernel's lanes per element = the Schur launch's workgroups per window in a large batch)
 constexpr size_t SCHW_LDS_BYTES = 4 * (size_t)SCH_R * SCH_PITCH * sizeof(double);      // two buffers x (Y, W): 104 448 B
 __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaWin& win, const BaCam& cam, double* __restrict__ lds) {
   const BaDims& d = win.d;
+  if (win.part_sums) spb = (d.ksplit + BA_GATHER_LANES - 1) / BA_GATHER_LANES;   // one workgroup per share of the gather
   const int ks0 = bx * spb, ks1 = min(ks0 + spb, d.ksplit);
   if (ks0 >= d.ksplit) return;                                        // (the whole workgroup, before any barrier)
   const int tid = threadIdx.x;
@@ -818,10 +838,10 @@ __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaW
   // step was some forty basic blocks, and no ds_read of the next k-step could be scheduled above the MFMAs of this one (the matrix pipe
   // ran 3456 of a step's ~6000 cycles).
   switch (tid >> 6) {
-    case 0: ba_schur_ws_consume<0>(win, lds, ks0, nT, tps); break;
-    case 1: ba_schur_ws_consume<1>(win, lds, ks0, nT, tps); break;
-    case 2: ba_schur_ws_consume<2>(win, lds, ks0, nT, tps); break;
-    default: ba_schur_ws_consume<3>(win, lds, ks0, nT, tps); break;
+    case 0: ba_schur_ws_consume<0>(win, lds, ks0, nT, tps, win.part_sums != 0); break;
+    case 1: ba_schur_ws_consume<1>(win, lds, ks0, nT, tps, win.part_sums != 0); break;
+    case 2: ba_schur_ws_consume<2>(win, lds, ks0, nT, tps, win.part_sums != 0); break;
+    default: ba_schur_ws_consume<3>(win, lds, ks0, nT, tps, win.part_sums != 0); break;
   }
 }
 
@@ -894,41 +914,48 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict_
   const int n = 6 * d.K;
   const size_t nn = (size_t)n * n;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
-  // S_red = sum of the k-split partials, upper triangle computed, mirrored on store.  Four lanes per element: each adds a
-  // quarter of the k-splits in order (sixteen or eight loads in flight), then ((q0 + q1) + (q2 + q3)) — a fixed tree, the same for every
-  // launch shape.  (One lane per element walked 40-80 dependent-latency loads: a quarter of a batch's iteration.)
-  const int ksq = (d.ksplit + 3) >> 2;
-  const int qd = threadIdx.x & 3;
+  // S_red = sum of the k-split partials, upper triangle computed, mirrored on store.  BA_GATHER_LANES lanes per element: each adds
+  // its share of the k-splits in order (ceil(ksplit / lanes) consecutive ones, up to sixteen loads in flight), then a fixed xor tree
+  // over the shares — the same for every launch shape.  (One lane per element walked 40-80 dependent-latency loads: a quarter of a
+  // batch's iteration.)  When `win.part_sums` is set the Schur launch has already added each share's partials in this same order
+  // (ba_schur_diag_ws_body with one workgroup per share) and left ONE tile set per share: the lane reads that instead — a sixteenth of the bytes.
+  // A lane adds its share for TWO neighbouring elements (i, j) and (i, j + 1), j even — one 16-byte load per k-split, a wave covers 16
+  // elements x 8 shares with 128 contiguous bytes per (share, k-split), half the load instructions of an element per lane.
+  constexpr int GL = BA_GATHER_LANES;
+  const int ksq = (d.ksplit + GL - 1) / GL;
+  const int qd = threadIdx.x & (GL - 1);
   const int k_lo = min(qd * ksq, d.ksplit), k_hi = min(k_lo + ksq, d.ksplit);
-  for (size_t idx = (size_t)(tid >> 2); idx < ((nn + 63) & ~(size_t)63); idx += (size_t)(nth >> 2)) {   // whole waves stay in the loop (shuffles below)
-    const bool in = idx < nn;
-    const int i = in ? (int)(idx / n) : 0, j = in ? (int)(idx - (size_t)i * n) : 0;
-    double s = 0.0;
-    if (in && i <= j) {
-      // element (i,j) with i<=j sits at row i%16, col j%16 of the upper tile (i/16, j/16)
+  const int npr = (n + 1) >> 1;                                      // element pairs per row
+  const size_t npairs = (size_t)n * npr;
+  for (size_t pidx = (size_t)(tid / GL); pidx < ((npairs + 63) & ~(size_t)63); pidx += (size_t)(nth / GL)) {   // whole waves stay in the loop (shuffles below)
+    const bool in = pidx < npairs;
+    const int i = in ? (int)(pidx / npr) : 0, j = in ? 2 * (int)(pidx - (size_t)i * npr) : 0;
+    const bool v0 = in && i <= j, v1 = in && i <= j + 1 && j + 1 < n;
+    double s0 = 0.0, s1 = 0.0;
+    if (v0 || v1) {
+      // elements (i, j), (i, j + 1) sit at row i%16, cols j%16, j%16 + 1 of the upper tile (i/16, j/16)
       const int ti = i >> 4, tj = j >> 4;
       const int tile = ti * d.ntile - ti * (ti - 1) / 2 + (tj - ti);
-      const double* p = part + (size_t)tile * d.ksplit * 256 + (i & 15) * 16 + (j & 15);
-      int ks = k_lo;
-      for (; ks + 16 <= k_hi; ks += 16) {                                  // (a 2000-point window: 16 k-splits per lane — one round trip, not two)
-        double v[16];
+      const double2_t* p = (const double2_t*)(part + (size_t)tile * d.ksplit * 256 + (i & 15) * 16 + (j & 15));
+      if (win.part_sums) { if (k_lo < k_hi) { const double2_t v = p[(size_t)k_lo * 128]; s0 = v[0]; s1 = v[1]; } }   // the share's sum sits in its first k-split's slot
+      else {
+        int ks = k_lo;
+        for (; ks + 8 <= k_hi; ks += 8) {
+          double2_t v[8];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = p[(size_t)(ks + q) * 256];
+          for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(ks + q) * 128];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s += v[q];
+          for (int q = 0; q < 8; ++q) { s0 += v[q][0]; s1 += v[q][1]; }
+        }
+        for (; ks < k_hi; ++ks) { const double2_t v = p[(size_t)ks * 128]; s0 += v[0]; s1 += v[1]; }
       }
-      for (; ks + 8 <= k_hi; ks += 8) {
-        double v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(ks + q) * 256];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += v[q];
-      }
-      for (; ks < k_hi; ++ks) s += p[(size_t)ks * 256];
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (in && i <= j && qd == 0) { rb[idx] = s; rb[(size_t)j * n + i] = s; }
+#pragma unroll
+    for (int off = 1; off < GL; off <<= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+    if (qd == 0) {
+      if (v0) { rb[(size_t)i * n + j] = s0; rb[(size_t)j * n + i] = s0; }
+      if (v1) { rb[(size_t)i * n + j + 1] = s1; rb[(size_t)(j + 1) * n + i] = s1; }
+    }
   }
   double* q = rb + nn;                 // U [36K] | gp [n] | bred [n] | chi2 | glsq
   for (int i = tid; i < 33 * d.K; i += nth) {
@@ -2522,11 +2549,15 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     maxM = std::max(maxM, pl.d.M); maxK = std::max(maxK, pl.d.K);
     max_schur_blocks = std::max(max_schur_blocks, pl.d.ncb * (pl.d.ncb + 1) / 2 * pl.d.ksplit);
     if (pl.d.ncb != 1) all_diag = 0;
-    max_gather = std::max(max_gather, std::min(256, (4 * pl.n * pl.n + 255) / 256));
+    max_gather = std::max(max_gather, std::min(256, (BA_GATHER_LANES * pl.n * ((pl.n + 1) / 2) + 255) / 256));
     max_back = std::max(max_back, (std::max(ptl * ((pl.d.M + ppg - 1) / ppg), pl.n) + 255) / 256);
     max_asm = std::max(max_asm, std::min(512, (pl.n * pl.n + 255) / 256));
   }
   const int pt_groups = (maxM + ppg - 1) / ppg;
+  // a batch large enough to fill the chip with one workgroup per (window, gather share): the Schur workgroups add their share's partials
+  // themselves (BaWin::part_sums) and the gather reads one tile set per share
+  const bool schur_sums = all_diag && W > 1 && (size_t)W * BA_GATHER_LANES * 2 >= (size_t)h->n_cu;
+  if (schur_sums) for (int w = 0; w < W; ++w) hw[w].part_sums = 1;
   BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, inertial ? inr->cfg->huber_threshold_mono : cfg->huber_threshold, global_mode ? 1 : 0,
            inertial ? 1 : 0, inertial ? inr->cfg->huber_threshold_stereo : 0.0, nullptr};
   BaInertialDev ind{};
@@ -2573,7 +2604,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   }
   // k-splits per workgroup of the batch's one-column-block Schur launch: as many as make the launch about one workgroup per CU (a
   // workgroup owns its CU: 102 KB of LDS); the partials do not depend on it
-  const int schur_spb = all_diag ? std::max(1, std::min(16, (int)(((size_t)W * max_schur_blocks + h->n_cu - 1) / std::max(1, h->n_cu)))) : 1;
+  int schur_spb = all_diag ? std::max(1, std::min(16, (int)(((size_t)W * max_schur_blocks + h->n_cu - 1) / std::max(1, h->n_cu)))) : 1;
+  if (schur_sums) schur_spb = 1;                                          // (a workgroup's range is its window's share: set in the kernel)
   const BaWin& w0 = hw[0];                                              // host copies of the device pointers of window 0
   double* res0 = w0.res;
   const dim3 gW1(1, W);
@@ -2645,7 +2677,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
         hipLaunchKernelGGL(ba_kf_kernel, dim3(maxK * BA_KFSPLIT, W), dim3(256), 0, st, d_wins, bc);
       }
       ProfScope ps(h, "ba_schur_kernel", nullptr, true);
-      if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3((max_schur_blocks + schur_spb - 1) / schur_spb, W), dim3(SCHW_THREADS), SCHW_LDS_BYTES, st, d_wins, bc, schur_spb);
+      if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(schur_sums ? BA_GATHER_LANES : (max_schur_blocks + schur_spb - 1) / schur_spb, W), dim3(SCHW_THREADS), SCHW_LDS_BYTES, st, d_wins, bc, schur_spb);
       else hipLaunchKernelGGL(ba_schur_kernel<false>, dim3(max_schur_blocks, W), dim3(256), 0, st, d_wins, bc, 1);
     }
     {
