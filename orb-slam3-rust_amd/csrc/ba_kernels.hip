@@ -2556,7 +2556,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   const int pt_groups = (maxM + ppg - 1) / ppg;
   // a batch large enough to fill the chip with one workgroup per (window, gather share): the Schur workgroups add their share's partials
   // themselves (BaWin::part_sums) and the gather reads one tile set per share
-  const bool schur_sums = all_diag && W > 1 && (size_t)W * BA_GATHER_LANES * 2 >= (size_t)h->n_cu;
+  // (the windows of a batch's other half, running on the peer stream at the same time, count: together they fill the chip)
+  const bool schur_sums = all_diag && W > 1 && (size_t)(W + h->ba_peer_windows) * BA_GATHER_LANES >= (size_t)h->n_cu;
   if (schur_sums) for (int w = 0; w < W; ++w) hw[w].part_sums = 1;
   BaCam bc{cam->fx, cam->fy, cam->cx, cam->cy, inertial ? inr->cfg->huber_threshold_mono : cfg->huber_threshold, global_mode ? 1 : 0,
            inertial ? 1 : 0, inertial ? inr->cfg->huber_threshold_stereo : 0.0, nullptr};
@@ -2604,7 +2605,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   }
   // k-splits per workgroup of the batch's one-column-block Schur launch: as many as make the launch about one workgroup per CU (a
   // workgroup owns its CU: 102 KB of LDS); the partials do not depend on it
-  int schur_spb = all_diag ? std::max(1, std::min(16, (int)(((size_t)W * max_schur_blocks + h->n_cu - 1) / std::max(1, h->n_cu)))) : 1;
+  int schur_spb = all_diag ? std::max(1, std::min(16, (int)(((size_t)(W + h->ba_peer_windows) * max_schur_blocks + h->n_cu - 1) / std::max(1, h->n_cu)))) : 1;
   if (schur_sums) schur_spb = 1;                                          // (a workgroup's range is its window's share: set in the kernel)
   const BaWin& w0 = hw[0];                                              // host copies of the device pointers of window 0
   double* res0 = w0.res;

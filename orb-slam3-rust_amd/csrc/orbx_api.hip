@@ -994,7 +994,8 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
       // the two halves preprocess at the same time: half the cores each
       const int half_cores = std::max(1, (int)std::thread::hardware_concurrency() / 2);
       h->ba_pool_cap = half_cores; h->ba_aux->ba_pool_cap = half_cores;
-      struct Uncap { orbx_handle* h; ~Uncap() { h->ba_pool_cap = 0; h->ba_aux->ba_pool_cap = 0; } } uncap{h};
+      h->ba_peer_windows = n_windows - n0; h->ba_aux->ba_peer_windows = n0;
+      struct Uncap { orbx_handle* h; ~Uncap() { h->ba_pool_cap = 0; h->ba_aux->ba_pool_cap = 0; h->ba_peer_windows = 0; h->ba_aux->ba_peer_windows = 0; } } uncap{h};
       try {
         std::thread helper([&] {
           hipSetDevice(h->device);

@@ -170,6 +170,7 @@ struct orbx_handle {
   int* h_abort = nullptr;    int* d_abort = nullptr;       // pinned, device-visible: should_stop() seen while the iterations drain
   OrbxWorkPool* ba_pool = nullptr;                         // host workers of the batch preprocessing (created by the first large batch)
   int ba_pool_cap = 0;                                     // > 0: at most this many threads for the next preprocessing (two halves share the cores)
+  int ba_peer_windows = 0;                                 // windows of the other half of a batch, solved at the same time on the peer handle's stream (launch-shape heuristics count them)
   // profiling
   bool profiling = false;
   std::vector<KernelTimer> timers;
