@@ -428,11 +428,20 @@ constexpr int BA_PPS_TARGET = ORBX_BA_PPS;   // map points per k-split of the Sc
 #ifndef ORBX_BA_KFSPLIT
 #define ORBX_BA_KFSPLIT 1
 #endif
+#ifndef ORBX_BA_KF_THREADS
+#define ORBX_BA_KF_THREADS 256
+#endif
 constexpr int BA_KFSPLIT = ORBX_BA_KFSPLIT;   // round 2 (stored blocks): 16 / 8 / 4 / 2 blocks per keyframe: 32-window batch 36.2 / 39.0 / 40.2 / 40.4 k LM it/s, single window unchanged: the 33 shuffle-tree reductions per block outweigh the observations a block adds up.  Round 3 (recomputed blocks): 8 / 4 / 2 / 1 blocks: keyframe partials 134 / 82.5 / 61.7 / 55.7 us per 32-window iteration, one window 22.4 us throughout: 1
 // BA_KFSPLIT blocks per optimised keyframe: partial U_k (21 unique), g_p (6), b_red (6) over a slice of its
 // observations; the gather kernel adds the partials in a fixed order.
+// NT threads per keyframe block (a template argument: the thread count fixes which observations a thread adds up and the width of the
+// final sum over waves, i.e. the rounding — every launch of one build uses the same NT)
+// (128 / 256 / 512 threads: keyframe partials of a 32-window batch 27.6 / 34.9 / 49.6 us, one window's fused launch 20.5 / 18.6 / 18.8 us,
+// configs[4]'s 131 / 126 / 152 us: 256)
+constexpr int BA_KF_THREADS = ORBX_BA_KF_THREADS;
+template <int NT>
 __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam& cam) {
-  __shared__ double red[4][33];
+  __shared__ double red[NT / 64][33];
   const int* __restrict__ kf_start = win.kf_start; const int* __restrict__ kf_obs = win.kf_obs; const int* __restrict__ kf_pt = win.kf_pt;
   const double* __restrict__ oP = win.oP; const double* __restrict__ vg = win.vg;
   double* __restrict__ kfpart = win.kfpart;   /*[K][BA_KFSPLIT][33]*/
@@ -460,8 +469,8 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
 #pragma unroll
     for (int a = 0; a < 3; ++a) v0[a] = vg[3 * (size_t)j0 + a];
   }
-  if (t + 256 < e) { i1 = kf_obs[t + 256]; j1 = kf_pt[t + 256]; }
-  if (t + 512 < e) { i2 = kf_obs[t + 512]; j2 = kf_pt[t + 512]; }
+  if (t + NT < e) { i1 = kf_obs[t + NT]; j1 = kf_pt[t + NT]; }
+  if (t + 2 * NT < e) { i2 = kf_obs[t + 2 * NT]; j2 = kf_pt[t + 2 * NT]; }
   while (have0) {
     const bool have1 = i1 >= 0;
     if (have1) {                                                             // next round's data: issued before this round's arithmetic
@@ -471,7 +480,7 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
       for (int a = 0; a < 3; ++a) v1[a] = vg[3 * (size_t)j1 + a];
     }
     i1 = i2; j1 = j2;
-    if (t + 768 < e) { i2 = kf_obs[t + 768]; j2 = kf_pt[t + 768]; } else i2 = -1;
+    if (t + 3 * NT < e) { i2 = kf_obs[t + 3 * NT]; j2 = kf_pt[t + 3 * NT]; } else i2 = -1;
     double A[12], B[6];
     obs_jac_from_proj(cam, Rt, q0[0], q0[1], q0[2], q0[3], A, B);         // no division, no square root: the build kernel stored what they gave
     const double r0 = q0[4], r1 = q0[5];
@@ -491,7 +500,7 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
     for (int a = 0; a < 6; ++a) q0[a] = q1[a];
 #pragma unroll
     for (int a = 0; a < 3; ++a) v0[a] = v1[a];
-    t += 256;
+    t += NT;
   }
 #pragma unroll
   for (int a = 0; a < 33; ++a) {
@@ -501,7 +510,12 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
     if (lane == 0) red[wave][a] = v;
   }
   __syncthreads();
-  if (tid < 33) kfpart[((size_t)k * BA_KFSPLIT + sp) * 33 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  if (tid < 33) {
+    double v = red[0][tid];
+#pragma unroll
+    for (int w2 = 1; w2 < NT / 64; ++w2) v += red[w2][tid];                 // (((w0 + w1) + w2) + ...)
+    kfpart[((size_t)k * BA_KFSPLIT + sp) * 33 + tid] = v;
+  }
 }
 
 // S_red partials.  A block owns (column-block pair (bi <= bj) of 128 columns each, k-split ks): the rows (= 3 per map point) of
@@ -849,16 +863,18 @@ __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaW
 // a launch less on a latency-bound chain, and ~200 blocks do not compete for LDS or registers).  Same block bodies: same results.
 // (DIAG: 512-thread workgroups with 102 KB of dynamic LDS for the producer / consumer Schur body; the keyframe blocks use the first 256
 // threads; the general body keeps 256-thread workgroups and its static tiles)
+constexpr int BA_KFS_GEN_THREADS = BA_KF_THREADS > 256 ? BA_KF_THREADS : 256;   // the fused launch with the general Schur body (which uses the first 256)
+static_assert(BA_KF_THREADS % 64 == 0 && BA_KF_THREADS >= 64 && BA_KF_THREADS <= SCHW_THREADS, "keyframe blocks: whole waves, at most the fused launch's workgroup");
 template <bool DIAG>
-__global__ __launch_bounds__(DIAG ? SCHW_THREADS : 256, DIAG ? 1 : 2) void ba_kf_schur_kernel(const BaWin* __restrict__ wins, BaCam cam) {
+__global__ __launch_bounds__(DIAG ? SCHW_THREADS : BA_KFS_GEN_THREADS, DIAG ? 1 : (BA_KFS_GEN_THREADS > 256 ? 1 : 2)) void ba_kf_schur_kernel(const BaWin* __restrict__ wins, BaCam cam) {
   extern __shared__ __align__(16) double s_dyn[];
   __shared__ double s_tiles[DIAG ? 1 : 2 * SCH_R * SCH_PITCH];
   const BaWin& win = wins[blockIdx.y];
   if (win.S->done) return;
   const int nkf = win.d.K * BA_KFSPLIT;
-  if ((int)blockIdx.x < nkf) { if (threadIdx.x < 256) ba_kf_body((int)blockIdx.x, win, cam); }
+  if ((int)blockIdx.x < nkf) { if (threadIdx.x < BA_KF_THREADS) ba_kf_body<BA_KF_THREADS>((int)blockIdx.x, win, cam); }
   else if (DIAG) ba_schur_diag_ws_body((int)blockIdx.x - nkf, 1, win, cam, s_dyn);
-  else ba_schur_body((int)blockIdx.x - nkf, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);
+  else if (threadIdx.x < 256) ba_schur_body((int)blockIdx.x - nkf, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);
 }
 
 // (their own launches in a batch: 51 KB of LDS and ~200 VGPRs per block would otherwise throttle the thousands of small keyframe blocks too)
@@ -875,7 +891,7 @@ __global__ __launch_bounds__(DIAG ? SCHW_THREADS : 256, DIAG ? 1 : 2) void ba_kf
 #ifndef ORBX_KF_XCD
 #define ORBX_KF_XCD 1
 #endif
-__global__ __launch_bounds__(256, ORBX_KF_MINBLOCKS) void ba_kf_kernel(const BaWin* __restrict__ wins, BaCam cam) {
+__global__ __launch_bounds__(BA_KF_THREADS, ORBX_KF_MINBLOCKS) void ba_kf_kernel(const BaWin* __restrict__ wins, BaCam cam) {
   int bx = blockIdx.x, by = blockIdx.y;
   if (ORBX_KF_XCD && (gridDim.y & 7) == 0) {
     const int lin = by * (int)gridDim.x + bx, xcd = lin & 7, slot = lin >> 3;      // slot: this block's place in its XCD's queue
@@ -884,7 +900,7 @@ __global__ __launch_bounds__(256, ORBX_KF_MINBLOCKS) void ba_kf_kernel(const BaW
   }
   const BaWin& win = wins[by];
   if (win.S->done || bx >= win.d.K * BA_KFSPLIT) return;
-  ba_kf_body(bx, win, cam);
+  ba_kf_body<BA_KF_THREADS>(bx, win, cam);
 }
 
 // DIAG: every window of the launch has a reduced system of at most 128 columns (host-checked)
@@ -2671,11 +2687,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       ProfScope ps(h, "ba_kf_schur_kernel");
       const dim3 g(maxK * BA_KFSPLIT + max_schur_blocks, 1);
       if (all_diag) hipLaunchKernelGGL(ba_kf_schur_kernel<true>, g, dim3(SCHW_THREADS), SCHW_LDS_BYTES, st, d_wins, bc);
-      else hipLaunchKernelGGL(ba_kf_schur_kernel<false>, g, dim3(256), 0, st, d_wins, bc);
+      else hipLaunchKernelGGL(ba_kf_schur_kernel<false>, g, dim3(BA_KFS_GEN_THREADS), 0, st, d_wins, bc);
     } else if (maxK > 0) {
       {
         ProfScope ps(h, "ba_kf_kernel");
-        hipLaunchKernelGGL(ba_kf_kernel, dim3(maxK * BA_KFSPLIT, W), dim3(256), 0, st, d_wins, bc);
+        hipLaunchKernelGGL(ba_kf_kernel, dim3(maxK * BA_KFSPLIT, W), dim3(BA_KF_THREADS), 0, st, d_wins, bc);
       }
       ProfScope ps(h, "ba_schur_kernel", nullptr, true);
       if (all_diag) hipLaunchKernelGGL(ba_schur_kernel<true>, dim3(schur_sums ? BA_GATHER_LANES : (max_schur_blocks + schur_spb - 1) / schur_spb, W), dim3(SCHW_THREADS), SCHW_LDS_BYTES, st, d_wins, bc, schur_spb);
