@@ -1165,10 +1165,13 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         }
       }
   }
+  // b and |g_p|^2: the n <= 128 entries sit in the first two waves — each sums its own, the barrier in front of the factorisation
+  // publishes the two sums (a block-wide sum took two barriers of its own)
+  const bool small_n = n <= 128;
   double gs = 0.0;
   for (int i = tid; i < n; i += nth) { sb[i] = -gp[i] + bred[i]; gs += gp[i] * gp[i]; }
-  gs = block_sum_fixed(gs, s_red);
-  if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(gs + bred[n + 1]); }
+  if (small_n) { if (tid < 128) { gs = wave_sum(gs); if ((tid & 63) == 0) s_red[tid >> 6] = gs; } }
+  else { gs = block_sum_fixed(gs, s_red); if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(gs + bred[n + 1]); } }
   // Right-looking blocked Cholesky, panels of 16 columns, S in LDS:
   //   1. wave 0 factors the 16x16 diagonal block — lane j owns row j in registers, a solved column is broadcast with
   //      v_readlane (no barrier inside the block);
@@ -1217,6 +1220,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   // brought that one tile up to date, while the other 15 waves finish the trailing update — the longest phase of a panel (the
   // serial 16-step factor) leaves the critical path and a panel costs two block barriers instead of three.
   __syncthreads();
+  if (small_n && tid == nth - 1) { res[0] = bred[n]; res[1] = sqrt((s_red[0] + s_red[1]) + bred[n + 1]); }
   if (tid < 64) factor_diag(0, min(16, n));
   for (int c0 = 0; c0 < n; c0 += 16) {
     const int nb = min(16, n - c0);
@@ -1383,8 +1387,13 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     };
     if (n > 64) run(std::true_type{}, n - 1, 64);
     run(std::false_type{}, min(n, 64) - 1, 0);
-    if (lane < n) sb[lane] = b0 * ri0;
-    if (lane + 64 < n) sb[lane + 64] = b1 * ri1;
+    // the solution is in this wave's registers: delta_p, |delta_p|^2 and |p|^2 from here, no block-wide pass behind it
+    const double x0 = lane < n ? b0 * ri0 : 0.0, x1 = lane + 64 < n ? b1 * ri1 : 0.0;
+    const double p0 = lane < n ? params[lane] : 0.0, p1 = lane + 64 < n ? params[lane + 64] : 0.0;
+    if (lane < n) dp[lane] = x0;
+    if (lane + 64 < n) dp[lane + 64] = x1;
+    const double dsq = wave_sum(x0 * x0 + x1 * x1), psq = wave_sum(p0 * p0 + p1 * p1);
+    if (lane == 0) { res[2] = 1.0; res[3] = dsq; res[4] = psq; }
   } else if (ok && tid < 64) {
     // general n: row dot products with shuffle reductions
     for (int r = n - 1; r >= 0; --r) {
@@ -1395,8 +1404,14 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       __builtin_amdgcn_wave_barrier();
     }
   }
-  __syncthreads();
   SOLVE_STAMP(5);
+  if (ok && small_n) {                                                          // (uniform) wave 0 has written everything
+#ifdef ORBX_SOLVE_STAMPS
+    if (threadIdx.x == 0) g_solve_stamps[15] += 1;
+#endif
+    return;
+  }
+  __syncthreads();
   double dsq = 0.0, psq = 0.0;
   for (int i = tid; i < n; i += nth) {
     const double v = ok ? sb[i] : 0.0;
