@@ -1006,7 +1006,10 @@ __global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict_
 // One workgroup.  S lives in LDS (n <= ~135; larger systems take the multi-kernel path below); the right-hand
 // side always in LDS.  Right-looking Cholesky: 2 barriers per column, trailing update on a 16x16 thread grid; the two
 // triangular solves run in wave 0 alone as row dot products with shuffle reductions (no block barriers).
-constexpr int BA_SOLVE_THREADS = 1024;
+#ifndef ORBX_BA_SOLVE_THREADS
+#define ORBX_BA_SOLVE_THREADS 1024
+#endif
+constexpr int BA_SOLVE_THREADS = ORBX_BA_SOLVE_THREADS;   // 256 / 512 / 1024 threads: 43.9 / 36.7 / 35.2 us per solve at n = 114 (end of round 3)
 constexpr int BA_MAX_N = 768;
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -1135,22 +1138,23 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   // run-time bounds waited for each global load in turn: 6 us of a 63 us solve at n = 114).
   {
     constexpr int AS = (135 + 31) / 32;                                         // the LDS path ends at n = 135
+    constexpr int TYN = BA_SOLVE_THREADS / 32, ASR = (135 + TYN - 1) / TYN;     // rows: thread rows of the launch, rounds
     const int ty = tid >> 5, tx = tid & 31;
-    double rv_[AS][AS], uv_[AS][AS];
+    double rv_[ASR][AS], uv_[ASR][AS];
 #pragma unroll
-    for (int a = 0; a < AS; ++a)
+    for (int a = 0; a < ASR; ++a)
 #pragma unroll
       for (int b2 = 0; b2 < AS; ++b2) {
-        const int i = ty + 32 * a, j = tx + 32 * b2;
+        const int i = ty + TYN * a, j = tx + 32 * b2;
         const bool low = i < n && j <= i;
         rv_[a][b2] = low ? rb[(size_t)i * n + j] : 0.0;
         uv_[a][b2] = (low && i / 6 == j / 6) ? U[36 * (size_t)(i / 6) + (i % 6) * 6 + (j % 6)] : 0.0;
       }
 #pragma unroll
-    for (int a = 0; a < AS; ++a)
+    for (int a = 0; a < ASR; ++a)
 #pragma unroll
       for (int b2 = 0; b2 < AS; ++b2) {
-        const int i = ty + 32 * a, j = tx + 32 * b2;
+        const int i = ty + TYN * a, j = tx + 32 * b2;
         if (i < n && j < n) {
           double v = 0.0;
           if (j <= i) {
