@@ -1137,14 +1137,19 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   // takes the entries (ty + 32 a, tx + 32 b): all of its loads are issued before the first is used (the nested loops with their
   // run-time bounds waited for each global load in turn: 6 us of a 63 us solve at n = 114).
   {
-    constexpr int AS = (135 + 31) / 32;                                         // the LDS path ends at n = 135
-    constexpr int TYN = BA_SOLVE_THREADS / 32, ASR = (135 + TYN - 1) / TYN;     // rows: thread rows of the launch, rounds
+    // (n <= 128 on this path: 160 KB of LDS less the static arrays, and n even.  Blocks of 32 x 32 entries right of the diagonal blocks
+    // take their zeros without a load or a compare: with all 25 blocks of a 160 x 160 grid treated alike the 16 waves issued ~6 k
+    // instructions' worth of cycles for 6.5 k live entries)
+    constexpr int AS = 128 / 32;
+    constexpr int TYN = BA_SOLVE_THREADS / 32, ASR = (128 + TYN - 1) / TYN, RPB = 32 / TYN;   // thread rows of the launch, row rounds, rounds per 32-row block
+    static_assert(TYN <= 32 && 32 % TYN == 0, "a 32-entry block row is a whole number of thread-row rounds");
     const int ty = tid >> 5, tx = tid & 31;
     double rv_[ASR][AS], uv_[ASR][AS];
 #pragma unroll
     for (int a = 0; a < ASR; ++a)
 #pragma unroll
       for (int b2 = 0; b2 < AS; ++b2) {
+        if (b2 > a / RPB) continue;                                            // (compile time) right of the diagonal block
         const int i = ty + TYN * a, j = tx + 32 * b2;
         const bool low = i < n && j <= i;
         rv_[a][b2] = low ? rb[(size_t)i * n + j] : 0.0;
@@ -1157,7 +1162,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         const int i = ty + TYN * a, j = tx + 32 * b2;
         if (i < n && j < n) {
           double v = 0.0;
-          if (j <= i) {
+          if (b2 <= a / RPB && j <= i) {
             v = -rv_[a][b2];
             if (i / 6 == j / 6) {
               double u = uv_[a][b2];
@@ -2334,10 +2339,6 @@ int pinned_reserve(orbx_handle* h, void** p, size_t* have, size_t need) {
 int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inertial, const BaInertialHost* inr) {
   const int K = w.K, F = w.F, M = w.M, N = w.N;
   const orbx_ba_obs* obs = w.obs;
-  for (int i = 0; i < N; ++i) {
-    const orbx_ba_obs& o = obs[i];
-    if (o.mp_idx < 0 || o.mp_idx >= M || o.kf_idx >= K || (o.kf_idx < 0 && o.fixed_idx >= F)) return i;
-  }
   double* params = (double*)(blob + pl.i_params);
   double* Rt_fix = (double*)(blob + pl.i_rtfix);
   int* pt_start = (int*)(blob + pl.i_ptstart);
@@ -2349,7 +2350,11 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
   int* kf_pt = (int*)(blob + pl.i_kfpt);
   int* o_flag = inertial ? (int*)(blob + pl.i_oflag) : nullptr;
   for (int j = 0; j <= M; ++j) pt_start[j] = 0;
-  for (int i = 0; i < N; ++i) pt_start[obs[i].mp_idx + 1]++;
+  for (int i = 0; i < N; ++i) {                                          // index checks and the per-point counts in one pass over the observations
+    const orbx_ba_obs& o = obs[i];
+    if (o.mp_idx < 0 || o.mp_idx >= M || o.kf_idx >= K || (o.kf_idx < 0 && o.fixed_idx >= F)) return i;
+    pt_start[o.mp_idx + 1]++;
+  }
   for (int j = 0; j < M; ++j) pt_start[j + 1] += pt_start[j];
   for (int k = 0; k <= K; ++k) kf_start[k] = 0;
   {
@@ -2451,7 +2456,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.n_upper = (size_t)d.ntile * (d.ntile + 1) / 2;
     pl.rb_len = (size_t)pl.n * pl.n + 36 * (size_t)K + 2 * (size_t)pl.n + 2;
     pl.lds_need = 8 * ((size_t)pl.n * pl.n + BA_SOLVE_THREADS);
-    pl.use_lds = (pl.lds_need <= BA_LDS_DYN_MAX && pl.n % 2 == 0) ? 1 : 0;   // (the LDS solve reads pairs of entries: even n, which 6K is)
+    pl.use_lds = (pl.lds_need <= BA_LDS_DYN_MAX && pl.n % 2 == 0 && pl.n <= 128) ? 1 : 0;   // (the LDS solve reads pairs of entries — even n, which 6K is — and lays its threads over a 128 x 128 grid)
     pl.n_res = 2.0 * (double)N;
     const size_t n1 = (size_t)std::max(N, 1), m1 = (size_t)std::max(M, 1), k1 = (size_t)std::max(K, 1);
     pl.i_state = cin.take(sizeof(BaState));
