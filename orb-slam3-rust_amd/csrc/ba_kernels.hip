@@ -528,6 +528,23 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
 // 144 B per observation instead of 2 x 8 B x 3M x 6K (393 MB at 32 windows of 20 keyframes / 2000 points).
 constexpr int SCH_R = 24;                 // rows per LDS tile (8 points, 6 MFMA k-steps)
 constexpr int SCH_PITCH = 136;            // doubles per LDS row: 128 + 16 — the two 16-lane row groups of a ds_read_b64 half-wave land 32 banks apart
+// one tile step of ba_schur_body's product for wave Q (tile rows Q and 7 - Q of the block pair; DG: a diagonal pair, upper tiles only)
+template <int Q, bool DG>
+__device__ __forceinline__ void ba_schur_gen_mfma(double4_t (&acc)[2][8], const double* __restrict__ sY, const double* __restrict__ sW, int lane) {
+#pragma unroll
+  for (int kq = 0; kq < SCH_R / 4; ++kq) {
+    const int row = 4 * kq + (lane >> 4);
+    const double a0 = sY[row * SCH_PITCH + Q * 16 + (lane & 15)];
+    const double a1 = sY[row * SCH_PITCH + (7 - Q) * 16 + (lane & 15)];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
+      if (!DG || c >= Q) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][c], 0, 0, 0);
+      if (!DG || c >= 7 - Q) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][c], 0, 0, 0);
+    }
+  }
+}
+
 __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const BaCam& cam, double* __restrict__ sY, double* __restrict__ sW) {
   const BaDims& d = win.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -608,18 +625,18 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
       }
     }
     __syncthreads();
-    // ---- multiply: 6 k-steps of 4 rows
-#pragma unroll
-    for (int kq = 0; kq < SCH_R / 4; ++kq) {
-      const int row = 4 * kq + (lane >> 4);
-      const double a0 = sY[row * SCH_PITCH + trow[0] * 16 + (lane & 15)];
-      const double a1 = sY[row * SCH_PITCH + trow[1] * 16 + (lane & 15)];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
-        if (!diag || c >= trow[0]) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][c], 0, 0, 0);
-        if (!diag || c >= trow[1]) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][c], 0, 0, 0);
-      }
+    // ---- multiply: 6 k-steps of 4 rows (wave index and diagonal flag as template arguments: with run-time predicates around the
+    // MFMAs a tile step was dozens of basic blocks and no operand read could be scheduled above the matrix instructions, as in the
+    // one-column-block body before its consumer loop was specialised)
+    switch (2 * wave + (diag ? 1 : 0)) {
+      case 0: ba_schur_gen_mfma<0, false>(acc, sY, sW, lane); break;
+      case 1: ba_schur_gen_mfma<0, true>(acc, sY, sW, lane); break;
+      case 2: ba_schur_gen_mfma<1, false>(acc, sY, sW, lane); break;
+      case 3: ba_schur_gen_mfma<1, true>(acc, sY, sW, lane); break;
+      case 4: ba_schur_gen_mfma<2, false>(acc, sY, sW, lane); break;
+      case 5: ba_schur_gen_mfma<2, true>(acc, sY, sW, lane); break;
+      case 6: ba_schur_gen_mfma<3, false>(acc, sY, sW, lane); break;
+      default: ba_schur_gen_mfma<3, true>(acc, sY, sW, lane); break;
     }
   }
   // ---- partials out: the gather kernel's layout, part[(upper tile, ks)][16][16]
