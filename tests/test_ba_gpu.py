@@ -279,6 +279,32 @@ def test_ba_batch_two_streams_path(gpu_handle, pkg):
     assert np.array_equal(again[17]["poses_wc"], batch[17]["poses_wc"])
 
 
+def test_ba_large_batch_share_sums_mixed_sizes(gpu_handle, pkg):
+    """A batch large enough that every Schur workgroup owns one share of its window's k-splits and writes the share's sum instead of
+    the partials (BaWin::part_sums; 32 windows x 8 shares = one workgroup per CU): windows of very different sizes in one call — 1 to 63
+    k-splits, so shares of 0, 1 and several k-splits, a window of a single keyframe, one the reference answers None for — each equal to
+    its single-window solve bit for bit; then the same windows with one 30-keyframe window added, which sends the whole batch through the
+    general Schur body (no share sums): the same results again."""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
+    shapes = [(20, 2000), (3, 40), (8, 100), (21, 900), (2, 30), (12, 260), (20, 1500), (5, 64), (16, 333), (10, 7 * 32 + 1)]
+    wins = [pkg.synth.ba_window(1500 + i, *shapes[i % len(shapes)], pkg.BA_OBS) for i in range(34)]
+    empty = dict(wins[9]); empty["obs"] = wins[9]["obs"][:0]
+    wins[20] = empty
+    batch = gpu_handle.ba_solve_visual_batch(cam, cfg, wins, should_stop=lambda: False)     # (a callback also keeps the call on one stream)
+    assert batch[20] is None
+    check = (0, 1, 3, 4, 7, 9, 13, 19, 26, 33)
+    single = {i: gpu_handle.ba_solve_visual(cam, cfg, wins[i]["poses_cw"], wins[i]["fixed_cw"], wins[i]["points"], wins[i]["obs"]) for i in check}
+    for i in check:
+        assert batch[i]["iterations"] == single[i]["iterations"], i
+        assert np.array_equal(batch[i]["poses_wc"], single[i]["poses_wc"]) and np.array_equal(batch[i]["points"], single[i]["points"]), i
+    big = pkg.synth.ba_window(1600, 30, 400, pkg.BA_OBS)
+    again = gpu_handle.ba_solve_visual_batch(cam, cfg, wins + [big], should_stop=lambda: False)
+    for i in check:
+        assert np.array_equal(again[i]["poses_wc"], single[i]["poses_wc"]) and np.array_equal(again[i]["points"], single[i]["points"]), i
+    sb = gpu_handle.ba_solve_visual(cam, cfg, big["poses_cw"], big["fixed_cw"], big["points"], big["obs"])
+    assert np.array_equal(again[-1]["poses_wc"], sb["poses_wc"]) and np.array_equal(again[-1]["points"], sb["points"])
+
+
 def test_ba_two_handles_two_host_threads(gpu_handle, pkg):
     """Two handles driven by two host threads at once (each a batch of 16 windows: its own stream, workspaces, persistent
     preprocessing workers and internal two-stream split), three rounds: every window equals the result of the same batch solved alone."""
