@@ -1132,9 +1132,33 @@ extern "C" int orbx_debug_solve_stamps(unsigned long long* out16, int reset) {
 #else
 #define SOLVE_STAMP(k) do { } while (0)
 #endif
-template <typename SPtr>
-__device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0, double* P1, const double* __restrict__ rb, int K, SPtr S,
-                           double* __restrict__ dp, double* __restrict__ res) {
+// Where the reduced system lives in LDS.  LaySquare: row-major n x n, n <= 128 (every local-BA window of the reference).  LayTiled: the
+// LOWER 16 x 16 tiles only, tile (ti, tj <= ti) at ((ti (ti + 1)) / 2 + tj) * 256 doubles — 55 tiles = 110 KB at n = 150 (the 15-d
+// system of a 10-keyframe inertial window), 66 = 132 KB at n = 176 — for systems that do not fit as a square but need not go through
+// the multi-launch path; a 16-column panel's rows are contiguous 16-double tile rows in both.  rd(): an entry right of the diagonal
+// TILE does not exist in the tiled layout and reads as the zero the square layout stores there.
+struct LaySquare {
+  double* p; int n;
+  static constexpr bool TILED = false;
+  __device__ __forceinline__ double* at(int i, int j) const { return p + (size_t)i * n + j; }
+  __device__ __forceinline__ const double* rd(int i, int j, const double*) const { return p + (size_t)i * n + j; }
+};
+struct LayTiled {
+  double* p;
+  static constexpr bool TILED = true;
+  __device__ __forceinline__ double* at(int i, int j) const {
+    const int ti = i >> 4, tj = j >> 4;
+    return p + (size_t)((ti * (ti + 1)) / 2 + tj) * 256 + (i & 15) * 16 + (j & 15);
+  }
+  __device__ __forceinline__ const double* rd(int i, int j, const double* zero) const { return (j >> 4) > (i >> 4) ? zero : at(i, j); }
+};
+constexpr int BA_TILED_MAX_N = 176;    // 66 lower tiles = 132 KB beside the 20 KB of static arrays
+
+// FROM_SG: the system was assembled in global memory (win.Sg, lower triangle, and win.bvec: ba_big_assemble_kernel / the inertial
+// assembly) and is copied in; otherwise S = blockdiag(U*) - S_red and b = -g_p + b_red are formed here from the gather's buffer `rb`.
+template <typename LAY, bool FROM_SG>
+__device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0, double* P1, const double* __restrict__ rb, int K, LAY S,
+                           double* __restrict__ dp, double* __restrict__ res, const double* __restrict__ Sg = nullptr, const double* __restrict__ bvec = nullptr) {
   if (St->done) return;
 #ifdef ORBX_SOLVE_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
@@ -1145,10 +1169,15 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   __shared__ double srinv[BA_MAX_N];
   __shared__ double s_red[BA_SOLVE_THREADS];
   const int tid = threadIdx.x, nth = BA_SOLVE_THREADS, lane = tid & 63;
+  constexpr int NRW = LAY::TILED ? 3 : 2;                                      // 64-row register sets of the one-wave phases (n <= 64 NRW)
+  __shared__ double s_zero;
+  if (tid == 0) s_zero = 0.0;
+  const bool small_n = n <= 64 * NRW;
   const size_t nn = (size_t)n * n;
-  const double* U = rb + nn;
+  const double* U = rb + nn;                                                     // (FROM_SG: rb unused)
   const double* gp = U + 36 * (size_t)K;
   const double* bred = gp + n;
+  if constexpr (!FROM_SG) {
   // S = blockdiag(U*) - S_red ; b = -g_p + b_red.  The factorisation reads and writes the lower triangle (j <= i) only; the upper
   // triangle is written as ZERO here and stays zero, which the backward substitution relies on.  Thread (ty, tx) of a 32 x 32 grid
   // takes the entries (ty + 32 a, tx + 32 b): all of its loads are issued before the first is used (the nested loops with their
@@ -1187,17 +1216,37 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
               v += u;
             }
           }
-          S[(size_t)i * n + j] = v;
+          *S.at(i, j) = v;
         }
       }
   }
   // b and |g_p|^2: the n <= 128 entries sit in the first two waves — each sums its own, the barrier in front of the factorisation
   // publishes the two sums (a block-wide sum took two barriers of its own)
-  const bool small_n = n <= 128;
   double gs = 0.0;
   for (int i = tid; i < n; i += nth) { sb[i] = -gp[i] + bred[i]; gs += gp[i] * gp[i]; }
-  if (small_n) { if (tid < 128) { gs = wave_sum(gs); if ((tid & 63) == 0) s_red[tid >> 6] = gs; } }
+  if (small_n) { if (tid < 64 * NRW) { gs = wave_sum(gs); if ((tid & 63) == 0) s_red[tid >> 6] = gs; } }
   else { gs = block_sum_fixed(gs, s_red); if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(gs + bred[n + 1]); } }
+  } else {
+    // copy the lower triangle in (entries right of the diagonal inside the diagonal tiles: zeros), all of a thread's loads first
+    constexpr int TYN = BA_SOLVE_THREADS / 32, CR = (BA_TILED_MAX_N + TYN - 1) / TYN, CC = (BA_TILED_MAX_N + 31) / 32;
+    const int ty = tid >> 5, tx = tid & 31;
+    double v_[CR][CC];
+#pragma unroll
+    for (int a = 0; a < CR; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < CC; ++b2) {
+        const int i = ty + TYN * a, j = tx + 32 * b2;
+        v_[a][b2] = (i < n && j <= i) ? Sg[(size_t)i * n + j] : 0.0;
+      }
+#pragma unroll
+    for (int a = 0; a < CR; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < CC; ++b2) {
+        const int i = ty + TYN * a, j = tx + 32 * b2;
+        if (i < n && j < n && (!LAY::TILED || (j >> 4) <= (i >> 4))) *S.at(i, j) = v_[a][b2];
+      }
+    for (int i = tid; i < n; i += nth) sb[i] = bvec[i];
+  }
   // Right-looking blocked Cholesky, panels of 16 columns, S in LDS:
   //   1. wave 0 factors the 16x16 diagonal block — lane j owns row j in registers, a solved column is broadcast with
   //      v_readlane (no barrier inside the block);
@@ -1219,12 +1268,12 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         // (rows 912 bytes apart land on distinct banks; the wave's four 16-lane rows read the same addresses)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-          const double2_t p2 = *(const double2_t*)&S[(size_t)(c0_ + j) * n + c0_ + i];
+          const double2_t p2 = *(const double2_t*)S.at(c0_ + j, c0_ + i);
           Lr[i] = p2[0]; Lr[i + 1] = p2[1];
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? S[(size_t)(c0_ + j) * n + c0_ + i] : 0.0;   // (rows >= nb_ take no pivot step: chol16_rows_dpp; a 1.0 on their diagonal was 16 loop-invariant constants held in — and spilled from — registers)
+        for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? *S.at(c0_ + j, c0_ + i) : 0.0;   // (rows >= nb_ take no pivot step: chol16_rows_dpp; a 1.0 on their diagonal was 16 loop-invariant constants held in — and spilled from — registers)
       }
       SOLVE_STAMP(8);
       const int good = chol16_rows_dpp(Lr, nb_, tid, s_rv);
@@ -1235,18 +1284,24 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         if (tid < 16) {
 #pragma unroll
           for (int i = 0; i < 16; i += 2)
-            *(double2_t*)&S[(size_t)(c0_ + j) * n + c0_ + i] = double2_t{i <= j ? Lr[i] : 0.0, i + 1 <= j ? Lr[i + 1] : 0.0};
+            *(double2_t*)S.at(c0_ + j, c0_ + i) = double2_t{i <= j ? Lr[i] : 0.0, i + 1 <= j ? Lr[i + 1] : 0.0};
         }
       } else if (good && tid < nb_) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) if (i <= j) S[(size_t)(c0_ + j) * n + c0_ + i] = Lr[i];
+        for (int i = 0; i < 16; ++i) if (i <= j) *S.at(c0_ + j, c0_ + i) = Lr[i];
       }
   };
   // Look-ahead: the diagonal block of panel p + 1 is factored by wave 0 inside the update phase of panel p, right after wave 0 has
   // brought that one tile up to date, while the other 15 waves finish the trailing update — the longest phase of a panel (the
   // serial 16-step factor) leaves the critical path and a panel costs two block barriers instead of three.
   __syncthreads();
-  if (small_n && tid == nth - 1) { res[0] = bred[n]; res[1] = sqrt((s_red[0] + s_red[1]) + bred[n + 1]); }
+  if constexpr (!FROM_SG) {
+    if (small_n && tid == nth - 1) {
+      double g2 = s_red[0] + s_red[1];
+      if (NRW > 2) g2 += s_red[2];
+      res[0] = bred[n]; res[1] = sqrt(g2 + bred[n + 1]);
+    }
+  }
   if (tid < 64) factor_diag(0, min(16, n));
   for (int c0 = 0; c0 < n; c0 += 16) {
     const int nb = min(16, n - c0);
@@ -1265,7 +1320,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       // is even and c0 a multiple of 16) — 64 + 8 reads instead of 120 + 16 in a wave that issues one instruction every ~8 cycles.
       const int r = c0 + 16 + tid;
       if (r <= n) {
-        double* row = r < n ? &S[(size_t)r * n + c0] : &sb[c0];
+        double* row = r < n ? S.at(r, c0) : &sb[c0];
         double x[16];
 #pragma unroll
         for (int jx = 0; jx < 16; jx += 2) {
@@ -1277,7 +1332,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
           double la[16], lb[16];                                                   // L[jx][t], L[jx][t + 1] for jx > t
 #pragma unroll
           for (int jx = t + 1; jx < 16; ++jx) {
-            const double2_t p2 = *(const double2_t*)&S[(size_t)(c0 + jx) * n + c0 + t];
+            const double2_t p2 = *(const double2_t*)S.at(c0 + jx, c0 + t);
             la[jx] = p2[0]; lb[jx] = p2[1];
           }
           const double2_t q = *(const double2_t*)&s_rv[t];
@@ -1302,7 +1357,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         if (jx < nb) {
           double v = x[jx];
 #pragma unroll
-          for (int t = 0; t < jx; ++t) v = fma(-x[t], S[(size_t)(c0 + jx) * n + c0 + t], v);
+          for (int t = 0; t < jx; ++t) v = fma(-x[t], *S.at(c0 + jx, c0 + t), v);
           x[jx] = v * s_rv[jx];
         }
       }
@@ -1313,11 +1368,11 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
     SOLVE_STAMP(3);
     const int c1 = c0 + 16, m = n - c1;
     if (m > 0) {
-      if (tid >= nth - 128 && tid - (nth - 128) < m) {                         // b_below -= L21 y_panel (the last two waves: not in wave 0's way)
-        const int rr = c1 + tid - (nth - 128);
+      if (tid >= nth - 192 && tid - (nth - 192) < m) {                         // b_below -= L21 y_panel (the last three waves: not in wave 0's way)
+        const int rr = c1 + tid - (nth - 192);
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc = fma(S[(size_t)rr * n + c0 + k], sb[c0 + k], acc);
+        for (int k = 0; k < 16; ++k) acc = fma(*S.at(rr, c0 + k), sb[c0 + k], acc);
         sb[rr] -= acc;
       }
       const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2, nw = (nth >> 6) - 1;
@@ -1330,14 +1385,14 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
         double av[4], bv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { av[q] = S[(size_t)ra * n + c0 + (lane >> 4) + 4 * q]; bv[q] = S[(size_t)rb2 * n + c0 + (lane >> 4) + 4 * q]; }
+        for (int q = 0; q < 4; ++q) { av[q] = *S.at(ra, c0 + (lane >> 4) + 4 * q); bv[q] = *S.at(rb2, c0 + (lane >> 4) + 4 * q); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
         const int col = c1 + 16 * tj + (lane & 15);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = c1 + 16 * ti + (lane >> 4) + 4 * q;
-          if (row < n && col <= row) S[(size_t)row * n + col] -= acc[q];
+          if (row < n && col <= row) *S.at(row, col) -= acc[q];
         }
       }
       SOLVE_STAMP(7);
@@ -1348,83 +1403,94 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   __syncthreads();
   SOLVE_STAMP(4);
   ok = s_ok;
-  if (tid < n) S[(size_t)tid * n + tid] = 0.0;                                    // L_cc itself is not read again (1 / L_cc is in srinv): see the backward substitution
+  if (tid < n) *S.at(tid, tid) = 0.0;                                    // L_cc itself is not read again (1 / L_cc is in srinv): see the backward substitution
   __syncthreads();
   // (A panel-blocked backward substitution — the panel's 16 unknowns by DPP row_newbcast steps in wave 0, the rows above it one
   // thread each, same operations in the same order, bit-identical — was built and measured: 15.0 us against the 12.2 us of the
   // single wave below at n = 114; its 16 block barriers and LDS round trips cost more than the readlane pairs they replace.
   // v_fmac_f64_dpp / v_mov_b64_dpp issue every 16 cycles, a v_readlane_b32 every 4: profiles/r03_valu_issue_probe2.txt.)
-  if (ok && tid < 64 && n <= 128) {
+  if (ok && tid < 64 && small_n) {
     // backward L^T x = y (y is already in sb: the forward substitution ran inside the factorisation), column oriented: lane holds
-    // rows `lane` and `lane + 64` of the right-hand side in registers; step c: x_c = b_c / L_cc reaches all lanes by a v_readlane
-    // pair, b_r -= L_cr x_c for r < c.  ONE wave issues an instruction every ~8.4 cycles whatever the instruction
-    // (profiles/r03_valu_issue_probe2.txt, 1 wave/SIMD), so what counts here is the instruction count of a step — now address add,
-    // ds_read, multiply, two readlanes, fma:
-    //   - rows r >= c need no mask: they read the upper triangle and the diagonal of S, which hold zeros (above), so the fma leaves
-    //     them alone — lane c keeps b_c and is scaled once at the end (the same product that was broadcast);
+    // rows `lane`, `lane + 64` (and `lane + 128` in the tiled layout) of the right-hand side in registers; step c: x_c = b_c / L_cc
+    // reaches all lanes by a v_readlane pair, b_r -= L_cr x_c for r < c.  ONE wave issues an instruction every ~8.4 cycles whatever the
+    // instruction (profiles/r03_valu_issue_probe2.txt, 1 wave/SIMD), so what counts here is the instruction count of a step — address
+    // add, ds_read, multiply, two readlanes, fma:
+    //   - rows r >= c need no mask: they read the upper triangle and the diagonal of S, which hold zeros (above; in the tiled layout a
+    //     shared zero for tiles that do not exist), so the fma leaves them alone — lane c keeps b_c and is scaled once at the end (the
+    //     same product that was broadcast);
     //   - 1 / L_cc is not fetched per step: every lane multiplies its own entry by its own 1 / L_rr and the readlane picks lane c's;
-    //   - columns >= 64 (both registers, pivot in the second) and < 64 run as two loops, chunks of 8 columns fetched one chunk ahead,
-    //     registers alternating (no copies); what does not fill a pair of chunks goes first, step by step.
+    //   - the columns of each 64-row set run as a loop of their own (the pivot sits in that set's register, only the sets up to it are
+    //     touched), chunks of columns fetched one chunk ahead, registers alternating (no copies); what does not fill a pair of chunks
+    //     goes first, step by step.
     // Until round 3 a step was 22 instructions with two exec-mask regions and a uniform branch: 11.8 us of a 68.7 us solve at n = 114.
     // Same operations on the same operands in the same order: same bits.
-    const int r0 = min(lane, n - 1), r1 = min(lane + 64, n - 1);
-    double b0 = lane < n ? sb[lane] : 0.0, b1 = lane + 64 < n ? sb[lane + 64] : 0.0;
-    const double ri0 = srinv[r0], ri1 = srinv[r1];
-    constexpr int CH = 8;
-    double l0a[CH], l1a[CH], l0b[CH], l1b[CH];
+    int rr_[NRW];
+    double bx[NRW], rix[NRW];
+#pragma unroll
+    for (int q = 0; q < NRW; ++q) {
+      rr_[q] = min(lane + 64 * q, n - 1);
+      bx[q] = lane + 64 * q < n ? sb[lane + 64 * q] : 0.0;
+      rix[q] = srinv[rr_[q]];
+    }
     auto bcast = [&](double t, int src) -> double {
       const int lo = __builtin_amdgcn_readlane(__double2loint(t), src), hi = __builtin_amdgcn_readlane(__double2hiint(t), src);
       return __hiloint2double(hi, lo);
     };
-    auto fetch = [&](auto hi_, int ctop, double (&l0)[CH], double (&l1)[CH]) {
-      constexpr bool HI = decltype(hi_)::value;
+    auto run = [&](auto p_, auto ch_) {                                         // columns of register set P, downwards
+      constexpr int P = decltype(p_)::value, CH = decltype(ch_)::value;
+      const int c_hi = min(n, 64 * P + 64) - 1, c_lo = 64 * P;
+      if (c_hi < c_lo) return;
+      double la[P + 1][CH], lb[P + 1][CH];
+      auto fetch = [&](int ctop, double (&l)[P + 1][CH]) {
 #pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const int cc = max(ctop - j, 0);                                          // (the prefetch past the last chunk: any row will do)
-        l0[j] = S[(size_t)cc * n + r0];
-        if (HI) l1[j] = S[(size_t)cc * n + r1];
-      }
-    };
-    auto chunk = [&](auto hi_, int ctop, const double (&l0)[CH], const double (&l1)[CH]) {
-      constexpr bool HI = decltype(hi_)::value;
+        for (int j = 0; j < CH; ++j) {
+          const int cc = max(ctop - j, 0);                                      // (the prefetch past the last chunk: any row will do)
 #pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const double xc = bcast(HI ? b1 * ri1 : b0 * ri0, (ctop - j) & 63);        // column c lives in lane c mod 64
-        b0 = fma(-l0[j], xc, b0);
-        if (HI) b1 = fma(-l1[j], xc, b1);
-      }
-    };
-    auto run = [&](auto hi_, int c_hi, int c_lo) {                                // columns c_hi .. c_lo, downwards
-      constexpr bool HI = decltype(hi_)::value;
+          for (int q = 0; q <= P; ++q) l[q][j] = *S.rd(cc, rr_[q], &s_zero);
+        }
+      };
+      auto chunk = [&](int ctop, const double (&l)[P + 1][CH]) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const double xc = bcast(bx[P] * rix[P], (ctop - j) & 63);              // column c lives in lane c mod 64
+#pragma unroll
+          for (int q = 0; q <= P; ++q) bx[q] = fma(-l[q][j], xc, bx[q]);
+        }
+      };
       const int cnt = c_hi - c_lo + 1, pairs = cnt / (2 * CH);
       int c = c_hi;
       for (; c >= c_lo + pairs * 2 * CH; --c) {                                   // the odd part first, one column at a time
-        const double xc = bcast(HI ? b1 * ri1 : b0 * ri0, c & 63);
-        b0 = fma(-S[(size_t)c * n + r0], xc, b0);
-        if (HI) b1 = fma(-S[(size_t)c * n + r1], xc, b1);
+        const double xc = bcast(bx[P] * rix[P], c & 63);
+#pragma unroll
+        for (int q = 0; q <= P; ++q) bx[q] = fma(-*S.rd(c, rr_[q], &s_zero), xc, bx[q]);
       }
-      if (pairs > 0) fetch(hi_, c, l0a, l1a);
-      for (int q = 0; q < pairs; ++q, c -= 2 * CH) {
-        fetch(hi_, c - CH, l0b, l1b);
-        chunk(hi_, c, l0a, l1a);
-        fetch(hi_, c - 2 * CH, l0a, l1a);
-        chunk(hi_, c - CH, l0b, l1b);
+      if (pairs > 0) fetch(c, la);
+      for (int q2 = 0; q2 < pairs; ++q2, c -= 2 * CH) {
+        fetch(c - CH, lb);
+        chunk(c, la);
+        fetch(c - 2 * CH, la);
+        chunk(c - CH, lb);
       }
     };
-    if (n > 64) run(std::true_type{}, n - 1, 64);
-    run(std::false_type{}, min(n, 64) - 1, 0);
+    if constexpr (NRW > 2) run(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+    run(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{});
+    run(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
     // the solution is in this wave's registers: delta_p, |delta_p|^2 and |p|^2 from here, no block-wide pass behind it
-    const double x0 = lane < n ? b0 * ri0 : 0.0, x1 = lane + 64 < n ? b1 * ri1 : 0.0;
-    const double p0 = lane < n ? params[lane] : 0.0, p1 = lane + 64 < n ? params[lane + 64] : 0.0;
-    if (lane < n) dp[lane] = x0;
-    if (lane + 64 < n) dp[lane + 64] = x1;
-    const double dsq = wave_sum(x0 * x0 + x1 * x1), psq = wave_sum(p0 * p0 + p1 * p1);
+    double d2 = 0.0, p2s = 0.0;
+#pragma unroll
+    for (int q = 0; q < NRW; ++q) {
+      const bool in = lane + 64 * q < n;
+      const double xq = in ? bx[q] * rix[q] : 0.0, pq = in ? params[lane + 64 * q] : 0.0;
+      if (in) dp[lane + 64 * q] = xq;
+      if (q == 0) { d2 = xq * xq; p2s = pq * pq; } else { d2 = d2 + xq * xq; p2s = p2s + pq * pq; }
+    }
+    const double dsq = wave_sum(d2), psq = wave_sum(p2s);
     if (lane == 0) { res[2] = 1.0; res[3] = dsq; res[4] = psq; }
   } else if (ok && tid < 64) {
     // general n: row dot products with shuffle reductions
     for (int r = n - 1; r >= 0; --r) {
       double acc = 0.0;
-      for (int k = r + 1 + lane; k < n; k += 64) acc = fma(S[(size_t)k * n + r], sb[k], acc);
+      for (int k = r + 1 + lane; k < n; k += 64) acc = fma(*S.at(k, r), sb[k], acc);
       acc = wave_sum(acc);
       if (lane == 0) sb[r] = (sb[r] - acc) * srinv[r];
       __builtin_amdgcn_wave_barrier();
@@ -1457,8 +1523,19 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(const BaWin* __restrict__ wins) {
   extern __shared__ __align__(16) double dyn[];
   const BaWin& win = wins[blockIdx.y];       // one workgroup per window
-  if (!win.use_lds) return;
-  solve_body(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, dyn, win.dp, win.res);
+  if (win.use_lds != 1) return;
+  solve_body<LaySquare, false>(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, LaySquare{dyn, win.n}, win.dp, win.res);
+}
+
+// The same factorisation and solve for systems of up to BA_TILED_MAX_N unknowns that do not fit LDS as a square (use_lds == 2: a visual
+// window of 22..29 keyframes, the 15-d system of an inertial window of up to 11): assembled in global memory by ba_big_assemble_kernel /
+// ba_inertial_assemble_kernel as for the multi-launch path, copied into lower 16 x 16 tiles, ONE launch instead of n / 16 + 1
+// (inertial BA, 10 keyframes: 11 launches, 129 us per iteration for the solve).
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_tiled_kernel(const BaWin* __restrict__ wins) {
+  extern __shared__ __align__(16) double dyn[];
+  const BaWin& win = wins[blockIdx.y];
+  if (win.use_lds != 2) return;
+  solve_body<LayTiled, true>(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, LayTiled{dyn}, win.dp, win.res, win.Sg, win.bvec);
 }
 
 // ---- large reduced systems (n > ~135: S does not fit LDS) -------------------------------------------------------
@@ -1472,7 +1549,7 @@ constexpr int BB_NB = 16;
 __global__ __launch_bounds__(256) void ba_big_assemble_kernel(const BaWin* __restrict__ wins) {
   const BaWin& win = wins[blockIdx.y];
   const BaState* St = win.S;
-  if (win.use_lds || St->done) return;
+  if (win.use_lds == 1 || St->done) return;                                // (the tiled LDS solve, use_lds == 2, reads what this kernel assembles)
   const int n = win.n, K = win.d.K;
   const double* __restrict__ rb = win.rb;
   double* __restrict__ Sg = win.Sg; double* __restrict__ bvec = win.bvec; double* __restrict__ res = win.res;
@@ -2474,6 +2551,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.rb_len = (size_t)pl.n * pl.n + 36 * (size_t)K + 2 * (size_t)pl.n + 2;
     pl.lds_need = 8 * ((size_t)pl.n * pl.n + BA_SOLVE_THREADS);
     pl.use_lds = (pl.lds_need <= BA_LDS_DYN_MAX && pl.n % 2 == 0 && pl.n <= 128) ? 1 : 0;   // (the LDS solve reads pairs of entries — even n, which 6K is — and lays its threads over a 128 x 128 grid)
+    if (!pl.use_lds && pl.n <= BA_TILED_MAX_N) {                          // lower 16 x 16 tiles in LDS: one launch where the multi-launch path takes n / 16 + 1
+      const size_t nt = (size_t)(pl.n + 15) / 16;
+      pl.use_lds = 2;
+      pl.lds_need = 8 * 256 * (nt * (nt + 1) / 2);
+    }
     pl.n_res = 2.0 * (double)N;
     const size_t n1 = (size_t)std::max(N, 1), m1 = (size_t)std::max(M, 1), k1 = (size_t)std::max(K, 1);
     pl.i_state = cin.take(sizeof(BaState));
@@ -2573,7 +2655,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // window descriptors + LM states into the blob
   BaWin* hw = (BaWin*)(hin + i_wins);
   size_t* hoff = (size_t*)(hin + i_outoff);
-  size_t lds_max = 0;
+  size_t lds_max = 0, tiled_lds_max = 0;
+  int any_tiled = 0;
   // points per 32-lane group of the build / back-substitution launches: 1 for a few windows, 4 in a large batch (one block prologue —
   // the K rotations — per 32 points instead of per 8; 32-window batch: build 0.103 -> 0.096, back-substitution 0.068 -> 0.064 ms per iteration)
   const int ppg = W >= 8 ? 4 : 1;
@@ -2601,7 +2684,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.res = (double*)(dar + pl.a_res);
     hoff[w] = pl.o_out / 8;
     if (pl.skip) continue;                                             // (its LM state says done: set with the window's preprocessing)
-    if (pl.use_lds && !inertial) { any_lds = 1; lds_max = std::max(lds_max, pl.lds_need); }
+    if (pl.use_lds == 1 && !inertial) { any_lds = 1; lds_max = std::max(lds_max, pl.lds_need); }
+    else if (pl.use_lds == 2 && !inertial) { any_tiled = 1; tiled_lds_max = std::max(tiled_lds_max, pl.lds_need); }
     else if (!inertial) { any_big = 1; n_big_max = std::max(n_big_max, pl.n); }
     maxM = std::max(maxM, pl.d.M); maxK = std::max(maxK, pl.d.K);
     max_schur_blocks = std::max(max_schur_blocks, pl.d.ncb * (pl.d.ncb + 1) / 2 * pl.d.ksplit);
@@ -2641,7 +2725,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     // the 15-d system: dp15 [n15 pad 16] | S [n15^2] | b [n15] | 1/L_jj [n15] | gradient [n15]
     BaWin& b15 = *(BaWin*)(hin + i_wins15);
     b15 = hw[0];
-    b15.n = n15; b15.use_lds = 0;
+    b15.n = n15; b15.use_lds = n15 <= BA_TILED_MAX_N ? 2 : 0;             // (the 15-d system of up to 11 keyframes: the tiled LDS solve)
+    if (b15.use_lds == 2) { const size_t nt = (size_t)(n15 + 15) / 16; tiled_lds_max = 8 * 256 * (nt * (nt + 1) / 2); }
     dp15 = (double*)h->ws_ba[B_S15].p;
     b15.dp = dp15;
     b15.Sg = dp15 + ((n15 + 15) & ~15); b15.bvec = b15.Sg + (size_t)n15 * n15; b15.ginv = b15.bvec + n15;
@@ -2655,6 +2740,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     hipError_t e_attr = hipSuccess;                                    // the largest size any window may ask for
     std::call_once(once[h->device & 63], [&] {
       e_attr = hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_LDS_DYN_MAX);
+      if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_solve_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_LDS_DYN_MAX);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_kf_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
     });
@@ -2748,17 +2834,21 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       const BaWin& b15 = *(const BaWin*)(hin + i_wins15);
       if (inr->E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, w0.S, w0.P0, w0.P1, 0, 1, ind, imu_buf);
       hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, ind, w0.rb, imu_buf, b15.Sg, b15.bvec, gfull, res0);
-      for (int c0 = 0; c0 < n15; c0 += BB_NB) {
-        const int nt = (n15 - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
-        hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + 3) / 4, 1), dim3(256), 0, st, d_wins15, c0);
+      if (n15 <= BA_TILED_MAX_N) hipLaunchKernelGGL(ba_solve_tiled_kernel, dim3(1, 1), dim3(BA_SOLVE_THREADS), tiled_lds_max, st, d_wins15);
+      else {
+        for (int c0 = 0; c0 < n15; c0 += BB_NB) {
+          const int nt = (n15 - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
+          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + 3) / 4, 1), dim3(256), 0, st, d_wins15, c0);
+        }
+        hipLaunchKernelGGL(ba_big_back_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15);
       }
-      hipLaunchKernelGGL(ba_big_back_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15);
       hipLaunchKernelGGL(ba_inertial_scatter_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, K0, M0, dp15, w0.dp);
     } else {
       ProfScope ps(h, "ba_solve_kernel");
       if (any_lds) hipLaunchKernelGGL(ba_solve_lds_kernel, gW1, dim3(BA_SOLVE_THREADS), lds_max, st, d_wins);
+      if (any_big || any_tiled) hipLaunchKernelGGL(ba_big_assemble_kernel, dim3(max_asm, W), dim3(256), 0, st, d_wins);
+      if (any_tiled) hipLaunchKernelGGL(ba_solve_tiled_kernel, gW1, dim3(BA_SOLVE_THREADS), tiled_lds_max, st, d_wins);
       if (any_big) {
-        hipLaunchKernelGGL(ba_big_assemble_kernel, dim3(max_asm, W), dim3(256), 0, st, d_wins);
         for (int c0 = 0; c0 < n_big_max; c0 += BB_NB) {
           const int nt = (n_big_max - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
           hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + 3) / 4, W), dim3(256), 0, st, d_wins, c0);

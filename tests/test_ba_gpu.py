@@ -60,6 +60,16 @@ def test_ba_large_window_gmem_cholesky(gpu_handle, oracle, pkg):
     assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL
 
 
+def test_ba_mid_window_tiled_lds_cholesky(gpu_handle, oracle, pkg):
+    """22..29 optimised keyframes (n = 132..174): the reduced system does not fit LDS as a square but does as lower 16 x 16 tiles — one
+    launch (ba_solve_tiled_kernel) instead of the multi-launch path; against the structured oracle at both ends and at an odd tile count."""
+    for seed, K, M in ((8, 23, 500), (9, 26, 450), (10, 30, 400)):
+        w = pkg.synth.ba_window(seed, K, M, pkg.BA_OBS)
+        g, o = _solve_both(gpu_handle, oracle, pkg, w, dense=False)
+        assert g["iterations"] == o["iterations"], (K, M)
+        assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL, (K, M)
+
+
 def test_ba_noise_free_and_golden(gpu_handle, oracle, pkg, golden):
     w = pkg.synth.ba_window(1, 5, 60, pkg.BA_OBS, noise_px=0.0, perturb=False)
     g, o = _solve_both(gpu_handle, oracle, pkg, w)
