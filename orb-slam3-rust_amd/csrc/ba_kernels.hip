@@ -1132,6 +1132,15 @@ extern "C" int orbx_debug_solve_stamps(unsigned long long* out16, int reset) {
 #else
 #define SOLVE_STAMP(k) do { } while (0)
 #endif
+// (inertial terms: src/optimizer/local_inertial_ba.rs:661-698, :806-880; the kernels that fill these records are further down)
+struct BaInertialDev {
+  int K, M, E;
+  double gw, aw;                 // sqrt of the random-walk informations
+  const int* edge_kf;            // [E][2]
+  const double* preint;          // [E][11]
+};
+constexpr int IMU_REC = 18 * 18 + 18 + 2;   // per edge: H (18x18) | g (18) | chi2(imu + random walk) | spare
+
 // Where the reduced system lives in LDS.  LaySquare: row-major n x n, n <= 128 (every local-BA window of the reference).  LayTiled: the
 // LOWER 16 x 16 tiles only, tile (ti, tj <= ti) at ((ti (ti + 1)) / 2 + tj) * 256 doubles — 55 tiles = 110 KB at n = 150 (the 15-d
 // system of a 10-keyframe inertial window), 66 = 132 KB at n = 176 — for systems that do not fit as a square but need not go through
@@ -1152,13 +1161,18 @@ struct LayTiled {
   }
   __device__ __forceinline__ const double* rd(int i, int j, const double* zero) const { return (j >> 4) > (i >> 4) ? zero : at(i, j); }
 };
-constexpr int BA_TILED_MAX_N = 176;    // 66 lower tiles = 132 KB beside the 20 KB of static arrays
+constexpr int BA_TILED_MAX_N = 176;    // 66 lower tiles = 132 KB beside the 20-23 KB of static arrays
+constexpr size_t BA_TILED_LDS_MAX = 8 * 256 * (size_t)(((BA_TILED_MAX_N + 15) / 16) * ((BA_TILED_MAX_N + 15) / 16 + 1) / 2);
 
-// FROM_SG: the system was assembled in global memory (win.Sg, lower triangle, and win.bvec: ba_big_assemble_kernel / the inertial
-// assembly) and is copied in; otherwise S = blockdiag(U*) - S_red and b = -g_p + b_red are formed here from the gather's buffer `rb`.
-template <typename LAY, bool FROM_SG>
+// MODE 0: S = blockdiag(U*) - S_red and b = -g_p + b_red are formed here from the gather's buffer `rb`.  MODE 1: the system was
+// assembled in global memory (win.Sg, lower triangle, and win.bvec: ba_big_assemble_kernel) and is copied in.  MODE 2: the 15-d system
+// of an inertial window is assembled here, in the tiles, from `rb`, the IMU edge records and the bias random walk — what
+// ba_inertial_assemble_kernel does in global memory with one 256-thread block (26 us at 10 keyframes) — same terms, same order per entry.
+template <typename LAY, int MODE>
 __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0, double* P1, const double* __restrict__ rb, int K, LAY S,
-                           double* __restrict__ dp, double* __restrict__ res, const double* __restrict__ Sg = nullptr, const double* __restrict__ bvec = nullptr) {
+                           double* __restrict__ dp, double* __restrict__ res, const double* __restrict__ Sg = nullptr, const double* __restrict__ bvec = nullptr,
+                           const BaInertialDev* inp = nullptr, const double* __restrict__ imu_buf = nullptr) {
+  constexpr bool FROM_SG = MODE != 0;                                           // (the system does not come from the visual assembly below)
   if (St->done) return;
 #ifdef ORBX_SOLVE_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
@@ -1226,6 +1240,69 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   for (int i = tid; i < n; i += nth) { sb[i] = -gp[i] + bred[i]; gs += gp[i] * gp[i]; }
   if (small_n) { if (tid < 64 * NRW) { gs = wave_sum(gs); if ((tid & 63) == 0) s_red[tid >> 6] = gs; } }
   else { gs = block_sum_fixed(gs, s_red); if (tid == 0) { res[0] = bred[n]; res[1] = sqrt(gs + bred[n + 1]); } }
+  } else if constexpr (MODE == 2) {
+    static_assert(LAY::TILED, "the inertial assembly writes tiles");
+    const BaInertialDev& in = *inp;
+    const int Kk = in.K, n6 = 6 * Kk;
+    const double* Uv = rb + (size_t)n6 * n6;
+    const double* gpv = Uv + 36 * (size_t)Kk;
+    const double* bredv = gpv + n6;
+    const double* ex = params + 6 * (size_t)Kk + 3 * (size_t)in.M;
+    double* gfull = s_red;                                                       // [n] gradient over the keyframe states (n <= 176 < nth)
+    const int ntl = (n + 15) >> 4;
+    for (int u = tid; u < ntl * (ntl + 1) / 2 * 256; u += nth) S.p[u] = 0.0;
+    for (int i = tid; i < n; i += nth) { sb[i] = 0.0; gfull[i] = 0.0; }
+    __syncthreads();
+    // J^T J of the IMU and random-walk rows, edge after edge (fixed order, no atomics); lower triangle only
+    for (int e = 0; e < in.E; ++e) {
+      const int kk[2] = {in.edge_kf[2 * e], in.edge_kf[2 * e + 1]};
+      const double* rec = imu_buf + (size_t)e * IMU_REC;
+      if (tid < 18 * 18) {
+        const int a = tid / 18, b2 = tid % 18;
+        const int i = 15 * kk[a / 9] + a % 9, j = 15 * kk[b2 / 9] + b2 % 9;
+        if (j <= i) *S.at(i, j) += rec[tid];
+      }
+      if (tid >= 512 && tid < 512 + 18) { const int t = tid - 512; gfull[15 * kk[t / 9] + t % 9] += rec[18 * 18 + t]; }
+      if (tid >= 576 && tid < 576 + 6) {                                        // :863-880 (the bias rows 9..14 of a state: no entry of the 18 x 18 block above)
+        const int k = tid - 576;
+        const double w = k < 3 ? in.gw : in.aw;
+        const int ii = 15 * kk[0] + 9 + k, jj = 15 * kk[1] + 9 + k;
+        const double r = (ex[9 * (size_t)kk[1] + 3 + k] - ex[9 * (size_t)kk[0] + 3 + k]) * w;
+        *S.at(ii, ii) += w * w; *S.at(jj, jj) += w * w;
+        *S.at(max(ii, jj), min(ii, jj)) -= w * w;
+        gfull[ii] += -w * r; gfull[jj] += w * r;
+      }
+      __syncthreads();
+    }
+    // visual part: U on the keyframe diagonal blocks, the gradient, damping with the full diagonal, then the Schur term
+    for (int t = tid; t < 36 * Kk; t += nth) {
+      const int k = t / 36, a = (t % 36) / 6, b2 = t % 6;
+      if (b2 <= a) *S.at(15 * k + a, 15 * k + b2) += Uv[t];
+    }
+    for (int t = tid; t < n6; t += nth) gfull[15 * (t / 6) + t % 6] += gpv[t];
+    __syncthreads();
+    for (int i = tid; i < n; i += nth) { double* dgp = S.at(i, i); *dgp += lambda * fmax(*dgp, 1e-6); }
+    __syncthreads();
+    for (int idx = tid; idx < n6 * n6; idx += nth) {
+      const int i = idx / n6, j = idx - i * n6;
+      if (j <= i) *S.at(15 * (i / 6) + i % 6, 15 * (j / 6) + j % 6) -= rb[idx];
+    }
+    for (int i = tid; i < n; i += nth) {
+      double b = -gfull[i];
+      if (i % 15 < 6) b += bredv[6 * (i / 15) + i % 15];
+      sb[i] = b;
+    }
+    // |gradient|^2 as ba_inertial_assemble_kernel forms it: 256 strided partials, a tree over them
+    __shared__ double red256[256];
+    if (tid < 256) { double gs2 = 0.0; for (int i = tid; i < n; i += 256) gs2 += gfull[i] * gfull[i]; red256[tid] = gs2; }
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) { if (tid < s2) red256[tid] += red256[tid + s2]; __syncthreads(); }
+    if (tid == 0) {
+      double chi = bredv[n6];                                                    // visual chi2 (gather kernel)
+      for (int e = 0; e < in.E; ++e) chi += imu_buf[(size_t)e * IMU_REC + 18 * 18 + 18];
+      res[0] = chi;
+      res[1] = sqrt(red256[0] + bredv[n6 + 1]);                                  // |gradient| over keyframe states and points (:1213)
+    }
   } else {
     // copy the lower triangle in (entries right of the diagonal inside the diagonal tiles: zeros), all of a thread's loads first
     constexpr int TYN = BA_SOLVE_THREADS / 32, CR = (BA_TILED_MAX_N + TYN - 1) / TYN, CC = (BA_TILED_MAX_N + 31) / 32;
@@ -1524,7 +1601,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(const Ba
   extern __shared__ __align__(16) double dyn[];
   const BaWin& win = wins[blockIdx.y];       // one workgroup per window
   if (win.use_lds != 1) return;
-  solve_body<LaySquare, false>(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, LaySquare{dyn, win.n}, win.dp, win.res);
+  solve_body<LaySquare, 0>(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, LaySquare{dyn, win.n}, win.dp, win.res);
 }
 
 // The same factorisation and solve for systems of up to BA_TILED_MAX_N unknowns that do not fit LDS as a square (use_lds == 2: a visual
@@ -1535,7 +1612,15 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_tiled_kernel(const 
   extern __shared__ __align__(16) double dyn[];
   const BaWin& win = wins[blockIdx.y];
   if (win.use_lds != 2) return;
-  solve_body<LayTiled, true>(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, LayTiled{dyn}, win.dp, win.res, win.Sg, win.bvec);
+  solve_body<LayTiled, 1>(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, LayTiled{dyn}, win.dp, win.res, win.Sg, win.bvec);
+}
+
+// the 15-d system of an inertial window (one window per call), assembled in the tiles and solved in the same launch
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_inertial_tiled_kernel(const BaWin* __restrict__ wins, BaInertialDev in,
+                                                                                   const double* __restrict__ imu_buf) {
+  extern __shared__ __align__(16) double dyn[];
+  const BaWin& win = wins[0];
+  solve_body<LayTiled, 2>(win.n, win.S, win.P0, win.P1, win.rb, in.K, LayTiled{dyn}, win.dp, win.res, nullptr, nullptr, &in, imu_buf);
 }
 
 // ---- large reduced systems (n > ~135: S does not fit LDS) -------------------------------------------------------
@@ -2096,13 +2181,6 @@ __global__ __launch_bounds__(256) void ba_decide_kernel(const BaWin* __restrict_
 
 // ---- inertial terms (src/optimizer/local_inertial_ba.rs:661-698, :806-880; src/optimizer/imu_factors.rs:66-103) --------------------
 // Device parameter layout in inertial mode: [6K T_wc pose | 3M points | 9K velocity, gyro bias, accel bias].
-struct BaInertialDev {
-  int K, M, E;
-  double gw, aw;                 // sqrt of the random-walk informations
-  const int* edge_kf;            // [E][2]
-  const double* preint;          // [E][11]
-};
-constexpr int IMU_REC = 18 * 18 + 18 + 2;   // per edge: H (18x18) | g (18) | chi2(imu + random walk) | spare
 
 __device__ __forceinline__ void dev_scaled_axis(const double* q, double* o) {   // nalgebra UnitQuaternion::scaled_axis
   double v0 = q[1], v1 = q[2], v2 = q[3];
@@ -2740,7 +2818,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     hipError_t e_attr = hipSuccess;                                    // the largest size any window may ask for
     std::call_once(once[h->device & 63], [&] {
       e_attr = hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_LDS_DYN_MAX);
-      if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_solve_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_LDS_DYN_MAX);
+      if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_solve_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_TILED_LDS_MAX);
+      if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_solve_inertial_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_TILED_LDS_MAX);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_kf_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
     });
@@ -2833,9 +2912,9 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       ProfScope ps(h, "ba_inertial_solve");
       const BaWin& b15 = *(const BaWin*)(hin + i_wins15);
       if (inr->E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(inr->E), dim3(64), 0, st, w0.S, w0.P0, w0.P1, 0, 1, ind, imu_buf);
-      hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, ind, w0.rb, imu_buf, b15.Sg, b15.bvec, gfull, res0);
-      if (n15 <= BA_TILED_MAX_N) hipLaunchKernelGGL(ba_solve_tiled_kernel, dim3(1, 1), dim3(BA_SOLVE_THREADS), tiled_lds_max, st, d_wins15);
+      if (n15 <= BA_TILED_MAX_N) hipLaunchKernelGGL(ba_solve_inertial_tiled_kernel, dim3(1, 1), dim3(BA_SOLVE_THREADS), tiled_lds_max, st, d_wins15, ind, (const double*)imu_buf);
       else {
+        hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, ind, w0.rb, imu_buf, b15.Sg, b15.bvec, gfull, res0);
         for (int c0 = 0; c0 < n15; c0 += BB_NB) {
           const int nt = (n15 - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
           hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + 3) / 4, 1), dim3(256), 0, st, d_wins15, c0);
