@@ -535,6 +535,30 @@ def schur_executed_flop(K_opt, M):
     return nt * (nt + 1) // 2 * (rows // 4) * 2048.0
 
 
+def bench_ba_inertial(P, h, cam, K=10, M=2000, seed=42):
+    """solve_inertial_ba (local_inertial_ba.rs:1074-1275; LocalInertialBAConfig::window_size = 10): what the local mapper runs once the
+    IMU is initialised.  15-d keyframe states, 9-d preintegration + 6-d bias-walk edges beside the reprojection residuals."""
+    w = P.synth.inertial_window(seed, K, M, P.BA_OBS)
+    icfg = P.LocalInertialBAConfig()
+    args = (cam, icfg, w["poses_wc"], w["velocities"], w["biases"], w["fixed_cw"], w["points"], w["obs"], w["edge_kf"], w["preint"])
+    r = h.ba_solve_inertial(*args)
+    reps = 5
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(reps):
+        its += h.ba_solve_inertial(*args)["iterations"]
+    dt = time.perf_counter() - t0
+    h.set_profiling(True)
+    h.ba_solve_inertial(*args)
+    kt = h.kernel_times()
+    h.set_profiling(False)
+    n_it = max(r["iterations"], 1)
+    return dict(workload="synth inertial window(seed=%d, K=%d, M=%d), %d observations, %d IMU edges (15-d states: reduced system n = %d)"
+                         % (seed, K, M, len(w["obs"]), len(w["edge_kf"]), 15 * K),
+                lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3), iterations=r["iterations"],
+                kernel_ms_per_iteration={k: round(v[0] / n_it, 4) for k, v in sorted(kt.items()) if k.startswith("ba_")})
+
+
 def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
     win = P.synth.ba_window(seed, K, M, P.BA_OBS)
     args = (cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
@@ -741,6 +765,7 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         # no longer fits LDS, so the factorisation is the multi-kernel form
         try:
             out["config5"] = bench_ba_config5(P, h, cam, cfg)
+            out["inertial"] = bench_ba_inertial(P, h, cam)
         except Exception as e:
             out["config5"] = dict(error=repr(e))
         # the CPU side of the BA half of the metric: the reference's literal dense-LM formulation at a size where it
