@@ -1652,6 +1652,9 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     }
     return ORBX_OK;
   };
+  // (Round 3: the previous batch's stereo matcher on a stream of its own, so that its latency-bound launches run under this batch's resize
+  // launches — describe waiting for it, since it rewrites what the matcher reads —: both stretch by what the other takes (resize 0.264 ->
+  // 0.360, matcher 0.091 -> 0.155 ms per 256 pairs), frames/s unchanged; withdrawn.)
   // (Two half-batches on two streams were measured: +0.3 % in round 1; again at the end of round 2, when FAST's 7 blocks per CU leave wave
   // slots free: 2 / 3 / 4 / 6 / 8 chunks alternating over two streams: +0.5 ... +2 % / -3 % / 0 / -3 % / -5 % without per-kernel events — so one stream.)
   if (int rc = run(h->stream, 0, n_images)) return rc;
