@@ -1675,8 +1675,12 @@ __global__ __launch_bounds__(256) void ba_big_assemble_kernel(const BaWin* __res
 // forward AND backward substitution in a one-block kernel afterwards — 38 + 1 dependent launches at n = 294, 381 us per solve; now
 // 19 + 1.)
 // (1024-thread blocks — the panel block's column tiles in two rounds, every row below in one — measured slower: 327 -> 438 us per solve.)
-constexpr int BB_STEP_THREADS = 256;
-constexpr int BB_COL_TILES = (BA_MAX_N / 16 + 3) / 4;      // column tiles per wave of the panel block, all in flight at once
+#ifndef ORBX_BB_STEP_THREADS
+#define ORBX_BB_STEP_THREADS 512
+#endif
+constexpr int BB_STEP_THREADS = ORBX_BB_STEP_THREADS, BB_STEP_WAVES = BB_STEP_THREADS / 64;   // 256 / 512 threads: 211.8 / 204.9 us per solve at n = 294 (round 1's 1024: slower)
+static_assert(BB_STEP_THREADS >= 256 && BB_STEP_THREADS % 64 == 0 && BB_STEP_THREADS <= 1024, "the panel block stages its 16 x 16 tile with 256 threads");
+constexpr int BB_COL_TILES = (BA_MAX_N / 16 + BB_STEP_WAVES - 1) / BB_STEP_WAVES;      // column tiles per wave of the panel block, all in flight at once
 __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWin* __restrict__ wins, int c0) {
   __shared__ __align__(16) double D[BB_NB][BB_NB + 2];                    // (even pitch: the row solves read L11 in pairs)
   __shared__ __align__(16) double rinv[BB_NB];
@@ -1691,7 +1695,7 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
   const int nt = (n - c0 + 15) / 16;                                      // tile rows of the trailing matrix [c0, n)
   if (blockIdx.x > 0) {
     if (prev < 0) return;
-    const int unit = ((int)blockIdx.x - 1) * 4 + wave;                     // tiles (ti, tj) with 1 <= tj <= ti < nt: unit = ti (ti - 1) / 2 + tj - 1
+    const int unit = ((int)blockIdx.x - 1) * BB_STEP_WAVES + wave;                     // tiles (ti, tj) with 1 <= tj <= ti < nt: unit = ti (ti - 1) / 2 + tj - 1
     if (unit >= nt * (nt - 1) / 2) return;
     int ti = 1, rem = unit;
     while (rem >= ti) { rem -= ti; ++ti; }
@@ -1717,7 +1721,7 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
   // ---- the panel block
   const int nb = min(BB_NB, n - c0);
   if (tid == 0) s_ok = 1;
-  {
+  if (tid < BB_NB * BB_NB) {
     const int i = tid / BB_NB, j = tid % BB_NB;
     D[i][j] = i == j ? 1.0 : 0.0;                                           // rows / columns beyond nb: the identity
   }
@@ -1733,7 +1737,7 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
     const int col = c0 + (lane & 15);
 #pragma unroll
     for (int t = 0; t < BB_COL_TILES; ++t) {
-      const int ti = wave + 4 * t;
+      const int ti = wave + BB_STEP_WAVES * t;
       if (ti < nt) {                                                       // wave-uniform
         const int ra = min(c0 + 16 * ti + (lane & 15), n - 1);
 #pragma unroll
@@ -1755,7 +1759,7 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
     }
 #pragma unroll
     for (int t = 0; t < BB_COL_TILES; ++t) {
-      const int ti = wave + 4 * t;
+      const int ti = wave + BB_STEP_WAVES * t;
       if (ti < nt) {
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1771,7 +1775,7 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
         }
       }
     }
-  } else {
+  } else if (tid < BB_NB * BB_NB) {
     const int i = tid / BB_NB, j = tid % BB_NB;
     if (i < nb && j <= i) D[i][j] = Sg[(size_t)(c0 + i) * n + c0 + j];
   }
@@ -2917,7 +2921,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
         hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, ind, w0.rb, imu_buf, b15.Sg, b15.bvec, gfull, res0);
         for (int c0 = 0; c0 < n15; c0 += BB_NB) {
           const int nt = (n15 - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
-          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + 3) / 4, 1), dim3(256), 0, st, d_wins15, c0);
+          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + BB_STEP_WAVES - 1) / BB_STEP_WAVES, 1), dim3(BB_STEP_THREADS), 0, st, d_wins15, c0);
         }
         hipLaunchKernelGGL(ba_big_back_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15);
       }
@@ -2930,7 +2934,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       if (any_big) {
         for (int c0 = 0; c0 < n_big_max; c0 += BB_NB) {
           const int nt = (n_big_max - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
-          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + 3) / 4, W), dim3(256), 0, st, d_wins, c0);
+          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + BB_STEP_WAVES - 1) / BB_STEP_WAVES, W), dim3(BB_STEP_THREADS), 0, st, d_wins, c0);
         }
         hipLaunchKernelGGL(ba_big_back_kernel, gW1, dim3(256), 0, st, d_wins);
       }
