@@ -2135,9 +2135,13 @@ __global__ __launch_bounds__(256) void ba_sum3_kernel(const BaWin* __restrict__ 
 // abort: device-visible word the host sets when should_stop() turns true while the enqueued iterations drain — the solve then
 // ends at the next iteration boundary, as the reference's poll at the top of the loop (:1013) does.  stop_vote (partitioned
 // runs): res[8] holds the all-reduced stop votes of the ranks for the NEXT iteration, so that every rank leaves together.
-__global__ __launch_bounds__(256) void ba_decide_kernel(const BaWin* __restrict__ wins, int reduce_here, const double* __restrict__ imu_buf, int E,
+#ifndef ORBX_BA_DECIDE_THREADS
+#define ORBX_BA_DECIDE_THREADS 1024
+#endif
+constexpr int BA_DECIDE_THREADS = ORBX_BA_DECIDE_THREADS;   // (the thread count fixes the order of the three sums; 256 / 512 / 1024: one window 7.5 / 6.6 / 6.3 us, configs[4] 15.1 / 10.6 / 8.6, 32-window batch 9.4 / 8.8 / 9.8)
+__global__ __launch_bounds__(BA_DECIDE_THREADS) void ba_decide_kernel(const BaWin* __restrict__ wins, int reduce_here, const double* __restrict__ imu_buf, int E,
                                                         const volatile int* __restrict__ abort_flag, int stop_vote) {
-  __shared__ double sh[3][256];
+  __shared__ double sh[3][BA_DECIDE_THREADS];
   const BaWin& win = wins[blockIdx.y];
   BaState* S = win.S;
   if (S->done) return;
@@ -2147,10 +2151,10 @@ __global__ __launch_bounds__(256) void ba_decide_kernel(const BaWin* __restrict_
   const int tid = threadIdx.x;
   if (M >= 0) {
     double x = 0.0, y = 0.0, z = 0.0;
-    for (int j = tid; j < M; j += 256) { x += pt_chi2[j]; y += pt_dsq[j]; z += pt_psq[j]; }
+    for (int j = tid; j < M; j += BA_DECIDE_THREADS) { x += pt_chi2[j]; y += pt_dsq[j]; z += pt_psq[j]; }
     sh[0][tid] = x; sh[1][tid] = y; sh[2][tid] = z;
     __syncthreads();
-    for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+    for (int s2 = BA_DECIDE_THREADS / 2; s2 >= 1; s2 >>= 1) {
       if (tid < s2) { sh[0][tid] += sh[0][tid + s2]; sh[1][tid] += sh[1][tid + s2]; sh[2][tid] += sh[2][tid + s2]; }
       __syncthreads();
     }
@@ -2957,12 +2961,12 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       ORBX_HIP(h, hipMemcpyAsync(res0 + 8, &votes[(size_t)iter], 8, hipMemcpyHostToDevice, st));
       if (int rc = allreduce(res0 + 5, 4)) return rc;
       ProfScope ps(h, "ba_decide_kernel");
-      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(256), 0, st, d_wins, 0, (const double*)nullptr, 0, (const volatile int*)nullptr, 1);
+      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(BA_DECIDE_THREADS), 0, st, d_wins, 0, (const double*)nullptr, 0, (const volatile int*)nullptr, 1);
     } else {
       ProfScope ps(h, "ba_decide_kernel");
       const int E = inertial ? inr->E : 0;
       if (E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(E), dim3(64), 0, st, w0.S, w0.P0, w0.P1, 1, 0, ind, imu_buf);
-      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(256), 0, st, d_wins, 1, (const double*)imu_buf, E, (const volatile int*)h->d_abort, 0);
+      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(BA_DECIDE_THREADS), 0, st, d_wins, 1, (const double*)imu_buf, E, (const volatile int*)h->d_abort, 0);
     }
   }
   {
