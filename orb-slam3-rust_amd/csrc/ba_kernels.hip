@@ -776,6 +776,10 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
 }
 
 constexpr int SCHW_THREADS = 512;      // 4 consumer + 4 producer waves
+#ifndef ORBX_BA_GATHER_MAX_BLOCKS
+#define ORBX_BA_GATHER_MAX_BLOCKS 2048
+#endif
+constexpr int BA_GATHER_MAX_BLOCKS = ORBX_BA_GATHER_MAX_BLOCKS;   // blocks per window of the gather launch (256 / 1024 / 2048: configs[4] 23.0 / 21.3 / 19.8 us; a 20-keyframe window needs 203)
 constexpr int BA_GATHER_LANES = 8;     // shares of a window's k-splits (ba_gather_kernel's lanes per element = the Schur launch's workgroups per window in a large batch)
 constexpr size_t SCHW_LDS_BYTES = 4 * (size_t)SCH_R * SCH_PITCH * sizeof(double);      // two buffers x (Y, W): 104 448 B
 __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaWin& win, const BaCam& cam, double* __restrict__ lds) {
@@ -2776,7 +2780,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     maxM = std::max(maxM, pl.d.M); maxK = std::max(maxK, pl.d.K);
     max_schur_blocks = std::max(max_schur_blocks, pl.d.ncb * (pl.d.ncb + 1) / 2 * pl.d.ksplit);
     if (pl.d.ncb != 1) all_diag = 0;
-    max_gather = std::max(max_gather, std::min(256, (BA_GATHER_LANES * pl.n * ((pl.n + 1) / 2) + 255) / 256));
+    max_gather = std::max(max_gather, std::min(BA_GATHER_MAX_BLOCKS, (BA_GATHER_LANES * pl.n * ((pl.n + 1) / 2) + 255) / 256));
     max_back = std::max(max_back, (std::max(ptl * ((pl.d.M + ppg - 1) / ppg), pl.n) + 255) / 256);
     max_asm = std::max(max_asm, std::min(512, (pl.n * pl.n + 255) / 256));
   }
