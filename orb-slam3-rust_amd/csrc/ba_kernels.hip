@@ -92,7 +92,8 @@ struct BaWin {
   const double* Rt_fix;  // [F+1][12]
   const int *pt_start, *o_kf, *o_fix;
   const double* o_uv;
-  const int *kf_start, *kf_obs, *kf_pt;   // keyframe CSR over the point-major order: observation index and its map point
+  const int* kf_start;              // keyframe CSR over the point-major order: [K + 1] (host)
+  int *kf_obs, *kf_pt;              // ... observation index and its map point, [kf_start[K]] each (ba_kflist_kernel, once per call)
   double *Vinv, *gl, *vg;           // per point: V*^-1 (9), g_l (3), V*^-1 g_l (3)
   double *pt_chi2, *pt_glsq, *pt_dsq, *pt_psq;
   double *oP;            // [N][6] per observation: x, y of the point in the camera frame, 1/z, sqrt(Huber weight), weighted residual (2) — what A, B, W are rebuilt from
@@ -203,6 +204,40 @@ __global__ __launch_bounds__(256) void ba_slots_kernel(const BaWin* __restrict__
     if (i < 0) { slot[k] = t; continue; }
     while (nxt[i] >= 0) i = nxt[i];                                      // (chains hold two, rarely three observations)
     nxt[i] = t;
+  }
+}
+
+// The keyframe lists (for each optimised keyframe the observations it makes, in point-major order, and their map points) from the slot
+// map: block k walks the points in chunks of 256, a thread counts its point's chain for keyframe k (0, 1, rarely more), a block-wide
+// exclusive scan places them behind the keyframe's host-computed start.  Until round 3's end the host built these 8 bytes per observation
+// and uploaded them with every call.  Same order as the host's pass produced (ascending observation index within a keyframe).
+__global__ __launch_bounds__(256) void ba_kflist_kernel(const BaWin* __restrict__ wins) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const BaWin& win = wins[blockIdx.y];
+  const int K = win.d.K, M = win.d.M, k = blockIdx.x;
+  if (win.S->done || k >= K) return;
+  const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ nxt = win.obs_next;
+  int* __restrict__ kf_obs = win.kf_obs; int* __restrict__ kf_pt = win.kf_pt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base = win.kf_start[k];
+  __syncthreads();
+  for (int j0 = 0; j0 < M; j0 += 256) {
+    const int j = j0 + tid;
+    const int first = j < M ? slot_first[(size_t)j * K + k] : -1;
+    int cnt = 0;
+    for (int i = first; i >= 0; i = nxt[i]) ++cnt;
+    int inc = cnt;                                                          // inclusive scan over the wave, then over the four waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int pos = s_base + inc - cnt;
+    for (int w2 = 0; w2 < wave; ++w2) pos += s_wave[w2];
+    for (int i = first; i >= 0; i = nxt[i]) { kf_obs[pos] = i; kf_pt[pos] = j; ++pos; }
+    __syncthreads();
+    if (tid == 255) s_base = pos;                                           // (the last thread's end = the chunk's end)
+    __syncthreads();
   }
 }
 
@@ -2502,8 +2537,8 @@ struct WinPlan {
   int n = 0, use_lds = 0, skip = 0;
   size_t np = 0, n_upper = 0, rb_len = 0, lds_need = 0;
   // byte offsets: input blob (host-prepared arrays), scratch arena, output blob
-  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_kfobs, i_kfpt, i_oflag;
-  size_t a_p1, a_oP, a_rtcur, a_slot, a_next, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
+  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_oflag;
+  size_t a_p1, a_oP, a_rtcur, a_slot, a_next, a_kfobs, a_kfpt, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
   size_t o_out;
   int n_kfobs = 0;
   double n_res = 0.0;
@@ -2530,8 +2565,6 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
   int* o_kf = (int*)(blob + pl.i_okf);
   int* o_fix = (int*)(blob + pl.i_ofix);
   double* o_uv = (double*)(blob + pl.i_ouv);
-  int* kf_obs = (int*)(blob + pl.i_kfobs);
-  int* kf_pt = (int*)(blob + pl.i_kfpt);
   int* o_flag = inertial ? (int*)(blob + pl.i_oflag) : nullptr;
   for (int j = 0; j <= M; ++j) pt_start[j] = 0;
   for (int i = 0; i < N; ++i) {                                          // index checks and the per-point counts in one pass over the observations
@@ -2553,15 +2586,7 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
       if (o.kf_idx >= 0) kf_start[o.kf_idx + 1]++;
     }
   }
-  for (int k = 0; k < K; ++k) kf_start[k + 1] += kf_start[k];
-  {
-    std::vector<int> fill(kf_start, kf_start + K);
-    int j = 0;
-    for (int t = 0; t < N; ++t) {
-      while (t >= pt_start[j + 1]) ++j;                                  // the map point of observation t (point-major order)
-      if (o_kf[t] >= 0) { const int q = fill[o_kf[t]]++; kf_obs[q] = t; kf_pt[q] = j; }
-    }
-  }
+  for (int k = 0; k < K; ++k) kf_start[k + 1] += kf_start[k];                 // (the lists themselves: ba_kflist_kernel, on the device)
   for (int k = 0; k < K; ++k) host_se3_to_params(w.poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);   // scaled axis + translation
   for (int j = 0; j < 3 * M; ++j) params[6 * (size_t)K + j] = w.points[j];
   if (inertial)                                                          // :1154-1173
@@ -2656,12 +2681,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.i_okf = cin.take(4 * n1);
     pl.i_ofix = cin.take(4 * n1);
     pl.i_ouv = cin.take(16 * n1);
-    pl.i_kfobs = cin.take(4 * n1);
-    pl.i_kfpt = cin.take(4 * n1);
     pl.i_oflag = inertial ? cin.take(4 * n1) : 0;
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
     pl.a_oP = car.take(48 * n1); pl.a_rtcur = car.take(96 * k1);
-    pl.a_slot = car.take(4 * m1 * k1); pl.a_next = car.take(4 * n1);
+    pl.a_slot = car.take(4 * m1 * k1); pl.a_next = car.take(4 * n1); pl.a_kfobs = car.take(4 * n1); pl.a_kfpt = car.take(4 * n1);
     pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_vg = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
     pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
     pl.a_part = car.take(8 * pl.n_upper * d.ksplit * 256);
@@ -2762,7 +2785,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.Rt_fix = (const double*)(din + pl.i_rtfix);
     b.pt_start = (const int*)(din + pl.i_ptstart); b.o_kf = (const int*)(din + pl.i_okf); b.o_fix = (const int*)(din + pl.i_ofix);
     b.o_uv = (const double*)(din + pl.i_ouv);
-    b.kf_start = (const int*)(din + pl.i_kfstart); b.kf_obs = (const int*)(din + pl.i_kfobs); b.kf_pt = (const int*)(din + pl.i_kfpt);
+    b.kf_start = (const int*)(din + pl.i_kfstart); b.kf_obs = (int*)(dar + pl.a_kfobs); b.kf_pt = (int*)(dar + pl.a_kfpt);
     b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl); b.vg = (double*)(dar + pl.a_vg);
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
     b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
@@ -2880,6 +2903,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   }
 
   if (maxM > 0 && maxK > 0) hipLaunchKernelGGL(ba_slots_kernel, dim3((maxM + 255) / 256, W), dim3(256), 0, st, d_wins);
+  if (maxM > 0 && maxK > 0) hipLaunchKernelGGL(ba_kflist_kernel, dim3(maxK, W), dim3(256), 0, st, d_wins);
   // initial error (:1000-1001) -> res[12]
   {
     ProfScope ps(h, "ba_chi2");
