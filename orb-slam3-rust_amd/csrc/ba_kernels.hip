@@ -90,7 +90,7 @@ struct BaWin {
   BaState* S;
   double *P0, *P1;       // the two parameter buffers [6K | 3M (| 9K)]
   const double* Rt_fix;  // [F+1][12]
-  const int *pt_start, *o_kf, *o_fix;
+  const int *pt_start, *o_kf;       // o_kf: the optimised keyframe of an observation, or -1 - f for the fixed observer f (f = F: the identity, :569)
   const double* o_uv;
   const int* kf_start;              // keyframe CSR over the point-major order: [K + 1] (host)
   int *kf_obs, *kf_pt;              // ... observation index and its map point, [kf_start[K]] each (ba_kflist_kernel, once per call)
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
   if (S->done || (int)blockIdx.x * (256 / LANES) >= max(d.M, 1)) return;   // (block 0 of a window without points still counts the iteration)
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ Rt_fix = win.Rt_fix;
-  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
+  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf;
   const double* __restrict__ o_uv = win.o_uv;
   double* __restrict__ Vinv = win.Vinv /*M*9*/; double* __restrict__ gl = win.gl /*M*3*/; double* __restrict__ vg = win.vg /*M*3*/;
   double* __restrict__ pt_chi2 = win.pt_chi2 /*M*/; double* __restrict__ pt_glsq = win.pt_glsq /*M*/;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
       for (int a = 0; a < 12; ++a) Rt[a] = sRt[12 * k + a];
     } else {
 #pragma unroll
-      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
+      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)(-1 - k) + a];
     }
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
@@ -2009,7 +2009,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   if (S->done || (int)blockIdx.x * 256 >= max(LANES * d.M, 6 * d.K)) return;
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ dp = dp_override ? dp_override : win.dp;     // (inertial: the 6-d pose steps scattered out of the 15-d solve)
-  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
+  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf;
   const double* __restrict__ o_uv = win.o_uv; const double* __restrict__ Rt_fix = win.Rt_fix;
   const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv; const double* __restrict__ gl = win.gl;
   double* __restrict__ pt_dsq = win.pt_dsq; double* __restrict__ pt_psq = win.pt_psq; double* __restrict__ pt_chi2 = win.pt_chi2;
@@ -2073,7 +2073,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
       for (int a = 0; a < 12; ++a) Rt[a] = sRt[12 * k + a];
     } else {
 #pragma unroll
-      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
+      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)(-1 - k) + a];
     }
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
@@ -2107,7 +2107,7 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
   if (S->done || (int)blockIdx.x * (256 / 32) >= d.M) return;
   double *P0 = win.P0, *P1 = win.P1;
   const double* __restrict__ Rt_fix = win.Rt_fix;
-  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf; const int* __restrict__ o_fix = win.o_fix;
+  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf;
   const double* __restrict__ o_uv = win.o_uv;
   double* __restrict__ pt_chi2 = win.pt_chi2;
   const double* params = which ? ba_trial(S, P0, P1) : ba_cur(S, P0, P1);
@@ -2127,7 +2127,7 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
       for (int a = 0; a < 12; ++a) Rt[a] = sRt[12 * k + a];
     } else {
 #pragma unroll
-      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)o_fix[i] + a];
+      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)(-1 - k) + a];
     }
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
@@ -2537,7 +2537,7 @@ struct WinPlan {
   int n = 0, use_lds = 0, skip = 0;
   size_t np = 0, n_upper = 0, rb_len = 0, lds_need = 0;
   // byte offsets: input blob (host-prepared arrays), scratch arena, output blob
-  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ofix, i_ouv, i_oflag;
+  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ouv, i_oflag;
   size_t a_p1, a_oP, a_rtcur, a_slot, a_next, a_kfobs, a_kfpt, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
   size_t o_out;
   int n_kfobs = 0;
@@ -2563,7 +2563,6 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
   int* pt_start = (int*)(blob + pl.i_ptstart);
   int* kf_start = (int*)(blob + pl.i_kfstart);
   int* o_kf = (int*)(blob + pl.i_okf);
-  int* o_fix = (int*)(blob + pl.i_ofix);
   double* o_uv = (double*)(blob + pl.i_ouv);
   int* o_flag = inertial ? (int*)(blob + pl.i_oflag) : nullptr;
   for (int j = 0; j <= M; ++j) pt_start[j] = 0;
@@ -2580,8 +2579,7 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
       const orbx_ba_obs& o = obs[i];
       const int t = fill[o.mp_idx]++;
       if (inertial) o_flag[t] = o._pad;
-      o_kf[t] = o.kf_idx >= 0 ? o.kf_idx : -1;
-      o_fix[t] = o.kf_idx >= 0 ? 0 : (o.fixed_idx >= 0 ? o.fixed_idx : F);   // slot F = identity (:569)
+      o_kf[t] = o.kf_idx >= 0 ? o.kf_idx : -1 - (o.fixed_idx >= 0 ? o.fixed_idx : F);   // a fixed observer f as -1 - f; slot F = identity (:569)
       o_uv[2 * (size_t)t] = o.u; o_uv[2 * (size_t)t + 1] = o.v;
       if (o.kf_idx >= 0) kf_start[o.kf_idx + 1]++;
     }
@@ -2679,7 +2677,6 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.i_ptstart = cin.take(4 * (size_t)(M + 1));
     pl.i_kfstart = cin.take(4 * (size_t)(K + 1));
     pl.i_okf = cin.take(4 * n1);
-    pl.i_ofix = cin.take(4 * n1);
     pl.i_ouv = cin.take(16 * n1);
     pl.i_oflag = inertial ? cin.take(4 * n1) : 0;
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
@@ -2783,7 +2780,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.S = (BaState*)(din + pl.i_state);
     b.P0 = (double*)(din + pl.i_params); b.P1 = (double*)(dar + pl.a_p1);
     b.Rt_fix = (const double*)(din + pl.i_rtfix);
-    b.pt_start = (const int*)(din + pl.i_ptstart); b.o_kf = (const int*)(din + pl.i_okf); b.o_fix = (const int*)(din + pl.i_ofix);
+    b.pt_start = (const int*)(din + pl.i_ptstart); b.o_kf = (const int*)(din + pl.i_okf);
     b.o_uv = (const double*)(din + pl.i_ouv);
     b.kf_start = (const int*)(din + pl.i_kfstart); b.kf_obs = (int*)(dar + pl.a_kfobs); b.kf_pt = (int*)(dar + pl.a_kfpt);
     b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl); b.vg = (double*)(dar + pl.a_vg);
