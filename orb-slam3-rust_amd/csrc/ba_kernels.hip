@@ -1130,7 +1130,11 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // L[kk][jj] reach all lanes of the row by DPP row_newbcast — 1 + (15 - jj) instructions where readlane pairs through SGPRs took
 // 2 + 3 (15 - jj).  On return Lr holds row j of L; rv[jj] = 1 / L[jj][jj] (written by thread jj; 1.0 past nb).  Returns 0 when a live
 // pivot is not positive (uniform).
-__device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid, double* __restrict__ rv) {
+// pub(jj, column, 1 / L[jj][jj]) is called once per pivot step, right after column jj of L is final (lane j holds L[j][jj]; rows >= jj
+// matter): the LDS solve hands each column to the waves that solve the rows below the block while the factorisation is still running.
+struct Chol16NoPub { template <typename J> __device__ __forceinline__ void operator()(J, double, double) const {} };
+template <typename Pub = Chol16NoPub>
+__device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid, double* __restrict__ rv, Pub&& pub = Pub{}) {
   const int j = tid & 15;
   int good = 1;
   double myri = 1.0;
@@ -1142,6 +1146,7 @@ __device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid
     const double ri = rsqrt_nr(d);                                            // (after a bad pivot: NaNs, which nobody stores)
     myri = (j == jj) ? ri : myri;                                             // (stored once, after the last step)
     Lr[jj] = Lr[jj] * ri;                                                     // column jj of L (rows >= jj matter; row jj itself holds d: d / sqrt d)
+    pub(jj_, Lr[jj], ri);
     static_for<16>([&](auto kk_) {
       constexpr int kk = decltype(kk_)::value;
       // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk); Lr[jj] was written just above: the first update waits for it, the others need not
@@ -1162,7 +1167,8 @@ __device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid
 // debug build only (-DORBX_SOLVE_STAMPS, scripts/build_stamps.sh + scripts/ba_solve_stamps.py): s_memtime ticks per phase of the
 // one-workgroup solve, summed over solves.  (Ticks are only comparable within one run: the counter's rate is not the shader clock's.)
 __device__ unsigned long long g_solve_stamps[16];
-#define SOLVE_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); g_solve_stamps[k] += now_ - t_prev_; t_prev_ = now_; } } while (0)
+#define SOLVE_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc_[k] += now_ - t_prev_; t_prev_ = now_; } while (0)   /* per-thread sums, flushed once (thread 0): a global read-modify-write per stamp cost 300-500 cycles and made every phase look longer */
+#define SOLVE_STAMP_FLUSH() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 15; ++k_) g_solve_stamps[k_] += st_acc_[k_]; g_solve_stamps[15] += 1; } } while (0)
 extern "C" int orbx_debug_solve_stamps(unsigned long long* out16, int reset) {
   if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_solve_stamps), 128) != hipSuccess) return -1;
   if (reset) { const unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_solve_stamps), z, 128) != hipSuccess) return -1; }
@@ -1170,6 +1176,7 @@ extern "C" int orbx_debug_solve_stamps(unsigned long long* out16, int reset) {
 }
 #else
 #define SOLVE_STAMP(k) do { } while (0)
+#define SOLVE_STAMP_FLUSH() do { } while (0)
 #endif
 // (inertial terms: src/optimizer/local_inertial_ba.rs:661-698, :806-880; the kernels that fill these records are further down)
 struct BaInertialDev {
@@ -1214,7 +1221,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   constexpr bool FROM_SG = MODE != 0;                                           // (the system does not come from the visual assembly below)
   if (St->done) return;
 #ifdef ORBX_SOLVE_STAMPS
-  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0};
 #endif
   const double lambda = St->lambda;
   const double* params = ba_cur(St, P0, P1);
@@ -1363,20 +1370,31 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       }
     for (int i = tid; i < n; i += nth) sb[i] = bvec[i];
   }
-  // Right-looking blocked Cholesky, panels of 16 columns, S in LDS:
-  //   1. wave 0 factors the 16x16 diagonal block — lane j owns row j in registers, a solved column is broadcast with
-  //      v_readlane (no barrier inside the block);
-  //   2. every row below the panel is solved against it (x = a L11^-T, one thread per row);
-  //   3. the trailing matrix takes the rank-16 update S22 -= L21 L21^T on v_mfma_f64_16x16x4_f64, one wave per lower tile.
-  // (The left-looking form it replaces spent 22 us in scalar panel updates and 31 us in 8x8 diagonal blocks that every
-  // row thread factored redundantly, at n = 114.)
-  __shared__ int s_ok;
+  // Right-looking blocked Cholesky, panels of 16 columns, S in LDS — ONE phase and one block barrier per panel p (first column c0):
+  //   - wave 0 brings the diagonal tile (c0, c0) up to date with the previous panel's rank-16 update, factors it (lane j owns row j in
+  //     registers, DPP row_newbcast: chol16_rows_dpp) and PUBLISHES every column of L11 the moment its pivot step is done: the column
+  //     and 1 / L_tt into s_col / s_rv, then the step counter (LDS performs one wave's operations in issue order: no wait in between);
+  //   - waves 1..15 apply the previous panel's update S22 -= L21 L21^T to the other lower tiles (v_mfma_f64_16x16x4_f64, one wave per
+  //     tile) and b -= L21 y to the right-hand side below it, and count themselves on s_upd when their part is written;
+  //   - the threads that own the rows below the panel — and the right-hand side as one more row: forward substitution L y = b rides
+  //     along — wait until all fifteen have counted (their row's 16 entries may be any wave's tile), then solve x = a L11^-T column by
+  //     column one step behind wave 0's pivots (poll the step counter, x_t *= 1/L_tt, x_jx -= x_t L[jx][t] for jx > t: per entry the
+  //     same fma sequence in the same order as a row-oriented substitution, same bits).
+  // Both counters only grow (panel p waits for 15 p and 16 p + t + 1), so nothing is reset between phases; a wave never waits before
+  // it has counted itself and wave 0 never waits at all, and every wait is bounded all the same (a solve that ran into the bound
+  // reports failure instead of hanging the queue).  Until the end of round 3: update phase (with wave 0's factor inside it as a
+  // look-ahead) and row-solve phase, two barriers per panel, the 15 waves idle through most of the first and 13 through the second:
+  // 9.0 k cycles per panel at n = 114.
+  __shared__ int s_ok, s_upd;
   __shared__ __align__(16) double s_rv[16];
+  __shared__ __align__(16) double s_col[16][16];                               // s_col[t][jx] = L[jx][t] of the block in flight
   SOLVE_STAMP(0);
-  if (tid == 0) s_ok = 1;
+  if (tid == 0) { s_ok = 1; s_upd = 0; }
+  for (int i = tid; i < n; i += nth) srinv[i] = 0.0;                             // (0 = column not published yet)
   int ok = 1;
-  // the 16x16 diagonal block at c0_ (nb_ live columns), by wave 0 alone: reads and writes only that block of S, s_rv and s_ok
-  auto factor_diag = [&](int c0_, int nb_) {
+  constexpr int SPIN_MAX = 1 << 22;
+  // the 16x16 diagonal block at c0_ (nb_ live columns), by wave 0 alone: reads and writes only that block of S, s_col, s_rv, s_step, s_ok
+  auto factor_diag = [&](int c0_, int nb_, int step0) {
       const int j = tid & 15;
       double Lr[16];
       if (nb_ == 16) {
@@ -1392,7 +1410,16 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         for (int i = 0; i < 16; ++i) Lr[i] = (j < nb_ && i <= j) ? *S.at(c0_ + j, c0_ + i) : 0.0;   // (rows >= nb_ take no pivot step: chol16_rows_dpp; a 1.0 on their diagonal was 16 loop-invariant constants held in — and spilled from — registers)
       }
       SOLVE_STAMP(8);
-      const int good = chol16_rows_dpp(Lr, nb_, tid, s_rv);
+      const int good = chol16_rows_dpp(Lr, nb_, tid, s_rv, [&](auto jj_, double col, double ri) {
+        constexpr int jj = decltype(jj_)::value;
+        if (tid < 16) {                                                            // (the wave's other three 16-lane rows hold copies)
+          s_col[jj][j] = col;
+          asm volatile("" ::: "memory");                                           // the column first; the LDS queue keeps the order
+          // 1 / L_tt doubles as the "column t is there" flag: srinv starts as zeros and a reciprocal pivot is never zero (a bad pivot
+          // leaves a NaN, which also compares unequal to zero) — two ds_writes per pivot step instead of four with a counter and s_rv
+          __hip_atomic_store(&srinv[c0_ + jj], ri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      });
       SOLVE_STAMP(9);
       if (tid == 0 && !good) s_ok = 0;
       if (good && nb_ == 16) {
@@ -1407,9 +1434,13 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         for (int i = 0; i < 16; ++i) if (i <= j) *S.at(c0_ + j, c0_ + i) = Lr[i];
       }
   };
-  // Look-ahead: the diagonal block of panel p + 1 is factored by wave 0 inside the update phase of panel p, right after wave 0 has
-  // brought that one tile up to date, while the other 15 waves finish the trailing update — the longest phase of a panel (the
-  // serial 16-step factor) leaves the critical path and a panel costs two block barriers instead of three.
+  auto wait_for = [&](int* ctr, int want, int& seen, int& spins) {                // until *ctr >= want (what was read last is kept in `seen`)
+    while (seen < want && spins < SPIN_MAX) {
+      seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (seen < want) { __builtin_amdgcn_s_sleep(1); ++spins; }
+    }
+    asm volatile("" ::: "memory");                                                 // what the counter vouches for is read after it, not before
+  };
   __syncthreads();
   if constexpr (!FROM_SG) {
     if (small_n && tid == nth - 1) {
@@ -1418,24 +1449,67 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       res[0] = bred[n]; res[1] = sqrt(g2 + bred[n + 1]);
     }
   }
-  if (tid < 64) factor_diag(0, min(16, n));
-  for (int c0 = 0; c0 < n; c0 += 16) {
-    const int nb = min(16, n - c0);
-    __syncthreads();
-    SOLVE_STAMP(2);
-    ok = s_ok;
-    if (!ok) break;
-    if (tid < nb) srinv[c0 + tid] = s_rv[tid];
-    if (nb == 16) {
-      // Rows below the panel, and the right-hand side as one more row (thread m, the first without a row of S: forward substitution
-      // L y = b rides along with the factorisation — y of this panel here, its effect on the entries below in the update phase —
-      // instead of 114 dependent steps in one wave afterwards; in the same wave as the last rows it costs no instruction stream of its
-      // own).  Column oriented: once x_t is final every later entry takes its term -x_t L[jx][t] — per entry the same fma sequence in
-      // the same order as a row-oriented loop (same bits), but the 15 - t updates of a step are independent, so the dependent chain
-      // through a row is 16 x (multiply, fma) instead of 136 fmas, and L11 comes in pairs (ds_read_b128 of L[jx][t], L[jx][t+1]: n = 6K
-      // is even and c0 a multiple of 16) — 64 + 8 reads instead of 120 + 16 in a wave that issues one instruction every ~8 cycles.
-      const int r = c0 + 16 + tid;
+  for (int c0 = 0, p = 0; c0 < n; c0 += 16, ++p) {
+    const int nb = min(16, n - c0), prev = c0 - 16;
+    // ---- the previous panel's update of the trailing matrix [c0, n) and of the right-hand side below it
+    if (prev >= 0) {
+      const int m = n - c0;
+      if (tid >= nth - 192 && tid - (nth - 192) < m) {                         // b_below -= L21 y_panel (the last three waves: not in wave 0's way)
+        const int rr = c0 + tid - (nth - 192);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(*S.at(rr, prev + k), sb[prev + k], acc);
+        sb[rr] -= acc;
+      }
+      const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2, nw = (nth >> 6) - 1;
+      // wave 0: tile (c0, c0) only — it factors that block next; waves 1..15: the other lower tiles
+      for (int unit = (tid < 64) ? 0 : (tid >> 6); unit < units; unit += (tid < 64) ? units : nw) {   // wave-uniform
+        int ti = 0, rem = unit;
+        while (rem > ti) { rem -= ti + 1; ++ti; }                              // unit = ti (ti + 1) / 2 + tj, tj <= ti
+        const int tj = rem;
+        const int ra = min(c0 + 16 * ti + (lane & 15), n - 1), rb2 = min(c0 + 16 * tj + (lane & 15), n - 1);
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        double av[4], bv[4], old_[4];
+        const int col = c0 + 16 * tj + (lane & 15);
+        // (a diagonal tile's two operands are the same rows: read once; the tile's current values are requested with the operands, not
+        // after the matrix instructions: they are on wave 0's chain to the next factorisation)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = *S.at(ra, prev + (lane >> 4) + 4 * q);
+        if (ti != tj) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bv[q] = *S.at(rb2, prev + (lane >> 4) + 4 * q);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bv[q] = av[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = c0 + 16 * ti + (lane >> 4) + 4 * q;
+          old_[q] = (row < n && col <= row) ? *S.at(row, col) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = c0 + 16 * ti + (lane >> 4) + 4 * q;
+          if (row < n && col <= row) *S.at(row, col) = old_[q] - acc[q];
+        }
+      }
+      if (tid >= 64 && lane == 0) {                                              // this wave's part of the update is written
+        asm volatile("" ::: "memory");
+        __hip_atomic_fetch_add(&s_upd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    SOLVE_STAMP(7);
+    // ---- the panel: factor (wave 0) and, a pivot step behind it, the rows below
+    if (tid < 64) { factor_diag(c0, nb, 16 * p); SOLVE_STAMP(10); }
+    else if (nb == 16) {
+      // rows below the panel (a panel with rows below it is a full one), the right-hand side as row n; both layouts keep a row's 16
+      // entries of the panel contiguous and 16-byte aligned (n = 6K even and c0 a multiple of 16 / tile rows)
+      const int r = c0 + 16 + tid - 64;
       if (r <= n) {
+        int seen_u = 0, spins = 0;
+        if (prev >= 0) wait_for(&s_upd, ((nth >> 6) - 1) * p, seen_u, spins);
         double* row = r < n ? S.at(r, c0) : &sb[c0];
         double x[16];
 #pragma unroll
@@ -1443,28 +1517,51 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
           const double2_t p2 = *(const double2_t*)&row[jx];
           x[jx] = p2[0]; x[jx + 1] = p2[1];
         }
+        // column t = its flag (1 / L_tt, zero until published) and L[jx][t], jx > t (pairs from the even index at or below t + 1), read
+        // in ONE round trip: the flag first, the entries right behind it without waiting — LDS performs a wave's reads in issue order, so
+        // a non-zero flag vouches for the entries read after it — and one step AHEAD of the arithmetic (two dependent round trips per
+        // step, poll then column, made the rows slower than the factorisation they follow)
+        auto fetch = [&](auto t_, double& rt, double (&lc)[16]) {
+          constexpr int t = decltype(t_)::value;
+          rt = __hip_atomic_load(&srinv[c0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
 #pragma unroll
-        for (int t = 0; t < 16; t += 2) {
-          double la[16], lb[16];                                                   // L[jx][t], L[jx][t + 1] for jx > t
-#pragma unroll
-          for (int jx = t + 1; jx < 16; ++jx) {
-            const double2_t p2 = *(const double2_t*)S.at(c0 + jx, c0 + t);
-            la[jx] = p2[0]; lb[jx] = p2[1];
+          for (int jx = (t + 1) & ~1; jx < 16; jx += 2) {
+            const double2_t p2 = *(const double2_t*)&s_col[t][jx];
+            lc[jx] = p2[0]; lc[jx + 1] = p2[1];
           }
-          const double2_t q = *(const double2_t*)&s_rv[t];
-          x[t] = x[t] * q[0];
+          asm volatile("" ::: "memory");
+        };
+        double rta = 0.0, rtb = 0.0, lca[16], lcb[16];
+        auto step = [&](auto t_, double& rt, double (&lc)[16], double& rtn, double (&lcn)[16]) {
+          constexpr int t = decltype(t_)::value;
+          while (rt == 0.0 && spins < SPIN_MAX) { __builtin_amdgcn_s_sleep(1); ++spins; fetch(t_, rt, lc); }   // not there yet when it was read: again
+          if constexpr (t + 1 < 16) fetch(std::integral_constant<int, t + 1>{}, rtn, lcn);
+          x[t] = x[t] * rt;
 #pragma unroll
-          for (int jx = t + 1; jx < 16; ++jx) x[jx] = fma(-x[t], la[jx], x[jx]);
-          x[t + 1] = x[t + 1] * q[1];
-#pragma unroll
-          for (int jx = t + 2; jx < 16; ++jx) x[jx] = fma(-x[t + 1], lb[jx], x[jx]);
-          __builtin_amdgcn_sched_barrier(0);                                       // (hoisting every step's reads to the top spilled 39 VGPRs)
-        }
+          for (int jx = t + 1; jx < 16; ++jx) x[jx] = fma(-x[t], lc[jx], x[jx]);
+          // the step ends here: without this the compiler polls for all 16 columns first, parks every column in scratch and does the
+          // arithmetic afterwards
+          asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]),
+                            "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]) :: "memory");
+        };
+        fetch(std::integral_constant<int, 0>{}, rta, lca);
+        static_for<8>([&](auto h_) {
+          constexpr int t = 2 * decltype(h_)::value;
+          step(std::integral_constant<int, t>{}, rta, lca, rtb, lcb);
+          step(std::integral_constant<int, t + 1>{}, rtb, lcb, rta, lca);
+        });
+        if (spins >= SPIN_MAX) s_ok = 0;                                           // never seen: fail the solve rather than trust x
 #pragma unroll
         for (int jx = 0; jx < 16; jx += 2) *(double2_t*)&row[jx] = double2_t{x[jx], x[jx + 1]};
       }
-    } else if (tid == nth - 1) {
-      // the short last panel has no rows below it: only the right-hand side, entry by entry
+    }
+    __syncthreads();
+    SOLVE_STAMP(2);
+    ok = s_ok;
+    if (!ok) break;
+    if (nb < 16 && tid == nth - 1) {
+      // the short last panel has no rows below it: only the right-hand side, entry by entry (nothing after it in this loop reads sb)
       double x[16];
 #pragma unroll
       for (int jx = 0; jx < 16; ++jx) x[jx] = (jx < nb) ? sb[c0 + jx] : 0.0;
@@ -1474,46 +1571,11 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
           double v = x[jx];
 #pragma unroll
           for (int t = 0; t < jx; ++t) v = fma(-x[t], *S.at(c0 + jx, c0 + t), v);
-          x[jx] = v * s_rv[jx];
+          x[jx] = v * srinv[c0 + jx];
         }
       }
 #pragma unroll
       for (int jx = 0; jx < 16; ++jx) if (jx < nb) sb[c0 + jx] = x[jx];
-    }
-    __syncthreads();
-    SOLVE_STAMP(3);
-    const int c1 = c0 + 16, m = n - c1;
-    if (m > 0) {
-      if (tid >= nth - 192 && tid - (nth - 192) < m) {                         // b_below -= L21 y_panel (the last three waves: not in wave 0's way)
-        const int rr = c1 + tid - (nth - 192);
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc = fma(*S.at(rr, c0 + k), sb[c0 + k], acc);
-        sb[rr] -= acc;
-      }
-      const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2, nw = (nth >> 6) - 1;
-      // wave 0: tile (c1, c1) only, then the factor of that block; waves 1..15: the other lower tiles
-      for (int unit = (tid < 64) ? 0 : (tid >> 6); unit < units; unit += (tid < 64) ? units : nw) {   // wave-uniform
-        int ti = 0, rem = unit;
-        while (rem > ti) { rem -= ti + 1; ++ti; }                              // unit = ti (ti + 1) / 2 + tj, tj <= ti
-        const int tj = rem;
-        const int ra = min(c1 + 16 * ti + (lane & 15), n - 1), rb2 = min(c1 + 16 * tj + (lane & 15), n - 1);
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        double av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { av[q] = *S.at(ra, c0 + (lane >> 4) + 4 * q); bv[q] = *S.at(rb2, c0 + (lane >> 4) + 4 * q); }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
-        const int col = c1 + 16 * tj + (lane & 15);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = c1 + 16 * ti + (lane >> 4) + 4 * q;
-          if (row < n && col <= row) *S.at(row, col) -= acc[q];
-        }
-      }
-      SOLVE_STAMP(7);
-      if (tid < 64) factor_diag(c1, min(16, n - c1));                          // (same wave wrote the tile: no barrier in between)
-      SOLVE_STAMP(10);
     }
   }
   __syncthreads();
@@ -1614,9 +1676,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   }
   SOLVE_STAMP(5);
   if (ok && small_n) {                                                          // (uniform) wave 0 has written everything
-#ifdef ORBX_SOLVE_STAMPS
-    if (threadIdx.x == 0) g_solve_stamps[15] += 1;
-#endif
+    SOLVE_STAMP_FLUSH();
     return;
   }
   __syncthreads();
@@ -1631,9 +1691,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   psq = block_sum_fixed(psq, s_red);
   if (tid == 0) { res[2] = (double)ok; res[3] = dsq; res[4] = psq; }
   SOLVE_STAMP(6);
-#ifdef ORBX_SOLVE_STAMPS
-  if (threadIdx.x == 0) g_solve_stamps[15] += 1;
-#endif
+  SOLVE_STAMP_FLUSH();
 }
 
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(const BaWin* __restrict__ wins) {
@@ -2523,7 +2581,7 @@ void host_params_to_pose_wc(const double* p6, double* out7) {
 // ---- host side of the solver ------------------------------------------------------------------------------------------
 namespace {
 
-constexpr size_t BA_LDS_STATIC = 20736;                              // static LDS of ba_solve_lds_kernel (sb, srinv, s_red, ...), rounded up
+constexpr size_t BA_LDS_STATIC = 22784;                              // static LDS of ba_solve_lds_kernel (sb, srinv, s_red, s_col, s_rv, ...), rounded up
 constexpr size_t BA_LDS_DYN_MAX = 160 * 1024 - BA_LDS_STATIC;
 
 struct Carve {                                                       // byte offsets inside one buffer, 256-byte aligned pieces

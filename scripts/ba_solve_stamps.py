@@ -16,9 +16,9 @@ for _ in range(3):
     h.ba_solve_visual_batch(cam, cfg, [w])
 L.orbx_debug_solve_stamps(buf, 0)
 n = buf[15]
-names = ["assemble S, b, |g|", "wait at the panel's top barrier (= trailing update)", "diagonal block factor (wave 0)", "row solves + right-hand side",
-         "last update + exit", "backward substitution", "dp, norms", "  wave 0: b_below + its tile of the update", "  wave 0: diagonal block from LDS",
-         "  wave 0: the 16 pivot steps", "  wave 0: diagonal block to LDS"]
+names = ["assemble S, b, |g|", "-", "wave 0 at the panel's barrier (the rows below still being solved)", "-",
+         "exit", "backward substitution + norms", "-", "wave 0: its tile of the previous panel's update", "wave 0: diagonal block from LDS",
+         "wave 0: the 16 pivot steps (columns published as they finish)", "wave 0: diagonal block to LDS"]
 tot = sum(buf[i] for i in range(11))
 print("solves %d, ticks per solve %.0f" % (n, tot / n))
 for i in range(11):
