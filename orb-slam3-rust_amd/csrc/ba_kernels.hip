@@ -1423,15 +1423,16 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       SOLVE_STAMP(9);
       if (tid == 0 && !good) s_ok = 0;
       if (good && nb_ == 16) {
-        // (the registers right of the diagonal hold the mirror entries' updates by now: zeros go back, the backward substitution counts on them)
+        // (the registers right of the diagonal hold the mirror entries' updates by now: zeros go back, the backward substitution counts on
+        // them — and on a zero ON the diagonal: L_cc itself is never read again, 1 / L_cc is in srinv)
         if (tid < 16) {
 #pragma unroll
           for (int i = 0; i < 16; i += 2)
-            *(double2_t*)S.at(c0_ + j, c0_ + i) = double2_t{i <= j ? Lr[i] : 0.0, i + 1 <= j ? Lr[i + 1] : 0.0};
+            *(double2_t*)S.at(c0_ + j, c0_ + i) = double2_t{i < j ? Lr[i] : 0.0, i + 1 < j ? Lr[i + 1] : 0.0};
         }
       } else if (good && tid < nb_) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) if (i <= j) *S.at(c0_ + j, c0_ + i) = Lr[i];
+        for (int i = 0; i < 16; ++i) if (i <= j) *S.at(c0_ + j, c0_ + i) = i < j ? Lr[i] : 0.0;
       }
   };
   auto wait_for = [&](int* ctr, int want, int& seen, int& spins) {                // until *ctr >= want (what was read last is kept in `seen`)
@@ -1578,11 +1579,8 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       for (int jx = 0; jx < 16; ++jx) if (jx < nb) sb[c0 + jx] = x[jx];
     }
   }
-  __syncthreads();
+  if (n & 15) __syncthreads();                                                    // (uniform) the short last panel's right-hand side was solved behind the loop's barrier
   SOLVE_STAMP(4);
-  ok = s_ok;
-  if (tid < n) *S.at(tid, tid) = 0.0;                                    // L_cc itself is not read again (1 / L_cc is in srinv): see the backward substitution
-  __syncthreads();
   // (A panel-blocked backward substitution — the panel's 16 unknowns by DPP row_newbcast steps in wave 0, the rows above it one
   // thread each, same operations in the same order, bit-identical — was built and measured: 15.0 us against the 12.2 us of the
   // single wave below at n = 114; its 16 block barriers and LDS round trips cost more than the readlane pairs they replace.
