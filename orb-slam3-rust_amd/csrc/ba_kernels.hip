@@ -18,9 +18,11 @@
 //                        accumulates its upper 16x16 tiles in registers — the one dense contraction of the path
 //                        (in a batch: ba_kf_kernel and ba_schur_kernel, their own launches)
 //   ba_gather_kernel     fixed-order reduction of the split-K and keyframe-split partials
-//   ba_solve_lds_kernel  one workgroup: S = U* - S_red in LDS, blocked right-looking Cholesky (diagonal blocks by DPP row_newbcast
-//                        in wave 0, look-ahead inside the MFMA trailing update, column-oriented row solves with the right-hand
-//                        side as one more row), branch-free backward substitution over the zeroed upper triangle, delta_p
+//   ba_solve_lds_kernel  one workgroup: S = U* - S_red in LDS, blocked right-looking Cholesky, one phase per 16-column panel: wave 0
+//                        factors the diagonal block (DPP row_newbcast) and publishes its columns, the other waves apply the previous
+//                        panel's MFMA update and solve the rows below (right-hand side as one more row) a pivot step behind it;
+//                        branch-free backward substitution over the zeroed upper triangle, delta_p
+//                        (128 < n <= 176, inertial windows: ba_solve_tiled_kernel / ba_solve_inertial_tiled_kernel, lower tiles in LDS)
 //                        (n > 135: ba_big_assemble + one ba_big_step_kernel per panel + ba_big_back_kernel, S in global memory)
 //   ba_backsub_kernel    delta_l = V*^-1 (-g_l - W^T delta_p), trial parameters and trial residuals
 //   ba_decide_kernel     sums, accept / reject, lambda, stop tests — the LM state lives on the device
@@ -1373,14 +1375,15 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   // Right-looking blocked Cholesky, panels of 16 columns, S in LDS — ONE phase and one block barrier per panel p (first column c0):
   //   - wave 0 brings the diagonal tile (c0, c0) up to date with the previous panel's rank-16 update, factors it (lane j owns row j in
   //     registers, DPP row_newbcast: chol16_rows_dpp) and PUBLISHES every column of L11 the moment its pivot step is done: the column
-  //     and 1 / L_tt into s_col / s_rv, then the step counter (LDS performs one wave's operations in issue order: no wait in between);
+  //     into s_col, then 1 / L_tt into srinv, which starts as zeros and so doubles as the flag (LDS performs one wave's operations in
+  //     issue order: no wait in between);
   //   - waves 1..15 apply the previous panel's update S22 -= L21 L21^T to the other lower tiles (v_mfma_f64_16x16x4_f64, one wave per
   //     tile) and b -= L21 y to the right-hand side below it, and count themselves on s_upd when their part is written;
   //   - the threads that own the rows below the panel — and the right-hand side as one more row: forward substitution L y = b rides
   //     along — wait until all fifteen have counted (their row's 16 entries may be any wave's tile), then solve x = a L11^-T column by
-  //     column one step behind wave 0's pivots (poll the step counter, x_t *= 1/L_tt, x_jx -= x_t L[jx][t] for jx > t: per entry the
-  //     same fma sequence in the same order as a row-oriented substitution, same bits).
-  // Both counters only grow (panel p waits for 15 p and 16 p + t + 1), so nothing is reset between phases; a wave never waits before
+  //     column one step behind wave 0's pivots (flag and column read in one round trip, one step ahead; x_t *= 1/L_tt, x_jx -= x_t
+  //     L[jx][t] for jx > t: per entry the same fma sequence in the same order as a row-oriented substitution, same bits).
+  // The counter only grows (panel p waits for 15 p) and a flag is written once per solve, so nothing is reset between phases; a wave never waits before
   // it has counted itself and wave 0 never waits at all, and every wait is bounded all the same (a solve that ran into the bound
   // reports failure instead of hanging the queue).  Until the end of round 3: update phase (with wave 0's factor inside it as a
   // look-ahead) and row-solve phase, two barriers per panel, the 15 waves idle through most of the first and 13 through the second:
@@ -1393,7 +1396,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
   for (int i = tid; i < n; i += nth) srinv[i] = 0.0;                             // (0 = column not published yet)
   int ok = 1;
   constexpr int SPIN_MAX = 1 << 22;
-  // the 16x16 diagonal block at c0_ (nb_ live columns), by wave 0 alone: reads and writes only that block of S, s_col, s_rv, s_step, s_ok
+  // the 16x16 diagonal block at c0_ (nb_ live columns), by wave 0 alone: reads and writes only that block of S, s_col, srinv, s_rv, s_ok
   auto factor_diag = [&](int c0_, int nb_, int step0) {
       const int j = tid & 15;
       double Lr[16];
