@@ -60,6 +60,18 @@ def test_ba_large_window_gmem_cholesky(gpu_handle, oracle, pkg):
     assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL
 
 
+def test_ba_reduced_system_sizes_around_panel_boundaries(gpu_handle, oracle, pkg):
+    """The LDS solve walks 16-column panels, the rows below a panel following the factorisation through flags in LDS: reduced systems of
+    exactly 3 and 6 panels (no short last panel: n = 48, 96), of one short panel only (n = 12), and of full panels plus a 2- and a
+    14-column one (n = 18, 114, 126) against the structured oracle."""
+    # (a two-keyframe window needs a few hundred points to be well conditioned: at 60 the oracle's own dense and Schur forms differ by 2.5e-6)
+    for seed, K, M in ((21, 9, 200), (22, 17, 320), (27, 3, 200), (24, 4, 80), (25, 20, 400), (26, 22, 420)):
+        w = pkg.synth.ba_window(seed, K, M, pkg.BA_OBS)
+        g, o = _solve_both(gpu_handle, oracle, pkg, w, dense=False)
+        assert g["iterations"] == o["iterations"], (K, M)
+        assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL, (K, M)
+
+
 def test_ba_mid_window_tiled_lds_cholesky(gpu_handle, oracle, pkg):
     """22..29 optimised keyframes (n = 132..174): the reduced system does not fit LDS as a square but does as lower 16 x 16 tiles — one
     launch (ba_solve_tiled_kernel) instead of the multi-launch path; against the structured oracle at both ends and at an odd tile count."""
