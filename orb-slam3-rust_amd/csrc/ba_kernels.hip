@@ -390,15 +390,32 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
   // possible for its latency chain), several in a large batch, where the block's prologue (K poses) is then paid once for all of
   // them.  A point's arithmetic does not depend on which block or round handles it.
   const int g0 = (blockIdx.x * blockDim.x + threadIdx.x) / LANES, gstride = (int)gridDim.x * (256 / LANES);
+  // Software pipeline over a group's points (a large batch gives a group several): a point's observation range and position are
+  // requested two points ahead, the first observation of each lane (its keyframe and pixel) one point ahead — the chain pt_start ->
+  // o_kf / o_uv -> arithmetic was two exposed memory round trips per point, in a kernel whose arithmetic takes a quarter of its time.
+  struct PtPre { int s, e; double X[3]; int k0; double u0, v0; };
+  auto load_pt = [&](int j, PtPre& q) {
+    const int jj = min(j, d.M - 1);                                                // (past the last point: a harmless repeat, never used)
+    q.s = pt_start[jj]; q.e = pt_start[jj + 1];
+    q.X[0] = params[6 * (size_t)d.K + 3 * (size_t)jj]; q.X[1] = params[6 * (size_t)d.K + 3 * (size_t)jj + 1]; q.X[2] = params[6 * (size_t)d.K + 3 * (size_t)jj + 2];
+  };
+  auto load_obs = [&](PtPre& q) {
+    const int i = q.s + lane32;
+    const bool in = i < q.e;
+    q.k0 = in ? o_kf[i] : 0; q.u0 = in ? o_uv[2 * (size_t)i] : 0.0; q.v0 = in ? o_uv[2 * (size_t)i + 1] : 0.0;
+  };
+  PtPre pa, pb, pc;
+  load_pt(g0, pa); load_pt(g0 + gstride, pb);
+  load_obs(pa);
   for (int j = g0; j < d.M; j += gstride) {   // group-uniform
-  const double X[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1],
-                       params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
-  const int s = pt_start[j], e = pt_start[j + 1];
+  load_obs(pb);
+  load_pt(j + 2 * gstride, pc);
+  const double X[3] = {pa.X[0], pa.X[1], pa.X[2]};
+  const int s = pa.s, e = pa.e;
   double Va[6] = {0, 0, 0, 0, 0, 0}, ga[3] = {0, 0, 0}, chia = 0.0, Vb[6] = {0, 0, 0, 0, 0, 0}, gb[3] = {0, 0, 0}, chib = 0.0;
   // residual + Jacobian, accumulate V, g_l (lane-strided, then a fixed shuffle tree); per observation only the six numbers the
   // consumers rebuild A, B and W = A^T B from are stored (48 B; until round 3: W itself, 144 B, written in a second pass)
-  auto one = [&](int i, double (&V)[6], double (&g)[3], double& chi) {
-    const int k = o_kf[i];
+  auto one = [&](int i, int k, double u, double v, double (&V)[6], double (&g)[3], double& chi) {
     double Rt[12];
     if (k >= 0) {
 #pragma unroll
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
       for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)(-1 - k) + a];
     }
     ObsOut o;
-    obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], true, o, cam.o_flag ? cam.o_flag[i] : 0);
+    obs_terms(cam, Rt, X, u, v, true, o, cam.o_flag ? cam.o_flag[i] : 0);
     {
       double* q = oP + 6 * (size_t)i;
       q[0] = o.px; q[1] = o.py; q[2] = o.piz; q[3] = o.psw; q[4] = o.r0; q[5] = o.r1;
@@ -425,8 +442,9 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
     g[2] += o.B[2] * o.r0 + o.B[5] * o.r1;
   };
   for (int i = s + lane32; i < e; i += 32) {
-    one(i, Va, ga, chia);
-    if (LANES == 16 && i + 16 < e) one(i + 16, Vb, gb, chib);
+    if (i == s + lane32) one(i, pa.k0, pa.u0, pa.v0, Va, ga, chia);               // (the lane's first observation came with the pipeline)
+    else one(i, o_kf[i], o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], Va, ga, chia);
+    if (LANES == 16 && i + 16 < e) one(i + 16, o_kf[i + 16], o_uv[2 * (size_t)(i + 16)], o_uv[2 * (size_t)(i + 16) + 1], Vb, gb, chib);
   }
   double V[6], g[3];
 #pragma unroll
@@ -455,6 +473,7 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
     pt_chi2[j] = chi;
     pt_glsq[j] = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
   }
+  pa = pb; pb = pc;
   }
 }
 
@@ -1119,8 +1138,10 @@ template <int L> __device__ __forceinline__ double fnma_row_bcast_f64(double acc
 // the same without the wait states: for a caller whose `bsrc` was written at least two instructions ago — the second and later updates of
 // a pivot step, which all read the column the first one read (an s_nop is an instruction like any other to a wave that issues one every
 // ~8 cycles: 105 of them were a fifth of the 16 x 16 factorisation)
-template <int L> __device__ __forceinline__ double fnma_row_bcast_f64_settled(double acc, double bsrc, double m) {
-  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(L));
+// `after`: the result of the update that carried the wait states — an operand the instruction does not read, there so that the compiler
+// cannot schedule this one ahead of it (round 3: in ba_big_factor_kernel's register allocation it did, and column 15 read a stale pivot column)
+template <int L> __device__ __forceinline__ double fnma_row_bcast_f64_settled(double acc, double bsrc, double m, double after) {
+  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(m), "n"(L), "v"(after));
   return acc;
 }
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -1153,7 +1174,7 @@ __device__ __forceinline__ int chol16_rows_dpp(double (&Lr)[16], int nb, int tid
       constexpr int kk = decltype(kk_)::value;
       // a[j][kk] -= L[j][jj] L[kk][jj] (used for j >= kk); Lr[jj] was written just above: the first update waits for it, the others need not
       if constexpr (kk == jj + 1) Lr[kk] = fnma_row_bcast_f64<kk>(Lr[kk], Lr[jj], Lr[jj]);
-      else if constexpr (kk > jj + 1) Lr[kk] = fnma_row_bcast_f64_settled<kk>(Lr[kk], Lr[jj], Lr[jj]);
+      else if constexpr (kk > jj + 1) Lr[kk] = fnma_row_bcast_f64_settled<kk>(Lr[kk], Lr[jj], Lr[jj], Lr[jj + 1]);
     });
   });
   if (tid < 16) rv[tid] = myri;
@@ -1779,7 +1800,7 @@ __global__ __launch_bounds__(256) void ba_big_assemble_kernel(const BaWin* __res
 constexpr int BB_STEP_THREADS = ORBX_BB_STEP_THREADS, BB_STEP_WAVES = BB_STEP_THREADS / 64;   // 256 / 512 threads: 211.8 / 204.9 us per solve at n = 294 (round 1's 1024: slower)
 static_assert(BB_STEP_THREADS >= 256 && BB_STEP_THREADS % 64 == 0 && BB_STEP_THREADS <= 1024, "the panel block stages its 16 x 16 tile with 256 threads");
 constexpr int BB_COL_TILES = (BA_MAX_N / 16 + BB_STEP_WAVES - 1) / BB_STEP_WAVES;      // column tiles per wave of the panel block, all in flight at once
-__global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWin* __restrict__ wins, int c0) {
+__global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWin* __restrict__ wins, int c0, int one_launch_max_n) {
   __shared__ __align__(16) double D[BB_NB][BB_NB + 2];                    // (even pitch: the row solves read L11 in pairs)
   __shared__ __align__(16) double rinv[BB_NB];
   __shared__ double ys[BB_NB];
@@ -1787,7 +1808,7 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
   const BaWin& win = wins[blockIdx.y];
   const int n = win.n;
   double* __restrict__ Sg = win.Sg; double* __restrict__ ginv = win.ginv; double* __restrict__ bvec = win.bvec; double* __restrict__ res = win.res;
-  if (win.use_lds || c0 >= n || win.S->done || res[2] == 0.0) return;
+  if (win.use_lds || n <= one_launch_max_n || c0 >= n || win.S->done || res[2] == 0.0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int prev = c0 - BB_NB;                                            // the finished panel whose update is applied here (none at c0 = 0)
   const int nt = (n - c0 + 15) / 16;                                      // tile rows of the trailing matrix [c0, n)
@@ -1955,6 +1976,270 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
     for (int j = 0; j < BB_NB; ++j) row[j] = xr[j];
   }
 }
+
+// The same factorisation in ONE launch for systems of up to BF_MAX_N unknowns (configs[4]: n = 294): one workgroup of 16 waves per window,
+// LEFT-looking with one panel of look-ahead.  Panel p (columns c0 .. c0 + 15) needs S[c0.., panel] - L[c0.., 0..c0) L[panel, 0..c0)^T, one
+// wave per 16-row tile on the f64 MFMA.  All of that sum but its last 16 columns is formed one panel EARLIER, while wave 0 factors the
+// previous diagonal block: the tile's rows of L straight from L2 (128 contiguous bytes per row and 16 columns, three chunks of loads in
+// flight), the panel's own rows as the B operand from an LDS copy (Bp, filled another phase earlier by the waves that have no row to
+// solve — 15 waves fetching the same 16 rows was half of the CU's L1 bandwidth), the columns of the panel just before from the LDS copy
+// of that panel (Lp).  The last 16 columns — what the row solves have just produced — come from Lp as well, so the dependent chain of a
+// panel is four MFMAs, the 16 x 16 factor (wave 0, DPP), the row solves (one thread per row, the arithmetic of ba_big_step_kernel's panel
+// block, the right-hand side as row n) and three barriers, with no global-memory round trip in it.  The tiles belong to the twelve waves
+// that do not share wave 0's SIMD: f64 MFMA and f64 VALU use one datapath, and the factor is the chain everything waits for.  Every entry
+// of L is written once and only read afterwards, by the workgroup that wrote it.  Larger systems keep the multi-launch path: their
+// trailing updates want more than one CU.
+constexpr int BF_THREADS = 1024, BF_MAX_N = 320;
+constexpr int BF_CPITCH = 356;                                            // rows per column of the updated panel (>= BF_MAX_N + 16; = 4 mod 32)
+constexpr int BF_LPITCH = 18;                                             // doubles per row of the LDS copy of a panel of L (144 bytes: 16 rows x 16 bytes fill the banks once)
+constexpr int BF_LROWS = BF_MAX_N + 16;                                   // rows below a panel, the right-hand side and the clamped rows of the last tile
+constexpr int BF_BPITCH = 290;                                            // doubles per row of the B operand (>= BF_MAX_N - 32; = 2 mod 32)
+constexpr int BF_BQ = (BF_MAX_N - 2 * 16 + 127) / 128;                         // slices of 64 column pairs in a row of Bp
+constexpr int BF_TILE_WAVES = 12, BF_TILES = 2;                           // tile ti of a panel: slot ti / 12 of the ti % 12-th wave that is not on wave 0's SIMD
+static_assert((BF_MAX_N + 1 + 15) / 16 <= BF_TILES * BF_TILE_WAVES, "every tile of a panel needs an owner");
+static_assert(BF_MAX_N + 1 - 16 <= 2 * 256, "the rows below a panel: at most two per thread of the four row waves");
+constexpr size_t BF_LDS_BYTES = (size_t)(16 * BF_CPITCH + BF_LROWS * BF_LPITCH + 16 * BF_BPITCH) * 8;
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));  // (rows of an odd-n system start 8 bytes off)
+#ifdef ORBX_BF_DEBUG
+__device__ unsigned long long g_bf_stamps[8];
+#define BF_STAMP(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bf_acc_[k] += now_ - bf_prev_; bf_prev_ = now_; } } while (0)
+#else
+#define BF_STAMP(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* __restrict__ wins) {
+  extern __shared__ __align__(16) double dyn[];
+  __shared__ __align__(16) double D[BB_NB][BB_NB + 2];
+  __shared__ __align__(16) double rinv[BB_NB];
+  __shared__ int s_ok;
+  const BaWin& win = wins[blockIdx.y];
+  const int n = win.n;
+  if (win.use_lds || n > BF_MAX_N || win.S->done) return;
+  double* Sg = win.Sg; double* ginv = win.ginv; double* bvec = win.bvec; double* res = win.res;
+  double* Cs = dyn;
+  double* Lp = Cs + 16 * BF_CPITCH;
+  double* Bp = Lp + BF_LROWS * BF_LPITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+  const int widx = (wave & 3) ? wave - 1 - (wave >> 2) : -1;                // 0 .. 11 among the tile waves
+  if (tid == 0) s_ok = 1;
+  auto rowp = [&](int r) -> double* { return r < n ? Sg + (size_t)r * n : bvec; };    // row n (and the clamped rows past it): the right-hand side
+  auto mfma4 = [](double4_t a, double2_t a0, double2_t a1, double2_t b0, double2_t b1) {
+    a = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], a, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], a, 0, 0, 0);
+  };
+  // 16 columns of a tile's sum from the LDS copy of the panel that holds them; lrow0: the tile's first row, brow0: the B rows' first, as Lp numbers them
+  auto lp_chunk = [&](double4_t a, int lrow0, int brow0) {
+    const double* ap = Lp + (lrow0 + m) * BF_LPITCH + 4 * g;
+    const double* bp = Lp + (brow0 + m) * BF_LPITCH + 4 * g;
+    return mfma4(a, *(const double2_t*)ap, *(const double2_t*)(ap + 2), *(const double2_t*)bp, *(const double2_t*)(bp + 2));
+  };
+  double4_t acc[BF_TILES];
+  double cv[BF_TILES][4];
+  // A tile's sum over columns k0 .. k1 - 1 (multiples of 16) for the panel starting at cn: the tile's rows of L from global memory, three
+  // chunks of loads in flight; the panel's own rows (the B operand) from Bp
+  auto bulk = [&](double4_t a, int cn, int ti, int k0, int k1) {
+    if (k1 <= k0) return a;
+    const double* ap = rowp(min(cn + 16 * ti + m, n)) + 4 * g;              // lane (m, g): row m of the tile, columns kb + 4 g .. + 3 of each 16
+    const double* bp = Bp + m * BF_BPITCH + 4 * g;
+    const int k1c = k1 - 16, ka = min(k0 + 16, k1c);
+    double2_t a0 = *(const double2_u*)(ap + k0), a1 = *(const double2_u*)(ap + k0 + 2);
+    double2_t c0_ = *(const double2_u*)(ap + ka), c1_ = *(const double2_u*)(ap + ka + 2);
+    for (int kb = k0; kb < k1; kb += 16) {
+      const int k2 = min(kb + 32, k1c);                                     // (past the end: a repeat, never used)
+      const double2_t e0 = *(const double2_u*)(ap + k2), e1 = *(const double2_u*)(ap + k2 + 2);
+      a = mfma4(a, a0, a1, *(const double2_t*)(bp + kb), *(const double2_t*)(bp + kb + 2));
+      a0 = c0_; a1 = c1_; c0_ = e0; c1_ = e1;
+    }
+    return a;
+  };
+  // The panel starting at column cn = c0 + 16, while panel c0 is being factored and the rows below it solved: its entries of S and its
+  // sum over the columns before c0, for this wave's tiles (kept in registers until the panel's turn).  Under the factor: columns
+  // c0 - 16 .. c0 - 1 from Lp (which numbers its rows from c0 and is rewritten by the row solves) and the first half of the columns before
+  // them; beside the row solves: the other half.
+  auto ahead_factor = [&](int c0) {
+    const int cn = c0 + BB_NB, ntn = (n + 1 - cn + 15) / 16, kend = c0 - BB_NB, ks = kend > 0 ? (kend >> 5) << 4 : 0;
+#pragma unroll
+    for (int t = 0; t < BF_TILES; ++t) {
+      const int ti = widx + BF_TILE_WAVES * t;
+      if (ti < ntn) {                                                       // wave-uniform
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = cn + 16 * ti + g + 4 * q;
+          cv[t][q] = rowp(min(r, n))[min(cn + m, n - 1)];                   // (clamped: rows past the right-hand side and columns past n are never stored)
+        }
+        double4_t a = {0.0, 0.0, 0.0, 0.0};
+        if (c0 > 0) a = lp_chunk(a, BB_NB + 16 * ti, BB_NB);
+        acc[t] = bulk(a, cn, ti, 0, ks);
+      }
+    }
+  };
+  auto ahead_rows = [&](int c0) {
+    const int cn = c0 + BB_NB, ntn = (n + 1 - cn + 15) / 16, kend = c0 - BB_NB, ks = kend > 0 ? (kend >> 5) << 4 : 0;
+#pragma unroll
+    for (int t = 0; t < BF_TILES; ++t) {
+      const int ti = widx + BF_TILE_WAVES * t;
+      if (ti < ntn) acc[t] = bulk(acc[t], cn, ti, ks, kend);
+    }
+  };
+#ifdef ORBX_BF_DEBUG
+  unsigned long long bf_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bf_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  // Two roles, two loops, the same three barriers per panel: what a tile wave keeps in registers from one panel to the next (its tiles'
+  // sums and entries of S) is not live in the code of the waves that factor and solve rows, and the other way round.
+  if (widx >= 0) {
+    // ---- the tile waves
+    ahead_factor(-BB_NB);                                                  // panel 0: its entries of S
+    // Bp for the look-ahead two panels on — rows c0 + 32 .. + 47 of L, the columns before c0 — is requested beside a panel's row solves and
+    // written at the start of the next panel, when nobody reads the old one; registers in between.  16 rows x BF_BQ slices of 64 column
+    // pairs, four (row, slice) units per tile wave.
+    static_assert(16 * BF_BQ <= 4 * BF_TILE_WAVES, "Bp staging: four units per tile wave");
+    double2_t bq[4];
+    for (int c0 = 0; c0 < n; c0 += BB_NB) {
+      const int nb = min(BB_NB, n - c0);
+      const int nt = (n + 1 - c0 + 15) / 16;
+      if (c0 > BB_NB && c0 + BB_NB < n) {                                  // (requested in the panel before; there is a look-ahead to use it)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int unit = 4 * widx + i, k2 = lane + 64 * (unit >> 4);
+          if (2 * k2 < c0 - BB_NB) *(double2_t*)&Bp[(unit & 15) * BF_BPITCH + 2 * k2] = bq[i];
+        }
+      }
+      // the last 16 columns of the panel's sum from the LDS copy of the previous panel (which numbers its rows from this panel's first row)
+#pragma unroll
+      for (int t = 0; t < BF_TILES; ++t) {
+        const int ti = widx + BF_TILE_WAVES * t;
+        if (ti < nt) {
+          double4_t a = acc[t];
+          if (c0 > 0) a = lp_chunk(a, 16 * ti, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int lr = 16 * ti + g + 4 * q;
+            const double v = cv[t][q] - a[q];
+            if (lr < nb) D[lr][m] = v;                                     // the diagonal block goes to the factor
+            else Cs[m * BF_CPITCH + lr] = v;
+          }
+        }
+      }
+      __syncthreads();
+      if (c0 + BB_NB < n) ahead_factor(c0);                                // under the factor: the first part of the next panel's sum over the columns before this panel
+      __syncthreads();
+      if (!s_ok) return;
+      // (every panel and every lane, at clamped addresses: a conditional load would keep the old value alive through the whole next panel)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int unit = 4 * widx + i;
+        bq[i] = *(const double2_u*)(rowp(min(c0 + 2 * BB_NB + (unit & 15), n)) + 2 * min(lane + 64 * (unit >> 4), max(c0 / 2 - 1, 0)));
+      }
+      if (c0 + BB_NB < n) ahead_rows(c0);                                  // beside the row solves: the rest of it
+      __syncthreads();
+    }
+  } else {
+    // ---- wave 0 (the factor) and the three waves that share its SIMD: the rows below a block, one thread each (two for the first panels
+    // of a system beyond 271 unknowns)
+    const int ridx = (wave >> 2) * 64 + lane;
+    for (int c0 = 0; c0 < n; c0 += BB_NB) {
+      const int nb = min(BB_NB, n - c0);
+      __syncthreads();
+      BF_STAMP(1);
+      if (tid < 64) {
+        const int j = tid & 15;
+        double Lr[16];
+        if (nb == BB_NB) {
+          // a full block: whole rows in pairs, no masks — what stands right of the diagonal never reaches an entry at or left of it
+          // (a per-lane identity there was 16 loop-invariant constants, spilled and reloaded one scratch round trip at a time: 8 of the
+          // 14 thousand cycles of this phase)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) { const double2_t p2 = *(const double2_t*)&D[j][i]; Lr[i] = p2[0]; Lr[i + 1] = p2[1]; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Lr[i] = (j < nb && i <= j) ? D[j][i] : 0.0;   // (rows >= nb take no pivot step)
+        }
+        const int good = chol16_rows_dpp(Lr, nb, tid, rinv);
+        if (tid == 0 && !good) s_ok = 0;
+        if (good && tid < BB_NB) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            D[j][i] = i <= j ? Lr[i] : 0.0;
+            if (j < nb && i <= j) Sg[(size_t)(c0 + j) * n + c0 + i] = Lr[i];
+          }
+        }
+        BF_STAMP(2);
+      }
+      __syncthreads();
+      BF_STAMP(3);
+      if (!s_ok) { if (tid == 0) res[2] = 0.0; return; }
+      if (tid < nb) ginv[c0 + tid] = rinv[tid];
+      // rows below the block, r = c0 + nb .. n (a short last panel: the right-hand side only)
+      for (int lr = nb + ridx; c0 + lr <= n; lr += 256) {
+        double xr[BB_NB];
+#pragma unroll
+        for (int j = 0; j < BB_NB; ++j) xr[j] = Cs[j * BF_CPITCH + lr];
+#pragma unroll
+        for (int t = 0; t < BB_NB; t += 2) {
+          double la[BB_NB], lb[BB_NB];
+#pragma unroll
+          for (int jx = t + 1; jx < BB_NB; ++jx) {
+            const double2_t p2 = *(const double2_t*)&D[jx][t];
+            la[jx] = p2[0]; lb[jx] = p2[1];
+          }
+          const double2_t q2 = *(const double2_t*)&rinv[t];
+          xr[t] = xr[t] * q2[0];
+#pragma unroll
+          for (int jx = t + 1; jx < BB_NB; ++jx) xr[jx] = fma(-xr[t], la[jx], xr[jx]);
+          xr[t + 1] = xr[t + 1] * q2[1];
+#pragma unroll
+          for (int jx = t + 2; jx < BB_NB; ++jx) xr[jx] = fma(-xr[t + 1], lb[jx], xr[jx]);
+          // (pins the pair of steps: without it all 72 LDS reads of the block are issued first and 128 VGPRs do not hold them)
+          asm volatile("" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]), "+v"(xr[8]), "+v"(xr[9]),
+                       "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15]) :: "memory");
+        }
+        double* dst = rowp(c0 + lr) + c0;
+        if (nb == BB_NB) {
+          double* lp = Lp + (lr - BB_NB) * BF_LPITCH;                        // the next panel numbers its rows from c0 + 16
+#pragma unroll
+          for (int j = 0; j < BB_NB; j += 2) { const double2_t v2 = {xr[j], xr[j + 1]}; *(double2_t*)(lp + j) = v2; *(double2_u*)(dst + j) = v2; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < BB_NB; ++j) if (j < nb) dst[j] = xr[j];
+        }
+      }
+      __syncthreads();                                                     // the panel's columns of L: the LDS copy for the next panel, global memory for the ones after
+      BF_STAMP(4);
+    }
+  }
+#ifdef ORBX_BF_DEBUG
+  if (tid == 0) for (int k = 0; k < 8; ++k) g_bf_stamps[k] = bf_acc_[k];
+#endif
+}
+
+#ifdef ORBX_BF_DEBUG
+// debug build only: the one-launch factorisation alone on a host matrix (scripts/bf_debug.py).  S: n x n row-major, b: n; out: L in S, y in b, 1/L_jj in ginv
+extern "C" int orbx_debug_big_factor(double* S, double* b, double* ginv_out, int n) {
+  double* d = nullptr; BaWin* dw = nullptr; BaState* ds = nullptr;
+  const size_t nn = (size_t)n * n;
+  if (hipMalloc(&d, (nn + 2 * (size_t)n + 16) * 8) != hipSuccess || hipMalloc(&dw, sizeof(BaWin)) != hipSuccess || hipMalloc(&ds, sizeof(BaState)) != hipSuccess) return -1;
+  hipMemset(ds, 0, sizeof(BaState));
+  BaWin w; memset(&w, 0, sizeof(w));
+  w.n = n; w.use_lds = 0; w.S = ds; w.Sg = d; w.bvec = d + nn; w.ginv = w.bvec + n; w.res = w.ginv + n;
+  hipMemcpy(d, S, nn * 8, hipMemcpyHostToDevice); hipMemcpy(w.bvec, b, (size_t)n * 8, hipMemcpyHostToDevice);
+  const double one[3] = {0, 0, 1.0}; hipMemcpy(w.res, one, 24, hipMemcpyHostToDevice);
+  hipMemcpy(dw, &w, sizeof(w), hipMemcpyHostToDevice);
+  hipFuncSetAttribute((const void*)ba_big_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
+  for (int rep = 0; rep < 3; ++rep) {                                      // (the stamps of the last, warm, run are reported)
+    hipMemcpy(d, S, nn * 8, hipMemcpyHostToDevice); hipMemcpy(w.bvec, b, (size_t)n * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(ba_big_factor_kernel, dim3(1, 1), dim3(BF_THREADS), BF_LDS_BYTES, 0, dw);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+  }
+  double r3[3]; hipMemcpy(r3, w.res, 24, hipMemcpyDeviceToHost);
+  hipMemcpy(S, d, nn * 8, hipMemcpyDeviceToHost); hipMemcpy(b, w.bvec, (size_t)n * 8, hipMemcpyDeviceToHost); hipMemcpy(ginv_out, w.ginv, (size_t)n * 8, hipMemcpyDeviceToHost);
+  hipFree(d); hipFree(dw); hipFree(ds);
+  unsigned long long st[8];
+  if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_bf_stamps), 64) == hipSuccess)
+    fprintf(stderr, "  ticks: first loads %llu | last chunk + barrier %llu | factor %llu | look-ahead past the factor %llu | row solves + barrier %llu\n", st[0], st[1], st[2], st[3], st[4]);
+  return r3[2] != 0.0 ? 0 : 1;
+}
+#endif
 
 // backward substitution L^T x = y (y = bvec after the last ba_big_step_kernel), |dp|^2, |p|^2: one block
 __global__ __launch_bounds__(256) void ba_big_back_kernel(const BaWin* __restrict__ wins) {
@@ -2830,6 +3115,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // the K rotations — per 32 points instead of per 8; 32-window batch: build 0.103 -> 0.096, back-substitution 0.068 -> 0.064 ms per iteration)
   const int ppg = W >= 8 ? 4 : 1;
   const int ptl = W >= 8 ? 16 : 32;   // lanes per point in those two kernels (group_sum<>: the sums do not depend on it)
+  static const int one_launch_max_n = getenv("ORBX_BA_BIG_STEPS") ? 0 : BF_MAX_N;   // (ORBX_BA_BIG_STEPS: the multi-launch factorisation for every size, for A/B runs)
+  int any_one = 0;
   int any_lds = 0, any_big = 0, n_big_max = 0, maxM = 0, maxK = 0, max_schur_blocks = 1, all_diag = 1, max_gather = 1, max_back = 1, max_asm = 1;
   for (int w = 0; w < W; ++w) {
     const WinPlan& pl = plan[w];
@@ -2855,7 +3142,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if (pl.skip) continue;                                             // (its LM state says done: set with the window's preprocessing)
     if (pl.use_lds == 1 && !inertial) { any_lds = 1; lds_max = std::max(lds_max, pl.lds_need); }
     else if (pl.use_lds == 2 && !inertial) { any_tiled = 1; tiled_lds_max = std::max(tiled_lds_max, pl.lds_need); }
-    else if (!inertial) { any_big = 1; n_big_max = std::max(n_big_max, pl.n); }
+    else if (!inertial) { any_big = 1; if (pl.n > one_launch_max_n) n_big_max = std::max(n_big_max, pl.n); else any_one = 1; }
     maxM = std::max(maxM, pl.d.M); maxK = std::max(maxK, pl.d.K);
     max_schur_blocks = std::max(max_schur_blocks, pl.d.ncb * (pl.d.ncb + 1) / 2 * pl.d.ksplit);
     if (pl.d.ncb != 1) all_diag = 0;
@@ -2863,7 +3150,15 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     max_back = std::max(max_back, (std::max(ptl * ((pl.d.M + ppg - 1) / ppg), pl.n) + 255) / 256);
     max_asm = std::max(max_asm, std::min(512, (pl.n * pl.n + 255) / 256));
   }
-  const int pt_groups = (maxM + ppg - 1) / ppg;
+  // the build launch holds 3 workgroups per CU (166 VGPRs): a grid past that runs a second, mostly empty round of workgroups, so a large
+  // batch gives each group as many points as keep the grid (with the peer half's windows) within one round
+  int ppg_build = ppg;
+  if (ptl == 16) {
+    const size_t cap = 3 * (size_t)h->n_cu, wt = (size_t)(W + h->ba_peer_windows);
+    while (ppg_build < 16 && wt * (size_t)((((maxM + ppg_build - 1) / ppg_build) * ptl + 255) / 256) > cap) ++ppg_build;
+    if (const char* e = getenv("ORBX_BA_PPG")) if (*e) ppg_build = std::max(1, atoi(e));
+  }
+  const int pt_groups = (maxM + ppg_build - 1) / ppg_build;
   // a batch large enough to fill the chip with one workgroup per (window, gather share): the Schur workgroups add their share's partials
   // themselves (BaWin::part_sums) and the gather reads one tile set per share
   // (the windows of a batch's other half, running on the peer stream at the same time, count: together they fill the chip)
@@ -2913,6 +3208,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_solve_inertial_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_TILED_LDS_MAX);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_kf_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
+      if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_big_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
     });
     ORBX_HIP(h, e_attr);
   }
@@ -3007,9 +3303,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       if (n15 <= BA_TILED_MAX_N) hipLaunchKernelGGL(ba_solve_inertial_tiled_kernel, dim3(1, 1), dim3(BA_SOLVE_THREADS), tiled_lds_max, st, d_wins15, ind, (const double*)imu_buf);
       else {
         hipLaunchKernelGGL(ba_inertial_assemble_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, ind, w0.rb, imu_buf, b15.Sg, b15.bvec, gfull, res0);
-        for (int c0 = 0; c0 < n15; c0 += BB_NB) {
+        if (n15 <= one_launch_max_n) hipLaunchKernelGGL(ba_big_factor_kernel, dim3(1, 1), dim3(BF_THREADS), BF_LDS_BYTES, st, d_wins15);
+        else for (int c0 = 0; c0 < n15; c0 += BB_NB) {
           const int nt = (n15 - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
-          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + BB_STEP_WAVES - 1) / BB_STEP_WAVES, 1), dim3(BB_STEP_THREADS), 0, st, d_wins15, c0);
+          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + BB_STEP_WAVES - 1) / BB_STEP_WAVES, 1), dim3(BB_STEP_THREADS), 0, st, d_wins15, c0, one_launch_max_n);
         }
         hipLaunchKernelGGL(ba_big_back_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15);
       }
@@ -3020,9 +3317,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       if (any_big || any_tiled) hipLaunchKernelGGL(ba_big_assemble_kernel, dim3(max_asm, W), dim3(256), 0, st, d_wins);
       if (any_tiled) hipLaunchKernelGGL(ba_solve_tiled_kernel, gW1, dim3(BA_SOLVE_THREADS), tiled_lds_max, st, d_wins);
       if (any_big) {
+        if (any_one) hipLaunchKernelGGL(ba_big_factor_kernel, gW1, dim3(BF_THREADS), BF_LDS_BYTES, st, d_wins);
         for (int c0 = 0; c0 < n_big_max; c0 += BB_NB) {
           const int nt = (n_big_max - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
-          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + BB_STEP_WAVES - 1) / BB_STEP_WAVES, W), dim3(BB_STEP_THREADS), 0, st, d_wins, c0);
+          hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + BB_STEP_WAVES - 1) / BB_STEP_WAVES, W), dim3(BB_STEP_THREADS), 0, st, d_wins, c0, one_launch_max_n);
         }
         hipLaunchKernelGGL(ba_big_back_kernel, gW1, dim3(256), 0, st, d_wins);
       }

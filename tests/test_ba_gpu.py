@@ -60,6 +60,30 @@ def test_ba_large_window_gmem_cholesky(gpu_handle, oracle, pkg):
     assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL
 
 
+def test_ba_one_launch_global_cholesky_and_its_boundary(gpu_handle, oracle, pkg):
+    """Reduced systems beyond the LDS tiles: up to 320 unknowns one workgroup factors them in one launch (ba_big_factor_kernel, left-looking
+    with a panel of look-ahead), beyond that one launch per panel.  n = 192 (full panels only), 318 (the largest one-launch size: a short
+    last panel and two rows per thread below the first panels) and 324 (the first multi-launch size) against the structured oracle."""
+    for seed, K, M in ((31, 33, 500), (32, 54, 700), (33, 55, 700)):
+        w = pkg.synth.ba_window(seed, K, M, pkg.BA_OBS)
+        g, o = _solve_both(gpu_handle, oracle, pkg, w, dense=False)
+        assert g["iterations"] == o["iterations"], (K, M)
+        assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL, (K, M)
+
+
+def test_ba_batch_with_global_cholesky_windows_equals_single(gpu_handle, pkg):
+    """A batch that mixes every reduced-system path — LDS square (n = 114), LDS tiles (n = 150), one-launch global (n = 186, 300) and
+    multi-launch global (n = 330) — returns each window's single-window result bit for bit."""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA)
+    cfg = pkg.LocalBAConfigLM()
+    wins = [pkg.synth.ba_window(40 + i, K, M, pkg.BA_OBS) for i, (K, M) in enumerate(((20, 300), (32, 400), (56, 600), (26, 350), (51, 500)))]
+    batch = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
+    for w, b in zip(wins, batch):
+        s = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+        assert b["iterations"] == s["iterations"]
+        assert np.array_equal(np.asarray(b["poses_wc"]), np.asarray(s["poses_wc"])) and np.array_equal(b["points"], s["points"])
+
+
 def test_ba_reduced_system_sizes_around_panel_boundaries(gpu_handle, oracle, pkg):
     """The LDS solve walks 16-column panels, the rows below a panel following the factorisation through flags in LDS: reduced systems of
     exactly 3 and 6 panels (no short last panel: n = 48, 96), of one short panel only (n = 12), and of full panels plus a 2- and a

@@ -83,6 +83,20 @@ def test_gpu_inertial_ba_matches_oracle(gpu_handle, seed, K, M, fixed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,K,M", [(11, 13, 300), (12, 22, 400)])
+def test_gpu_inertial_ba_beyond_the_lds_tiles(gpu_handle, seed, K, M):
+    """15 K = 195 unknowns: the one-launch factorisation in global memory; 15 K = 330: one launch per panel (inertial windows of the
+    reference hold 10 keyframes; these sizes are the same code paths a 50-keyframe visual window takes)."""
+    w = P.synth.inertial_window(seed, K, M, P.BA_OBS, n_fixed=1)
+    o = _oracle(w)
+    g = _gpu(gpu_handle, w)
+    assert g["iterations"] == o["iterations"]
+    assert abs(g["final_error"] - o["final_error"]) < 1e-7 * o["final_error"]
+    for key in ("poses_wc", "velocities", "biases", "points"):
+        assert _rel(g[key], o[key]) < TOL, key
+
+
+@pytest.mark.gpu
 def test_gpu_inertial_ba_config_abort_and_none(gpu_handle):
     w = P.synth.inertial_window(5, 5, 120, P.BA_OBS)
     cfg = P.LocalInertialBAConfig(max_iterations=6, initial_lambda=1e-1, gyro_rw_info=1e5, accel_rw_info=1e3, huber_threshold_mono=1.5)
