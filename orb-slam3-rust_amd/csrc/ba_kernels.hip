@@ -585,7 +585,9 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
 constexpr int SCH_R = 24;                 // rows per LDS tile (8 points, 6 MFMA k-steps)
 constexpr int SCH_PITCH = 136;            // doubles per LDS row: 128 + 16 — the two 16-lane row groups of a ds_read_b64 half-wave land 32 banks apart
 // one tile step of ba_schur_body's product for wave Q (tile rows Q and 7 - Q of the block pair; DG: a diagonal pair, upper tiles only)
-template <int Q, bool DG>
+// CM: the tile columns of block bj that exist (8, or fewer in the last block: n = 294 is 8 + 8 + 3 tiles — multiplying the 5 padded
+// ones as well was 37 % of the launch's MFMAs at configs[4]'s size).  A compile-time bound like Q and DG, for the same reason.
+template <int Q, bool DG, int CM>
 __device__ __forceinline__ void ba_schur_gen_mfma(double4_t (&acc)[2][8], const double* __restrict__ sY, const double* __restrict__ sW, int lane) {
 #pragma unroll
   for (int kq = 0; kq < SCH_R / 4; ++kq) {
@@ -593,11 +595,24 @@ __device__ __forceinline__ void ba_schur_gen_mfma(double4_t (&acc)[2][8], const 
     const double a0 = sY[row * SCH_PITCH + Q * 16 + (lane & 15)];
     const double a1 = sY[row * SCH_PITCH + (7 - Q) * 16 + (lane & 15)];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < CM; ++c) {
       const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
       if (!DG || c >= Q) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][c], 0, 0, 0);
       if (!DG || c >= 7 - Q) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][c], 0, 0, 0);
     }
+  }
+}
+template <int CM>
+__device__ __forceinline__ void ba_schur_gen_step(int wave, bool diag, double4_t (&acc)[2][8], const double* __restrict__ sY, const double* __restrict__ sW, int lane) {
+  switch (2 * wave + (diag ? 1 : 0)) {
+    case 0: ba_schur_gen_mfma<0, false, CM>(acc, sY, sW, lane); break;
+    case 1: ba_schur_gen_mfma<0, true, CM>(acc, sY, sW, lane); break;
+    case 2: ba_schur_gen_mfma<1, false, CM>(acc, sY, sW, lane); break;
+    case 3: ba_schur_gen_mfma<1, true, CM>(acc, sY, sW, lane); break;
+    case 4: ba_schur_gen_mfma<2, false, CM>(acc, sY, sW, lane); break;
+    case 5: ba_schur_gen_mfma<2, true, CM>(acc, sY, sW, lane); break;
+    case 6: ba_schur_gen_mfma<3, false, CM>(acc, sY, sW, lane); break;
+    default: ba_schur_gen_mfma<3, true, CM>(acc, sY, sW, lane); break;
   }
 }
 
@@ -620,6 +635,7 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[a][c] = double4_t{0.0, 0.0, 0.0, 0.0};
   const int trow[2] = {wave, 7 - wave};                             // this wave's two tile rows inside the block
+  const int cm = min(8, d.ntile - 8 * bj);                          // tile columns of block bj that exist
   const int kf_lo_i = (128 * bi) / 6, kf_lo_j = (128 * bj) / 6;   // first keyframe whose 6 columns reach into the block; at most 23 do
   constexpr int NPT = SCH_R / 3, NSLOT = NPT * 23;
   // columns past 6K and slots of keyframes that do not exist are never written below: zero both tiles once
@@ -637,6 +653,9 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
     return j < d.M ? slot_first[(size_t)j * d.K + k] : -1;
   };
   int nxt[2] = {slot_index(tid, j_begin), slot_index(tid + 256, j_begin)};
+  // (the whole loop once per column count: two multiply variants inside one loop body cost 67 spilled registers)
+  auto run = [&](auto cm_) {
+  constexpr int CM = decltype(cm_)::value;
   for (int j0 = j_begin; j0 < j_begin + d.pps; j0 += NPT) {
     // ---- fill: one thread per (side, point, keyframe): side 0 = the Y tile (columns of block bi; in a diagonal block also the W
     // tile, same columns), side 1 = the W tile of block bj
@@ -684,17 +703,13 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
     // ---- multiply: 6 k-steps of 4 rows (wave index and diagonal flag as template arguments: with run-time predicates around the
     // MFMAs a tile step was dozens of basic blocks and no operand read could be scheduled above the matrix instructions, as in the
     // one-column-block body before its consumer loop was specialised)
-    switch (2 * wave + (diag ? 1 : 0)) {
-      case 0: ba_schur_gen_mfma<0, false>(acc, sY, sW, lane); break;
-      case 1: ba_schur_gen_mfma<0, true>(acc, sY, sW, lane); break;
-      case 2: ba_schur_gen_mfma<1, false>(acc, sY, sW, lane); break;
-      case 3: ba_schur_gen_mfma<1, true>(acc, sY, sW, lane); break;
-      case 4: ba_schur_gen_mfma<2, false>(acc, sY, sW, lane); break;
-      case 5: ba_schur_gen_mfma<2, true>(acc, sY, sW, lane); break;
-      case 6: ba_schur_gen_mfma<3, false>(acc, sY, sW, lane); break;
-      default: ba_schur_gen_mfma<3, true>(acc, sY, sW, lane); break;
-    }
+    ba_schur_gen_step<CM>(wave, diag, acc, sY, sW, lane);
   }
+  };
+  if (cm <= 2) run(std::integral_constant<int, 2>{});
+  else if (cm <= 4) run(std::integral_constant<int, 4>{});
+  else if (cm <= 6) run(std::integral_constant<int, 6>{});
+  else run(std::integral_constant<int, 8>{});
   // ---- partials out: the gather kernel's layout, part[(upper tile, ks)][16][16]
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
@@ -3000,6 +3015,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     // (24 points per split measured best for one window of 20 keyframes / 2000 points — 8, 16, 24, 32, 48, 96, 192 tried: the
     // Schur blocks take 8.5 us + 3.6 us per 8 points, the reduction of the partials grows with the number of splits)
     d.ksplit = std::max(1, std::min(128, (M + BA_PPS_TARGET - 1) / BA_PPS_TARGET));
+    // (configs[4], 6 column-block pairs x 128 splits = 768 workgroups at 2 per CU: capping the splits at 100 / 85 / 64 / 48 / 32 to fit one
+    // round of workgroups measured 95.7 / 99.2 / 102.8 / 120.7 / 180.0 us against 94.1 — many short workgroups it stays)
     d.pps = std::max(8, (((M + d.ksplit - 1) / d.ksplit) + 7) & ~7);
     d.rows = 3 * d.pps * d.ksplit;
     pl.n = 6 * K;
