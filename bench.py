@@ -578,7 +578,7 @@ def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
     flop = schur_executed_flop(k_opt, M)
     fused = kt.get("ba_kf_schur_kernel", (0.0, 1))
     fused_ms = fused[0] / max(fused[1], 1)
-    res = dict(workload="synth_ba(seed=%d, K=%d, M=%d), %d observations, %d optimised keyframes (reduced system n = %d, multi-kernel Cholesky)"
+    res = dict(workload="synth_ba(seed=%d, K=%d, M=%d), %d observations, %d optimised keyframes (reduced system n = %d, one-launch Cholesky in global memory)"
                         % (seed, K, M, len(win["obs"]), k_opt, 6 * k_opt),
                lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3), iterations=r["iterations"],
                initial_error_px=round(r["initial_error"], 4), final_error_px=round(r["final_error"], 4),
