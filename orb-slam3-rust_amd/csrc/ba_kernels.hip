@@ -2015,6 +2015,13 @@ static_assert((BF_MAX_N + 1 + 15) / 16 <= BF_TILES * BF_TILE_WAVES, "every tile 
 static_assert(BF_MAX_N + 1 - 16 <= 2 * 256, "the rows below a panel: at most two per thread of the four row waves");
 constexpr size_t BF_LDS_BYTES = (size_t)(16 * BF_CPITCH + BF_LROWS * BF_LPITCH + 16 * BF_BPITCH) * 8;
 typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));  // (rows of an odd-n system start 8 bytes off)
+// Loads of L and S in ba_big_factor_kernel, as GLOBAL loads: the row pointers come out of a select between two members of BaWin and were
+// generic to the compiler — flat loads, which count on lgkmcnt as well, so that every wait for an LDS read also waited for the prefetched
+// chunks of L.
+typedef __attribute__((address_space(1))) const double2_u bf_g2_t;
+typedef __attribute__((address_space(1))) const double bf_g1_t;
+__device__ __forceinline__ double2_t bf_ldg2(const double* p) { return *(bf_g2_t*)p; }
+__device__ __forceinline__ double bf_ldg1(const double* p) { return *(bf_g1_t*)p; }
 #ifdef ORBX_BF_DEBUG
 __device__ unsigned long long g_bf_stamps[8];
 #define BF_STAMP(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); bf_acc_[k] += now_ - bf_prev_; bf_prev_ = now_; } } while (0)
@@ -2051,20 +2058,32 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
   };
   double4_t acc[BF_TILES];
   double cv[BF_TILES][4];
-  // A tile's sum over columns k0 .. k1 - 1 (multiples of 16) for the panel starting at cn: the tile's rows of L from global memory, three
-  // chunks of loads in flight; the panel's own rows (the B operand) from Bp
+  // A tile's sum over columns k0 .. k1 - 1 (multiples of 16) for the panel starting at cn: the tile's rows of L from global memory, the
+  // panel's own rows (the B operand) from Bp.  (One run over all the columns with a RAW s_barrier half way, so that the loads in flight
+  // survive the panel's second barrier instead of two runs that each begin with an exposed L2 round trip, was built: 143.8 -> 147.3 us.)
   auto bulk = [&](double4_t a, int cn, int ti, int k0, int k1) {
     if (k1 <= k0) return a;
     const double* ap = rowp(min(cn + 16 * ti + m, n)) + 4 * g;              // lane (m, g): row m of the tile, columns kb + 4 g .. + 3 of each 16
     const double* bp = Bp + m * BF_BPITCH + 4 * g;
     const int k1c = k1 - 16, ka = min(k0 + 16, k1c);
-    double2_t a0 = *(const double2_u*)(ap + k0), a1 = *(const double2_u*)(ap + k0 + 2);
-    double2_t c0_ = *(const double2_u*)(ap + ka), c1_ = *(const double2_u*)(ap + ka + 2);
-    for (int kb = k0; kb < k1; kb += 16) {
-      const int k2 = min(kb + 32, k1c);                                     // (past the end: a repeat, never used)
-      const double2_t e0 = *(const double2_u*)(ap + k2), e1 = *(const double2_u*)(ap + k2 + 2);
-      a = mfma4(a, a0, a1, *(const double2_t*)(bp + kb), *(const double2_t*)(bp + kb + 2));
-      a0 = c0_; a1 = c1_; c0_ = e0; c1_ = e1;
+    // Three register sets, the loop unrolled three times: a chunk's loads are issued two chunks before its MFMAs and nothing is copied
+    // (a rotation by moves made every copy wait for its load).  The offsets are opaque to the compiler (the empty asm): nothing in the
+    // loop stores, so it had replaced the carried registers by a fresh load of the same address right before the MFMAs — no prefetch
+    // left, one exposed L2 round trip per chunk.  Offsets past the end are clamped: a repeat, never used.
+    auto ld = [&](int k, double2_t& x0, double2_t& x1) {
+      k = min(k, k1c);
+      asm volatile("" : "+s"(k));
+      x0 = bf_ldg2(ap + k); x1 = bf_ldg2(ap + k + 2);
+    };
+    auto mm = [&](int kb, const double2_t& x0, const double2_t& x1) { a = mfma4(a, x0, x1, *(const double2_t*)(bp + kb), *(const double2_t*)(bp + kb + 2)); };
+    double2_t r0a, r0b, r1a, r1b, r2a, r2b;
+    ld(k0, r0a, r0b); ld(ka, r1a, r1b);
+    for (int kb = k0; kb < k1; kb += 48) {
+      ld(kb + 32, r2a, r2b); mm(kb, r0a, r0b);
+      if (kb + 16 >= k1) break;
+      ld(kb + 48, r0a, r0b); mm(kb + 16, r1a, r1b);
+      if (kb + 32 >= k1) break;
+      ld(kb + 64, r1a, r1b); mm(kb + 32, r2a, r2b);
     }
     return a;
   };
@@ -2081,7 +2100,7 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int r = cn + 16 * ti + g + 4 * q;
-          cv[t][q] = rowp(min(r, n))[min(cn + m, n - 1)];                   // (clamped: rows past the right-hand side and columns past n are never stored)
+          cv[t][q] = bf_ldg1(rowp(min(r, n)) + min(cn + m, n - 1));         // (clamped: rows past the right-hand side and columns past n are never stored)
         }
         double4_t a = {0.0, 0.0, 0.0, 0.0};
         if (c0 > 0) a = lp_chunk(a, BB_NB + 16 * ti, BB_NB);
@@ -2144,7 +2163,7 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int unit = 4 * widx + i;
-        bq[i] = *(const double2_u*)(rowp(min(c0 + 2 * BB_NB + (unit & 15), n)) + 2 * min(lane + 64 * (unit >> 4), max(c0 / 2 - 1, 0)));
+        bq[i] = bf_ldg2(rowp(min(c0 + 2 * BB_NB + (unit & 15), n)) + 2 * min(lane + 64 * (unit >> 4), max(c0 / 2 - 1, 0)));
       }
       if (c0 + BB_NB < n) ahead_rows(c0);                                  // beside the row solves: the rest of it
       __syncthreads();
