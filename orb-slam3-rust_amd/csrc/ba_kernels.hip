@@ -108,6 +108,50 @@ struct BaWin {
   double *res;           // [16] result block, see ba_decide_kernel
 };
 
+// The pointers a kernel takes out of its window descriptor are generic to the compiler (loaded from memory, not kernel arguments): every
+// access through them was a FLAT load or store, which counts on lgkmcnt as well as vmcnt and may complete out of order with LDS traffic —
+// each wait became a full drain of both counters, and no load stayed in flight across an LDS access.  (A cast to the global address
+// space and back is folded away before the address-space inference runs, and llvm.assume(!is_shared & !is_private) is not picked up by
+// this compiler; a pointer that is LOADED as a global pointer is.)  So a kernel reads its descriptor through a view of the same bytes
+// whose pointer members are declared in the global address space — ba_win_global() — and works on the copy it returns.
+#define BA_AS1 __attribute__((address_space(1)))
+struct BaWinView {
+  BaDims d;
+  int n, use_lds, part_sums;
+  BA_AS1 BaState* S;
+  BA_AS1 double *P0, *P1;
+  BA_AS1 const double* Rt_fix;
+  BA_AS1 const int *pt_start, *o_kf;
+  BA_AS1 const double* o_uv;
+  BA_AS1 const int* kf_start;
+  BA_AS1 int *kf_obs, *kf_pt;
+  BA_AS1 double *Vinv, *gl, *vg;
+  BA_AS1 double *pt_chi2, *pt_glsq, *pt_dsq, *pt_psq;
+  BA_AS1 double *oP;
+  BA_AS1 double *Rt_cur;
+  BA_AS1 int *slot_first;
+  BA_AS1 int *obs_next;
+  BA_AS1 double *kfpart, *part, *rb;
+  BA_AS1 double *dp;
+  BA_AS1 double *Sg, *bvec, *ginv;
+  BA_AS1 double *res;
+};
+static_assert(sizeof(BaWinView) == sizeof(BaWin) && offsetof(BaWinView, S) == offsetof(BaWin, S) && offsetof(BaWinView, oP) == offsetof(BaWin, oP) &&
+              offsetof(BaWinView, res) == offsetof(BaWin, res), "BaWinView is BaWin with its pointers in the global address space");
+__device__ __forceinline__ BaWin ba_win_global(const BaWin* __restrict__ wins, int i) {
+  const BaWinView& v = ((const BaWinView*)wins)[i];
+  BaWin g;
+  g.d = v.d; g.n = v.n; g.use_lds = v.use_lds; g.part_sums = v.part_sums;
+  g.S = (BaState*)v.S; g.P0 = (double*)v.P0; g.P1 = (double*)v.P1; g.Rt_fix = (const double*)v.Rt_fix;
+  g.pt_start = (const int*)v.pt_start; g.o_kf = (const int*)v.o_kf; g.o_uv = (const double*)v.o_uv; g.kf_start = (const int*)v.kf_start;
+  g.kf_obs = (int*)v.kf_obs; g.kf_pt = (int*)v.kf_pt; g.Vinv = (double*)v.Vinv; g.gl = (double*)v.gl; g.vg = (double*)v.vg;
+  g.pt_chi2 = (double*)v.pt_chi2; g.pt_glsq = (double*)v.pt_glsq; g.pt_dsq = (double*)v.pt_dsq; g.pt_psq = (double*)v.pt_psq;
+  g.oP = (double*)v.oP; g.Rt_cur = (double*)v.Rt_cur; g.slot_first = (int*)v.slot_first; g.obs_next = (int*)v.obs_next;
+  g.kfpart = (double*)v.kfpart; g.part = (double*)v.part; g.rb = (double*)v.rb; g.dp = (double*)v.dp;
+  g.Sg = (double*)v.Sg; g.bvec = (double*)v.bvec; g.ginv = (double*)v.ginv; g.res = (double*)v.res;
+  return g;
+}
+
 // ---- small device math ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
   const double w = q[0], i = q[1], j = q[2], k = q[3];
@@ -179,7 +223,7 @@ __device__ __forceinline__ void block_poses(const double* params, int K, int ine
 
 // iteration counter only (windows without points never launch the build kernel)
 __global__ void ba_iter_kernel(const BaWin* __restrict__ wins, int iter) {
-  BaState* S = wins[blockIdx.y].S;
+  BaState* S = ba_win_global(wins, blockIdx.y).S;
   if (S->done) return;
   S->iters = iter + 1;                                                  // local_ba_lm.rs:1017
 }
@@ -190,7 +234,7 @@ __global__ void ba_iter_kernel(const BaWin* __restrict__ wins, int iter) {
 // order through obs_next — the tile slot then holds the sum of their W blocks, as J^T J does.  Built here once per call instead of
 // on the host: 4 (M K + N) bytes per window less to prepare and to upload (a fifth of the input blob at 20 keyframes / 2000 points).
 __global__ __launch_bounds__(256) void ba_slots_kernel(const BaWin* __restrict__ wins) {
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const int K = win.d.K, M = win.d.M;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (win.S->done || j >= M || K <= 0) return;        // (a window the reference answers None for was never prepared: its index arrays hold nothing)
@@ -216,7 +260,7 @@ __global__ __launch_bounds__(256) void ba_slots_kernel(const BaWin* __restrict__
 __global__ __launch_bounds__(256) void ba_kflist_kernel(const BaWin* __restrict__ wins) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const int K = win.d.K, M = win.d.M, k = blockIdx.x;
   if (win.S->done || k >= K) return;
   const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ nxt = win.obs_next;
@@ -369,7 +413,7 @@ template <int LANES> __device__ __forceinline__ double group_sum(double a, doubl
 template <int LANES>
 __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(const BaWin* __restrict__ wins, BaCam cam, int iter) {
   __shared__ double sRt[12 * BA_MAX_K];
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const BaDims d = win.d;
   BaState* S = win.S;
   if (S->done || (int)blockIdx.x * (256 / LANES) >= max(d.M, 1)) return;   // (block 0 of a window without points still counts the iteration)
@@ -961,7 +1005,7 @@ template <bool DIAG>
 __global__ __launch_bounds__(DIAG ? SCHW_THREADS : BA_KFS_GEN_THREADS, DIAG ? 1 : (BA_KFS_GEN_THREADS > 256 ? 1 : 2)) void ba_kf_schur_kernel(const BaWin* __restrict__ wins, BaCam cam) {
   extern __shared__ __align__(16) double s_dyn[];
   __shared__ double s_tiles[DIAG ? 1 : 2 * SCH_R * SCH_PITCH];
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   if (win.S->done) return;
   const int nkf = win.d.K * BA_KFSPLIT;
   if ((int)blockIdx.x < nkf) { if (threadIdx.x < BA_KF_THREADS) ba_kf_body<BA_KF_THREADS>((int)blockIdx.x, win, cam); }
@@ -990,7 +1034,7 @@ __global__ __launch_bounds__(BA_KF_THREADS, ORBX_KF_MINBLOCKS) void ba_kf_kernel
     by = xcd + 8 * (slot / (int)gridDim.x);
     bx = slot - (slot / (int)gridDim.x) * (int)gridDim.x;
   }
-  const BaWin& win = wins[by];
+  const BaWin win = ba_win_global(wins, by);
   if (win.S->done || bx >= win.d.K * BA_KFSPLIT) return;
   ba_kf_body<BA_KF_THREADS>(bx, win, cam);
 }
@@ -1005,7 +1049,7 @@ template <bool DIAG>
 __global__ __launch_bounds__(DIAG ? SCHW_THREADS : 256, DIAG ? 1 : 2) void ba_schur_kernel(const BaWin* __restrict__ wins, BaCam cam, int spb) {
   extern __shared__ __align__(16) double s_dyn[];
   __shared__ double s_tiles[DIAG ? 1 : 2 * SCH_R * SCH_PITCH];     // Y and W operand tiles of the general body (51 KB)
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   if (win.S->done) return;
   if (DIAG) ba_schur_diag_ws_body((int)blockIdx.x, spb, win, cam, s_dyn);
   else ba_schur_body((int)blockIdx.x, win, cam, s_tiles, s_tiles + SCH_R * SCH_PITCH);   // (blocks beyond this window's need return inside)
@@ -1013,7 +1057,7 @@ __global__ __launch_bounds__(DIAG ? SCHW_THREADS : 256, DIAG ? 1 : 2) void ba_sc
 
 // reduce-buffer layout (doubles): [Sred n*n | U 36K | gp n | bred n | chi2 | glsq], n = 6K
 __global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict__ wins) {
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   if (win.S->done) return;
   const BaDims d = win.d;
   const double* __restrict__ part = win.part; const double* __restrict__ kfpart = win.kfpart;
@@ -1733,7 +1777,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
 
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(const BaWin* __restrict__ wins) {
   extern __shared__ __align__(16) double dyn[];
-  const BaWin& win = wins[blockIdx.y];       // one workgroup per window
+  const BaWin win = ba_win_global(wins, blockIdx.y);       // one workgroup per window
   if (win.use_lds != 1) return;
   solve_body<LaySquare, 0>(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, LaySquare{dyn, win.n}, win.dp, win.res);
 }
@@ -1744,7 +1788,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_lds_kernel(const Ba
 // (inertial BA, 10 keyframes: 11 launches, 129 us per iteration for the solve).
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_tiled_kernel(const BaWin* __restrict__ wins) {
   extern __shared__ __align__(16) double dyn[];
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   if (win.use_lds != 2) return;
   solve_body<LayTiled, 1>(win.n, win.S, win.P0, win.P1, win.rb, win.d.K, LayTiled{dyn}, win.dp, win.res, win.Sg, win.bvec);
 }
@@ -1753,7 +1797,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_tiled_kernel(const 
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_inertial_tiled_kernel(const BaWin* __restrict__ wins, BaInertialDev in,
                                                                                    const double* __restrict__ imu_buf) {
   extern __shared__ __align__(16) double dyn[];
-  const BaWin& win = wins[0];
+  const BaWin win = ba_win_global(wins, 0);
   solve_body<LayTiled, 2>(win.n, win.S, win.P0, win.P1, win.rb, in.K, LayTiled{dyn}, win.dp, win.res, nullptr, nullptr, &in, imu_buf);
 }
 
@@ -1766,7 +1810,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_inertial_tiled_kern
 constexpr int BB_NB = 16;
 
 __global__ __launch_bounds__(256) void ba_big_assemble_kernel(const BaWin* __restrict__ wins) {
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const BaState* St = win.S;
   if (win.use_lds == 1 || St->done) return;                                // (the tiled LDS solve, use_lds == 2, reads what this kernel assembles)
   const int n = win.n, K = win.d.K;
@@ -1820,7 +1864,7 @@ __global__ __launch_bounds__(BB_STEP_THREADS) void ba_big_step_kernel(const BaWi
   __shared__ __align__(16) double rinv[BB_NB];
   __shared__ double ys[BB_NB];
   __shared__ int s_ok;
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const int n = win.n;
   double* __restrict__ Sg = win.Sg; double* __restrict__ ginv = win.ginv; double* __restrict__ bvec = win.bvec; double* __restrict__ res = win.res;
   if (win.use_lds || n <= one_launch_max_n || c0 >= n || win.S->done || res[2] == 0.0) return;
@@ -2033,7 +2077,7 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
   __shared__ __align__(16) double D[BB_NB][BB_NB + 2];
   __shared__ __align__(16) double rinv[BB_NB];
   __shared__ int s_ok;
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const int n = win.n;
   if (win.use_lds || n > BF_MAX_N || win.S->done) return;
   double* Sg = win.Sg; double* ginv = win.ginv; double* bvec = win.bvec; double* res = win.res;
@@ -2280,7 +2324,7 @@ __global__ __launch_bounds__(256) void ba_big_back_kernel(const BaWin* __restric
   __shared__ double sb[BA_MAX_N];
   __shared__ double y[BB_NB];
   __shared__ double red[256];
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const BaState* St = win.S;
   if (win.use_lds || St->done) return;
   const int n = win.n;
@@ -2381,7 +2425,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   // its trial position, and the trial rotations follow from the pose step alone, so chi2(trial) needs no launch of its own
   __shared__ double sRt[12 * BA_MAX_K];      // trial poses
   __shared__ double sRt0[12 * BA_MAX_K];     // current poses (the linearisation point: ba_build_kernel's, read back)
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const BaDims d = win.d;
   const BaState* S = win.S;
   if (S->done || (int)blockIdx.x * 256 >= max(LANES * d.M, 6 * d.K)) return;
@@ -2479,7 +2523,7 @@ __global__ void ba_diff_kernel(size_t n, const double* __restrict__ a, const dou
 // chi2 of a parameter vector: per-point partial sums (fixed order)
 __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ wins, BaCam cam, int which) {
   __shared__ double sRt[12 * BA_MAX_K];
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const BaDims d = win.d;
   const BaState* S = win.S;
   if (S->done || (int)blockIdx.x * (256 / 32) >= d.M) return;
@@ -2520,7 +2564,7 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
 // three = 0: out = res + 12 <- sum pt_chi2 (the initial error); three = 1: res + 5 <- sums of pt_chi2, pt_dsq, pt_psq
 __global__ __launch_bounds__(256) void ba_sum3_kernel(const BaWin* __restrict__ wins, int three) {
   __shared__ double sh[3][256];
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const BaState* S = win.S;
   if (S->done) return;
   const int M = win.d.M;
@@ -2559,7 +2603,7 @@ constexpr int BA_DECIDE_THREADS = ORBX_BA_DECIDE_THREADS;   // (the thread count
 __global__ __launch_bounds__(BA_DECIDE_THREADS) void ba_decide_kernel(const BaWin* __restrict__ wins, int reduce_here, const double* __restrict__ imu_buf, int E,
                                                         const volatile int* __restrict__ abort_flag, int stop_vote) {
   __shared__ double sh[3][BA_DECIDE_THREADS];
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   BaState* S = win.S;
   if (S->done) return;
   double* __restrict__ res = win.res;
@@ -2815,7 +2859,7 @@ __global__ void ba_inertial_scatter_kernel(const BaState* S, double* P0, double*
 // [4] done [8...] parameters.
 __global__ __launch_bounds__(256) void ba_finish_kernel(const BaWin* __restrict__ wins, double* __restrict__ out_base,
                                                         const size_t* __restrict__ out_off, int np_extra_per_kf) {
-  const BaWin& win = wins[blockIdx.y];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
   const BaState* S = win.S;
   double* out = out_base + out_off[blockIdx.y];
   const size_t np = 6 * (size_t)win.d.K + 3 * (size_t)win.d.M + (size_t)np_extra_per_kf * win.d.K;
