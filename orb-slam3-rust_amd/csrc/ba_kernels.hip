@@ -1016,8 +1016,10 @@ __global__ __launch_bounds__(DIAG ? SCHW_THREADS : BA_KFS_GEN_THREADS, DIAG ? 1 
 // (their own launches in a batch: 51 KB of LDS and ~200 VGPRs per block would otherwise throttle the thousands of small keyframe blocks too)
 // (242 VGPRs, 2 waves per SIMD: a cap of 128 VGPRs / 4 waves per SIMD measured 61.1 -> 61.5 us per batch iteration, 64 VGPRs with spills 78 us:
 // the kernel is not occupancy-bound)
+// (end of round 3, 182 VGPRs once its loads were global loads: the 640 workgroups of a 32-window batch are 1.25 rounds at 2 per CU — a cap
+// of 168 VGPRs (2 spilled) holds 3 per CU, one round: 36.8 -> 32.3 us per batch iteration)
 #ifndef ORBX_KF_MINBLOCKS
-#define ORBX_KF_MINBLOCKS 1
+#define ORBX_KF_MINBLOCKS 3
 #endif
 // Workgroups go to the 8 XCDs round-robin in launch order, and a window's keyframe blocks share cache lines: consecutive observations
 // (48 B each) belong to the same point and to DIFFERENT keyframes, so a 128-byte line of the store is wanted by two or three blocks.  With
