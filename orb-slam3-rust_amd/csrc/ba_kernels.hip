@@ -1548,7 +1548,9 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
         sb[rr] -= acc;
       }
       const int nt = (m + 15) / 16, units = nt * (nt + 1) / 2, nw = (nth >> 6) - 1;
-      // wave 0: tile (c0, c0) only — it factors that block next; waves 1..15: the other lower tiles
+      // wave 0: tile (c0, c0) only — it factors that block next; waves 1..15: the other lower tiles  (keeping them off waves 4, 8 and 12,
+      // which share wave 0's SIMD and its f64 datapath — what the one-launch global factorisation needs — measured 32.4 -> 32.8 us at
+      // n = 114 and 80.6 -> 82.6 at n = 162: a tile here is four MFMAs, the extra round costs more than the contention)
       for (int unit = (tid < 64) ? 0 : (tid >> 6); unit < units; unit += (tid < 64) ? units : nw) {   // wave-uniform
         int ti = 0, rem = unit;
         while (rem > ti) { rem -= ti + 1; ++ti; }                              // unit = ti (ti + 1) / 2 + tj, tj <= ti
