@@ -23,7 +23,8 @@
 //                        panel's MFMA update and solve the rows below (right-hand side as one more row) a pivot step behind it;
 //                        branch-free backward substitution over the zeroed upper triangle, delta_p
 //                        (128 < n <= 176, inertial windows: ba_solve_tiled_kernel / ba_solve_inertial_tiled_kernel, lower tiles in LDS)
-//                        (n > 135: ba_big_assemble + one ba_big_step_kernel per panel + ba_big_back_kernel, S in global memory)
+//                        (176 < n <= 320, S in global memory: ba_big_assemble_kernel + ba_big_factor_kernel — one workgroup, left-looking,
+//                        one panel of look-ahead — + ba_big_back_kernel; beyond 320: one ba_big_step_kernel per panel instead of the factor kernel)
 //   ba_backsub_kernel    delta_l = V*^-1 (-g_l - W^T delta_p), trial parameters and trial residuals
 //   ba_decide_kernel     sums, accept / reject, lambda, stop tests — the LM state lives on the device
 //
