@@ -1536,6 +1536,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       res[0] = bred[n]; res[1] = sqrt(g2 + bred[n + 1]);
     }
   }
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);                       // the wave index as a scalar: the roles below branch on SGPRs
   for (int c0 = 0, p = 0; c0 < n; c0 += 16, ++p) {
     const int nb = min(16, n - c0), prev = c0 - 16;
     // ---- the previous panel's update of the trailing matrix [c0, n) and of the right-hand side below it
@@ -1552,7 +1553,7 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
       // wave 0: tile (c0, c0) only — it factors that block next; waves 1..15: the other lower tiles  (keeping them off waves 4, 8 and 12,
       // which share wave 0's SIMD and its f64 datapath — what the one-launch global factorisation needs — measured 32.4 -> 32.8 us at
       // n = 114 and 80.6 -> 82.6 at n = 162: a tile here is four MFMAs, the extra round costs more than the contention)
-      for (int unit = (tid < 64) ? 0 : (tid >> 6); unit < units; unit += (tid < 64) ? units : nw) {   // wave-uniform
+      for (int unit = wv; unit < units; unit += wv == 0 ? units : nw) {        // wave-uniform, and a scalar to the compiler
         int ti = 0, rem = unit;
         while (rem > ti) { rem -= ti + 1; ++ti; }                              // unit = ti (ti + 1) / 2 + tj, tj <= ti
         const int tj = rem;
@@ -1584,14 +1585,14 @@ __device__ __forceinline__ void solve_body(int n, const BaState* St, double* P0,
           if (row < n && col <= row) *S.at(row, col) = old_[q] - acc[q];
         }
       }
-      if (tid >= 64 && lane == 0) {                                              // this wave's part of the update is written
+      if (wv != 0 && lane == 0) {                                                // this wave's part of the update is written
         asm volatile("" ::: "memory");
         __hip_atomic_fetch_add(&s_upd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
     SOLVE_STAMP(7);
     // ---- the panel: factor (wave 0) and, a pivot step behind it, the rows below
-    if (tid < 64) { factor_diag(c0, nb, 16 * p); SOLVE_STAMP(10); }
+    if (wv == 0) { factor_diag(c0, nb, 16 * p); SOLVE_STAMP(10); }
     else if (nb == 16) {
       // rows below the panel (a panel with rows below it is a full one), the right-hand side as row n; both layouts keep a row's 16
       // entries of the panel contiguous and 16-byte aligned (n = 6K even and c0 a multiple of 16 / tile rows)
@@ -2089,7 +2090,7 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
   double* Cs = dyn;
   double* Lp = Cs + 16 * BF_CPITCH;
   double* Bp = Lp + BF_LROWS * BF_LPITCH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;   // (the wave index as a scalar — the roles and tiles derived from it branch on SGPRs: 138.1 -> 136.0 us)
   const int widx = (wave & 3) ? wave - 1 - (wave >> 2) : -1;                // 0 .. 11 among the tile waves
   if (tid == 0) s_ok = 1;
   auto rowp = [&](int r) -> double* { return r < n ? Sg + (size_t)r * n : bvec; };    // row n (and the clamped rows past it): the right-hand side
