@@ -909,7 +909,8 @@ __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaW
   const int nT = (ks1 - ks0) * tps;
   const int j_begin = ks0 * d.pps;
   for (int u = tid; u < 4 * TILE; u += SCHW_THREADS) lds[u] = 0.0;    // columns past 6K and slots of absent keyframes stay zero in both buffers
-  if (tid >= 256) {
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);            // (a scalar: the two roles and the consumer's tile rows branch on SGPRs; 108.4 -> 107.2 us per 32-window launch)
+  if (wv >= 4) {
 #ifdef ORBX_SCHUR_STAMPS
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0};
 #endif
@@ -988,7 +989,7 @@ __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaW
   // The wave index is a template argument of the loop: with q a run-time value every `if (c >= q)` around an MFMA was a branch, a tile
   // step was some forty basic blocks, and no ds_read of the next k-step could be scheduled above the MFMAs of this one (the matrix pipe
   // ran 3456 of a step's ~6000 cycles).
-  switch (tid >> 6) {
+  switch (wv) {
     case 0: ba_schur_ws_consume<0>(win, lds, ks0, nT, tps, win.part_sums != 0); break;
     case 1: ba_schur_ws_consume<1>(win, lds, ks0, nT, tps, win.part_sums != 0); break;
     case 2: ba_schur_ws_consume<2>(win, lds, ks0, nT, tps, win.part_sums != 0); break;
