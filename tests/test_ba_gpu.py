@@ -71,6 +71,18 @@ def test_ba_one_launch_global_cholesky_and_its_boundary(gpu_handle, oracle, pkg)
         assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL, (K, M)
 
 
+def test_ba_multi_block_schur_last_column_block_widths(gpu_handle, oracle, pkg):
+    """The Schur product of a window with more than 128 reduced unknowns multiplies only the 16-column tiles that exist in its last
+    128-column block, with the tile count as a compile-time bound of 2, 4, 6 or 8: 14 tiles (8 + 6: n = 210), 15 (8 + 7: n = 234, the
+    8-variant on a partial block) and 17 (8 + 8 + 1: n = 258, three column blocks, the 2-variant) against the structured oracle (9 to 11
+    tiles — the 2- and 4-variants with two blocks — are test_ba_mid_window_tiled_lds_cholesky's sizes, 19 and 20 configs[4]'s and n = 318)."""
+    for seed, K, M in ((34, 36, 500), (35, 40, 500), (36, 44, 550)):
+        w = pkg.synth.ba_window(seed, K, M, pkg.BA_OBS)
+        g, o = _solve_both(gpu_handle, oracle, pkg, w, dense=False)
+        assert g["iterations"] == o["iterations"], (K, M)
+        assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL, (K, M)
+
+
 def test_ba_batch_with_global_cholesky_windows_equals_single(gpu_handle, pkg):
     """A batch that mixes every reduced-system path — LDS square (n = 114), LDS tiles (n = 150), one-launch global (n = 186, 300) and
     multi-launch global (n = 330) — returns each window's single-window result bit for bit."""
