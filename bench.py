@@ -346,6 +346,8 @@ def main():
             res["local_ba"] = bench_ba(P, h, cam, rank, world, dev)
         except Exception as e:  # BA leg must not hide the headline number
             res["local_ba"] = dict(error=repr(e))
+        if world > 1 and isinstance(res["local_ba"], dict) and res["local_ba"].get("transport"):
+            res["config"]["parallelism"] += "; local BA: map points partitioned over the ranks, normal equations all-reduced — " + res["local_ba"]["transport"]
     if rank == 0 and world == 1 and not args.no_files and (W, H) == (752, 480):
         try:
             res["from_png_files"] = bench_from_files(P, h, torch, args.features)
@@ -583,7 +585,7 @@ def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
                lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3), iterations=r["iterations"],
                initial_error_px=round(r["initial_error"], 4), final_error_px=round(r["final_error"], 4),
                kernel_ms_per_iteration={k: round(v[0] / n_it, 4) for k, v in sorted(kt.items()) if k.startswith("ba_")},
-               algorithmic_GFLOP_per_iteration=4.3,
+               algorithmic_GFLOP_per_iteration=round(ba_algorithmic_flop(k_opt, M, len(win["obs"])) / 1e9, 3),   # SURVEY §8(d)'s formula at this window's K, M, N
                schur=dict(executed_GFLOP_per_launch=round(flop / 1e9, 3), fused_launch_ms=round(fused_ms, 4),
                           executed_TFLOPs_fused_launch=round(flop / (fused_ms * 1e-3) / 1e12, 2) if fused_ms > 0 else None,
                           mfma_frac_fused_launch=round(flop / (fused_ms * 1e-3) / 78.6e12, 4) if fused_ms > 0 else None,
@@ -606,9 +608,11 @@ def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
 
 
 def bench_ba_cpu(P):
-    """The oracle's two LM solvers timed on one host core: ba_solve_dense = the reference's literal formulation (dense J, J^T J,
+    """The oracle's two LM solvers timed on the host: ba_solve_dense = the reference's literal formulation (dense J, J^T J,
     LU of all 6K+3M unknowns, local_ba_lm.rs:1012-1056) at K=8 / M=400 where it fits; ba_solve_schur = the structured variant at
-    configs[2] and configs[4] sizes.  A bounded sample (about 10-20 s), kind "port"."""
+    configs[2] and configs[4] sizes.  One thread, and all host threads with one independent window per thread.  A bounded
+    sample (about 10-25 s), kind "port"."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     flags = "-O2 (portable build)"
     try:
@@ -628,8 +632,52 @@ def bench_ba_cpu(P):
         dt = time.perf_counter() - t0
         out[key] = dict(lm_iters_per_s=round(its / dt, 3), ms_per_iteration=round(dt / max(its, 1) * 1e3, 3), observations=len(w["obs"]),
                         unknowns=6 * len(w["poses_cw"]) + 3 * M, solves=reps)
+    # all host threads: independent windows, one per thread at a time (ctypes releases the GIL inside the oracle's solver)
+    nthr = os.cpu_count() or 1
+    wins = [P.synth.ba_window(200 + i, 20, 2000, P.BA_OBS) for i in range(min(nthr, 16))]
+
+    def one(i):
+        w = wins[i % len(wins)]
+        return O.ba_solve_schur(ocam, O.ba_config(), w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])["iterations"]
+
+    n_solves = 3 * nthr
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=nthr) as ex:
+        its = sum(ex.map(one, range(n_solves)))
+    dt = time.perf_counter() - t0
+    out["schur_K20_M2000_all_threads"] = dict(lm_iters_per_s=round(its / dt, 3), threads=nthr, cores=nthr, solves=n_solves,
+                                              note="independent windows, one per host thread (BASELINE.md §3: window-level parallelism)")
     out["sample"] = ("oracle.ba_solve_dense (the reference's literal dense LM, local_ba_lm.rs:1012-1056) on synth_ba(42, 8, 400): 1 solve; "
-                     "oracle.ba_solve_schur (structured) on synth_ba(42, 20, 2000): 6 solves and synth_ba(43, 50, 8000): 1 solve; 10 LM iterations each")
+                     "oracle.ba_solve_schur (structured) on synth_ba(42, 20, 2000): 6 solves on one thread and %d solves over %d threads, "
+                     "and synth_ba(43, 50, 8000): 1 solve; 10 LM iterations each" % (n_solves, nthr))
+    return out
+
+
+def ba_algorithmic_flop(K_opt, M, N):
+    """F_iter = N*370 + N*100 + M*60 + 2*(6K)^2*(3M) + (6K)^3/3 + N*36 (structured local BA, per LM iteration)."""
+    n = 6 * K_opt
+    return N * 370.0 + N * 100.0 + M * 60.0 + 2.0 * n * n * 3.0 * M + n ** 3 / 3.0 + N * 36.0
+
+
+def bench_ba_c_abi(P, wins, reps=8):
+    """orbx_ba_solve_visual_batch timed from a compiled caller (tests/cpp/ba_batch_driver.cpp, built here with g++): the C ABI itself,
+    no Python mirror in the process — with the observations in one orbx_host_alloc buffer and in pageable memory."""
+    import subprocess
+    import tempfile
+    libdir = os.path.join(ROOT, "orb-slam3-rust_amd")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "ba_batch_driver")
+        subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "ba_batch_driver.cpp"),
+                        "-o", exe, "-L", libdir, "-lorbx_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True)
+        P.synth.write_ba_batch_file(os.path.join(tmp, "batch.bin"), wins, P.BA_OBS)
+        for mode in ("pinned", "pageable"):
+            r = subprocess.run([exe, os.path.join(tmp, "batch.bin"), os.path.join(tmp, "out.bin"), str(reps), mode], check=True, capture_output=True, text=True, timeout=300)
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            its = sum(x["iterations"] for x in P.synth.read_ba_batch_results(os.path.join(tmp, "out.bin"), wins))
+            out[mode] = dict(ms_per_call_median=line["ms_per_call_median"], ms_per_call_min=line["ms_per_call_min"],
+                             lm_iters_per_s=round(its / (line["ms_per_call_median"] * 1e-3), 1), obs_memory=line["obs_memory"])
+    out["note"] = "tests/cpp/ba_batch_driver.cpp: the call as a compiled host makes it (median of %d calls after one untimed call)" % reps
     return out
 
 
@@ -677,8 +725,18 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
     dt = time.perf_counter() - t0
     if world > 1:
         dt = P.dist.allreduce_max_seconds(dt, dev)
+    comm = None
+    if world > 1 and native:
+        try:
+            comm = h.rccl_world()                        # (ranks, this rank) from ncclCommCount / ncclCommUserRank
+        except Exception as e:
+            comm = repr(e)
     out = dict(workload="synth_ba(seed=42, K=20, M=2000), %d observations%s" % (
                    len(win["obs"]), ", points partitioned over %d ranks + %s" % (world, "native RCCL all-reduce (ncclAllReduce issued by the library)" if native else "all-reduce hook") if world > 1 else ""),
+               transport=("one GPU, no collective" if world == 1 else
+                          ("native RCCL: communicator of %s ranks (ncclCommCount), this is rank %s" % (comm[0], comm[1]) if native and isinstance(comm, tuple)
+                           else "native RCCL (ncclCommCount unavailable: %s)" % (comm,) if native
+                           else "all-reduce hook over torch.distributed (%s)" % ("gloo, REHEARSAL" if os.environ.get("ORBX_DIST_REHEARSE") == "1" else "nccl = RCCL"))),
                lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3),
                iterations=r["iterations"], initial_error_px=round(r["initial_error"], 4),
                final_error_px=round(r["final_error"], 4))
@@ -709,7 +767,10 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         out["concurrent_windows"] = dict(windows=nwin, lm_iters_per_s=round(sum(counts) / dtc, 2), note="8 independent windows, one handle and host thread each")
         # many windows per launch (SURVEY §8d "batched problems (>= 32 windows per launch)"): orbx_ba_solve_visual_batch
         nb = 32
-        bw = [P.synth.ba_window(200 + i, 20, 2000, P.BA_OBS) for i in range(nb)]
+        bw_pageable = [P.synth.ba_window(200 + i, 20, 2000, P.BA_OBS) for i in range(nb)]
+        # the caller's observation storage: one page-locked buffer (orbx.h: the copy engine then reads it where it lies, one copy per half);
+        # the pageable form (the library stages it through its own pinned blob) is timed beside it
+        bw = P.Handle.pack_ba_windows(bw_pageable)
         rb = h.ba_solve_visual_batch(cam, cfg, bw)
         nrep = 6
         # the rate: as a caller sees it (a batch of this size runs as two halves on two streams inside the call, see orbx.h)
@@ -736,9 +797,23 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
                               kernel_ms_per_iteration={k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(kt.items()) if k.startswith("ba_")},
                               schur_executed_TFLOPs=round(flop / (sch_ms * 1e-3) / 1e12, 2) if sch_ms > 0 else None,
                               mfma_frac=round(flop / (sch_ms * 1e-3) / 78.6e12, 4) if sch_ms > 0 else None,
-                              note="orbx_ba_solve_visual_batch: host preprocessing + upload + 10 LM iterations of all windows + download per call, the batch as two "
-                                   "halves on two streams inside the call; device_ms / kernel_ms from a second set of calls with per-kernel events (one stream); "
-                                   "every window equals its single-window result bit for bit (tests/test_ba_gpu.py)")
+                              note="orbx_ba_solve_visual_batch through the Python mirror: upload of the caller's observations (one pinned buffer) + device-side CSR "
+                                   "build + 10 LM iterations of all windows + download per call, the batch as two halves on two streams inside the call; device_ms / "
+                                   "kernel_ms from a second set of calls with per-kernel events (one stream); every window equals its single-window result bit for bit "
+                                   "(tests/test_ba_gpu.py)")
+        out["batched"]["call_vs_device_only"] = round(out["batched"]["lm_iters_per_s"] / out["batched"]["lm_iters_per_s_device_only"], 3) if dev_ms > 0 else None
+        h.ba_solve_visual_batch(cam, cfg, bw_pageable)
+        t0 = time.perf_counter()
+        itp = 0
+        for _ in range(nrep):
+            itp += sum(x["iterations"] for x in h.ba_solve_visual_batch(cam, cfg, bw_pageable))
+        dtp = time.perf_counter() - t0
+        out["batched"]["pageable_observations"] = dict(lm_iters_per_s=round(itp / dtp, 1), ms_per_call=round(dtp / nrep * 1e3, 3),
+                                                       note="the same call with the observations in pageable numpy arrays: staged through the handle's pinned blob by its workers")
+        try:
+            out["batched"]["c_abi"] = bench_ba_c_abi(P, bw_pageable)
+        except Exception as e:
+            out["batched"]["c_abi"] = dict(error=repr(e))
         # two such batches in flight (two handles = two HIP streams, one host thread each): the host preprocessing, upload and
         # download of one batch run under the kernels of the other
         h2 = [P.Handle(cam, 100, device=dev.index if dev is not None else 0) for _ in range(2)]
@@ -765,9 +840,12 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         # no longer fits LDS, so the factorisation is the multi-kernel form
         try:
             out["config5"] = bench_ba_config5(P, h, cam, cfg)
-            out["inertial"] = bench_ba_inertial(P, h, cam)
         except Exception as e:
             out["config5"] = dict(error=repr(e))
+        try:
+            out["inertial"] = bench_ba_inertial(P, h, cam)
+        except Exception as e:
+            out["inertial"] = dict(error=repr(e))
         # the CPU side of the BA half of the metric: the reference's literal dense-LM formulation at a size where it
         # fits, and the structured (Schur) variant at the GPU's sizes — the oracle, one thread, same run
         try:

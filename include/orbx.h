@@ -400,6 +400,10 @@ int orbx_ba_set_rccl_comm(orbx_handle* h, void* nccl_comm);
  * librccl is bound on first use of the three calls above (dlopen by soname: a process that already mapped a librccl.so.1,
  * e.g. PyTorch's, gets that copy); a single-GPU process never loads it. */
 int orbx_ba_has_collective(orbx_handle* h);
+/* What the handle's RCCL communicator spans, from the communicator itself (ncclCommCount / ncclCommUserRank): the number of ranks its
+ * all-reduce sums over and this rank's index.  ORBX_ERR_INVALID without a communicator.  (bench.py prints it, so that a multi-GPU record
+ * shows how many ranks RCCL really saw.) */
+int orbx_ba_rccl_world(orbx_handle* h, int* n_ranks, int* rank);
 
 /* Replaces solve_visual_ba (local_ba_lm.rs:912-1098).
  *   poses_cw [K][7]  (qw,qx,qy,qz,tx,ty,tz) T_cw of the optimised keyframes (:966-977)
@@ -428,13 +432,18 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
  *   ORBX_OK and solves the others (also when that window is the only one of the batch).  An observation index out of range fails
  *   the whole call (ORBX_ERR_INVALID): every window's status then carries the error, and the in/out `points` / `poses_wc_out` of
  *   windows that had already finished (the other half of a two-stream batch) hold their results — hand in the original points
- *   again when retrying.  No C++ exception leaves the call: allocation or thread-creation failure is an error code.
+ *   again when retrying.  No C++ exception leaves this call or any other orbx_ba_* entry point: allocation or thread-creation failure is an error code.
  * The all-reduce hook / RCCL communicator is not used here (independent windows need no collective).
  * A batch of 16 or more windows without a should_stop callback runs as two halves at once: the second half on an internal second
  * stream with its own workspaces, driven by a helper thread for the duration of the call, so that one half's host preprocessing and
  * transfers run under the other half's kernels (+12 % LM iterations/s at 32 windows); the halves are cut where the observation
  * count is halved; if the second stream cannot be created the whole batch runs on the first.  Results do not depend on it.  With a callback
- * (which would otherwise be called from two threads), or with per-kernel profiling on, the call keeps to one stream. */
+ * (which would otherwise be called from two threads), or with per-kernel profiling on, the call keeps to one stream.
+ * Observations are handed over as they are: the index checks, the per-point grouping and the per-keyframe lists are made on the
+ * device (four short launches per call shared by all windows), so the host makes no pass over them.  If `obs` lies in page-locked host
+ * memory (orbx_host_alloc, hipHostMalloc or a registered range — the library asks the runtime) the copy engine reads it where it lies;
+ * windows whose `obs` arrays follow each other in memory travel as ONE copy.  Pageable `obs` is first copied into the handle's pinned
+ * staging blob (a plain copy, on worker threads when large).  The same holds for the one-window entry points. */
 typedef struct {
   int K;                        /* in: optimised keyframes                         */
   const double* poses_cw;       /* in: [K][7]                                      */

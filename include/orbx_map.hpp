@@ -1,10 +1,17 @@
 // orbx_map.hpp — the host side of local BA over FLAT arrays: the three phases of
-// LocalMapper::local_bundle_adjustment (src/local_mapping/local_mapper.rs:334-410, visual branch :378-408):
+// LocalMapper::local_bundle_adjustment (src/local_mapping/local_mapper.rs:334-410), both branches:
 //
+//   visual (:378-408, before IMU initialisation)
 //   collect_visual_ba_data    src/optimizer/local_ba_lm.rs:800-897 (with collect_local_keyframes :665-683,
 //                             collect_local_map_points :686-704, collect_fixed_keyframes :707-726)
 //   solve_visual_ba           orbx.hpp (GPU)
 //   apply_visual_ba_results   local_ba_lm.rs:1112-1138
+//
+//   inertial (:343-375, once Map::is_imu_initialized())
+//   collect_inertial_ba_data  src/optimizer/local_inertial_ba.rs:933-1072 (with collect_temporal_keyframes :366-384,
+//                             collect_map_points :387-403, collect_fixed_keyframes :406-429)
+//   solve_inertial_ba         orbx.hpp (GPU)
+//   apply_inertial_ba_results local_inertial_ba.rs:1289-1330
 //
 // The reference walks its HashMap-based `Map` under a read lock.  A GPU-side BA wants the same information as a handful
 // of arrays, so the snapshot here is CSR: keyframes with their features (map-point id or none, keypoint position), their
@@ -26,6 +33,7 @@
 #ifndef ORBX_MAP_HPP
 #define ORBX_MAP_HPP
 
+#include <algorithm>
 #include <functional>
 #include <optional>
 #include <unordered_map>
@@ -53,6 +61,16 @@ struct MapSnapshot {
   std::vector<double> mp_pos;                  // [nmp][3]
   std::vector<int> mp_obs_start;               // [nmp+1] observations.keys(), in the stated order
   std::vector<KeyFrameId> mp_obs_kf_id;
+  // what the inertial branch reads besides (keyframe.rs: prev_kf, velocity, imu_bias, imu_preintegrated, points_cam; map_point.rs:
+  // observations' feature index).  May stay empty for a map that never takes the inertial branch (imu_initialized = 0).
+  std::vector<int64_t> kf_prev_id;             // [nkf] prev_kf, -1 = None
+  std::vector<double> kf_velocity;             // [nkf][3]
+  std::vector<double> kf_bias;                 // [nkf][6] gyro, accel
+  std::vector<uint8_t> kf_has_preint;          // [nkf] imu_preintegrated.is_some()
+  std::vector<double> kf_preint;               // [nkf][11] delta_rot (qw,qx,qy,qz) | delta_vel | delta_pos | dt — from prev_kf to this keyframe
+  std::vector<uint8_t> feat_stereo;            // [nfeat] points_cam[i].is_some()
+  std::vector<int> mp_obs_feat_idx;            // [nobs] the feature index of the observation (observations: HashMap<KeyFrameId, usize>)
+  uint8_t imu_initialized = 0;                 // Map::is_imu_initialized()
 
   // id -> index (map.get_keyframe / map.get_map_point); call after filling or changing the id arrays
   void build_index() {
@@ -192,16 +210,167 @@ inline size_t apply_visual_ba_results(MapSnapshot& m, const VisualBAResultData& 
   return updated;
 }
 
-// The visual branch of LocalMapper::local_bundle_adjustment (local_mapper.rs:378-408).  The reference takes the map's read
+// ---- the inertial branch ---------------------------------------------------------------------------------------------------------
+// local_inertial_ba.rs:366-384: the temporal chain through prev_kf, oldest first (the anchor)
+inline std::vector<KeyFrameId> collect_temporal_keyframes(const MapSnapshot& m, KeyFrameId current_kf_id, size_t window_size) {
+  std::vector<KeyFrameId> kf_ids{current_kf_id};
+  auto prev_of = [&](KeyFrameId id) -> int64_t { const int k = m.kf_index(id); return k >= 0 && (size_t)k < m.kf_prev_id.size() ? m.kf_prev_id[(size_t)k] : -1; };
+  int64_t prev = prev_of(current_kf_id);
+  while (kf_ids.size() < window_size && prev >= 0) {
+    kf_ids.push_back((KeyFrameId)prev);
+    prev = prev_of((KeyFrameId)prev);
+  }
+  std::reverse(kf_ids.begin(), kf_ids.end());
+  return kf_ids;
+}
+
+// local_inertial_ba.rs:406-429 (set in first-seen order; unlike the visual one, existence and is_bad ARE checked)
+inline std::vector<KeyFrameId> collect_fixed_keyframes_inertial(const MapSnapshot& m, const std::vector<KeyFrameId>& opt_kf_ids,
+                                                                const std::vector<MapPointId>& mp_ids) {
+  const std::unordered_set<KeyFrameId> opt(opt_kf_ids.begin(), opt_kf_ids.end());
+  std::unordered_set<KeyFrameId> seen;
+  std::vector<KeyFrameId> out;
+  for (MapPointId id : mp_ids) {
+    const int j = m.mp_index(id);
+    if (j < 0) continue;
+    for (int o = m.mp_obs_start[(size_t)j]; o < m.mp_obs_start[(size_t)j + 1]; ++o) {
+      const KeyFrameId kf = m.mp_obs_kf_id[(size_t)o];
+      if (opt.count(kf)) continue;
+      const int k = m.kf_index(kf);
+      if (k >= 0 && !m.kf_bad[(size_t)k] && seen.insert(kf).second) out.push_back(kf);
+    }
+  }
+  return out;
+}
+
+// PHASE 1, local_inertial_ba.rs:933-1072
+inline std::optional<InertialBAProblemData> collect_inertial_ba_data(const MapSnapshot& m, KeyFrameId current_kf_id,
+                                                                     const LocalInertialBAConfig& config) {
+  InertialBAProblemData p;
+  p.opt_kf_ids = collect_temporal_keyframes(m, current_kf_id, (size_t)config.window_size);
+  if (p.opt_kf_ids.size() < 2) return std::nullopt;                                  // :940-942
+  p.mp_ids = collect_local_map_points(m, p.opt_kf_ids);                               // :387-403: the same walk as the visual one
+  if (p.mp_ids.empty()) return std::nullopt;                                         // :946-948
+  const std::vector<KeyFrameId> fixed_kf_ids = collect_fixed_keyframes_inertial(m, p.opt_kf_ids, p.mp_ids);
+  const std::unordered_set<KeyFrameId> opt_kf_set(p.opt_kf_ids.begin(), p.opt_kf_ids.end());
+  for (KeyFrameId id : p.opt_kf_ids) {                                                // :955-964
+    const int k = m.kf_index(id);
+    if (k < 0) continue;
+    p.kf_poses[id] = m.kf_pose(k);                                                    // T_wc
+    std::array<double, 3> v{0, 0, 0};
+    ImuBias b;
+    if (3 * (size_t)k + 2 < m.kf_velocity.size()) for (int i = 0; i < 3; ++i) v[(size_t)i] = m.kf_velocity[3 * (size_t)k + i];
+    if (6 * (size_t)k + 5 < m.kf_bias.size())
+      for (int i = 0; i < 3; ++i) { b.gyro[(size_t)i] = m.kf_bias[6 * (size_t)k + i]; b.accel[(size_t)i] = m.kf_bias[6 * (size_t)k + 3 + i]; }
+    p.kf_velocities[id] = v;
+    p.kf_biases[id] = b;
+  }
+  for (KeyFrameId id : fixed_kf_ids) {                                                // :967-972
+    const int k = m.kf_index(id);
+    if (k >= 0) p.fixed_kf_poses[id] = se3_inverse(m.kf_pose(k));                     // T_cw
+  }
+  {
+    const int k = m.kf_index(p.opt_kf_ids.front());                                   // :974-978: the anchor's pose too
+    if (k >= 0) p.fixed_kf_poses[p.opt_kf_ids.front()] = se3_inverse(m.kf_pose(k));
+  }
+  for (MapPointId id : p.mp_ids) {                                                    // :981-986
+    const int j = m.mp_index(id);
+    if (j >= 0) p.mp_positions[id] = {m.mp_pos[3 * (size_t)j], m.mp_pos[3 * (size_t)j + 1], m.mp_pos[3 * (size_t)j + 2]};
+  }
+  std::unordered_set<KeyFrameId> all_kf(p.opt_kf_ids.begin(), p.opt_kf_ids.end());
+  all_kf.insert(fixed_kf_ids.begin(), fixed_kf_ids.end());
+  for (MapPointId mp_id : p.mp_ids) {                                                 // :996-1029: by map point, its observers in list order
+    const int j = m.mp_index(mp_id);
+    if (j < 0) continue;
+    for (int o = m.mp_obs_start[(size_t)j]; o < m.mp_obs_start[(size_t)j + 1]; ++o) {
+      const KeyFrameId kf_id = m.mp_obs_kf_id[(size_t)o];
+      if (!all_kf.count(kf_id)) continue;
+      const int k = m.kf_index(kf_id);
+      if (k < 0) continue;
+      const int fi = (size_t)o < m.mp_obs_feat_idx.size() ? m.mp_obs_feat_idx[(size_t)o] : -1;
+      const int s = m.kf_feat_start[(size_t)k], e = m.kf_feat_start[(size_t)k + 1];
+      if (fi < 0 || fi >= m.kf_n_keypoints[(size_t)k] || s + fi >= e) continue;       // keypoints.get(feat_idx) is Err
+      const size_t f = (size_t)(s + fi);
+      const bool is_stereo = f < m.feat_stereo.size() && m.feat_stereo[f] != 0;       // points_cam.get(i).map_or(false, |p| p.is_some())
+      const bool in_window = opt_kf_set.count(kf_id) != 0 && p.opt_kf_ids.front() != kf_id;   // the anchor is treated as fixed
+      p.visual_observations.push_back(InertialVisualObs{kf_id, mp_id, {(double)m.feat_uv[2 * f], (double)m.feat_uv[2 * f + 1]}, is_stereo, in_window});
+    }
+  }
+  for (size_t i = 0; i + 1 < p.opt_kf_ids.size(); ++i) {                              // :1032-1049
+    const int kj = m.kf_index(p.opt_kf_ids[i + 1]);
+    if (kj < 0 || (size_t)kj >= m.kf_has_preint.size() || !m.kf_has_preint[(size_t)kj]) continue;
+    const double* q = &m.kf_preint[11 * (size_t)kj];
+    if (!(q[10] > 0.0)) continue;                                                     // preint.dt > 0.0
+    ImuEdgeData e{p.opt_kf_ids[i], p.opt_kf_ids[i + 1], {}};
+    for (int a = 0; a < 4; ++a) e.preint.delta_rot[(size_t)a] = q[a];
+    for (int a = 0; a < 3; ++a) { e.preint.delta_vel[(size_t)a] = q[4 + a]; e.preint.delta_pos[(size_t)a] = q[7 + a]; }
+    e.preint.dt = q[10];
+    p.imu_edges.push_back(e);
+  }
+  return p;
+}
+
+// PHASE 3, local_inertial_ba.rs:1289-1330: gone or bad entities are skipped silently; poses and points count, velocities and biases do not
+inline size_t apply_inertial_ba_results(MapSnapshot& m, const InertialBAResultData& r) {
+  size_t updated = 0;
+  for (const auto& kv : r.optimized_poses) {
+    const int k = m.kf_index(kv.first);
+    if (k >= 0 && !m.kf_bad[(size_t)k]) {
+      for (int i = 0; i < 4; ++i) m.kf_pose_wc[7 * (size_t)k + i] = kv.second.rotation[(size_t)i];
+      for (int i = 0; i < 3; ++i) m.kf_pose_wc[7 * (size_t)k + 4 + i] = kv.second.translation[(size_t)i];
+      ++updated;
+    }
+  }
+  for (const auto& kv : r.optimized_velocities) {
+    const int k = m.kf_index(kv.first);
+    if (k >= 0 && !m.kf_bad[(size_t)k] && 3 * (size_t)k + 2 < m.kf_velocity.size())
+      for (int i = 0; i < 3; ++i) m.kf_velocity[3 * (size_t)k + i] = kv.second[(size_t)i];
+  }
+  for (const auto& kv : r.optimized_biases) {
+    const int k = m.kf_index(kv.first);
+    if (k >= 0 && !m.kf_bad[(size_t)k] && 6 * (size_t)k + 5 < m.kf_bias.size())
+      for (int i = 0; i < 3; ++i) { m.kf_bias[6 * (size_t)k + i] = kv.second.gyro[(size_t)i]; m.kf_bias[6 * (size_t)k + 3 + i] = kv.second.accel[(size_t)i]; }
+  }
+  for (const auto& kv : r.optimized_points) {
+    const int j = m.mp_index(kv.first);
+    if (j >= 0 && !m.mp_bad[(size_t)j]) {
+      for (int i = 0; i < 3; ++i) m.mp_pos[3 * (size_t)j + i] = kv.second[(size_t)i];
+      ++updated;
+    }
+  }
+  return updated;
+}
+
+// LocalMapper::local_bundle_adjustment (local_mapper.rs:334-410), both branches.  The reference takes the map's read
 // lock around phase 1 and its write lock around phase 3 and holds none while solving; `lock_read` / `lock_write` wrap the
-// two phases the same way (pass no-ops for a snapshot nobody else touches).  `map_for_apply` is looked up again for phase
-// 3 because the map may have changed meanwhile.  Returns nullopt where the reference returns early (:384, :391), else the
-// number of updated entities — 0 without touching the map when the solve ran no iteration (:396).
+// two phases the same way (pass no-ops for a snapshot nobody else touches), plus the short read lock in which the reference asks
+// is_imu_initialized().  Returns nullopt where the reference returns early (:351, :359, :384, :391), else the number of updated
+// entities — 0 without touching the map when the solve ran no iteration (:363, :396).
 inline std::optional<size_t> local_bundle_adjustment(Handle& h, MapSnapshot& map, KeyFrameId kf_id, const CameraModel& camera,
                                                      const std::function<bool()>& should_stop,
                                                      const std::function<void(const std::function<void()>&)>& lock_read = nullptr,
                                                      const std::function<void(const std::function<void()>&)>& lock_write = nullptr,
-                                                     VisualBAResultData* result_out = nullptr) {
+                                                     VisualBAResultData* result_out = nullptr,
+                                                     InertialBAResultData* inertial_result_out = nullptr) {
+  bool is_inertial = false;                                                          // :338-341: a quick read lock of its own
+  auto phase0 = [&] { is_inertial = map.imu_initialized != 0; };
+  if (lock_read) lock_read(phase0); else phase0();
+  if (is_inertial) {                                                                 // :343-375
+    const LocalInertialBAConfig config;                                              // :345
+    std::optional<InertialBAProblemData> problem;
+    auto phase1 = [&] { problem = collect_inertial_ba_data(map, kf_id, config); };   // :348-354
+    if (lock_read) lock_read(phase1); else phase1();
+    if (!problem) return std::nullopt;
+    std::optional<InertialBAResultData> result = solve_inertial_ba(h, *problem, camera, config, should_stop);   // :357-360, no lock
+    if (!result) return std::nullopt;
+    if (inertial_result_out) *inertial_result_out = *result;
+    size_t updated = 0;
+    if (result->iterations > 0) {                                                    // :363
+      auto phase3 = [&] { updated = apply_inertial_ba_results(map, *result); };
+      if (lock_write) lock_write(phase3); else phase3();
+    }
+    return updated;
+  }
   const LocalBAConfigLM config;                                                      // :380
   std::optional<VisualBAProblemData> problem;
   auto phase1 = [&] { problem = collect_visual_ba_data(map, kf_id, config); };       // :383-389

@@ -3,7 +3,10 @@
     collect_local_keyframes / collect_local_map_points / collect_fixed_keyframes   local_ba_lm.rs:665-726
     collect_visual_ba_data                                                         local_ba_lm.rs:800-897
     apply_visual_ba_results                                                        local_ba_lm.rs:1112-1138
-    LocalMapper::local_bundle_adjustment (visual branch)                           local_mapper.rs:334-410
+    LocalMapper::local_bundle_adjustment (visual and inertial branches)            local_mapper.rs:334-410
+    collect_temporal_keyframes / collect_map_points / collect_fixed_keyframes      local_inertial_ba.rs:366-429
+    collect_inertial_ba_data                                                       local_inertial_ba.rs:933-1072
+    apply_inertial_ba_results                                                      local_inertial_ba.rs:1289-1330
 
 over a Map made of Python dicts, written line by line after the Rust.  The reference iterates `HashMap`s and `HashSet`s
 (covisibility weights :675, the map-point set :704, the fixed-keyframe set :725, observations.keys() :718), whose order is
@@ -24,6 +27,12 @@ class KeyFrame:                      # atlas/map/keyframe.rs — the fields the 
     map_point_ids: List[Optional[int]]
     covisibility_weights: Dict[int, int] = field(default_factory=dict)
     is_bad: bool = False
+    # what the inertial branch reads besides (keyframe.rs: prev_kf, velocity, imu_bias, imu_preintegrated, points_cam)
+    prev_kf: Optional[int] = None
+    velocity: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    imu_bias: np.ndarray = field(default_factory=lambda: np.zeros(6))            # gyro, accel
+    imu_preintegrated: Optional[np.ndarray] = None                                # (delta_rot qw,qx,qy,qz | delta_vel | delta_pos | dt) from prev_kf
+    points_cam: List[bool] = field(default_factory=list)                          # points_cam[i].is_some()
 
 
 @dataclass
@@ -37,6 +46,7 @@ class MapPoint:                      # atlas/map/map_point.rs
 class Map:
     keyframes: Dict[int, KeyFrame] = field(default_factory=dict)
     map_points: Dict[int, MapPoint] = field(default_factory=dict)
+    imu_initialized: bool = False                                                 # Map::is_imu_initialized()
 
 
 def se3_inverse(p):                   # geometry/se3.rs:56-63 (nalgebra quaternion * vector)
@@ -147,8 +157,129 @@ def apply_visual_ba_results(m: Map, optimized_poses, optimized_points):    # :11
     return updated
 
 
-def local_bundle_adjustment(m: Map, kf_id, solve, max_covisible_keyframes=20):   # local_mapper.rs:378-408 (visual branch)
-    """solve(problem) -> None | dict(optimized_poses, optimized_points, iterations, ...).  Returns #updated or None."""
+# ---- the inertial branch ------------------------------------------------------------------------------------------------------
+def collect_temporal_keyframes(m: Map, current_kf_id, window_size):          # local_inertial_ba.rs:366-384
+    kf_ids = [current_kf_id]
+    kf = m.keyframes.get(current_kf_id)
+    prev_id = kf.prev_kf if kf is not None else None
+    while len(kf_ids) < window_size and prev_id is not None:
+        kf_ids.append(prev_id)
+        kf = m.keyframes.get(prev_id)
+        prev_id = kf.prev_kf if kf is not None else None
+    kf_ids.reverse()                                                        # oldest first: the anchor
+    return kf_ids
+
+
+def collect_map_points_inertial(m: Map, kf_ids):                             # :387-403
+    return collect_local_map_points(m, kf_ids)                              # (the same walk; HashSet order = first seen)
+
+
+def collect_fixed_keyframes_inertial(m: Map, opt_kf_ids, mp_ids):            # :406-429: unlike the visual one, existence and is_bad are checked
+    opt = set(opt_kf_ids)
+    fixed = {}
+    for mp_id in mp_ids:
+        mp = m.map_points.get(mp_id)
+        if mp is not None:
+            for obs_kf_id in mp.observations.keys():
+                if obs_kf_id not in opt:
+                    kf = m.keyframes.get(obs_kf_id)
+                    if kf is not None and not kf.is_bad:
+                        fixed.setdefault(obs_kf_id, True)
+    return list(fixed.keys())
+
+
+def collect_inertial_ba_data(m: Map, current_kf_id, window_size=10):         # :933-1072
+    opt_kf_ids = collect_temporal_keyframes(m, current_kf_id, window_size)
+    if len(opt_kf_ids) < 2:                                                 # :940-942
+        return None
+    mp_ids = collect_map_points_inertial(m, opt_kf_ids)
+    if not mp_ids:                                                          # :946-948
+        return None
+    fixed_kf_ids = collect_fixed_keyframes_inertial(m, opt_kf_ids, mp_ids)
+    opt_kf_set = set(opt_kf_ids)
+    kf_poses, kf_velocities, kf_biases = {}, {}, {}
+    for kf_id in opt_kf_ids:                                                # :955-964
+        kf = m.keyframes.get(kf_id)
+        if kf is not None:
+            kf_poses[kf_id] = np.array(kf.pose, np.float64)
+            kf_velocities[kf_id] = np.array(kf.velocity, np.float64)
+            kf_biases[kf_id] = np.array(kf.imu_bias, np.float64)
+    fixed_kf_poses = {}
+    for kf_id in fixed_kf_ids:                                              # :967-972
+        kf = m.keyframes.get(kf_id)
+        if kf is not None:
+            fixed_kf_poses[kf_id] = se3_inverse(kf.pose)
+    kf = m.keyframes.get(opt_kf_ids[0])                                     # :974-978 the anchor's pose too
+    if kf is not None:
+        fixed_kf_poses[opt_kf_ids[0]] = se3_inverse(kf.pose)
+    mp_positions = {}
+    for mp_id in mp_ids:                                                    # :981-986
+        mp = m.map_points.get(mp_id)
+        if mp is not None:
+            mp_positions[mp_id] = np.array(mp.position, np.float64)
+    all_kf_ids = set(opt_kf_ids) | set(fixed_kf_ids)
+    visual_observations = []
+    for mp_id in mp_ids:                                                    # :996-1029: by map point, its observers in map order
+        mp = m.map_points.get(mp_id)
+        if mp is None:
+            continue
+        for obs_kf_id, feat_idx in mp.observations.items():
+            if obs_kf_id not in all_kf_ids:
+                continue
+            kf = m.keyframes.get(obs_kf_id)
+            if kf is None or not (0 <= feat_idx < len(kf.keypoints)):       # keypoints.get(feat_idx) is Err
+                continue
+            x, y = kf.keypoints[feat_idx]
+            is_stereo = bool(kf.points_cam[feat_idx]) if feat_idx < len(kf.points_cam) else False    # points_cam.get(i).map_or(false, ..)
+            is_kf_in_window = obs_kf_id in opt_kf_set and opt_kf_ids[0] != obs_kf_id
+            visual_observations.append(dict(kf_id=obs_kf_id, mp_id=mp_id, uv=(float(np.float32(x)), float(np.float32(y))),
+                                            is_stereo=is_stereo, is_kf_in_window=is_kf_in_window))
+    imu_edges = []
+    for i in range(max(len(opt_kf_ids) - 1, 0)):                            # :1032-1049
+        kf_j = m.keyframes.get(opt_kf_ids[i + 1])
+        if kf_j is not None and kf_j.imu_preintegrated is not None and kf_j.imu_preintegrated[10] > 0.0:
+            imu_edges.append(dict(kf_i_id=opt_kf_ids[i], kf_j_id=opt_kf_ids[i + 1], preint=np.array(kf_j.imu_preintegrated, np.float64)))
+    return dict(kf_poses=kf_poses, kf_velocities=kf_velocities, kf_biases=kf_biases, mp_positions=mp_positions, fixed_kf_poses=fixed_kf_poses,
+                visual_observations=visual_observations, imu_edges=imu_edges, opt_kf_ids=opt_kf_ids, mp_ids=mp_ids)
+
+
+def apply_inertial_ba_results(m: Map, optimized_poses, optimized_velocities, optimized_biases, optimized_points):   # :1289-1330
+    updated = 0
+    for kf_id, pose in optimized_poses.items():
+        kf = m.keyframes.get(kf_id)
+        if kf is not None and not kf.is_bad:
+            kf.pose = np.array(pose, np.float64)
+            updated += 1
+    for kf_id, vel in optimized_velocities.items():                         # (velocities and biases are written, not counted)
+        kf = m.keyframes.get(kf_id)
+        if kf is not None and not kf.is_bad:
+            kf.velocity = np.array(vel, np.float64)
+    for kf_id, bias in optimized_biases.items():
+        kf = m.keyframes.get(kf_id)
+        if kf is not None and not kf.is_bad:
+            kf.imu_bias = np.array(bias, np.float64)
+    for mp_id, pos in optimized_points.items():
+        mp = m.map_points.get(mp_id)
+        if mp is not None and not mp.is_bad:
+            mp.position = np.array(pos, np.float64)
+            updated += 1
+    return updated
+
+
+def local_bundle_adjustment(m: Map, kf_id, solve, max_covisible_keyframes=20, solve_inertial=None, window_size=10):   # local_mapper.rs:334-410
+    """solve(problem) -> None | dict(optimized_poses, optimized_points, iterations, ...); solve_inertial(problem) likewise with
+    optimized_velocities / optimized_biases.  Returns #updated or None.  The branch is the map's is_imu_initialized() (:338-341)."""
+    if m.imu_initialized:                                                   # :343-375
+        problem = collect_inertial_ba_data(m, kf_id, window_size)
+        if problem is None:
+            return None
+        result = solve_inertial(problem)
+        if result is None:
+            return None
+        if result["iterations"] > 0:                                        # :361
+            return apply_inertial_ba_results(m, result["optimized_poses"], result["optimized_velocities"], result["optimized_biases"],
+                                             result["optimized_points"])
+        return 0
     problem = collect_visual_ba_data(m, kf_id, max_covisible_keyframes)
     if problem is None:
         return None

@@ -53,7 +53,7 @@ ABI_SYMBOLS = [
     "orbx_keyframe_create", "orbx_keyframe_destroy", "orbx_keyframe_info", "orbx_keyframe_set_pose", "orbx_keyframe_set_map_points",
     "orbx_keyframe_get_map_points", "orbx_keyframe_download", "orbx_keyframe_device_keypoints", "orbx_keyframe_device_descriptors",
     "orbx_keyframe_guided_match", "orbx_keyframe_search_for_triangulation", "orbx_keyframe_fuse_search",
-    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_has_collective", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_debug_imu_residual", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_has_collective", "orbx_ba_rccl_world", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_debug_imu_residual", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
     "orbx_fuse_search", "orbx_fuse_search_device",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
@@ -618,6 +618,14 @@ class Handle:
         self._L.orbx_ba_has_collective.restype = C.c_int
         return int(self._L.orbx_ba_has_collective(self._h))
 
+    def rccl_world(self):
+        """(ranks, this rank) of the handle's RCCL communicator, from ncclCommCount / ncclCommUserRank (orbx_ba_rccl_world)."""
+        n, r = C.c_int(0), C.c_int(-1)
+        self._L.orbx_ba_rccl_world.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self._L.orbx_ba_rccl_world.restype = C.c_int
+        self._check(self._L.orbx_ba_rccl_world(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
     def ba_solve_visual(self, camera, cfg, poses_cw, fixed_cw, points, obs, should_stop=None):
         poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)
         fixed_cw = np.ascontiguousarray(fixed_cw, np.float64).reshape(-1, 7)
@@ -636,6 +644,23 @@ class Handle:
         self._check(rc)
         return dict(poses_wc=out_wc[:K], points=pts, iterations=it.value, initial_error=e0.value,
                     final_error=e1.value)
+
+    @staticmethod
+    def pack_ba_windows(windows):
+        """The same windows with every `obs` array a consecutive slice of ONE page-locked host buffer (window order): what a caller that
+        owns its observation storage would hand to orbx_ba_solve_visual_batch — the copy engine then reads the observations where they lie
+        and each half of the batch travels as one copy (orbx.h).  The buffer is a pinned torch tensor kept alive by the returned dicts."""
+        import torch
+        arrs = [np.ascontiguousarray(w["obs"], BA_OBS) for w in windows]
+        total = sum(len(a) for a in arrs)
+        buf = torch.empty(max(total, 1) * BA_OBS.itemsize, dtype=torch.uint8).pin_memory()
+        flat = buf.numpy().view(BA_OBS)
+        out, o = [], 0
+        for w, a in zip(windows, arrs):
+            flat[o:o + len(a)] = a
+            d = dict(w); d["obs"] = flat[o:o + len(a)]; d["_pinned_obs"] = buf
+            out.append(d); o += len(a)
+        return out
 
     def ba_solve_visual_batch(self, camera, cfg, windows, should_stop=None):
         """orbx_ba_solve_visual_batch: `windows` = list of dicts with poses_cw, fixed_cw, points, obs (as ba_solve_visual).
@@ -962,18 +987,30 @@ class MapSnapshot:
                   kf_feat_start i32[nkf+1], feat_mp_id i64[nfeat] (-1 = None), feat_uv f32[nfeat,2],
                   cov_start i32[nkf+1], cov_kf_id u64[ncov] (covisibility neighbours in the stated order)
       map points: mp_ids u64[nmp], mp_bad u8[nmp], mp_pos f64[nmp,3], mp_obs_start i32[nmp+1], mp_obs_kf_id u64[nobs]
+      inertial branch (optional, default "no IMU"): kf_prev_id i64[nkf] (-1 = None), kf_velocity f64[nkf,3], kf_bias f64[nkf,6] (gyro, accel),
+                  kf_has_preint u8[nkf], kf_preint f64[nkf,11] (delta_rot qw,qx,qy,qz | delta_vel | delta_pos | dt, from prev_kf),
+                  feat_stereo u8[nfeat] (points_cam[i].is_some()), mp_obs_feat_idx i32[nobs], imu_initialized (Map::is_imu_initialized())
     """
     FIELDS = (("kf_ids", np.uint64), ("kf_bad", np.uint8), ("kf_pose_wc", np.float64), ("kf_n_keypoints", np.int32),
               ("kf_feat_start", np.int32), ("feat_mp_id", np.int64), ("feat_uv", np.float32), ("cov_start", np.int32),
               ("cov_kf_id", np.uint64), ("mp_ids", np.uint64), ("mp_bad", np.uint8), ("mp_pos", np.float64),
               ("mp_obs_start", np.int32), ("mp_obs_kf_id", np.uint64))
+    INERTIAL_FIELDS = (("kf_prev_id", np.int64), ("kf_velocity", np.float64), ("kf_bias", np.float64), ("kf_has_preint", np.uint8),
+                       ("kf_preint", np.float64), ("feat_stereo", np.uint8), ("mp_obs_feat_idx", np.int32))
 
-    def __init__(self, **arrays):
+    def __init__(self, imu_initialized=False, **arrays):
         for name, dt in self.FIELDS:
             setattr(self, name, np.ascontiguousarray(arrays[name], dt))
         self.kf_pose_wc = self.kf_pose_wc.reshape(-1, 7)
         self.feat_uv = self.feat_uv.reshape(-1, 2)
         self.mp_pos = self.mp_pos.reshape(-1, 3)
+        nkf, nfeat, nobs = len(self.kf_ids), len(self.feat_mp_id), len(self.mp_obs_kf_id)
+        default = dict(kf_prev_id=np.full(nkf, -1, np.int64), kf_velocity=np.zeros((nkf, 3)), kf_bias=np.zeros((nkf, 6)), kf_has_preint=np.zeros(nkf, np.uint8),
+                       kf_preint=np.zeros((nkf, 11)), feat_stereo=np.zeros(nfeat, np.uint8), mp_obs_feat_idx=np.full(nobs, -1, np.int32))
+        for name, dt in self.INERTIAL_FIELDS:
+            setattr(self, name, np.ascontiguousarray(arrays.get(name, default[name]), dt))
+        self.kf_velocity = self.kf_velocity.reshape(-1, 3); self.kf_bias = self.kf_bias.reshape(-1, 6); self.kf_preint = self.kf_preint.reshape(-1, 11)
+        self.imu_initialized = bool(imu_initialized)
         self.build_index()
 
     def build_index(self):
@@ -981,9 +1018,9 @@ class MapSnapshot:
         self._mp = {int(k): i for i, k in enumerate(self.mp_ids)}
 
     def to_bytes(self):
-        """[14 x u64 element counts] then the arrays in FIELDS order (tests/cpp/local_mapper_driver.cpp reads this)."""
-        arrs = [getattr(self, n).reshape(-1) for n, _ in self.FIELDS]
-        return np.array([len(a) for a in arrs], np.uint64).tobytes() + b"".join(a.tobytes() for a in arrs)
+        """[22 x u64: 21 element counts, imu_initialized] then the arrays in FIELDS + INERTIAL_FIELDS order (tests/cpp/local_mapper_driver.cpp reads this)."""
+        arrs = [getattr(self, n).reshape(-1) for n, _ in self.FIELDS + self.INERTIAL_FIELDS]
+        return np.array([len(a) for a in arrs] + [1 if self.imu_initialized else 0], np.uint64).tobytes() + b"".join(a.tobytes() for a in arrs)
 
     # ---- local_ba_lm.rs:665-726 --------------------------------------------------------------------------------
     def _local_keyframes(self, current, max_cov):
@@ -1058,6 +1095,98 @@ class MapSnapshot:
             return None
         return VisualBAProblemData(local_kf_poses, local_mp_positions, fixed_kf_poses, anchor, obs, optimized, mp_ids)
 
+    # ---- local_inertial_ba.rs:366-429, :933-1072, :1289-1330 ----------------------------------------------------
+    def _temporal_keyframes(self, current, window_size):
+        ids = [int(current)]
+        prev = int(self.kf_prev_id[self._kf[int(current)]]) if int(current) in self._kf else -1
+        while len(ids) < window_size and prev >= 0:
+            ids.append(prev)
+            prev = int(self.kf_prev_id[self._kf[prev]]) if prev in self._kf else -1
+        ids.reverse()                                                 # oldest first: the anchor
+        return ids
+
+    def _fixed_keyframes_inertial(self, opt, mp_ids):
+        o = set(opt)
+        seen = {}
+        for mid in mp_ids:
+            j = self._mp.get(mid, -1)
+            if j < 0:
+                continue
+            for kid in self.mp_obs_kf_id[int(self.mp_obs_start[j]):int(self.mp_obs_start[j + 1])]:
+                kid = int(kid)
+                if kid not in o:
+                    k = self._kf.get(kid, -1)
+                    if k >= 0 and not self.kf_bad[k]:                 # (:419-423: checked here, not in the visual collect)
+                        seen.setdefault(kid, True)
+        return list(seen)
+
+    def collect_inertial_ba_data(self, current_kf_id, config: "LocalInertialBAConfig" = None) -> Optional["InertialBAProblemData"]:
+        """PHASE 1 = collect_inertial_ba_data, local_inertial_ba.rs:933-1072."""
+        config = config or LocalInertialBAConfig()
+        opt = self._temporal_keyframes(current_kf_id, config.window_size)
+        if len(opt) < 2:
+            return None
+        mp_ids = self._local_map_points(opt)
+        if not mp_ids:
+            return None
+        fixed = self._fixed_keyframes_inertial(opt, mp_ids)
+        kf_poses, kf_vel, kf_bias = {}, {}, {}
+        for kid in opt:
+            k = self._kf.get(kid, -1)
+            if k >= 0:
+                kf_poses[kid] = self.kf_pose_wc[k].copy(); kf_vel[kid] = self.kf_velocity[k].copy(); kf_bias[kid] = self.kf_bias[k].copy()
+        fixed_poses = {kid: se3_inverse(self.kf_pose_wc[self._kf[kid]]) for kid in fixed if kid in self._kf}
+        if opt[0] in self._kf:
+            fixed_poses[opt[0]] = se3_inverse(self.kf_pose_wc[self._kf[opt[0]]])
+        mp_positions = {m: self.mp_pos[self._mp[m]].copy() for m in mp_ids if m in self._mp}
+        opt_set, all_kf = set(opt), set(opt) | set(fixed)
+        obs = []
+        for mid in mp_ids:
+            j = self._mp.get(mid, -1)
+            if j < 0:
+                continue
+            for o in range(int(self.mp_obs_start[j]), int(self.mp_obs_start[j + 1])):
+                kid = int(self.mp_obs_kf_id[o])
+                k = self._kf.get(kid, -1)
+                if kid not in all_kf or k < 0:
+                    continue
+                fi = int(self.mp_obs_feat_idx[o])
+                s, e = int(self.kf_feat_start[k]), int(self.kf_feat_start[k + 1])
+                if fi < 0 or fi >= int(self.kf_n_keypoints[k]) or s + fi >= e:       # keypoints.get(feat_idx) is Err
+                    continue
+                f = s + fi
+                obs.append(InertialVisualObs(kid, mid, (float(self.feat_uv[f, 0]), float(self.feat_uv[f, 1])), bool(self.feat_stereo[f]),
+                                             kid in opt_set and kid != opt[0]))
+        edges = []
+        for i in range(len(opt) - 1):
+            kj = self._kf.get(opt[i + 1], -1)
+            if kj >= 0 and self.kf_has_preint[kj] and self.kf_preint[kj, 10] > 0.0:
+                edges.append(ImuEdgeData(opt[i], opt[i + 1], self.kf_preint[kj].copy()))
+        return InertialBAProblemData(kf_poses, kf_vel, kf_bias, mp_positions, fixed_poses, obs, edges, opt, mp_ids)
+
+    def apply_inertial_ba_results(self, result: "InertialBAResultData") -> int:
+        """PHASE 3 = apply_inertial_ba_results, local_inertial_ba.rs:1289-1330: poses and points count, velocities and biases do not."""
+        updated = 0
+        for kid, pose in result.optimized_poses.items():
+            k = self._kf.get(int(kid), -1)
+            if k >= 0 and not self.kf_bad[k]:
+                self.kf_pose_wc[k] = pose
+                updated += 1
+        for kid, v in result.optimized_velocities.items():
+            k = self._kf.get(int(kid), -1)
+            if k >= 0 and not self.kf_bad[k]:
+                self.kf_velocity[k] = v
+        for kid, b in result.optimized_biases.items():
+            k = self._kf.get(int(kid), -1)
+            if k >= 0 and not self.kf_bad[k]:
+                self.kf_bias[k] = b
+        for mid, pos in result.optimized_points.items():
+            j = self._mp.get(int(mid), -1)
+            if j >= 0 and not self.mp_bad[j]:
+                self.mp_pos[j] = pos
+                updated += 1
+        return updated
+
     def apply_visual_ba_results(self, result: "VisualBAResultData") -> int:
         """PHASE 3 = apply_visual_ba_results, local_ba_lm.rs:1112-1138: gone or bad entities are skipped silently."""
         updated = 0
@@ -1076,8 +1205,18 @@ class MapSnapshot:
 
 def local_bundle_adjustment(snapshot: MapSnapshot, kf_id, camera: "CameraModel", should_stop: Callable[[], bool] = None,
                             handle: "Handle" = None):
-    """The visual branch of LocalMapper::local_bundle_adjustment (local_mapper.rs:378-408): collect -> solve (GPU, no lock)
-    -> apply only if the solve ran an iteration (:396).  Returns (updated | None where the reference returns early, result)."""
+    """LocalMapper::local_bundle_adjustment (local_mapper.rs:334-410): the inertial branch (:343-375) once the map's IMU is
+    initialised, else the visual one (:378-408); each collect -> solve (GPU, no lock) -> apply only if the solve ran an iteration
+    (:363, :396).  Returns (updated | None where the reference returns early, result)."""
+    if snapshot.imu_initialized:
+        iconfig = LocalInertialBAConfig()
+        iproblem = snapshot.collect_inertial_ba_data(kf_id, iconfig)
+        if iproblem is None:
+            return None, None
+        iresult = solve_inertial_ba(iproblem, camera, iconfig, should_stop or (lambda: False), handle=handle)
+        if iresult is None:
+            return None, None
+        return (snapshot.apply_inertial_ba_results(iresult) if iresult.iterations > 0 else 0), iresult
     config = LocalBAConfigLM()
     problem = snapshot.collect_visual_ba_data(kf_id, config)
     if problem is None:

@@ -75,7 +75,8 @@ struct BaCam {
 // is "current" (the other one receives the trial step).
 struct BaState {
   double lambda, cur_sq, final_sq, gtol, ptol;
-  int done, iters, sel, pad;
+  int done, iters, sel;
+  int bad;      // 0, or INT_MAX - (index of the first observation with an index out of range): ba_prep_count_kernel; such a window never runs
 };
 __device__ __forceinline__ double* ba_cur(const BaState* S, double* P0, double* P1) { return S->sel ? P1 : P0; }
 __device__ __forceinline__ double* ba_trial(const BaState* S, double* P0, double* P1) { return S->sel ? P0 : P1; }
@@ -107,6 +108,11 @@ struct BaWin {
   double *dp;            // step of the reduced system [n pad 16]
   double *Sg, *bvec, *ginv;   // global-memory factorisation (n > ~135 and the inertial system)
   double *res;           // [16] result block, see ba_decide_kernel
+  // the observation CSR is built on the device once per call (ba_prep_*_kernel) from the caller's observations as they were handed over
+  const orbx_ba_obs* obs_raw;   // [N], input order
+  int *pt_fill;          // [M] per-point counters: observations of the point (count pass), then its fill position (place pass)
+  int *obs_tmp;          // [N] observation indices grouped by map point, in arrival order within a point (sorted by ba_prep_order_kernel)
+  int *o_flag;           // [N] inertial: orbx_ba_obs::_pad (bit 0 = stereo) in point-major order, else null
 };
 
 // The pointers a kernel takes out of its window descriptor are generic to the compiler (loaded from memory, not kernel arguments): every
@@ -136,9 +142,14 @@ struct BaWinView {
   BA_AS1 double *dp;
   BA_AS1 double *Sg, *bvec, *ginv;
   BA_AS1 double *res;
+  BA_AS1 const orbx_ba_obs* obs_raw;
+  BA_AS1 int *pt_fill;
+  BA_AS1 int *obs_tmp;
+  BA_AS1 int *o_flag;
 };
 static_assert(sizeof(BaWinView) == sizeof(BaWin) && offsetof(BaWinView, S) == offsetof(BaWin, S) && offsetof(BaWinView, oP) == offsetof(BaWin, oP) &&
-              offsetof(BaWinView, res) == offsetof(BaWin, res), "BaWinView is BaWin with its pointers in the global address space");
+              offsetof(BaWinView, res) == offsetof(BaWin, res) && offsetof(BaWinView, o_flag) == offsetof(BaWin, o_flag),
+              "BaWinView is BaWin with its pointers in the global address space");
 __device__ __forceinline__ BaWin ba_win_global(const BaWin* __restrict__ wins, int i) {
   const BaWinView& v = ((const BaWinView*)wins)[i];
   BaWin g;
@@ -150,6 +161,7 @@ __device__ __forceinline__ BaWin ba_win_global(const BaWin* __restrict__ wins, i
   g.oP = (double*)v.oP; g.Rt_cur = (double*)v.Rt_cur; g.slot_first = (int*)v.slot_first; g.obs_next = (int*)v.obs_next;
   g.kfpart = (double*)v.kfpart; g.part = (double*)v.part; g.rb = (double*)v.rb; g.dp = (double*)v.dp;
   g.Sg = (double*)v.Sg; g.bvec = (double*)v.bvec; g.ginv = (double*)v.ginv; g.res = (double*)v.res;
+  g.obs_raw = (const orbx_ba_obs*)v.obs_raw; g.pt_fill = (int*)v.pt_fill; g.obs_tmp = (int*)v.obs_tmp; g.o_flag = (int*)v.o_flag;
   return g;
 }
 
@@ -227,6 +239,130 @@ __global__ void ba_iter_kernel(const BaWin* __restrict__ wins, int iter) {
   BaState* S = ba_win_global(wins, blockIdx.y).S;
   if (S->done) return;
   S->iters = iter + 1;                                                  // local_ba_lm.rs:1017
+}
+
+// ---- the observation CSR, built on the device once per call -------------------------------------------------------------------
+// Until round 4 the host made two passes over every window's observations per call (index checks + per-point counts, then a stable
+// scatter into point-major order): 0.07 ms per 32 k-observation window on one core, and in a 32-window batch — spread over a pool of
+// workers that each also enqueued their window's upload — 1.4-2.8 ms per half in which the GPU stood still (ORBX_BA_TIMING, round 3).
+// Now the caller's observations go up as they are (straight out of the caller's memory when that is pinned) and four short launches
+// per call, shared by all windows, build what the solver reads: pt_start / kf_start, and o_kf / o_uv (/ o_flag) in point-major order with
+// the observations of a point in INPUT order — the order the host's stable scatter produced, so every sum downstream keeps its order
+// and its bits.  The order is made deterministic without a stable sort: the place pass groups observation INDICES by point in whatever
+// order its atomics land, and the order pass sorts each point's (short) index list.
+//   count: index checks (local_ba_lm.rs has none: an index out of range is a caller's bug — the window is flagged and never runs, the
+//          call fails with ORBX_ERR_INVALID as before), observations per point and per optimised keyframe
+//   scan:  pt_start, kf_start
+//   place: observation index -> its point's segment of obs_tmp
+//   order: per point, sort the segment; gather the observations into o_kf / o_uv / o_flag
+constexpr int BA_PREP_OPB = 1024;   // observations per block of the count / place passes (256 threads x 4)
+__global__ __launch_bounds__(256) void ba_prep_count_kernel(const BaWin* __restrict__ wins) {
+  __shared__ int s_kf[BA_MAX_K];
+  const BaWin win = ba_win_global(wins, blockIdx.y);
+  const int K = win.d.K, F = win.d.F, M = win.d.M, N = win.d.N;
+  const int i0 = blockIdx.x * BA_PREP_OPB;
+  if (win.S->done || i0 >= N) return;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < K; k += 256) s_kf[k] = 0;
+  __syncthreads();
+  const orbx_ba_obs* __restrict__ obs = win.obs_raw;
+  int* __restrict__ pt_fill = win.pt_fill;
+#pragma unroll
+  for (int r = 0; r < BA_PREP_OPB / 256; ++r) {
+    const int i = i0 + r * 256 + tid;
+    if (i >= N) break;
+    const int4 q = *reinterpret_cast<const int4*>(&obs[i]);              // kf_idx, fixed_idx, mp_idx, _pad
+    if (q.z < 0 || q.z >= M || q.x >= K || (q.x < 0 && q.y >= F)) { atomicMax(&win.S->bad, 0x7fffffff - i); continue; }
+    atomicAdd(&pt_fill[q.z], 1);
+    if (q.x >= 0) atomicAdd(&s_kf[q.x], 1);
+  }
+  __syncthreads();
+  int* kf_cnt = const_cast<int*>(win.kf_start) + 1;                      // kf_start[k + 1] = count of keyframe k until the scan
+  for (int k = tid; k < K; k += 256) if (s_kf[k]) atomicAdd(&kf_cnt[k], s_kf[k]);
+}
+
+// one block per window: exclusive scans.  pt_fill is left zeroed for the place pass.
+__global__ __launch_bounds__(1024) void ba_prep_scan_kernel(const BaWin* __restrict__ wins) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const BaWin win = ba_win_global(wins, blockIdx.y);
+  BaState* S = win.S;
+  if (S->done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (S->bad != 0) {                                                      // (uniform: written by the previous launch)
+    __syncthreads();
+    if (tid == 0) S->done = 1;
+    return;
+  }
+  const int K = win.d.K, M = win.d.M;
+  int* __restrict__ pt_start = const_cast<int*>(win.pt_start);
+  int* __restrict__ pt_fill = win.pt_fill;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < M; j0 += 1024) {
+    const int j = j0 + tid;
+    const int c = j < M ? pt_fill[j] : 0;
+    if (j < M) pt_fill[j] = 0;
+    int inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int base = s_carry;
+    for (int w2 = 0; w2 < wave; ++w2) base += s_wave[w2];
+    if (j < M) pt_start[j] = base + inc - c;
+    __syncthreads();
+    if (tid == 1023) s_carry = base + inc;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    pt_start[M] = s_carry;
+    int* kf_start = const_cast<int*>(win.kf_start);
+    int run = 0;
+    for (int k = 0; k < K; ++k) { run += kf_start[k + 1]; kf_start[k + 1] = run; }   // (kf_start[0] = 0: zeroed with the counters)
+  }
+}
+
+__global__ __launch_bounds__(256) void ba_prep_place_kernel(const BaWin* __restrict__ wins) {
+  const BaWin win = ba_win_global(wins, blockIdx.y);
+  const int N = win.d.N;
+  const int i0 = blockIdx.x * BA_PREP_OPB;
+  if (win.S->done || i0 >= N) return;
+  const orbx_ba_obs* __restrict__ obs = win.obs_raw;
+  const int* __restrict__ pt_start = win.pt_start;
+#pragma unroll
+  for (int r = 0; r < BA_PREP_OPB / 256; ++r) {
+    const int i = i0 + r * 256 + threadIdx.x;
+    if (i >= N) break;
+    const int mp = obs[i].mp_idx;
+    win.obs_tmp[pt_start[mp] + atomicAdd(&win.pt_fill[mp], 1)] = i;
+  }
+}
+
+// 16 lanes per map point: the point's observation indices into ascending (= input) order by counting, for each, the smaller ones
+// (a track is ~16 observations; a long one costs its square over 16 lanes), then the observations themselves into that order.
+__global__ __launch_bounds__(256) void ba_prep_order_kernel(const BaWin* __restrict__ wins) {
+  const BaWin win = ba_win_global(wins, blockIdx.y);
+  const int F = win.d.F, M = win.d.M;
+  const int j = (blockIdx.x * 256 + threadIdx.x) >> 4, li = threadIdx.x & 15;
+  if (win.S->done || j >= M) return;
+  const int s = win.pt_start[j], n = win.pt_start[j + 1] - s;
+  const int* __restrict__ tmp = win.obs_tmp + s;
+  const orbx_ba_obs* __restrict__ obs = win.obs_raw;
+  int* __restrict__ o_kf = const_cast<int*>(win.o_kf);
+  double* __restrict__ o_uv = const_cast<double*>(win.o_uv);
+  int* __restrict__ o_flag = win.o_flag;
+  for (int e = li; e < n; e += 16) {
+    const int idx = tmp[e];
+    int rank = 0;
+    for (int k = 0; k < n; ++k) rank += tmp[k] < idx ? 1 : 0;
+    const int4 q = *reinterpret_cast<const int4*>(&obs[idx]);
+    const double2_t uv = *reinterpret_cast<const double2_t*>(&obs[idx].u);
+    const size_t t = (size_t)(s + rank);
+    o_kf[t] = q.x >= 0 ? q.x : -1 - (q.y >= 0 ? q.y : F);                 // a fixed observer f as -1 - f; slot F = identity (:569)
+    *reinterpret_cast<double2_t*>(&o_uv[2 * t]) = uv;
+    if (o_flag) o_flag[t] = q.w;
+  }
 }
 
 // (point, keyframe) -> its observation(s): what fills the operand tiles of the Schur product.  One thread per map point walks the
@@ -2866,7 +3002,7 @@ __global__ void ba_inertial_scatter_kernel(const BaState* S, double* P0, double*
 
 // End of a solve: the window's state, result block and CURRENT parameters into one contiguous record of the output blob
 // (one D2H copy for the whole batch).  out: [0] iterations [1] final_sq [2] chi2 of the initial parameters [3] sel
-// [4] done [8...] parameters.
+// [4] done [5] bad-index code (BaState::bad) [8...] parameters.
 __global__ __launch_bounds__(256) void ba_finish_kernel(const BaWin* __restrict__ wins, double* __restrict__ out_base,
                                                         const size_t* __restrict__ out_off, int np_extra_per_kf) {
   const BaWin win = ba_win_global(wins, blockIdx.y);
@@ -2876,6 +3012,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(const BaWin* __restrict_
   const double* cur = ba_cur(S, win.P0, win.P1);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     out[0] = (double)S->iters; out[1] = S->final_sq; out[2] = win.res[12]; out[3] = (double)S->sel; out[4] = (double)S->done;
+    out[5] = (double)S->bad;
   }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < np; i += (size_t)gridDim.x * blockDim.x) out[8 + i] = cur[i];
 }
@@ -2957,6 +3094,8 @@ namespace {
 
 constexpr size_t BA_LDS_STATIC = 22784;                              // static LDS of ba_solve_lds_kernel (sb, srinv, s_red, s_col, s_rv, ...), rounded up
 constexpr size_t BA_LDS_DYN_MAX = 160 * 1024 - BA_LDS_STATIC;
+static_assert(BA_TILED_LDS_MAX + BA_LDS_STATIC <= 160 * 1024 && BF_LDS_BYTES + 8 * 1024 <= 160 * 1024 && SCHW_LDS_BYTES + 8 * 1024 <= 160 * 1024,
+              "dynamic LDS of the tiled solve / one-launch factorisation / Schur kernels beside their static arrays (the exact check, against the code object, runs once per device in ba_solve_batch)");
 
 struct Carve {                                                       // byte offsets inside one buffer, 256-byte aligned pieces
   size_t off = 0;
@@ -2968,13 +3107,30 @@ struct WinPlan {
   BaDims d{};
   int n = 0, use_lds = 0, skip = 0;
   size_t np = 0, n_upper = 0, rb_len = 0, lds_need = 0;
-  // byte offsets: input blob (host-prepared arrays), scratch arena, output blob
-  size_t i_state, i_params, i_rtfix, i_ptstart, i_kfstart, i_okf, i_ouv, i_oflag;
+  // byte offsets: input blob (LM state, parameters, fixed poses; the caller's observations behind all of them), counter zone,
+  // scratch arena, output blob
+  size_t i_state, i_params, i_rtfix, i_obs;
+  size_t c_fill, c_kfstart;
   size_t a_p1, a_oP, a_rtcur, a_slot, a_next, a_kfobs, a_kfpt, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
+  size_t a_ptstart, a_okf, a_ouv, a_oflag, a_tmp;
   size_t o_out;
   int n_kfobs = 0;
   double n_res = 0.0;
 };
+static_assert(sizeof(orbx_ba_obs) == 32 && offsetof(orbx_ba_obs, mp_idx) == 8 && offsetof(orbx_ba_obs, u) == 16,
+              "ba_prep_*_kernel read an observation as one int4 (kf_idx, fixed_idx, mp_idx, _pad) and one double2 (u, v)");
+
+// Is [p, p + bytes) pinned (hipHostMalloc / hipHostRegister) host memory — something the copy engine can read where it lies?
+bool host_is_pinned(const void* p, size_t bytes) {
+  if (!p || bytes == 0) return false;
+  auto one = [](const void* q) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // (older runtimes answer an error for pageable memory)
+    return a.type == hipMemoryTypeHost;
+  };
+  return one(p) && one((const char*)p + bytes - 1);
+}
 
 int pinned_reserve(orbx_handle* h, void** p, size_t* have, size_t need) {
   if (need <= *have) return ORBX_OK;
@@ -2985,40 +3141,14 @@ int pinned_reserve(orbx_handle* h, void** p, size_t* have, size_t need) {
   return ORBX_OK;
 }
 
-// host preprocessing of one window straight into the (pinned) input blob: parameters, fixed poses, point-major CSR of the
-// observations, keyframe CSR over that order.  Returns the index of a bad observation or -1.
-int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inertial, const BaInertialHost* inr) {
-  const int K = w.K, F = w.F, M = w.M, N = w.N;
-  const orbx_ba_obs* obs = w.obs;
+// The O(K + M) host part of one window, straight into the (pinned) input blob: pose parameters, map points, fixed poses.  Everything
+// per observation happens on the device (ba_prep_*_kernel).
+void prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inertial, const BaInertialHost* inr) {
+  const int K = w.K, F = w.F, M = w.M;
   double* params = (double*)(blob + pl.i_params);
   double* Rt_fix = (double*)(blob + pl.i_rtfix);
-  int* pt_start = (int*)(blob + pl.i_ptstart);
-  int* kf_start = (int*)(blob + pl.i_kfstart);
-  int* o_kf = (int*)(blob + pl.i_okf);
-  double* o_uv = (double*)(blob + pl.i_ouv);
-  int* o_flag = inertial ? (int*)(blob + pl.i_oflag) : nullptr;
-  for (int j = 0; j <= M; ++j) pt_start[j] = 0;
-  for (int i = 0; i < N; ++i) {                                          // index checks and the per-point counts in one pass over the observations
-    const orbx_ba_obs& o = obs[i];
-    if (o.mp_idx < 0 || o.mp_idx >= M || o.kf_idx >= K || (o.kf_idx < 0 && o.fixed_idx >= F)) return i;
-    pt_start[o.mp_idx + 1]++;
-  }
-  for (int j = 0; j < M; ++j) pt_start[j + 1] += pt_start[j];
-  for (int k = 0; k <= K; ++k) kf_start[k] = 0;
-  {
-    std::vector<int> fill(pt_start, pt_start + M);
-    for (int i = 0; i < N; ++i) {                                       // stable: input order within a point
-      const orbx_ba_obs& o = obs[i];
-      const int t = fill[o.mp_idx]++;
-      if (inertial) o_flag[t] = o._pad;
-      o_kf[t] = o.kf_idx >= 0 ? o.kf_idx : -1 - (o.fixed_idx >= 0 ? o.fixed_idx : F);   // a fixed observer f as -1 - f; slot F = identity (:569)
-      o_uv[2 * (size_t)t] = o.u; o_uv[2 * (size_t)t + 1] = o.v;
-      if (o.kf_idx >= 0) kf_start[o.kf_idx + 1]++;
-    }
-  }
-  for (int k = 0; k < K; ++k) kf_start[k + 1] += kf_start[k];                 // (the lists themselves: ba_kflist_kernel, on the device)
   for (int k = 0; k < K; ++k) host_se3_to_params(w.poses_cw + 7 * (size_t)k, &params[6 * (size_t)k]);   // scaled axis + translation
-  for (int j = 0; j < 3 * M; ++j) params[6 * (size_t)K + j] = w.points[j];
+  if (M > 0) memcpy(&params[6 * (size_t)K], w.points, 24 * (size_t)M);
   if (inertial)                                                          // :1154-1173
     for (int k = 0; k < K; ++k) {
       double* ex = &params[6 * (size_t)K + 3 * (size_t)M + 9 * (size_t)k];
@@ -3031,7 +3161,6 @@ int prep_window(const BaWinHost& w, const WinPlan& pl, uint8_t* blob, bool inert
     host_quat_to_R(p, &Rt_fix[12 * (size_t)f]);
     Rt_fix[12 * (size_t)f + 9] = p[4]; Rt_fix[12 * (size_t)f + 10] = p[5]; Rt_fix[12 * (size_t)f + 11] = p[6];
   }
-  return -1;
 }
 
 }  // namespace
@@ -3061,13 +3190,14 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   auto mark = [&](int i) { if (timing) t_mark[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   mark(0);
 
-  // ---- plan: dimensions and the layout of the four buffers
+  // ---- plan: dimensions and the layout of the buffers
   std::vector<WinPlan> plan(W);
-  Carve cin, car, cout;
+  Carve cin, car, cout, ccnt;
   const size_t i_wins = cin.take(sizeof(BaWin) * (size_t)W);
   const size_t i_wins15 = cin.take(sizeof(BaWin));                      // inertial: the same window seen by the 15-d solve
   const size_t i_outoff = cin.take(sizeof(size_t) * (size_t)W);
-  int live = 0;
+  int live = 0, maxN = 0;
+  size_t obs_bytes = 0;
   for (int w = 0; w < W; ++w) {
     const BaWinHost& ww = win[w];
     WinPlan& pl = plan[w];
@@ -3076,7 +3206,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if ((6 * (size_t)K + 3 * (size_t)M == 0) || (N == 0 && !dist && !inertial)) {
       win[w].status = ORBX_ERR_EMPTY;
       pl.skip = 1;
-    } else ++live;
+    } else { ++live; maxN = std::max(maxN, N); }
     if (6 * K > BA_MAX_N || K > BA_MAX_K) return orbx_fail(h, ORBX_ERR_INVALID, "window %d: at most %d optimised keyframes per window", w, BA_MAX_N / 6);
     BaDims& d = pl.d;
     d.K = K; d.F = F; d.M = M; d.N = N;
@@ -3108,11 +3238,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.i_state = cin.take(sizeof(BaState));
     pl.i_params = cin.take(8 * std::max<size_t>(pl.np, 1));
     pl.i_rtfix = cin.take(8 * 12 * (size_t)(F + 1));
-    pl.i_ptstart = cin.take(4 * (size_t)(M + 1));
-    pl.i_kfstart = cin.take(4 * (size_t)(K + 1));
-    pl.i_okf = cin.take(4 * n1);
-    pl.i_ouv = cin.take(16 * n1);
-    pl.i_oflag = inertial ? cin.take(4 * n1) : 0;
+    pl.i_obs = obs_bytes; obs_bytes += sizeof(orbx_ba_obs) * (size_t)(pl.skip ? 0 : N);   // (relative to the observation region, packed)
+    pl.c_fill = ccnt.take(4 * m1); pl.c_kfstart = ccnt.take(4 * (k1 + 1));
+    pl.a_ptstart = car.take(4 * (m1 + 1)); pl.a_okf = car.take(4 * n1); pl.a_ouv = car.take(16 * n1);
+    pl.a_oflag = inertial ? car.take(4 * n1) : 0; pl.a_tmp = car.take(4 * n1);
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
     pl.a_oP = car.take(48 * n1); pl.a_rtcur = car.take(96 * k1);
     pl.a_slot = car.take(4 * m1 * k1); pl.a_next = car.take(4 * n1); pl.a_kfobs = car.take(4 * n1); pl.a_kfpt = car.take(4 * n1);
@@ -3128,17 +3257,37 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     if (single_call) return orbx_fail(h, ORBX_ERR_EMPTY, "no parameters or no residuals");
     return ORBX_OK;                                                      // every window reports ORBX_ERR_EMPTY in its status
   }
+  const size_t small_bytes = cin.take(0);                                // descriptors, LM states, parameters, fixed poses of every window: ONE upload
+  const size_t a_cnt = car.take(ccnt.off);                               // per-point / per-keyframe counters of every window: ONE memset
+  // Where each window's observations come from: straight out of the caller's memory when that is pinned (the copy engine reads it where
+  // it lies: no host pass over the observations at all), else through the pinned blob (a plain copy, on the handle's workers when it is
+  // large).  Windows whose observations follow each other in memory travel as one copy.
+  static const bool force_stage = getenv("ORBX_BA_STAGE_OBS") != nullptr;   // (A/B and tests: never read the caller's memory directly)
+  struct Run { int w0, w1; size_t off, bytes; const void* src; bool direct; };
+  std::vector<Run> runs;
+  bool any_stage = false;
+  for (int w = 0; w < W; ++w) {
+    if (plan[w].skip || win[w].N == 0) continue;
+    const size_t bytes = sizeof(orbx_ba_obs) * (size_t)win[w].N;
+    if (!runs.empty() && (const char*)runs.back().src + runs.back().bytes == (const char*)win[w].obs && runs.back().off + runs.back().bytes == plan[w].i_obs) {
+      runs.back().bytes += bytes; runs.back().w1 = w + 1;
+    } else runs.push_back(Run{w, w + 1, plan[w].i_obs, bytes, win[w].obs, false});
+  }
+  for (Run& r : runs) {
+    r.direct = !force_stage && host_is_pinned(r.src, r.bytes);
+    if (!r.direct) any_stage = true;
+  }
   enum { B_IN, B_ARENA, B_OUT, B_IMU, B_S15 };
   const int K0 = win[0].K, M0 = win[0].M;                               // inertial / partitioned: the one window
   const int n15 = 15 * K0;
   if (inertial && n15 > BA_MAX_N) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d keyframes per inertial window", BA_MAX_N / 15);
-  if (int rc = orbx_reserve(h, h->ws_ba[B_IN], cin.off)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_ba[B_IN], small_bytes + obs_bytes + 256)) return rc;
   if (int rc = orbx_reserve(h, h->ws_ba[B_ARENA], car.off)) return rc;
   if (int rc = orbx_reserve(h, h->ws_ba[B_OUT], cout.off)) return rc;
   // inertial: edges (int [E][2]) | preint [E][11] | per-edge J^T J records;  dp15 [n15 pad 16] | S [n15^2] | b | 1/L_jj | gradient
   if (int rc = orbx_reserve(h, h->ws_ba[B_IMU], inertial ? 8 * ((size_t)inr->E * (1 + 11 + IMU_REC) + 8) : 8)) return rc;
   if (int rc = orbx_reserve(h, h->ws_ba[B_S15], inertial ? 8 * ((size_t)n15 * n15 + 4 * (size_t)n15 + 64) : 8)) return rc;
-  if (int rc = pinned_reserve(h, &h->h_ba_in, &h->h_ba_in_bytes, cin.off)) return rc;
+  if (int rc = pinned_reserve(h, &h->h_ba_in, &h->h_ba_in_bytes, small_bytes + (any_stage ? obs_bytes : 0))) return rc;
   if (int rc = pinned_reserve(h, &h->h_ba_out, &h->h_ba_out_bytes, cout.off)) return rc;
   if (!h->h_abort) {
     ORBX_HIP(h, hipHostMalloc((void**)&h->h_abort, 64));
@@ -3149,18 +3298,29 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   uint8_t* din = (uint8_t*)h->ws_ba[B_IN].p;
   uint8_t* dar = (uint8_t*)h->ws_ba[B_ARENA].p;
   double* dout = (double*)h->ws_ba[B_OUT].p;
+  uint8_t* dobs = din + small_bytes;                                     // the observation region of the device blob
+  uint8_t* hobs = hin + small_bytes;                                     // ... and of the pinned one (staged windows only)
 
+  // The second half of a batch (orbx_ba_solve_visual_batch) orders its uploads behind the first half's: both share one PCIe link, and the
+  // first half's kernels start when ITS bytes have arrived.  Whatever happens below, the first half opens the gate when it leaves.
+  struct GateOpen { std::atomic<int>* g; ~GateOpen() { if (g) g->store(1, std::memory_order_release); } } gate_open{h->ba_gate_signal};
+  bool direct_sent = false;
+  auto send_direct = [&]() -> int {
+    if (h->ba_gate_wait) {
+      while (h->ba_gate_wait->load(std::memory_order_acquire) == 0) std::this_thread::yield();
+      if (h->ba_gate_event) ORBX_HIP(h, hipStreamWaitEvent(st, h->ba_gate_event, 0));
+    }
+    for (const Run& r : runs)
+      if (r.direct) ORBX_HIP(h, hipMemcpyAsync(dobs + r.off, r.src, r.bytes, hipMemcpyHostToDevice, st));
+    direct_sent = true;
+    return ORBX_OK;
+  };
   mark(1);
-  // ---- host preprocessing, one window per task (threads when the batch is large enough to pay for them)
-  std::vector<int> bad(W, -1);
-  std::atomic<int> up_failed{0};
-  bool piecewise = false;                                                  // windows uploaded one by one by the preprocessing workers
+  if (!h->ba_gate_wait) { if (int rc = send_direct()) return rc; }        // the copy engine starts at once; the host's O(K + M) part runs under it
+
+  // ---- host part, one window per task: LM state, pose parameters, points, fixed poses — and the observations of a window whose memory
+  // the copy engine cannot read, copied into the pinned blob (threads when that is large enough to pay for them)
   {
-    // A window's task: its LM state and its preprocessed arrays into its own region of the pinned blob and — when the tasks run on the
-    // handle's workers — that region's upload enqueued by the worker itself the moment it is written, so that the copy engine works
-    // through the first windows while the last are still being sorted (the single 34 MB copy of a 32-window batch used to start only
-    // after all preprocessing: 0.4 ms of a 4.7 ms call with the GPU idle).  The stream takes the copies in whatever order they arrive;
-    // everything that reads them is enqueued by this thread after the workers are done.
     auto work = [&](int w) {
       const WinPlan& pl = plan[w];
       BaState& s0 = *(BaState*)(hin + pl.i_state);
@@ -3169,33 +3329,31 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       s0.gtol = inertial ? 1e-8 : cfg->gradient_tolerance;              // local_inertial_ba.rs:1213
       s0.ptol = inertial ? 0.0 : cfg->param_tolerance;                  // the inertial loop has no step-size test
       s0.done = pl.skip;                                                 // a window the reference answers None for (:923-925) never runs
-      if (!pl.skip) bad[w] = prep_window(win[w], pl, hin, inertial, inr);
-      if (piecewise) {
-        const size_t lo = pl.i_state, hi = w + 1 < W ? plan[w + 1].i_state : cin.off;
-        if (hipSetDevice(h->device) != hipSuccess || hipMemcpyAsync(din + lo, hin + lo, hi - lo, hipMemcpyHostToDevice, st) != hipSuccess) up_failed.store(1);
-      }
+      if (!pl.skip) prep_window(win[w], pl, hin, inertial, inr);
     };
-    size_t total_obs = 0;
-    for (int w = 0; w < W; ++w) total_obs += (size_t)win[w].N;
-    int nthr = (int)std::min<size_t>({(size_t)W, (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, total_obs / 20000 + 1});
+    size_t staged = 0;
+    std::vector<int> stage_w;
+    for (const Run& r : runs) if (!r.direct) { staged += r.bytes; for (int w = r.w0; w < r.w1; ++w) if (!plan[w].skip && win[w].N > 0) stage_w.push_back(w); }
+    auto stage = [&](int i) { const int w = stage_w[(size_t)i]; memcpy(hobs + plan[w].i_obs, win[w].obs, sizeof(orbx_ba_obs) * (size_t)win[w].N); };
+    int nthr = (int)std::min<size_t>({stage_w.size(), (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, staged / (1u << 20) + 1});
     if (h->ba_pool_cap > 0) nthr = std::min(nthr, h->ba_pool_cap);
     if (nthr > 1 && !h->ba_pool) {
       try { h->ba_pool = new OrbxWorkPool((int)std::min<size_t>(15, std::max(1u, std::thread::hardware_concurrency()) - 1)); }
       catch (...) { h->ba_pool = nullptr; }                              // no workers: this thread does it all
     }
-    piecewise = nthr > 1 && h->ba_pool != nullptr;
-    if (!piecewise) { for (int w = 0; w < W; ++w) work(w); }
-    else if (!h->ba_pool->run(W, nthr - 1, work)) return orbx_fail(h, ORBX_ERR_HIP, "batch preprocessing: out of host memory");
-    if (up_failed.load()) return orbx_fail(h, ORBX_ERR_HIP, "batch upload failed: %s", hipGetErrorString(hipGetLastError()));
+    if (nthr > 1 && h->ba_pool) {
+      // the workers copy observations while this thread does the small per-window part: item 0 = that part, items 1.. = staged windows
+      const std::function<void(int)> job = [&](int i) { if (i == 0) { for (int w = 0; w < W; ++w) work(w); } else stage(i - 1); };
+      if (!h->ba_pool->run((int)stage_w.size() + 1, nthr - 1, job)) return orbx_fail(h, ORBX_ERR_HIP, "batch preprocessing: out of host memory");
+    } else {
+      for (int w = 0; w < W; ++w) work(w);
+      for (int i = 0; i < (int)stage_w.size(); ++i) stage(i);
+    }
   }
   mark(2);
-  int first_bad = -1;
-  for (int w = 0; w < W && first_bad < 0; ++w) if (bad[w] >= 0) first_bad = w;
-  if (first_bad >= 0 && !dist) {
-    const orbx_ba_obs& o = win[first_bad].obs[bad[first_bad]];
-    return orbx_fail(h, ORBX_ERR_INVALID, "window %d observation %d: index out of range (kf %d/%d, fixed %d/%d, mp %d/%d)", first_bad,
-                     bad[first_bad], o.kf_idx, win[first_bad].K, o.fixed_idx, win[first_bad].F, o.mp_idx, win[first_bad].M);
-  }
+  if (!direct_sent) { if (int rc = send_direct()) return rc; }
+  for (const Run& r : runs)
+    if (!r.direct) ORBX_HIP(h, hipMemcpyAsync(dobs + r.off, hobs + r.off, r.bytes, hipMemcpyHostToDevice, st));
   // window descriptors + LM states into the blob
   BaWin* hw = (BaWin*)(hin + i_wins);
   size_t* hoff = (size_t*)(hin + i_outoff);
@@ -3216,9 +3374,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.S = (BaState*)(din + pl.i_state);
     b.P0 = (double*)(din + pl.i_params); b.P1 = (double*)(dar + pl.a_p1);
     b.Rt_fix = (const double*)(din + pl.i_rtfix);
-    b.pt_start = (const int*)(din + pl.i_ptstart); b.o_kf = (const int*)(din + pl.i_okf);
-    b.o_uv = (const double*)(din + pl.i_ouv);
-    b.kf_start = (const int*)(din + pl.i_kfstart); b.kf_obs = (int*)(dar + pl.a_kfobs); b.kf_pt = (int*)(dar + pl.a_kfpt);
+    b.pt_start = (const int*)(dar + pl.a_ptstart); b.o_kf = (const int*)(dar + pl.a_okf);
+    b.o_uv = (const double*)(dar + pl.a_ouv);
+    b.kf_start = (const int*)(dar + a_cnt + pl.c_kfstart); b.kf_obs = (int*)(dar + pl.a_kfobs); b.kf_pt = (int*)(dar + pl.a_kfpt);
+    b.obs_raw = (const orbx_ba_obs*)(dobs + pl.i_obs); b.pt_fill = (int*)(dar + a_cnt + pl.c_fill); b.obs_tmp = (int*)(dar + pl.a_tmp);
+    b.o_flag = inertial ? (int*)(dar + pl.a_oflag) : nullptr;
     b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl); b.vg = (double*)(dar + pl.a_vg);
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
     b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
@@ -3265,7 +3425,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     for (int e = 0; e < inr->E; ++e)
       if (inr->edge_kf[2 * e] < 0 || inr->edge_kf[2 * e] >= K0 || inr->edge_kf[2 * e + 1] < 0 || inr->edge_kf[2 * e + 1] >= K0)
         return orbx_fail(h, ORBX_ERR_INVALID, "IMU edge %d: keyframe index out of range", e);
-    bc.o_flag = (const int*)(din + plan[0].i_oflag);
+    bc.o_flag = hw[0].o_flag;
     int* d_edges = (int*)h->ws_ba[B_IMU].p;
     double* d_pre = (double*)h->ws_ba[B_IMU].p + inr->E;               // 2 ints per edge = 1 double slot per edge
     imu_buf = d_pre + 11 * (size_t)inr->E;
@@ -3286,21 +3446,41 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b15.Sg = dp15 + ((n15 + 15) & ~15); b15.bvec = b15.Sg + (size_t)n15 * n15; b15.ginv = b15.bvec + n15;
     gfull = b15.ginv + n15;
   }
-  // the window descriptors (and, unless the workers already sent them, the windows): one upload
-  ORBX_HIP(h, hipMemcpyAsync(din, hin, piecewise ? plan[0].i_state : cin.off, hipMemcpyHostToDevice, st));
+  // the window descriptors, LM states, parameters and fixed poses of every window: one upload
+  ORBX_HIP(h, hipMemcpyAsync(din, hin, small_bytes, hipMemcpyHostToDevice, st));
+  if (h->ba_gate_signal) {                                                // this half's bytes are on their way: the other half's may follow
+    if (h->ba_up_event) ORBX_HIP(h, hipEventRecord(h->ba_up_event, st));
+    h->ba_gate_signal->store(1, std::memory_order_release);
+  }
   mark(3);
   {
-    static std::once_flag once[64];                                    // process-wide function attribute: set once per device to
-    hipError_t e_attr = hipSuccess;                                    // the largest size any window may ask for
-    std::call_once(once[h->device & 63], [&] {
-      e_attr = hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_LDS_DYN_MAX);
+    // process-wide function attributes, set once per device to the largest size any window may ask for.  The result is kept per
+    // device: a failed attempt is reported by every call that finds it, and retried — never a launch with the attribute unset.
+    static std::mutex attr_m;
+    static int attr_state[64];                                         // 0 = not yet, 1 = set
+    std::lock_guard<std::mutex> g(attr_m);
+    if (attr_state[h->device & 63] != 1) {
+      hipError_t e_attr = hipFuncSetAttribute((const void*)ba_solve_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_LDS_DYN_MAX);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_solve_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_TILED_LDS_MAX);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_solve_inertial_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BA_TILED_LDS_MAX);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_kf_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_schur_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCHW_LDS_BYTES);
       if (e_attr == hipSuccess) e_attr = hipFuncSetAttribute((const void*)ba_big_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
-    });
-    ORBX_HIP(h, e_attr);
+      ORBX_HIP(h, e_attr);
+      // what the kernels declare statically plus the largest dynamic size must fit the CU's 160 KB — checked against the code object itself,
+      // so a static array that grows fails here, by name, and not as a launch error of the one window size that needs the maximum
+      const struct { const void* f; size_t dyn; const char* name; } lds[] = {
+          {(const void*)ba_solve_lds_kernel, BA_LDS_DYN_MAX, "ba_solve_lds_kernel"}, {(const void*)ba_solve_tiled_kernel, BA_TILED_LDS_MAX, "ba_solve_tiled_kernel"},
+          {(const void*)ba_solve_inertial_tiled_kernel, BA_TILED_LDS_MAX, "ba_solve_inertial_tiled_kernel"}, {(const void*)ba_kf_schur_kernel<true>, SCHW_LDS_BYTES, "ba_kf_schur_kernel"},
+          {(const void*)ba_schur_kernel<true>, SCHW_LDS_BYTES, "ba_schur_kernel"}, {(const void*)ba_big_factor_kernel, BF_LDS_BYTES, "ba_big_factor_kernel"}};
+      for (const auto& k : lds) {
+        hipFuncAttributes fa;
+        ORBX_HIP(h, hipFuncGetAttributes(&fa, k.f));
+        if (fa.sharedSizeBytes + k.dyn > 160 * 1024)
+          return orbx_fail(h, ORBX_ERR_INVALID, "internal: %s needs %zu B static + %zu B dynamic LDS, more than the 160 KB of a CU", k.name, (size_t)fa.sharedSizeBytes, k.dyn);
+      }
+      attr_state[h->device & 63] = 1;
+    }
   }
   // k-splits per workgroup of the batch's one-column-block Schur launch: as many as make the launch about one workgroup per CU (a
   // workgroup owns its CU: 102 KB of LDS); the partials do not depend on it
@@ -3329,16 +3509,29 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   double n_res = plan[0].n_res;
   std::vector<double> votes((size_t)std::max(cfg->max_iterations, 0) + 2, 0.0);
   bool my_stop = false;
+  // the observation CSR of every window (see ba_prep_count_kernel)
+  ORBX_HIP(h, hipMemsetAsync(dar + a_cnt, 0, ccnt.off, st));
+  if (maxN > 0) {
+    ProfScope ps(h, "ba_prep");
+    const dim3 go((maxN + BA_PREP_OPB - 1) / BA_PREP_OPB, W);
+    hipLaunchKernelGGL(ba_prep_count_kernel, go, dim3(256), 0, st, d_wins);
+    hipLaunchKernelGGL(ba_prep_scan_kernel, gW1, dim3(1024), 0, st, d_wins);
+    hipLaunchKernelGGL(ba_prep_place_kernel, go, dim3(256), 0, st, d_wins);
+    if (maxM > 0) hipLaunchKernelGGL(ba_prep_order_kernel, dim3((maxM * 16 + 255) / 256, W), dim3(256), 0, st, d_wins);
+  }
   if (dist) {
     my_stop = should_stop && should_stop(user);
-    const double head[3] = {n_res, my_stop ? 1.0 : 0.0, first_bad >= 0 ? 1.0 : 0.0};
+    int bad0 = 0;                                                         // this rank's index check, from the device (the stream is drained here anyway)
+    ORBX_HIP(h, hipMemcpyAsync(&bad0, &w0.S->bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    ORBX_HIP(h, hipStreamSynchronize(st));
+    const double head[3] = {n_res, my_stop ? 1.0 : 0.0, bad0 != 0 ? 1.0 : 0.0};
     ORBX_HIP(h, hipMemcpyAsync(res0 + 8, head, 24, hipMemcpyHostToDevice, st));
     ORBX_HIP(h, hipStreamSynchronize(st));
     if (int rc = allreduce(res0 + 8, 3)) return rc;
     double tot[3];
     ORBX_HIP(h, hipMemcpyAsync(tot, res0 + 8, 24, hipMemcpyDeviceToHost, st));
     ORBX_HIP(h, hipStreamSynchronize(st));
-    if (tot[2] > 0.0) return orbx_fail(h, ORBX_ERR_INVALID, "an observation index is out of range on %d rank(s)%s", (int)tot[2], first_bad >= 0 ? " (this one too)" : "");
+    if (tot[2] > 0.0) return orbx_fail(h, ORBX_ERR_INVALID, "an observation index is out of range on %d rank(s)%s", (int)tot[2], bad0 != 0 ? " (this one too)" : "");
     n_res = tot[0];
     if (n_res == 0.0) return orbx_fail(h, ORBX_ERR_EMPTY, "no residuals on any rank");
     my_stop = tot[1] > 0.0;                                              // the collective decision for iteration 0
@@ -3461,6 +3654,15 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   ORBX_HIP(h, hipGetLastError());
   mark(5);
 
+  for (int w = 0; w < W; ++w) {                                          // an observation index out of range (found by ba_prep_count_kernel): the call fails, nothing is written
+    if (plan[w].skip) continue;
+    const int code = (int)hout[plan[w].o_out / 8 + 5];
+    if (code == 0) continue;
+    const int i = 0x7fffffff - code;
+    const orbx_ba_obs& o = win[w].obs[i];
+    return orbx_fail(h, ORBX_ERR_INVALID, "window %d observation %d: index out of range (kf %d/%d, fixed %d/%d, mp %d/%d)", w, i, o.kf_idx,
+                     win[w].K, o.fixed_idx, win[w].F, o.mp_idx, win[w].M);
+  }
   for (int w = 0; w < W; ++w) {
     if (plan[w].skip) continue;
     const WinPlan& pl = plan[w];

@@ -1382,6 +1382,220 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
   }
 }
 
+// ---- A.7 + A.8 with the blur inside (round 4): no blurred pyramid ----------------------------------------------------------------
+// The blurred levels exist for ONE reader, this kernel, which takes a 37 x 37 patch per keypoint out of them — so the whole-level blur
+// (0.31 ms per 256 pairs, 1.39 GB of HBM traffic per launch) and the second image per keypoint that the texture addresser had to walk
+// (31 + 37 row segments) are replaced by ONE 43-row window of the unblurred level per keypoint, staged in LDS, from which the kernel
+// takes the intensity centroid and computes the patch's blur itself.  The blur is exact integer arithmetic whichever way it is summed —
+// oracle/orb_ref.cpp:119-133: an 8.8 horizontal pass that fits 16 bits without rounding, a 16.16 vertical pass, ONE rounding
+// (v + 32768) >> 16 — i.e. blur(y, x) = (sum_ij g_i g_j p(y + i - 3, x + j - 3) + 32768) >> 16, g = {18, 34, 48, 56, 48, 34, 18}.  On the
+// VALU the two passes cost ~9 instructions per patch pixel and the patches of an image overlap 3.3-fold: 0.44 ms of issue slots, more
+// than the kernel it would replace.  On the matrix pipe they are two banded products on v_mfma_i32_16x16x64_i8 per keypoint:
+//   H' = (W - 128) T1      W: 48 x 64 window bytes (row pitch 48: the k-slots 48..63 of a row are the next row's bytes, under zero taps),
+//                          T1[c][x] = g[c - x - 2]: 9 MFMAs (3 row blocks x 3 column blocks);  H' = H - 32768 fits 16 bits
+//   V' = T2 H'             H' split into a signed high byte and a low byte (xor 0x80 -> signed): two i8 products per tile, 18 MFMAs,
+//                          V = 256 S_hi + S_lo + 2^15 + 2^23,  byte = (V + 32768) >> 16
+// with NO data movement between the two: the accumulator of the first product has its column on the lane and four consecutive rows in its
+// registers, and the k index of the second product is a summation index — the k-slot (lane group q, byte j) of the second product is DEFINED
+// as row 16 (j >> 2) + 4 q + (j & 3) of H', which is what lane group q holds, and the tap operand T2 is laid out to match (a table built by
+// the host: orb_prepare_geometry).  Only the A/B pairing of equal (lane group, byte) slots is assumed of the instruction's k layout.
+// The result goes back to LDS column-major (a lane's register = four vertically adjacent bytes of one column = one dword), over the
+// keypoint's own window, which is dead once its three A operands are in registers; the test points read byte (x + 18) * 48 + (y + 18).
+// Per keypoint 27 MFMAs (16 cycles each) beside ~110 VALU instructions of glue, against ~1400 VALU instructions for the two passes.
+constexpr int DF_WP = 48;                         // window / patch pitch in bytes; the window is 48 rows (43 staged), the patch 48 columns (37 used)
+constexpr int DF_WIN_BYTES = 48 * DF_WP;          // 2304 B per keypoint
+constexpr int DF_X0 = 23, DF_Y0 = 21;             // window origin = keypoint - (23, 21): the centroid's 31-px rows start at window byte 8 (aligned 8-byte LDS reads)
+typedef int df_i4 __attribute__((ext_vector_type(4)));
+__constant__ __attribute__((aligned(16))) unsigned c_blur_band[6 * 64 * 4];   // [operand set: T1 for column block 0..2, T2 for row block 0..2][lane][4 dwords]
+
+__global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, int blocks_per_img,
+                                                             const unsigned long long* __restrict__ sel2,
+                                                             const unsigned long long* __restrict__ spatial,
+                                                             const unsigned* __restrict__ kept,
+                                                             orbx_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
+                                                             int* __restrict__ nkp, int cap_kp, float patch_size,
+                                                             unsigned* __restrict__ status) {
+  // 16 windows, then the tables: the last window's A operand reads 16 bytes past its end (k-slots under zero taps) — into the tables
+  __shared__ __attribute__((aligned(16))) unsigned char s_win[DG_PER_BLOCK * DF_WIN_BYTES + 3 * 1024];
+  int* s_pat = reinterpret_cast<int*>(s_win + DG_PER_BLOCK * DF_WIN_BYTES);
+  unsigned* s_ones = reinterpret_cast<unsigned*>(s_pat + 256);
+  unsigned* s_col = s_ones + 256;
+  int img, bx;
+  if (!xcd_decode(xm, n_img, img, bx)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, li = lane & 15;
+  s_pat[tid] = reinterpret_cast<const int*>(c_pattern)[tid];
+  s_ones[tid] = c_ic_ones[tid];
+  s_col[tid] = c_ic_col[tid];
+  __syncthreads();
+  unsigned start[ORBX_MAX_LEVELS + 1];
+  start[0] = 0;
+#pragma unroll
+  for (int l = 0; l < ORBX_MAX_LEVELS; ++l)
+    start[l + 1] = start[l] + (l < g.n_levels ? kept[img * g.n_levels + l] : 0u);
+  const unsigned total = start[ORBX_MAX_LEVELS];
+  const unsigned limit = min(total, (unsigned)cap_kp);
+  if (bx == 0 && tid == 0) {
+    nkp[img] = (int)limit;
+    if (total > (unsigned)cap_kp) atomicOr(status, ORBX_ST_KP_OVERFLOW);
+  }
+  unsigned char* wwin = s_win + wave * DG_PER_WAVE * DF_WIN_BYTES;          // the wave's four windows
+  unsigned char* mywin = wwin + grp * DF_WIN_BYTES;
+  // staging tasks: 43 rows x 6 chunks of 8 bytes = 258, task t = 16 it + li -> (row t / 6, chunk t % 6); the pattern repeats every 3
+  // rounds (48 tasks = 8 rows), so a lane keeps three (row, chunk) pairs and adds 8 rows per period
+  unsigned st_g[3], st_l[3];
+#pragma unroll
+  for (int ph = 0; ph < 3; ++ph) {
+    const unsigned t0 = 16u * ph + (unsigned)li, r0 = (t0 * 171u) >> 10, c6 = t0 - 6u * r0;
+    st_g[ph] = r0; st_l[ph] = r0 * DF_WP + 8u * c6;                         // (st_g: row; the byte offset follows from st_l)
+  }
+  for (unsigned base = (bx * 4 + wave) * DG_PER_WAVE; base < total; base += blocks_per_img * DG_PER_BLOCK) {
+    const unsigned pos_raw = base + grp;
+    const unsigned pos = pos_raw < total ? pos_raw : base;  // idle groups shadow the wave's first keypoint
+    int l = 0;
+    unsigned lbase = 0;
+#pragma unroll
+    for (int i = 1; i < ORBX_MAX_LEVELS; ++i) if (pos >= start[i]) { l = i; lbase = start[i]; }
+    const size_t lofs = (size_t)img * g.cand_total + g.lv[l].cand_off;
+    const unsigned long long ent = spatial[lofs + (pos - lbase)];
+    const int kx = (int)(ent & 0xffffu), ky = (int)((ent >> 16) & 0xffffu);
+    const unsigned j2 = (unsigned)(ent >> 32) & 0xffffu;
+    const unsigned slot = lbase + j2;
+    const bool active = pos_raw < total && slot < limit;
+    const float resp = from_orderable(~(unsigned)(sel2[lofs + j2] >> 32));   // only needed for the output record
+    int pitch;
+    const uint8_t* src = level_ptr(s, g, img, l, pitch);
+    // ---- the 43 x 48 window of the level around the keypoint (rows ky - 21 .. ky + 21, bytes kx - 23 .. kx + 24) into LDS
+    {
+      const uint8_t* w0 = src + (unsigned)(__umul24((unsigned)(ky - DF_Y0), (unsigned)pitch) + (unsigned)(kx - DF_X0));
+      const unsigned p8 = 8u * (unsigned)pitch;
+      unsigned go[3];
+#pragma unroll
+      for (int ph = 0; ph < 3; ++ph) go[ph] = __umul24(st_g[ph], (unsigned)pitch) + (st_l[ph] - st_g[ph] * DF_WP);
+      unsigned long long v[17];
+#pragma unroll
+      for (int it = 0; it < 17; ++it) {
+        const int ph = it % 3, k = it / 3;
+        if (it < 16 || li < 2) __builtin_memcpy(&v[it], w0 + (go[ph] + (unsigned)k * p8), 8);
+      }
+#pragma unroll
+      for (int it = 0; it < 17; ++it) {
+        const int ph = it % 3, k = it / 3;
+        if (it < 16 || li < 2) *reinterpret_cast<unsigned long long*>(mywin + st_l[ph] + (unsigned)k * (8u * DF_WP)) = v[it];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);   // the four windows are in LDS for the whole wave
+    // ---- intensity centroid over the 749-pixel disc, from the window (integer, order independent)
+    int sA = 0, sB = 0, sC = 0;
+    {
+      const unsigned char* c0 = mywin + ((li >> 2) + 6) * DF_WP + 8 + 8 * (li & 3);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = 4 * it + (li >> 2);
+        const int r = min(row, 30);
+        const unsigned long long px = *reinterpret_cast<const unsigned long long*>(c0 + (it * 4 - (row > 30 ? 1 : 0)) * DF_WP);
+        const int t0 = row * 8 + 2 * (li & 3);
+        const uint2 w1 = *reinterpret_cast<const uint2*>(&s_ones[t0]);
+        const uint2 wc = *reinterpret_cast<const uint2*>(&s_col[t0]);
+        const unsigned sI = __builtin_amdgcn_udot4((unsigned)(px >> 32), w1.y, __builtin_amdgcn_udot4((unsigned)px, w1.x, 0u, false), false);
+        sA += (int)__builtin_amdgcn_udot4((unsigned)(px >> 32), wc.y, __builtin_amdgcn_udot4((unsigned)px, wc.x, 0u, false), false);
+        sB += (int)sI;
+        sC += (r - 15) * (int)sI;
+      }
+    }
+    sA = row16_sum(sA); sB = row16_sum(sB); sC = row16_sum(sC);
+    const int m10 = sA - 15 * sB, m01 = sC;
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    float ca, sa;
+    sincos_deg(angle, ca, sa);
+    // ---- the blurred patch of each of the wave's four keypoints, by the whole wave, on the matrix pipe
+    {
+      const int m16 = lane & 15, q = lane >> 4;
+      const df_i4* band = reinterpret_cast<const df_i4*>(c_blur_band) + lane;
+#pragma unroll 1
+      for (int kp = 0; kp < DG_PER_WAVE; ++kp) {
+        unsigned char* win = wwin + kp * DF_WIN_BYTES;
+        df_i4 a1[3];
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb) {
+          a1[mb] = *reinterpret_cast<const df_i4*>(win + (16 * mb + m16) * DF_WP + 16 * q);
+          a1[mb] ^= (int)0x80808080;                                           // p - 128 as a signed byte
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0): the window is in registers — its bytes may be overwritten
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+          const df_i4 t1 = band[64 * nb];
+          df_i4 hh[3];
+#pragma unroll
+          for (int mb = 0; mb < 3; ++mb) hh[mb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[mb], t1, (df_i4){0, 0, 0, 0}, 0, 0, 0);
+          // split: k-slot (q, j = 4 mb + i) = row 16 mb + 4 q + i of H' = register i of hh[mb]
+          df_i4 bhi, blo;
+#pragma unroll
+          for (int mb = 0; mb < 3; ++mb) {
+            const unsigned p01 = __builtin_amdgcn_perm((unsigned)hh[mb][1], (unsigned)hh[mb][0], 0x05010400u);
+            const unsigned p23 = __builtin_amdgcn_perm((unsigned)hh[mb][3], (unsigned)hh[mb][2], 0x05010400u);
+            blo[mb] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+            bhi[mb] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
+          }
+          blo[3] = 0; bhi[3] = 0;
+#pragma unroll
+          for (int mb2 = 0; mb2 < 3; ++mb2) {
+            const df_i4 t2 = band[64 * (3 + mb2)];
+            const df_i4 shi = __builtin_amdgcn_mfma_i32_16x16x64_i8(t2, bhi, (df_i4){0, 0, 0, 0}, 0, 0, 0);
+            const df_i4 slo = __builtin_amdgcn_mfma_i32_16x16x64_i8(t2, blo, (df_i4){8454144, 8454144, 8454144, 8454144}, 0, 0, 0);   // 2^16 + 2^23
+            const unsigned v0 = ((unsigned)shi[0] << 8) + (unsigned)slo[0], v1 = ((unsigned)shi[1] << 8) + (unsigned)slo[1];
+            const unsigned v2 = ((unsigned)shi[2] << 8) + (unsigned)slo[2], v3 = ((unsigned)shi[3] << 8) + (unsigned)slo[3];
+            const unsigned u01 = __builtin_amdgcn_perm(v1, v0, 0x00000602u), u23 = __builtin_amdgcn_perm(v3, v2, 0x00000602u);
+            *reinterpret_cast<unsigned*>(win + (16 * nb + m16) * DF_WP + 16 * mb2 + 4 * q) = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);   // the four patches are in LDS for the whole wave
+    const unsigned char* pbb = mywin;
+    unsigned long long word[4] = {0ull, 0ull, 0ull, 0ull};
+    const desc_f2 ca2 = {ca, ca}, sa2 = {sa, sa}, magic2 = {12582912.f, 12582912.f};
+    // byte (col + 18) * 48 + row + 18 of the column-major patch from the raw float bits: the 24-bit multiply sees 0x400000 + col, the
+    // row term carries the whole 0x4B400000 + row
+    constexpr unsigned kBias = 0x400000u * DF_WP + 0x4B400000u - (18u * DF_WP + 18u);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pr = s_pat[r * 16 + li];
+      const desc_f2 X = {(float)(signed char)(pr & 0xff), (float)(signed char)((pr >> 16) & 0xff)};
+      const desc_f2 Y = {(float)(signed char)((pr >> 8) & 0xff), (float)(signed char)((pr >> 24) & 0xff)};
+      const desc_f2 fx = X * ca2 - Y * sa2 + magic2;
+      const desc_f2 fy = X * sa2 + Y * ca2 + magic2;
+      const unsigned a0 = __umul24(__float_as_uint(fx[0]), DF_WP) + __float_as_uint(fy[0]) - kBias;
+      const unsigned a1 = __umul24(__float_as_uint(fx[1]), DF_WP) + __float_as_uint(fy[1]) - kBias;
+      const int t0 = pbb[a0];
+      const int t1 = pbb[a1];
+      const unsigned long long bal = __ballot(t0 < t1);
+      const unsigned chunk = (unsigned)(bal >> (16 * grp)) & 0xffffu;        // this keypoint's bits 16r .. 16r+15
+      word[r >> 2] |= (unsigned long long)chunk << (16 * (r & 3));
+    }
+    if (active && li < 4) {
+      const unsigned long long wv = li == 0 ? word[0] : li == 1 ? word[1] : li == 2 ? word[2] : word[3];
+      reinterpret_cast<unsigned long long*>(desc_out + ((size_t)img * cap_kp + slot) * 32)[li] = wv;
+    }
+    if (active && li == 4) {
+      const float sc = g.lv[l].scale;
+      orbx_keypoint o;
+      o.x = __fmul_rn((float)kx, sc);
+      o.y = __fmul_rn((float)ky, sc);
+      o.size = __fmul_rn(patch_size, sc);
+      o.angle = angle;
+      o.response = resp;
+      o.octave = l;
+      o.class_id = -1;
+      kp_out[(size_t)img * cap_kp + slot] = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---- host: geometry, tables, launch sequence ---------------------------------------------------------------
 
 void build_resize_tab(int src, int dst, std::vector<unsigned>& out) {
@@ -1530,6 +1744,25 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
   }
   ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_ic_ones), ones, sizeof(ones)));
   ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_ic_col), colw, sizeof(colw)));
+  // tap operands of describe_fused_kernel's two banded products (A.8's taps, oracle/orb_ref.cpp:113), per lane (m = lane & 15, g = lane >> 4):
+  //   sets 0..2  T1 for output-column block nb: byte j of the lane's 16 = tap[c - x - 2], c = 16 g + j (window byte), x = 16 nb + m
+  //   sets 3..5  T2 for output-row block mb:    byte j = tap[rho - y], rho = 16 (j >> 2) + 4 g + (j & 3) (the row of H' that k-slot (g, j)
+  //              stands for: what lane group g's accumulator registers hold), y = 16 mb + m; k-slots of the fourth register set (rows >= 48): 0
+  {
+    static const int tap[7] = {18, 34, 48, 56, 48, 34, 18};
+    std::vector<unsigned> band(6 * 64 * 4, 0u);
+    for (int set = 0; set < 6; ++set)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 16; ++j) {
+          const int m = lane & 15, gq = lane >> 4;
+          int idx;
+          if (set < 3) idx = (16 * gq + j) - (16 * set + m) - 2;
+          else idx = (j >> 2) < 3 ? (16 * (j >> 2) + 4 * gq + (j & 3)) - (16 * (set - 3) + m) : -1;
+          const unsigned v = (idx >= 0 && idx <= 6) ? (unsigned)tap[idx] : 0u;
+          band[((size_t)set * 64 + lane) * 4 + (j >> 2)] |= v << (8 * (j & 3));
+        }
+    ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_blur_band), band.data(), band.size() * sizeof(unsigned)));
+  }
   h->geom = g;
   h->geom_w = w;
   h->geom_h = h_px;
@@ -1544,7 +1777,8 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
   const int nl = g.n_levels;
   const size_t n_il = (size_t)n_images * nl;
   if (int rc = orbx_reserve(h, h->ws_pyr, (size_t)g.slot_bytes * n_images)) return rc;
-  if (int rc = orbx_reserve(h, h->ws_blur, (size_t)g.slot_bytes * n_images)) return rc;
+  static const bool unfused_ws = getenv("ORBX_DESC_UNFUSED") != nullptr;
+  if (unfused_ws) { if (int rc = orbx_reserve(h, h->ws_blur, (size_t)g.slot_bytes * n_images)) return rc; }
   if (int rc = orbx_reserve(h, h->ws_cand, sizeof(unsigned) * (size_t)g.cand_total * n_images)) return rc;
   if (int rc = orbx_reserve(h, h->ws_sel, sizeof(unsigned long long) * (size_t)g.cand_total * n_images)) return rc;
   if (int rc = orbx_reserve(h, h->ws_sel2, sizeof(unsigned long long) * (size_t)g.cand_total * n_images)) return rc;
@@ -1572,6 +1806,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
                          g.slot_bytes, g.lv[0].pitch);
       s.l0 = s.pyr; s.l0_img_stride = g.slot_bytes; s.l0_pitch = g.lv[0].pitch;
     }
+    h->last_src = s; h->last_n_images = n;
     unsigned* cc = cand_count + (size_t)img0 * nl;
     unsigned* sc = sel_count + (size_t)img0 * nl;
     unsigned* kp = kept + (size_t)img0 * nl;
@@ -1600,7 +1835,10 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     // second stream (+2-3 % frames/s).  Off by default and never while per-kernel profiling is on: two kernels sharing the
     // chip stretch each other's duration, so per-kernel times (HIP events, rocprof) would describe the overlap instead of
     // the kernels and no longer agree between runs.
-    const bool fork = n >= 16 && !h->profiling && getenv("ORBX_FORK_BLUR") != nullptr;
+    // Round 4: describe_fused_kernel blurs each keypoint's patch itself (matrix pipe): no blurred pyramid, no blur launch.  ORBX_DESC_UNFUSED=1
+    // keeps the two-kernel form (whole-level blur + describe_kernel) for A/B runs; orbx_debug_read_level(which = 1) blurs on demand.
+    static const bool unfused = getenv("ORBX_DESC_UNFUSED") != nullptr;
+    const bool fork = unfused && n >= 16 && !h->profiling && getenv("ORBX_FORK_BLUR") != nullptr;
     if (fork && !h->s_aux) {
       ORBX_HIP(h, hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
       ORBX_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -1610,7 +1848,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
       ORBX_HIP(h, hipEventRecord(h->ev_fork, st));
       ORBX_HIP(h, hipStreamWaitEvent(h->s_aux, h->ev_fork, 0));
     }
-    {
+    if (unfused) {
       ProfScope ps(h, "blur_kernel", fork ? h->s_aux : st, true);
       hipLaunchKernelGGL(blur_kernel, xcd_grid(g.btiles_total, n), dim3(256), 0, fork ? h->s_aux : st, s, g, n, xcd_map(g.btiles_total),
                          tab + h->btile_tab_off);
@@ -1646,9 +1884,14 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     {
       ProfScope ps(h, "describe_kernel", nullptr, true);
       const int blocks_x = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block
-      hipLaunchKernelGGL(describe_kernel, xcd_grid(blocks_x, n), dim3(256), 0, st, s, g, n, xcd_map(blocks_x), blocks_x,
-                         (const unsigned long long*)sel2, (const unsigned long long*)sel, kp, d_kp + (size_t)img0 * cap_kp, d_desc + (size_t)img0 * cap_kp * 32,
-                         d_nkp + img0, cap_kp, (float)h->orb.patch_size, h->d_status);
+      if (unfused)
+        hipLaunchKernelGGL(describe_kernel, xcd_grid(blocks_x, n), dim3(256), 0, st, s, g, n, xcd_map(blocks_x), blocks_x,
+                           (const unsigned long long*)sel2, (const unsigned long long*)sel, kp, d_kp + (size_t)img0 * cap_kp, d_desc + (size_t)img0 * cap_kp * 32,
+                           d_nkp + img0, cap_kp, (float)h->orb.patch_size, h->d_status);
+      else
+        hipLaunchKernelGGL(describe_fused_kernel, xcd_grid(blocks_x, n), dim3(256), 0, st, s, g, n, xcd_map(blocks_x), blocks_x,
+                           (const unsigned long long*)sel2, (const unsigned long long*)sel, kp, d_kp + (size_t)img0 * cap_kp, d_desc + (size_t)img0 * cap_kp * 32,
+                           d_nkp + img0, cap_kp, (float)h->orb.patch_size, h->d_status);
     }
     return ORBX_OK;
   };
@@ -1674,6 +1917,18 @@ extern "C" int orbx_debug_read_level(orbx_handle* h, int image_index, int level,
   if (which == 0 && level == 0) return orbx_fail(h, ORBX_ERR_INVALID, "level 0 is the caller's image");
   ORBX_HIP(h, hipSetDevice(h->device));
   ORBX_HIP(h, hipStreamSynchronize(h->stream));
+  if (which == 1) {
+    // the blurred level as oracle/orb_ref.cpp:119-133 defines it, made here by the whole-level blur kernel (the product path blurs each
+    // keypoint's patch inside describe_fused_kernel and keeps no blurred pyramid): same integers, so the descriptors' inputs can be inspected
+    if (image_index >= h->last_n_images) return orbx_fail(h, ORBX_ERR_INVALID, "image index out of range");
+    if (int rc = orbx_reserve(h, h->ws_blur, (size_t)g.slot_bytes * h->last_n_images)) return rc;
+    OrbSrc sb = h->last_src;
+    sb.blur = (uint8_t*)h->ws_blur.p;
+    hipLaunchKernelGGL(blur_kernel, xcd_grid(g.btiles_total, h->last_n_images), dim3(256), 0, h->stream, sb, g, h->last_n_images, xcd_map(g.btiles_total),
+                       (const unsigned*)h->resize_tab.p + h->btile_tab_off);
+    ORBX_HIP(h, hipStreamSynchronize(h->stream));
+    ORBX_HIP(h, hipGetLastError());
+  }
   const DevBuf& b = which ? h->ws_blur : h->ws_pyr;
   if ((size_t)(image_index + 1) * g.slot_bytes > b.bytes) return orbx_fail(h, ORBX_ERR_INVALID, "image index out of range");
   const uint8_t* src = (const uint8_t*)b.p + (size_t)image_index * g.slot_bytes + g.lv[level].off;

@@ -842,6 +842,8 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;            // (optional: only orbx_ba_rccl_world asks)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   char err[256] = {0};
 };
 RcclApi g_rccl_api;
@@ -860,6 +862,8 @@ RcclApi* rccl_api() {
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+    api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
       snprintf(api.err, sizeof(api.err), "librccl: a collective entry point is missing");
       api.lib = nullptr;
@@ -918,6 +922,18 @@ int orbx_ba_has_collective(orbx_handle* h) {
   return (h->rccl_comm ? 1 : 0) | (h->allreduce ? 2 : 0);
 }
 
+int orbx_ba_rccl_world(orbx_handle* h, int* n_ranks, int* rank) {
+  if (!h || !n_ranks || !rank) return ORBX_ERR_INVALID;
+  *n_ranks = 0; *rank = -1;
+  if (!h->rccl_comm) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_rccl_world: the handle holds no RCCL communicator");
+  RcclApi* R = rccl_api();
+  if (!R || !R->CommCount || !R->CommUserRank) return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_rccl_world: %s", R ? "librccl has no ncclCommCount" : rccl_why());
+  ncclResult_t r = R->CommCount((ncclComm_t)h->rccl_comm, n_ranks);
+  if (r == ncclSuccess) r = R->CommUserRank((ncclComm_t)h->rccl_comm, rank);
+  if (r != ncclSuccess) return orbx_fail(h, ORBX_ERR_HIP, "ncclCommCount failed: %s", R->GetErrorString(r));
+  return ORBX_OK;
+}
+
 }  // extern "C"
 int orbx_rccl_allreduce_sum(orbx_handle* h, double* d_buf, size_t n, hipStream_t st) {
   RcclApi* R = rccl_api();
@@ -940,8 +956,14 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
     return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual: bad argument");
   ORBX_HIP(h, hipSetDevice(h->device));
   orbx_prof_begin_call(h);
-  return ba_solve_visual(h, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, should_stop, user,
-                         poses_wc_out, iterations, initial_error, final_error);
+  try {
+    return ba_solve_visual(h, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, obs, should_stop, user,
+                           poses_wc_out, iterations, initial_error, final_error);
+  } catch (const std::bad_alloc&) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual: out of host memory");
+  } catch (...) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual: unexpected C++ exception");
+  }
 }
 
 int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int n_windows,
@@ -997,7 +1019,12 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
       const int half_cores = std::max(1, (int)std::thread::hardware_concurrency() / 2);
       h->ba_pool_cap = half_cores; h->ba_aux->ba_pool_cap = half_cores;
       h->ba_peer_windows = n_windows - n0; h->ba_aux->ba_peer_windows = n0;
-      struct Uncap { orbx_handle* h; ~Uncap() { h->ba_pool_cap = 0; h->ba_aux->ba_pool_cap = 0; h->ba_peer_windows = 0; h->ba_aux->ba_peer_windows = 0; } } uncap{h};
+      // one PCIe link: the second half's uploads go behind the first half's (orbx_internal.hpp: ba_gate_*)
+      std::atomic<int> gate{0};
+      if (!h->ba_up_event && hipEventCreateWithFlags(&h->ba_up_event, hipEventDisableTiming) != hipSuccess) h->ba_up_event = nullptr;
+      h->ba_gate_signal = &gate; h->ba_aux->ba_gate_wait = &gate; h->ba_aux->ba_gate_event = h->ba_up_event;
+      struct Uncap { orbx_handle* h; ~Uncap() { h->ba_pool_cap = 0; h->ba_aux->ba_pool_cap = 0; h->ba_peer_windows = 0; h->ba_aux->ba_peer_windows = 0;
+                                                h->ba_gate_signal = nullptr; h->ba_aux->ba_gate_wait = nullptr; h->ba_aux->ba_gate_event = nullptr; } } uncap{h};
       try {
         std::thread helper([&] {
           hipSetDevice(h->device);
@@ -1007,8 +1034,10 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
         helper_ran = true;
         try { rc = ba_solve_batch(h, cam, cfg, n0, w.data(), nullptr, nullptr); }
         catch (...) { rc = orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_batch: out of host memory"); }
+        gate.store(1, std::memory_order_release);                              // (however the first half ended, the second must not wait for it)
         helper.join();
       } catch (const std::system_error&) {                                  // no thread: both halves here, one after the other
+        h->ba_gate_signal = nullptr;
         if (!helper_ran) rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), nullptr, nullptr);
         else rc = orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_batch: helper thread failed");
       }
@@ -1067,8 +1096,14 @@ int orbx_ba_solve_inertial(orbx_handle* h, const orbx_camera* cam, const orbx_in
   orbx_prof_begin_call(h);
   orbx_ba_config vc{cfg->max_iterations, 0.0, 1e-8, cfg->huber_threshold_mono, 0};
   BaInertialHost in{cfg, velocities, biases, E, edge_kf, preint, vel_out, bias_out};
-  return ba_solve_visual(h, cam, &vc, K, poses_wc, F, fixed_poses_cw, M, points, N, obs, should_stop, user, poses_wc_out, iterations,
-                         initial_error, final_error, false, &in);
+  try {
+    return ba_solve_visual(h, cam, &vc, K, poses_wc, F, fixed_poses_cw, M, points, N, obs, should_stop, user, poses_wc_out, iterations,
+                           initial_error, final_error, false, &in);
+  } catch (const std::bad_alloc&) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_inertial: out of host memory");
+  } catch (...) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_inertial: unexpected C++ exception");
+  }
 }
 
 int orbx_ba_solve_global(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw,
@@ -1083,8 +1118,14 @@ int orbx_ba_solve_global(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
   if (K < 1 || M == 0) return orbx_fail(h, ORBX_ERR_EMPTY, "global BA needs two keyframes and a map point");   // global_ba.rs:194-196
   ORBX_HIP(h, hipSetDevice(h->device));
   orbx_prof_begin_call(h);
-  return ba_solve_visual(h, cam, cfg, K, poses_cw, 1, fixed_pose_cw, M, points, N, obs, should_stop, user, poses_wc_out,
-                         iterations, initial_error, final_error, true);
+  try {
+    return ba_solve_visual(h, cam, cfg, K, poses_cw, 1, fixed_pose_cw, M, points, N, obs, should_stop, user, poses_wc_out,
+                           iterations, initial_error, final_error, true);
+  } catch (const std::bad_alloc&) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_global: out of host memory");
+  } catch (...) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_global: unexpected C++ exception");
+  }
 }
 
 }  // extern "C"

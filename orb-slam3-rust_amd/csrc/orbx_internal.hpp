@@ -149,6 +149,8 @@ struct orbx_handle {
   DevBuf resize_tab;                     // per level l>=1: xtab[w_l], ytab[h_l] packed (ofs<<16 | c1)
   std::vector<unsigned> resize_tab_off;  // element offsets: [2*l] x table, [2*l+1] y table
   unsigned btile_tab_off = 0, ftile_tab_off = 0;   // tile -> (level, tx, ty) tables of the blur / FAST launches, same buffer
+  OrbSrc last_src{};                               // where the level images of the last extraction live, and how many images it held:
+  int last_n_images = 0;                           // orbx_debug_read_level(which = 1) blurs them on demand (the product path keeps no blurred pyramid)
   // grow-only workspaces
   DevBuf ws_pyr, ws_blur, ws_cand, ws_counters, ws_sel, ws_sel2, ws_match, ws_io[12];
   DevBuf ws_ba[28];
@@ -171,6 +173,13 @@ struct orbx_handle {
   OrbxWorkPool* ba_pool = nullptr;                         // host workers of the batch preprocessing (created by the first large batch)
   int ba_pool_cap = 0;                                     // > 0: at most this many threads for the next preprocessing (two halves share the cores)
   int ba_peer_windows = 0;                                 // windows of the other half of a batch, solved at the same time on the peer handle's stream (launch-shape heuristics count them)
+  // the two halves of a batch share one PCIe link: the second half's uploads are ordered behind the first half's (its kernels then start
+  // as early as they can, and the second half's bytes travel under them).  The first half records ba_up_event on its stream once its
+  // uploads are enqueued and sets *ba_gate_signal; the second half waits for *ba_gate_wait, then makes its stream wait for ba_gate_event.
+  hipEvent_t ba_up_event = nullptr;
+  std::atomic<int>* ba_gate_signal = nullptr;
+  std::atomic<int>* ba_gate_wait = nullptr;
+  hipEvent_t ba_gate_event = nullptr;
   // profiling
   bool profiling = false;
   std::vector<KernelTimer> timers;

@@ -437,3 +437,34 @@ def inertial_window(seed, K, M, obs_dtype, n_fixed=2, dt=0.25, w=752, h=480, cam
     return dict(poses_wc=poses, velocities=vel, biases=bias, fixed_cw=np.array(fixed_cw).reshape(-1, 7), points=pts + rng.normal(0, 0.03, (M, 3)),
                 obs=obs, edge_kf=np.array(edge_kf, np.int32).reshape(-1, 2), preint=np.array(preint).reshape(-1, 11), camera=cam,
                 gt_poses_wc=gt_poses, gt_velocities=gt_vel, gt_points=pts)
+
+
+def write_ba_batch_file(path, windows, obs_dtype):
+    """`windows` (dicts of ba_window) in the layout tests/cpp/ba_batch_driver.cpp reads: int32 W, then per window int32 K, F, M, N |
+    poses_cw [K][7] | fixed_cw [F][7] | points [M][3] | obs [N] (orbx_ba_obs)."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(windows)))
+        for w in windows:
+            poses = np.ascontiguousarray(w["poses_cw"], np.float64).reshape(-1, 7)
+            fixed = np.ascontiguousarray(w["fixed_cw"], np.float64).reshape(-1, 7)
+            pts = np.ascontiguousarray(w["points"], np.float64).reshape(-1, 3)
+            obs = np.ascontiguousarray(w["obs"], obs_dtype)
+            f.write(struct.pack("<iiii", len(poses), len(fixed), len(pts), len(obs)))
+            for a in (poses, fixed, pts, obs):
+                f.write(a.tobytes())
+
+
+def read_ba_batch_results(path, windows):
+    """out.bin of tests/cpp/ba_batch_driver.cpp -> list of dicts (status, iterations, initial_error, final_error, poses_wc, points)."""
+    import struct
+    out = []
+    with open(path, "rb") as f:
+        for w in windows:
+            K = len(np.asarray(w["poses_cw"]).reshape(-1, 7)); M = len(np.asarray(w["points"]).reshape(-1, 3))
+            status, iters = struct.unpack("<ii", f.read(8))
+            e0, e1 = struct.unpack("<dd", f.read(16))
+            poses = np.frombuffer(f.read(56 * K), np.float64).reshape(K, 7)
+            pts = np.frombuffer(f.read(24 * M), np.float64).reshape(M, 3)
+            out.append(dict(status=status, iterations=iters, initial_error=e0, final_error=e1, poses_wc=poses, points=pts))
+    return out

@@ -10,16 +10,18 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 cam = P.CameraModel(**P.synth.EUROC_CAMERA)
 h = P.Handle(cam, 100)
-wins = [P.synth.ba_window(200 + i, K, M, P.BA_OBS) for i in range(W)]
+pageable = [P.synth.ba_window(200 + i, K, M, P.BA_OBS) for i in range(W)]
+wins = P.Handle.pack_ba_windows(pageable)          # the observations of all windows in one page-locked buffer (orbx.h)
 cfg = P.LocalBAConfigLM()
-h.ba_solve_visual_batch(cam, cfg, wins)
-t0 = time.perf_counter()
-reps = 3
-its = 0
-for _ in range(reps):
-    its += sum(r["iterations"] for r in h.ba_solve_visual_batch(cam, cfg, wins))
-dt = time.perf_counter() - t0
-print("%d windows (K=%d, M=%d, %d observations each): %.3f ms per call, %.0f LM iterations/s" % (W, K, M, len(wins[0]["obs"]), dt / reps * 1e3, its / dt))
+reps = int(os.environ.get("ORBX_PROFILE_REPS", "3"))
+for name, ws in (("pinned, one buffer", wins), ("pageable", pageable)):
+    h.ba_solve_visual_batch(cam, cfg, ws)
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(reps):
+        its += sum(r["iterations"] for r in h.ba_solve_visual_batch(cam, cfg, ws))
+    dt = time.perf_counter() - t0
+    print("%d windows (K=%d, M=%d, %d observations each; observations %s): %.3f ms per call, %.0f LM iterations/s" % (W, K, M, len(ws[0]["obs"]), name, dt / reps * 1e3, its / dt))
 if len(sys.argv) > 4 and sys.argv[4] == "kernels":     # per-kernel HIP-event times of one more call (one stream)
     h.set_profiling(True)
     h.ba_solve_visual_batch(cam, cfg, wins)

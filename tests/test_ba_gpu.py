@@ -244,16 +244,29 @@ def test_ba_allreduce_hook_rccl_world1(gpu_handle, pkg):
 
 
 def test_ba_config5_size(gpu_handle, oracle, pkg):
-    """BASELINE configs[4]: 50 keyframes / 8000 points (n = 294: global-memory factorisation, 19x19 MFMA tiles).
-    Three LM iterations keep the CPU oracle's share of the test short."""
+    """BASELINE configs[4]: 50 keyframes / 8000 points (n = 294: one-launch global-memory factorisation, multi-block Schur product on
+    19 x 19 MFMA tiles) over the metric's own loop — LocalBAConfigLM::default(), 10 LM iterations (local_ba_lm.rs:1012-1056): iteration
+    count, the accept / reject outcome of every iteration (through the error trace's end points), final error and every pose / point
+    against the structured oracle (about 0.12 s of CPU per oracle iteration)."""
     w = pkg.synth.ba_window(43, 50, 8000, pkg.BA_OBS)
     cam = pkg.CameraModel(**w["camera"]); ocam = oracle.Camera(**w["camera"])
-    cfg = pkg.LocalBAConfigLM(max_iterations=3); ocfg = oracle.ba_config(); ocfg.max_iterations = 3
+    cfg = pkg.LocalBAConfigLM(); ocfg = oracle.ba_config()
+    assert cfg.max_iterations == ocfg.max_iterations == 10
     g = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
     o = oracle.ba_solve_schur(ocam, ocfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
-    assert g["iterations"] == o["iterations"] == 3 and len(w["obs"]) > 150000
+    assert g["iterations"] == o["iterations"] == 10 and len(w["obs"]) > 150000
+    assert abs(g["initial_error"] - o["initial_error"]) < 1e-12 * o["initial_error"]
     assert abs(g["final_error"] - o["final_error"]) < 1e-8 * o["final_error"]
     assert _rel(g["poses_wc"], o["poses_wc"]) < POSE_TOL and _rel(g["points"], o["points"]) < POSE_TOL
+    # every prefix of the loop too: the state after 3 and after 7 iterations (an accept / reject decision that differed at iteration
+    # i would leave a different lambda, hence different poses, in every later prefix)
+    for it in (3, 7):
+        cfg_i = pkg.LocalBAConfigLM(max_iterations=it); ocfg_i = oracle.ba_config(); ocfg_i.max_iterations = it
+        gi = gpu_handle.ba_solve_visual(cam, cfg_i, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+        oi = oracle.ba_solve_schur(ocam, ocfg_i, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+        assert gi["iterations"] == oi["iterations"] == it
+        assert abs(gi["final_error"] - oi["final_error"]) < 1e-8 * oi["final_error"], it
+        assert _rel(gi["poses_wc"], oi["poses_wc"]) < POSE_TOL and _rel(gi["points"], oi["points"]) < POSE_TOL, it
 
 
 def test_ba_batch_equals_single_bit_for_bit(gpu_handle, pkg):
@@ -335,6 +348,68 @@ def test_ba_batch_two_streams_path(gpu_handle, pkg):
     # and the handle still works afterwards
     again = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
     assert np.array_equal(again[17]["poses_wc"], batch[17]["poses_wc"])
+
+
+def test_ba_observations_from_pinned_memory_equal_staged(gpu_handle, pkg):
+    """The observation CSR is built on the device from the observations as handed over (ba_prep_*_kernel).  Windows whose `obs` arrays are
+    consecutive slices of one page-locked buffer are read by the copy engine where they lie, one copy per half (Handle.pack_ba_windows);
+    pageable arrays go through the handle's pinned staging blob.  Both, and the single-window entry point (one pinned, one pageable), give
+    the same bits — 18 windows (two streams), mixed sizes, a window the reference answers None for, points seen twice by one keyframe."""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
+    shapes = [(20, 1200), (6, 150), (12, 400), (3, 40), (25, 600), (9, 333)]
+    wins = [pkg.synth.ba_window(2100 + i, *shapes[i % len(shapes)], pkg.BA_OBS, n_fixed_extra=i % 3) for i in range(18)]
+    dup = wins[4]["obs"][:50].copy(); dup["u"] += 0.25                      # 50 (point, keyframe) pairs observed twice
+    wins[4] = dict(wins[4]); wins[4]["obs"] = np.concatenate([wins[4]["obs"], dup])
+    empty = dict(wins[11]); empty["obs"] = wins[11]["obs"][:0]
+    wins[11] = empty
+    packed = pkg.Handle.pack_ba_windows(wins)
+    full = [p for p in packed if len(p["obs"])]                            # (the address of an empty slice says nothing)
+    assert all(p["obs"].ctypes.data + p["obs"].nbytes == q["obs"].ctypes.data for p, q in zip(full[:-1], full[1:]))
+    a = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
+    b = gpu_handle.ba_solve_visual_batch(cam, cfg, packed)
+    assert a[11] is None and b[11] is None
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x is None:
+            continue
+        assert x["iterations"] == y["iterations"] and x["final_error"] == y["final_error"], i
+        assert np.array_equal(x["poses_wc"], y["poses_wc"]) and np.array_equal(x["points"], y["points"]), i
+    for i in (0, 4, 17):
+        for w in (wins[i], packed[i]):
+            s = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+            assert np.array_equal(s["poses_wc"], a[i]["poses_wc"]) and np.array_equal(s["points"], a[i]["points"]), i
+    # an index out of range inside pinned memory is found by the device-side check and named
+    o = packed[15]["obs"]; keep = int(o["mp_idx"][7]); o["mp_idx"][7] = len(packed[15]["points"]) + 3
+    with pytest.raises(pkg.OrbxError) as e:
+        gpu_handle.ba_solve_visual_batch(cam, cfg, packed)
+    assert "out of range" in str(e.value) and "observation 7" in str(e.value)
+    o["mp_idx"][7] = keep
+    again = gpu_handle.ba_solve_visual_batch(cam, cfg, packed)
+    assert np.array_equal(again[17]["points"], a[17]["points"])
+
+
+def test_ba_batch_through_the_c_abi_from_a_compiled_caller(gpu_handle, pkg, tmp_path):
+    """tests/cpp/ba_batch_driver.cpp: orbx_ba_solve_visual_batch called from C++ with no Python in the process — observations in one
+    orbx_host_alloc buffer, and again in pageable memory — returns what the Python mirror returns, bit for bit (20 windows: two streams)."""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "orb-slam3-rust_amd")
+    exe = str(tmp_path / "ba_batch_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "ba_batch_driver.cpp"),
+                    "-o", exe, "-L", libdir, "-lorbx_hip", "-Wl,-rpath," + libdir], check=True)
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA); cfg = pkg.LocalBAConfigLM()
+    shapes = [(20, 900), (7, 200), (14, 500), (4, 60)]
+    wins = [pkg.synth.ba_window(2300 + i, *shapes[i % 4], pkg.BA_OBS, n_fixed_extra=i % 2) for i in range(20)]
+    want = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
+    pkg.synth.write_ba_batch_file(str(tmp_path / "batch.bin"), wins, pkg.BA_OBS)
+    for mode in ("pinned", "pageable"):
+        r = subprocess.run([exe, str(tmp_path / "batch.bin"), str(tmp_path / "out.bin"), "2", mode], check=True, capture_output=True, text=True)
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["windows"] == 20 and line["reps"] == 2 and len(line["ms_per_call"]) == 2
+        got = pkg.synth.read_ba_batch_results(str(tmp_path / "out.bin"), wins)
+        for i, (g, w_) in enumerate(zip(got, want)):
+            assert g["status"] == 0 and g["iterations"] == w_["iterations"], (mode, i)
+            assert g["initial_error"] == w_["initial_error"] and g["final_error"] == w_["final_error"], (mode, i)
+            assert np.array_equal(g["poses_wc"], w_["poses_wc"]) and np.array_equal(g["points"], w_["points"]), (mode, i)
 
 
 def test_ba_large_batch_share_sums_mixed_sizes(gpu_handle, pkg):
@@ -462,6 +537,7 @@ def test_ba_native_rccl_world1(gpu_handle, pkg):
         uid = h.rccl_unique_id()
         assert len(uid) == 128
         h.init_rccl(uid, 0, 1)
+        assert h.rccl_world() == (1, 0)                              # ncclCommCount / ncclCommUserRank of the communicator the library made
         got = pkg.dist.ba_solve_partitioned(h, cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"], 0, 1)
         assert got["iterations"] == ref["iterations"] and got["final_error"] == ref["final_error"]
         assert np.array_equal(got["poses_wc"], ref["poses_wc"])

@@ -1,6 +1,7 @@
 """The host side of local BA: collect_visual_ba_data (local_ba_lm.rs:665-726, :800-897),
-apply_visual_ba_results (:1112-1138) and the three-phase driver LocalMapper::local_bundle_adjustment
-(local_mapper.rs:334-410), as host code over FLAT arrays — include/orbx_map.hpp (C++, compiled here) and api.MapSnapshot
+apply_visual_ba_results (:1112-1138), their inertial counterparts collect_inertial_ba_data / apply_inertial_ba_results
+(local_inertial_ba.rs:366-429, :933-1072, :1289-1330) and the three-phase driver LocalMapper::local_bundle_adjustment with its
+is_imu_initialized switch (local_mapper.rs:334-410), as host code over FLAT arrays — include/orbx_map.hpp (C++, compiled here) and api.MapSnapshot
 (Python) — against the line-by-line restatement over a dict-based Map in oracle/local_mapper_ref.py.
 
 CPU: phases 1 and 3 on random maps with bad / deleted keyframes and map points, dangling ids, features without a
@@ -42,7 +43,14 @@ def random_map(seed, n_kf=14, n_mp=120, feats=40, damage=True):
                 mps.append(int(rng.choice(mp_ids)))
         n_kp = n - (2 if damage and i % 5 == 0 else 0)      # fewer keypoints than map_point_ids: keypoints.get() fails
         kps = [(float(np.float32(rng.uniform(0, 752))), float(np.float32(rng.uniform(0, 480)))) for _ in range(n_kp)]
-        m.keyframes[kid] = R.KeyFrame(pose=pose, keypoints=kps, map_point_ids=mps, is_bad=damage and i in (3, 9))
+        pre = None
+        if i > 0 and not (damage and i == 6):                # keyframe 6 has no preintegration: no edge into it
+            dq = rng.normal(0, 1, 4) * [1, 0.02, 0.02, 0.02]; dq /= np.linalg.norm(dq)
+            pre = np.concatenate([dq, rng.normal(0, 0.3, 3), rng.normal(0, 0.1, 3), [0.0 if damage and i == 11 else 0.25]])   # dt = 0: dropped (:1040)
+        m.keyframes[kid] = R.KeyFrame(pose=pose, keypoints=kps, map_point_ids=mps, is_bad=damage and i in (3, 9),
+                                      prev_kf=(kf_ids[i - 1] if i > 0 else None) if not (damage and i == 2) else 555555,   # a chain that runs into a deleted keyframe
+                                      velocity=rng.normal(0, 1, 3), imu_bias=rng.normal(0, 0.01, 6), imu_preintegrated=pre,
+                                      points_cam=[bool(rng.random() < 0.5) for _ in range(n_kp)])
     for kid, kf in m.keyframes.items():                     # observer lists (insertion order = the stated order)
         for f, mid in enumerate(kf.map_point_ids):
             if mid is not None and mid in m.map_points:
@@ -76,10 +84,21 @@ def snapshot_of(pkg, m):
         feat_start.append(len(feat_mp)); nkp.append(len(kf.keypoints))
         cov.extend(kf.covisibility_weights.keys()); cov_start.append(len(cov))
     mp_ids = list(m.map_points)
-    obs_start = [0]; obs = []
+    obs_start = [0]; obs = []; obs_feat = []
     for mid in mp_ids:
-        obs.extend(m.map_points[mid].observations.keys()); obs_start.append(len(obs))
-    return pkg.MapSnapshot(kf_ids=kf_ids, kf_bad=[m.keyframes[k].is_bad for k in kf_ids],
+        obs.extend(m.map_points[mid].observations.keys()); obs_feat.extend(m.map_points[mid].observations.values()); obs_start.append(len(obs))
+    feat_stereo = []
+    for kid in kf_ids:
+        kf = m.keyframes[kid]
+        feat_stereo.extend(bool(kf.points_cam[f]) if f < len(kf.points_cam) else False for f in range(len(kf.map_point_ids)))
+    z11 = np.zeros(11)
+    return pkg.MapSnapshot(imu_initialized=m.imu_initialized,
+                           kf_prev_id=[-1 if m.keyframes[k].prev_kf is None else m.keyframes[k].prev_kf for k in kf_ids],
+                           kf_velocity=[m.keyframes[k].velocity for k in kf_ids] or np.zeros((0, 3)), kf_bias=[m.keyframes[k].imu_bias for k in kf_ids] or np.zeros((0, 6)),
+                           kf_has_preint=[m.keyframes[k].imu_preintegrated is not None for k in kf_ids],
+                           kf_preint=[z11 if m.keyframes[k].imu_preintegrated is None else m.keyframes[k].imu_preintegrated for k in kf_ids] or np.zeros((0, 11)),
+                           feat_stereo=feat_stereo, mp_obs_feat_idx=obs_feat,
+                           kf_ids=kf_ids, kf_bad=[m.keyframes[k].is_bad for k in kf_ids],
                            kf_pose_wc=[m.keyframes[k].pose for k in kf_ids], kf_n_keypoints=nkp, kf_feat_start=feat_start,
                            feat_mp_id=feat_mp, feat_uv=np.array(feat_uv, np.float32).reshape(-1, 2), cov_start=cov_start, cov_kf_id=cov,
                            mp_ids=mp_ids, mp_bad=[m.map_points[k].is_bad for k in mp_ids],
@@ -140,6 +159,62 @@ def test_apply_skips_deleted_and_bad(pkg):
     assert got == want == n_ok and n_ok < 68
     for i, k in enumerate(snap.kf_ids):
         assert np.array_equal(snap.kf_pose_wc[i], m.keyframes[int(k)].pose)
+    for i, j in enumerate(snap.mp_ids):
+        assert np.array_equal(snap.mp_pos[i], m.map_points[int(j)].position)
+
+
+def inertial_problems_equal(o, p):
+    """oracle dict problem vs api.InertialBAProblemData, bit for bit"""
+    if o is None or p is None:
+        return o is None and p is None
+    ok = o["opt_kf_ids"] == list(p.opt_kf_ids) and o["mp_ids"] == list(p.mp_ids) and len(o["visual_observations"]) == len(p.visual_observations)
+    for a, b in zip(o["visual_observations"], p.visual_observations):
+        ok = ok and (a["kf_id"], a["mp_id"], a["uv"], a["is_stereo"], a["is_kf_in_window"]) == (b.kf_id, b.mp_id, tuple(b.observed_uv), b.is_stereo, b.is_kf_in_window)
+    ok = ok and len(o["imu_edges"]) == len(p.imu_edges)
+    for a, b in zip(o["imu_edges"], p.imu_edges):
+        ok = ok and (a["kf_i_id"], a["kf_j_id"]) == (b.kf_i_id, b.kf_j_id) and np.asarray(a["preint"]).tobytes() == np.asarray(b.preint, np.float64).tobytes()
+    for name in ("kf_poses", "kf_velocities", "kf_biases", "fixed_kf_poses", "mp_positions"):
+        A, B = o[name], getattr(p, name)
+        ok = ok and set(A) == set(B) and all(np.asarray(A[k]).tobytes() == np.asarray(B[k], np.float64).tobytes() for k in A)
+    return ok
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_inertial_collect_matches_reference_restatement(pkg, seed):
+    """collect_inertial_ba_data (local_inertial_ba.rs:933-1072): the temporal chain through prev_kf (a chain that ends at a deleted
+    keyframe, windows shorter than the chain), fixed observers that must exist and not be bad (:419-423), stereo flags from points_cam,
+    the anchor's observations marked not-in-window, IMU edges only where a preintegration with dt > 0 exists."""
+    m, kf_ids, _ = random_map(seed)
+    snap = snapshot_of(pkg, m)
+    hit = 0
+    for cur in kf_ids + [424242]:
+        for window in (10, 4, 2, 1):
+            o = R.collect_inertial_ba_data(m, cur, window)
+            p = snap.collect_inertial_ba_data(cur, pkg.LocalInertialBAConfig(window_size=window))
+            assert inertial_problems_equal(o, p), (cur, window)
+            hit += o is not None
+    assert hit > 15
+    o = R.collect_inertial_ba_data(m, kf_ids[-1], 10)
+    assert o["opt_kf_ids"][-1] == kf_ids[-1] and len(o["opt_kf_ids"]) == 10 and len(o["imu_edges"]) < 9     # (no preintegration into one keyframe, dt = 0 into another)
+    assert all(not v["is_kf_in_window"] for v in o["visual_observations"] if v["kf_id"] == o["opt_kf_ids"][0])
+    assert R.collect_inertial_ba_data(m, kf_ids[0], 10) is None                                              # a chain of one: fewer than 2 keyframes (:940)
+
+
+def test_inertial_apply_skips_deleted_and_bad(pkg):
+    m, kf_ids, mp_ids = random_map(9)
+    snap = snapshot_of(pkg, m)
+    rng = np.random.default_rng(2)
+    ks = kf_ids[:8] + [123456789]
+    poses = {k: np.concatenate([[1.0, 0, 0, 0], rng.normal(0, 1, 3)]) for k in ks}
+    vels = {k: rng.normal(0, 1, 3) for k in ks}; biases = {k: rng.normal(0, 1, 6) for k in ks}
+    points = {j: rng.normal(0, 1, 3) for j in mp_ids[:60] + [987654321]}
+    want = R.apply_inertial_ba_results(m, poses, vels, biases, points)
+    got = snap.apply_inertial_ba_results(pkg.InertialBAResultData(poses, vels, biases, points, 3, 1.0, 0.5))
+    n_ok = sum(not m.keyframes[k].is_bad for k in kf_ids[:8]) + sum(not m.map_points[j].is_bad for j in mp_ids[:60])
+    assert got == want == n_ok                                     # poses and points count; velocities and biases are written, not counted
+    for i, k in enumerate(snap.kf_ids):
+        kf = m.keyframes[int(k)]
+        assert np.array_equal(snap.kf_pose_wc[i], kf.pose) and np.array_equal(snap.kf_velocity[i], kf.velocity) and np.array_equal(snap.kf_bias[i], kf.imu_bias)
     for i, j in enumerate(snap.mp_ids):
         assert np.array_equal(snap.mp_pos[i], m.map_points[int(j)].position)
 
@@ -221,6 +296,160 @@ def test_cpp_collect_and_apply_match_restatement(pkg, tmp_path):
         assert all(np.array_equal(mp_pos[i], m.map_points[int(j)].position) for i, j in enumerate(snap.mp_ids))
 
 
+def _read_inertial_problem(b):
+    some, = struct.unpack_from("<Q", b, 0)
+    if not some:
+        return None
+    nk, nm, no, ne, nf = struct.unpack_from("<5Q", b, 8)
+    off = 48
+    opt = [int(x) for x in np.frombuffer(b, np.uint64, nk, off)]; off += 8 * nk
+    mps = [int(x) for x in np.frombuffer(b, np.uint64, nm, off)]; off += 8 * nm
+    obs = []
+    for _ in range(no):
+        kid, mid, st, inw = struct.unpack_from("<4Q", b, off); u, v = struct.unpack_from("<2d", b, off + 32); off += 48
+        obs.append((kid, mid, (u, v), bool(st), bool(inw)))
+    edges = []
+    for _ in range(ne):
+        ki, kj = struct.unpack_from("<2Q", b, off); pre = np.frombuffer(b, np.float64, 11, off + 16).copy(); off += 104
+        edges.append((ki, kj, pre))
+    poses, vels, biases = {}, {}, {}
+    for kid in opt:
+        present, = struct.unpack_from("<Q", b, off); v = np.frombuffer(b, np.float64, 16, off + 8).copy(); off += 136
+        if present:
+            poses[kid], vels[kid], biases[kid] = v[:7], v[7:10], v[10:16]
+    fixed = {}
+    for _ in range(nf):
+        kid, = struct.unpack_from("<Q", b, off); fixed[kid] = np.frombuffer(b, np.float64, 7, off + 8).copy(); off += 64
+    pts = {}
+    for mid in mps:
+        present, = struct.unpack_from("<Q", b, off); p = np.frombuffer(b, np.float64, 3, off + 8).copy(); off += 32
+        if present:
+            pts[mid] = p
+    return dict(opt=opt, mps=mps, obs=obs, edges=edges, poses=poses, vels=vels, biases=biases, fixed=fixed, pts=pts)
+
+
+def test_cpp_inertial_collect_and_apply_match_restatement(pkg, tmp_path):
+    """The inertial phases 1 and 3 of include/orbx_map.hpp, compiled with g++, against the restatement."""
+    pkg.load_library()
+    tmp = str(tmp_path)
+    exe = _build(tmp)
+    m, kf_ids, mp_ids = random_map(2)
+    snap = snapshot_of(pkg, m)
+    open(os.path.join(tmp, "snap.bin"), "wb").write(snap.to_bytes())
+    for cur, window in ((kf_ids[-1], 10), (kf_ids[8], 4), (kf_ids[5], 10), (kf_ids[0], 10), (424242, 10)):
+        subprocess.run([exe, "icollect", os.path.join(tmp, "snap.bin"), str(cur), str(window), os.path.join(tmp, "iprob.bin")], check=True)
+        got = _read_inertial_problem(open(os.path.join(tmp, "iprob.bin"), "rb").read())
+        o = R.collect_inertial_ba_data(m, cur, window)
+        assert (got is None) == (o is None), (cur, window)
+        if o is None:
+            continue
+        assert got["opt"] == o["opt_kf_ids"] and got["mps"] == o["mp_ids"]
+        assert got["obs"] == [(a["kf_id"], a["mp_id"], a["uv"], a["is_stereo"], a["is_kf_in_window"]) for a in o["visual_observations"]]
+        assert [(a, b_) for a, b_, _ in got["edges"]] == [(e["kf_i_id"], e["kf_j_id"]) for e in o["imu_edges"]]
+        assert all(g[2].tobytes() == np.asarray(e["preint"]).tobytes() for g, e in zip(got["edges"], o["imu_edges"]))
+        for name, key in (("poses", "kf_poses"), ("vels", "kf_velocities"), ("biases", "kf_biases"), ("fixed", "fixed_kf_poses"), ("pts", "mp_positions")):
+            assert set(got[name]) == set(o[key]) and all(got[name][k].tobytes() == np.asarray(o[key][k]).tobytes() for k in o[key]), name
+    rng = np.random.default_rng(4)
+    ks = kf_ids[:8] + [123456789]
+    poses = {k: np.concatenate([[1.0, 0, 0, 0], rng.normal(0, 1, 3)]) for k in ks}
+    vels = {k: rng.normal(0, 1, 3) for k in ks}; biases = {k: rng.normal(0, 1, 6) for k in ks}
+    points = {j: rng.normal(0, 1, 3) for j in mp_ids[:60] + [987654321]}
+    with open(os.path.join(tmp, "ires.bin"), "wb") as f:
+        f.write(struct.pack("<2Q", len(poses), len(points)))
+        for k in ks:
+            f.write(struct.pack("<Q", k)); f.write(np.concatenate([poses[k], vels[k], biases[k]]).astype(np.float64).tobytes())
+        for j, p_ in points.items():
+            f.write(struct.pack("<Q", j)); f.write(np.asarray(p_, np.float64).tobytes())
+    subprocess.run([exe, "iapply", os.path.join(tmp, "snap.bin"), os.path.join(tmp, "ires.bin"), os.path.join(tmp, "iapplied.bin")], check=True)
+    b = open(os.path.join(tmp, "iapplied.bin"), "rb").read()
+    updated, = struct.unpack_from("<Q", b, 0)
+    assert updated == R.apply_inertial_ba_results(m, poses, vels, biases, points)
+    nk, nm = len(snap.kf_ids), len(snap.mp_ids)
+    kf_pose = np.frombuffer(b, np.float64, 7 * nk, 8).reshape(-1, 7)
+    mp_pos = np.frombuffer(b, np.float64, 3 * nm, 8 + 56 * nk).reshape(-1, 3)
+    kf_vel = np.frombuffer(b, np.float64, 3 * nk, 8 + 56 * nk + 24 * nm).reshape(-1, 3)
+    kf_bias = np.frombuffer(b, np.float64, 6 * nk, 8 + 56 * nk + 24 * nm + 24 * nk).reshape(-1, 6)
+    for i, k in enumerate(snap.kf_ids):
+        kf = m.keyframes[int(k)]
+        assert np.array_equal(kf_pose[i], kf.pose) and np.array_equal(kf_vel[i], kf.velocity) and np.array_equal(kf_bias[i], kf.imu_bias)
+    assert all(np.array_equal(mp_pos[i], m.map_points[int(j)].position) for i, j in enumerate(snap.mp_ids))
+
+
+def _inertial_map(pkg, seed=3, K=5, M=120, n_fixed=2):
+    """A consistent map out of a synthetic inertial window: keyframe ids 20.. in temporal order — the n_fixed older observers first, not
+    linked into the chain's window (the oldest window keyframe has no prev_kf) — map point ids 700..; every keyframe but the chain's
+    first carries the preintegration from its predecessor; imu_initialized."""
+    w = pkg.synth.inertial_window(seed, K, M, pkg.BA_OBS, n_fixed=n_fixed)
+    inv = pkg.se3_inverse
+    m = R.Map(imu_initialized=True)
+    fixed_ids = [20 + i for i in range(n_fixed)]
+    win_ids = [40 + i for i in range(K)]
+    for i, kid in enumerate(fixed_ids):
+        m.keyframes[kid] = R.KeyFrame(pose=inv(w["fixed_cw"][i]), keypoints=[], map_point_ids=[], points_cam=[])
+    for i, kid in enumerate(win_ids):
+        pre = None
+        for e, (a, b_) in enumerate(w["edge_kf"]):
+            if b_ == i:
+                pre = w["preint"][e].copy()
+        m.keyframes[kid] = R.KeyFrame(pose=w["poses_wc"][i].copy(), keypoints=[], map_point_ids=[], points_cam=[], prev_kf=win_ids[i - 1] if i > 0 else None,
+                                      velocity=w["velocities"][i].copy(), imu_bias=w["biases"][i].copy(), imu_preintegrated=pre)
+    for j in range(M):
+        m.map_points[700 + j] = R.MapPoint(position=w["points"][j].copy())
+    for o in w["obs"]:
+        kid = win_ids[o["kf_idx"]] if o["kf_idx"] >= 0 else fixed_ids[o["fixed_idx"]]
+        kf = m.keyframes[kid]
+        kf.keypoints.append((float(np.float32(o["u"])), float(np.float32(o["v"]))))
+        kf.map_point_ids.append(700 + int(o["mp_idx"]))
+        kf.points_cam.append(bool(o["_pad"] & 1))
+        m.map_points[700 + int(o["mp_idx"])].observations[kid] = len(kf.keypoints) - 1
+    return m, win_ids, w
+
+
+@pytest.mark.gpu
+def test_three_phase_inertial_local_bundle_adjustment(pkg, gpu_handle):
+    """local_mapper.rs:343-375 end to end: with the map's IMU initialised the driver takes the inertial branch — collect the temporal
+    window, solve_inertial_ba on the MI355X, apply iff an iteration ran — against the restatement's driver over the dict Map fed by the
+    same GPU solve; with imu_initialized cleared the same snapshot takes the visual branch."""
+    m, win_ids, w = _inertial_map(pkg)
+    snap = snapshot_of(pkg, m)
+    cam = pkg.CameraModel(**w["camera"])
+    before = (snap.kf_pose_wc.copy(), snap.kf_velocity.copy())
+    updated, res = pkg.local_bundle_adjustment(snap, win_ids[-1], cam, handle=gpu_handle)
+    assert isinstance(res, pkg.InertialBAResultData) and res.iterations > 0
+    n_seen = sum(1 for mp in m.map_points.values() if any(k in win_ids for k in mp.observations))
+    assert updated == len(win_ids) - 1 + n_seen                    # the window's first keyframe is the anchor: not reported, not written
+    a = list(snap.kf_ids).index(win_ids[0])
+    assert np.array_equal(snap.kf_pose_wc[a], before[0][a]) and np.array_equal(snap.kf_velocity[a], before[1][a])
+    moved = [list(snap.kf_ids).index(k) for k in win_ids[1:]]
+    assert all(not np.array_equal(snap.kf_pose_wc[i], before[0][i]) and not np.array_equal(snap.kf_velocity[i], before[1][i]) for i in moved)
+
+    def solve_inertial(problem):
+        p = pkg.InertialBAProblemData(problem["kf_poses"], problem["kf_velocities"], problem["kf_biases"], problem["mp_positions"], problem["fixed_kf_poses"],
+                                      [pkg.InertialVisualObs(o["kf_id"], o["mp_id"], o["uv"], o["is_stereo"], o["is_kf_in_window"]) for o in problem["visual_observations"]],
+                                      [pkg.ImuEdgeData(e["kf_i_id"], e["kf_j_id"], e["preint"]) for e in problem["imu_edges"]], problem["opt_kf_ids"], problem["mp_ids"])
+        r = pkg.solve_inertial_ba(p, cam, pkg.LocalInertialBAConfig(), lambda: False, handle=gpu_handle)
+        return None if r is None else dict(optimized_poses=r.optimized_poses, optimized_velocities=r.optimized_velocities, optimized_biases=r.optimized_biases,
+                                           optimized_points=r.optimized_points, iterations=r.iterations)
+    assert R.local_bundle_adjustment(m, win_ids[-1], None, solve_inertial=solve_inertial) == updated
+    for i, k in enumerate(snap.kf_ids):
+        kf = m.keyframes[int(k)]
+        assert np.array_equal(snap.kf_pose_wc[i], kf.pose) and np.array_equal(snap.kf_velocity[i], kf.velocity) and np.array_equal(snap.kf_bias[i], kf.imu_bias)
+    for i, j in enumerate(snap.mp_ids):
+        assert np.array_equal(snap.mp_pos[i], m.map_points[int(j)].position)
+    # abort before the first iteration: nothing is written (:363)
+    m2, win2, _ = _inertial_map(pkg, seed=4)
+    snap2 = snapshot_of(pkg, m2)
+    b4 = (snap2.kf_pose_wc.copy(), snap2.mp_pos.copy(), snap2.kf_velocity.copy())
+    updated, res = pkg.local_bundle_adjustment(snap2, win2[-1], cam, should_stop=lambda: True, handle=gpu_handle)
+    assert res.iterations == 0 and updated == 0 and all(np.array_equal(x, y) for x, y in zip((snap2.kf_pose_wc, snap2.mp_pos, snap2.kf_velocity), b4))
+    # the oldest keyframe has no predecessor: a window of one -> the reference returns at phase 1 (:940)
+    assert pkg.local_bundle_adjustment(snap2, win2[0], cam, handle=gpu_handle) == (None, None)
+    # IMU not initialised: the same map goes through the visual branch
+    snap2.imu_initialized = False
+    updated, res = pkg.local_bundle_adjustment(snap2, win2[-1], cam, handle=gpu_handle)
+    assert isinstance(res, pkg.VisualBAResultData)
+
+
 def _ba_map(pkg, seed=5, K=7, M=150):
     """A consistent map out of a synthetic BA window: keyframe ids 10.., map point ids 500..; keyframe K-1... the window's
     fixed anchor becomes the CURRENT keyframe (local_kf_ids[0] = anchor, :821), the optimised ones its neighbours."""
@@ -298,7 +527,21 @@ def test_cpp_three_phase_driver(pkg, gpu_handle, tmp_path):
     (updated, iters, rl, wl, polls), kf, mp = run(0)
     py_updated, res = pkg.local_bundle_adjustment(snap, ids[0], pkg.CameraModel(**pkg.synth.EUROC_CAMERA), handle=gpu_handle)
     n_seen = sum(1 for mp in m.map_points.values() if mp.observations)
-    assert updated == py_updated == nk - 1 + n_seen and iters == res.iterations > 0 and rl == 1 and wl == 1
+    assert updated == py_updated == nk - 1 + n_seen and iters == res.iterations > 0 and rl == 2 and wl == 1   # read locks: is_imu_initialized (:338-341), collect
     assert np.array_equal(kf, snap.kf_pose_wc) and np.array_equal(mp, snap.mp_pos)      # C++ and Python drivers: same bytes
     (updated, iters, rl, wl, polls), kf, mp = run(1)                                      # should_stop() true at once
-    assert updated == 0 and iters == 0 and rl == 1 and wl == 0 and polls >= 1
+    assert updated == 0 and iters == 0 and rl == 2 and wl == 0 and polls >= 1
+    # the inertial branch through the compiled driver: same bytes as the Python driver
+    mi, win_ids, wi = _inertial_map(pkg, seed=7)
+    isnap = snapshot_of(pkg, mi)
+    open(os.path.join(tmp, "snap.bin"), "wb").write(isnap.to_bytes())
+    nk, nm = len(isnap.kf_ids), len(isnap.mp_ids)
+    subprocess.run([exe, "lba", os.path.join(tmp, "snap.bin"), str(win_ids[-1]), "0", os.path.join(tmp, "lba.bin")], check=True)
+    b = open(os.path.join(tmp, "lba.bin"), "rb").read()
+    updated, iters, rl, wl, polls = struct.unpack_from("<5q", b, 0)
+    kf = np.frombuffer(b, np.float64, 7 * nk, 56).reshape(-1, 7)
+    mp = np.frombuffer(b, np.float64, 3 * nm, 56 + 56 * nk).reshape(-1, 3)
+    vel = np.frombuffer(b, np.float64, 3 * nk, 56 + 56 * nk + 24 * nm).reshape(-1, 3)
+    py_updated, ires = pkg.local_bundle_adjustment(isnap, win_ids[-1], pkg.CameraModel(**pkg.synth.EUROC_CAMERA), handle=gpu_handle)
+    assert updated == py_updated > 0 and iters == ires.iterations > 0 and rl == 2 and wl == 1
+    assert np.array_equal(kf, isnap.kf_pose_wc) and np.array_equal(mp, isnap.mp_pos) and np.array_equal(vel, isnap.kf_velocity)
