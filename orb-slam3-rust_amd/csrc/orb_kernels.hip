@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(256) void describe_kernel(OrbSrc s, OrbGeom g, int 
 // (0.31 ms per 256 pairs, 1.39 GB of HBM traffic per launch) and the second image per keypoint that the texture addresser had to walk
 // (31 + 37 row segments) are replaced by ONE 43-row window of the unblurred level per keypoint, staged in LDS, from which the kernel
 // takes the intensity centroid and computes the patch's blur itself.  The blur is exact integer arithmetic whichever way it is summed —
-// oracle/orb_ref.cpp:119-133: an 8.8 horizontal pass that fits 16 bits without rounding, a 16.16 vertical pass, ONE rounding
+// the written CPU specification of A.8 (orb_ref.cpp:119-133 of the test checker): an 8.8 horizontal pass that fits 16 bits without rounding, a 16.16 vertical pass, ONE rounding
 // (v + 32768) >> 16 — i.e. blur(y, x) = (sum_ij g_i g_j p(y + i - 3, x + j - 3) + 32768) >> 16, g = {18, 34, 48, 56, 48, 34, 18}.  On the
 // VALU the two passes cost ~9 instructions per patch pixel and the patches of an image overlap 3.3-fold: 0.44 ms of issue slots, more
 // than the kernel it would replace.  On the matrix pipe they are two banded products on v_mfma_i32_16x16x64_i8 per keypoint:
@@ -1744,7 +1744,7 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
   }
   ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_ic_ones), ones, sizeof(ones)));
   ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_ic_col), colw, sizeof(colw)));
-  // tap operands of describe_fused_kernel's two banded products (A.8's taps, oracle/orb_ref.cpp:113), per lane (m = lane & 15, g = lane >> 4):
+  // tap operands of describe_fused_kernel's two banded products (A.8 taps {18, 34, 48, 56, 48, 34, 18}), per lane (m = lane & 15, g = lane >> 4):
   //   sets 0..2  T1 for output-column block nb: byte j of the lane's 16 = tap[c - x - 2], c = 16 g + j (window byte), x = 16 nb + m
   //   sets 3..5  T2 for output-row block mb:    byte j = tap[rho - y], rho = 16 (j >> 2) + 4 g + (j & 3) (the row of H' that k-slot (g, j)
   //              stands for: what lane group g's accumulator registers hold), y = 16 mb + m; k-slots of the fourth register set (rows >= 48): 0
@@ -1918,7 +1918,7 @@ extern "C" int orbx_debug_read_level(orbx_handle* h, int image_index, int level,
   ORBX_HIP(h, hipSetDevice(h->device));
   ORBX_HIP(h, hipStreamSynchronize(h->stream));
   if (which == 1) {
-    // the blurred level as oracle/orb_ref.cpp:119-133 defines it, made here by the whole-level blur kernel (the product path blurs each
+    // the blurred level as the CPU specification of A.8 defines it, made here by the whole-level blur kernel (the product path blurs each
     // keypoint's patch inside describe_fused_kernel and keeps no blurred pyramid): same integers, so the descriptors' inputs can be inspected
     if (image_index >= h->last_n_images) return orbx_fail(h, ORBX_ERR_INVALID, "image index out of range");
     if (int rc = orbx_reserve(h, h->ws_blur, (size_t)g.slot_bytes * h->last_n_images)) return rc;
