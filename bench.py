@@ -265,7 +265,7 @@ def main():
         "fast_kernel": n_img * (sum(px) + 4 * 2 * args.features),          # read every level once, write candidates
         "blur_kernel": n_img * 2 * sum(px),                                # read + write every level
         "resize_kernel": n_img * (sum(px[:-1]) + sum(px[1:])) / 7.0,       # 7 launches: read l-1, write l
-        "describe_kernel": n_img * args.features * (31 * 31 + 37 * 37 + 28 + 32),
+        "describe_kernel": n_img * args.features * (43 * 43 + 28 + 32),  # one 43 x 43 window of the level per keypoint (centroid disc + the 37 x 37 patch's blur support), the keypoint record, the descriptor
         "harris_select_kernel": n_img * 2 * args.features * (81 + 4 + 8),
         "rank_select_kernel": n_img * 2 * args.features * 16,
         "stereo_bucket_kernel": args.batch * args.features * (8 + 12),
@@ -771,13 +771,14 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         # the caller's observation storage: one page-locked buffer (orbx.h: the copy engine then reads it where it lies, one copy per half);
         # the pageable form (the library stages it through its own pinned blob) is timed beside it
         bw = P.Handle.pack_ba_windows(bw_pageable)
-        rb = h.ba_solve_visual_batch(cam, cfg, bw)
-        nrep = 6
+        batch = h.prepare_ba_batch(bw_pageable)      # api.BaBatch: the windows kept in the ABI's own layout, as a host that owns its window storage would
+        rb = batch.solve(cam, cfg)
+        nrep = 8
         # the rate: as a caller sees it (a batch of this size runs as two halves on two streams inside the call, see orbx.h)
         t0 = time.perf_counter()
         itb = 0
         for _ in range(nrep):
-            rb = h.ba_solve_visual_batch(cam, cfg, bw)
+            rb = batch.solve(cam, cfg)
             itb += sum(x["iterations"] for x in rb)
         dtb = time.perf_counter() - t0
         # the per-kernel times: the same calls with the per-kernel events on (the call then keeps to one stream)
@@ -797,11 +798,20 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
                               kernel_ms_per_iteration={k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(kt.items()) if k.startswith("ba_")},
                               schur_executed_TFLOPs=round(flop / (sch_ms * 1e-3) / 1e12, 2) if sch_ms > 0 else None,
                               mfma_frac=round(flop / (sch_ms * 1e-3) / 78.6e12, 4) if sch_ms > 0 else None,
-                              note="orbx_ba_solve_visual_batch through the Python mirror: upload of the caller's observations (one pinned buffer) + device-side CSR "
-                                   "build + 10 LM iterations of all windows + download per call, the batch as two halves on two streams inside the call; device_ms / "
+                              note="orbx_ba_solve_visual_batch on a prepared api.BaBatch (the windows kept in the ABI's layout; per call: refresh of the in/out points, the C "
+                                   "call, result views): upload of the caller's observations (one pinned buffer) + device-side CSR build + 10 LM iterations of all windows + "
+                                   "download per call, the batch as two halves on two streams inside the call; device_ms / "
                                    "kernel_ms from a second set of calls with per-kernel events (one stream); every window equals its single-window result bit for bit "
                                    "(tests/test_ba_gpu.py)")
         out["batched"]["call_vs_device_only"] = round(out["batched"]["lm_iters_per_s"] / out["batched"]["lm_iters_per_s_device_only"], 3) if dev_ms > 0 else None
+        t0 = time.perf_counter()
+        ita = 0
+        for _ in range(nrep):
+            ita += sum(x["iterations"] for x in h.ba_solve_visual_batch(cam, cfg, bw))
+        dta = time.perf_counter() - t0
+        out["batched"]["adhoc_mirror_call"] = dict(lm_iters_per_s=round(ita / dta, 1), ms_per_call=round(dta / nrep * 1e3, 3),
+                                                   note="Handle.ba_solve_visual_batch(list of dicts): the orbx_ba_window array, the in/out points and the result dicts built per call "
+                                                        "(observations in one pinned buffer all the same)")
         h.ba_solve_visual_batch(cam, cfg, bw_pageable)
         t0 = time.perf_counter()
         itp = 0

@@ -699,6 +699,10 @@ class Handle:
                             final_error=a.final_error))
         return res
 
+    def prepare_ba_batch(self, windows):
+        """A BaBatch: the windows laid out once the way orbx_ba_solve_visual_batch takes them (see BaBatch)."""
+        return BaBatch(self, windows)
+
     def debug_ba_blocks(self, camera, cfg, poses_cw, fixed_cw, points, obs, global_mode=False):
         """orbx_debug_ba_blocks: (residual [N,2], A [N,2,6], B [N,2,3]) of every observation, from the solver's device functions."""
         poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)
@@ -977,6 +981,59 @@ class KeyFrame:
                 self.close()
         except Exception:
             pass
+
+
+class BaBatch:
+    """A batch of local-BA windows kept in the layout orbx_ba_solve_visual_batch takes — what a host that owns its window storage (the Rust
+    crate behind INTEGRATION.md's shim) hands over without any marshalling: the orbx_ba_window array filled once, every window's
+    observations consecutive slices of ONE page-locked buffer (the copy engine reads them where they lie, one copy per half of the batch),
+    poses / fixed poses / points / output poses each one array.  solve() refreshes the in/out points from the initial ones and makes the
+    call; Handle.ba_solve_visual_batch(list of dicts) is the ad-hoc form that builds all of this per call."""
+
+    def __init__(self, handle, windows):
+        import torch
+        self._handle = handle
+        obs = [np.ascontiguousarray(w["obs"], BA_OBS) for w in windows]
+        self._obs_buf = torch.empty(max(sum(len(a) for a in obs), 1) * BA_OBS.itemsize, dtype=torch.uint8).pin_memory()
+        self.obs = self._obs_buf.numpy().view(BA_OBS)
+        self.poses = [np.ascontiguousarray(w["poses_cw"], np.float64).reshape(-1, 7) for w in windows]
+        self.fixed = [np.ascontiguousarray(w["fixed_cw"], np.float64).reshape(-1, 7) for w in windows]
+        pts = [np.asarray(w["points"], np.float64).reshape(-1, 3) for w in windows]
+        self.points0 = np.concatenate(pts) if pts else np.zeros((0, 3))
+        self.points = self.points0.copy()
+        self.out = np.zeros((sum(max(len(p), 1) for p in self.poses), 7))
+        self.arr = (_BaWindow * max(len(windows), 1))()
+        self._views = []
+        o_obs = o_pts = o_out = 0
+        for i, a_obs in enumerate(obs):
+            n, M, K = len(a_obs), len(pts[i]), len(self.poses[i])
+            self.obs[o_obs:o_obs + n] = a_obs
+            a = self.arr[i]
+            a.K, a.F, a.M, a.N = K, len(self.fixed[i]), M, n
+            a.poses_cw = self.poses[i].ctypes.data; a.fixed_poses_cw = self.fixed[i].ctypes.data
+            a.points = self.points.ctypes.data + 24 * o_pts; a.obs = self.obs.ctypes.data + BA_OBS.itemsize * o_obs
+            a.poses_wc_out = self.out.ctypes.data + 56 * o_out
+            self._views.append((self.out[o_out:o_out + K], self.points[o_pts:o_pts + M]))
+            o_obs += n; o_pts += M; o_out += max(K, 1)
+        self.n = len(windows)
+
+    def solve(self, camera, cfg, should_stop=None):
+        """One orbx_ba_solve_visual_batch call.  Returns one dict per window (None where the reference returns None); `poses_wc` and `points`
+        are views of the batch's own arrays, valid until the next solve()."""
+        h = self._handle
+        np.copyto(self.points, self.points0)
+        cb = SHOULD_STOP_FN((lambda user: 1 if should_stop() else 0)) if should_stop else C.cast(None, SHOULD_STOP_FN)
+        cam = camera._c(); c = cfg._c()
+        h._check(h._L.orbx_ba_solve_visual_batch(h._h, C.byref(cam), C.byref(c), C.c_int(self.n), self.arr, cb, None))
+        res = []
+        for i in range(self.n):
+            a = self.arr[i]
+            if a.status == ORBX_ERR_EMPTY:
+                res.append(None)
+            else:
+                res.append(dict(poses_wc=self._views[i][0], points=self._views[i][1], iterations=a.iterations, initial_error=a.initial_error,
+                                final_error=a.final_error))
+        return res
 
 
 class MapSnapshot:

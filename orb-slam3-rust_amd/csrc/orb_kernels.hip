@@ -1407,6 +1407,17 @@ constexpr int DF_WIN_BYTES = 48 * DF_WP;          // 2304 B per keypoint
 constexpr int DF_X0 = 23, DF_Y0 = 21;             // window origin = keypoint - (23, 21): the centroid's 31-px rows start at window byte 8 (aligned 8-byte LDS reads)
 typedef int df_i4 __attribute__((ext_vector_type(4)));
 __constant__ __attribute__((aligned(16))) unsigned c_blur_band[6 * 64 * 4];   // [operand set: T1 for column block 0..2, T2 for row block 0..2][lane][4 dwords]
+#ifndef ORBX_DF_ITERS
+#define ORBX_DF_ITERS 2        // keypoint groups per wave: the block prologue (tables, level starts) is paid once per ORBX_DF_ITERS x 16 keypoints (1 / 2: 0.705 / 0.699 ms)
+#endif
+// Measured on the way (round 4, same box, per 256 pairs; every variant bit-exact on the frozen digests):
+//   whole-level blur + describe_kernel 0.299 + 0.484 = 0.783 ms;  this kernel as first written 0.785 — the compiler put the MFMA destinations in
+//   AGPRs and every VALU consumer behind a v_accvgpr_read_b32 (108 of 261 vector instructions per keypoint); with -mllvm
+//   -amdgpu-mfma-vgpr-form=1 (Makefile, this file only) 0.705;  the patch bytes stored one by one straight from bits 16..23 of the sums
+//   (ds_write_b8_d16_hi by inline asm — as C++ byte stores the compiler merges them back into a dword with MORE VALU work — 27 v_perm_b32
+//   fewer per keypoint, 36 LDS stores instead of 9): 0.853, the LDS pipe pays more than the VALU saves;  the test pattern as f16 pairs
+//   (one v_cvt_f32_f16 per coordinate): no change, the byte table already converts with one SDWA instruction per coordinate.
+// The kernel is bound by VALU issue: per 4 keypoints ~1250 vector instructions + 108 MFMAs that hold the issue port for 8 cycles each.
 
 __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, int blocks_per_img,
                                                              const unsigned long long* __restrict__ sel2,
@@ -1416,9 +1427,11 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
                                                              int* __restrict__ nkp, int cap_kp, float patch_size,
                                                              unsigned* __restrict__ status) {
   // 16 windows, then the tables: the last window's A operand reads 16 bytes past its end (k-slots under zero taps) — into the tables
-  __shared__ __attribute__((aligned(16))) unsigned char s_win[DG_PER_BLOCK * DF_WIN_BYTES + 3 * 1024];
+  constexpr int kPatBytes = 1024;
+  __shared__ __attribute__((aligned(16))) unsigned char s_win[DG_PER_BLOCK * DF_WIN_BYTES + kPatBytes + 2 * 1024];
+  static_assert(sizeof(s_win) <= 40960, "four blocks per CU (160 KB of LDS)");
   int* s_pat = reinterpret_cast<int*>(s_win + DG_PER_BLOCK * DF_WIN_BYTES);
-  unsigned* s_ones = reinterpret_cast<unsigned*>(s_pat + 256);
+  unsigned* s_ones = reinterpret_cast<unsigned*>(s_win + DG_PER_BLOCK * DF_WIN_BYTES + kPatBytes);
   unsigned* s_col = s_ones + 256;
   int img, bx;
   if (!xcd_decode(xm, n_img, img, bx)) return;
@@ -1883,7 +1896,8 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     if (fork) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
     {
       ProfScope ps(h, "describe_kernel", nullptr, true);
-      const int blocks_x = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block
+      const int blocks_x16 = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block and round
+      const int blocks_x = unfused ? blocks_x16 : (blocks_x16 + ORBX_DF_ITERS - 1) / ORBX_DF_ITERS;
       if (unfused)
         hipLaunchKernelGGL(describe_kernel, xcd_grid(blocks_x, n), dim3(256), 0, st, s, g, n, xcd_map(blocks_x), blocks_x,
                            (const unsigned long long*)sel2, (const unsigned long long*)sel, kp, d_kp + (size_t)img0 * cap_kp, d_desc + (size_t)img0 * cap_kp * 32,

@@ -150,6 +150,7 @@ void orbx_destroy(orbx_handle* h) {
   if (!h) return;
   if (h->ba_aux) { orbx_destroy(h->ba_aux); h->ba_aux = nullptr; }
   delete h->ba_pool; h->ba_pool = nullptr;
+  delete h->ba_helper; h->ba_helper = nullptr;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->resize_tab, &h->ws_pyr, &h->ws_blur, &h->ws_cand, &h->ws_counters,
@@ -1008,11 +1009,13 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
     if (split) {
       size_t total = 0, run = 0;
       for (int i = 0; i < n_windows; ++i) total += (size_t)w[i].N;
+      // the first part's upload is the one nothing hides (the second part's travels under the first part's kernels): ORBX_BA_SPLIT_FRAC
+      // (default 0.5) moves the cut for A/B runs
+      static const double split_frac = [] { const char* e = getenv("ORBX_BA_SPLIT_FRAC"); const double f = e ? atof(e) : 0.5; return f > 0.05 && f < 0.95 ? f : 0.5; }();
       int n0 = 0;
-      while (n0 < n_windows - 1 && 2 * (run + (size_t)w[n0].N) <= total + (size_t)w[n0].N) run += (size_t)w[n0++].N;
+      while (n0 < n_windows - 1 && (double)(run + (size_t)w[n0].N) - 0.5 * (double)w[n0].N <= split_frac * (double)total) run += (size_t)w[n0++].N;
       n0 = std::max(1, std::min(n_windows - 1, n0));
       int rc1 = ORBX_OK;
-      bool helper_ran = false;
       // the two halves preprocess at the same time: half the cores each  (one after the other with all the cores each, so that the first
       // half's kernels run under the second half's preprocessing, was built: 16 threads sort a half in 0.33 ms where 8 take 0.41, so the
       // second half was ready at 0.7 ms instead of 0.45 — no gain)
@@ -1025,21 +1028,22 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
       h->ba_gate_signal = &gate; h->ba_aux->ba_gate_wait = &gate; h->ba_aux->ba_gate_event = h->ba_up_event;
       struct Uncap { orbx_handle* h; ~Uncap() { h->ba_pool_cap = 0; h->ba_aux->ba_pool_cap = 0; h->ba_peer_windows = 0; h->ba_aux->ba_peer_windows = 0;
                                                 h->ba_gate_signal = nullptr; h->ba_aux->ba_gate_wait = nullptr; h->ba_aux->ba_gate_event = nullptr; } } uncap{h};
-      try {
-        std::thread helper([&] {
+      if (!h->ba_helper) {
+        try { h->ba_helper = new OrbxHelperThread(); } catch (...) { h->ba_helper = nullptr; }
+      }
+      if (h->ba_helper) {
+        h->ba_helper->start([&] {
           hipSetDevice(h->device);
           try { rc1 = ba_solve_batch(h->ba_aux, cam, cfg, n_windows - n0, w.data() + n0, nullptr, nullptr); }
           catch (...) { rc1 = ORBX_ERR_HIP; }
         });
-        helper_ran = true;
         try { rc = ba_solve_batch(h, cam, cfg, n0, w.data(), nullptr, nullptr); }
         catch (...) { rc = orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_batch: out of host memory"); }
         gate.store(1, std::memory_order_release);                              // (however the first half ended, the second must not wait for it)
-        helper.join();
-      } catch (const std::system_error&) {                                  // no thread: both halves here, one after the other
-        h->ba_gate_signal = nullptr;
-        if (!helper_ran) rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), nullptr, nullptr);
-        else rc = orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_batch: helper thread failed");
+        h->ba_helper->wait();
+      } else {                                                              // no thread: the whole batch here, on one stream
+        h->ba_gate_signal = nullptr; h->ba_peer_windows = 0;
+        rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), nullptr, nullptr);
       }
       if (rc == ORBX_OK && rc1 != ORBX_OK) rc = orbx_fail(h, rc1, "(windows %d..%d, numbered from %d) %s", n0, n_windows - 1, n0, orbx_last_error(h->ba_aux));
     } else rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), should_stop, user);

@@ -77,6 +77,47 @@ class OrbxWorkPool {
   bool quit_ = false, failed_ = false;
 };
 
+// One persistent helper thread of a handle: start(f) hands it a job and returns, wait() blocks until the job is done.  (The second half of
+// a large BA batch runs on it: creating and joining a std::thread per call was 40-70 us of a 3.5 ms call.)  One job at a time.
+class OrbxHelperThread {
+ public:
+  OrbxHelperThread() : th_([this] { loop(); }) {}                          // std::system_error if the thread cannot be created
+  ~OrbxHelperThread() {
+    { std::lock_guard<std::mutex> g(m_); quit_ = true; }
+    cv_.notify_all();
+    th_.join();
+  }
+  void start(std::function<void()> f) {
+    { std::lock_guard<std::mutex> g(m_); job_ = std::move(f); busy_ = true; }
+    cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> g(m_);
+    cv_.wait(g, [&] { return !busy_; });
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return quit_ || (busy_ && job_); });
+        if (quit_) return;
+        f = std::move(job_); job_ = nullptr;
+      }
+      try { f(); } catch (...) {}                                        // (the job reports its own errors; nothing may escape a thread)
+      { std::lock_guard<std::mutex> g(m_); busy_ = false; }
+      cv_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  bool busy_ = false, quit_ = false;
+  std::thread th_;                                                        // last: starts when every other member exists
+};
+
 // ---- launch descriptors shared by host code and kernels ------------------------------------------
 // Geometry of one pyramid level inside the per-image pyramid / blur slots (identical layout).
 struct OrbLevelGeom {
@@ -171,6 +212,7 @@ struct orbx_handle {
   void* h_ba_out = nullptr;  size_t h_ba_out_bytes = 0;
   int* h_abort = nullptr;    int* d_abort = nullptr;       // pinned, device-visible: should_stop() seen while the iterations drain
   OrbxWorkPool* ba_pool = nullptr;                         // host workers of the batch preprocessing (created by the first large batch)
+  OrbxHelperThread* ba_helper = nullptr;                   // drives the second half of a large batch (orbx_ba_solve_visual_batch)
   int ba_pool_cap = 0;                                     // > 0: at most this many threads for the next preprocessing (two halves share the cores)
   int ba_peer_windows = 0;                                 // windows of the other half of a batch, solved at the same time on the peer handle's stream (launch-shape heuristics count them)
   // the two halves of a batch share one PCIe link: the second half's uploads are ordered behind the first half's (its kernels then start

@@ -6,8 +6,10 @@ NAME=$1; SRC=$2; shift 2
 cd "$(dirname "$0")/../orb-slam3-rust_amd/csrc"
 make -s
 OBJ=/tmp/orbx_variant_${NAME}_$$.o
+EXTRA=""
+if [ "$SRC" = "orb_kernels.hip" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"; fi   # as the Makefile builds that file
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-result \
-    -Wno-unused-value -Wno-pass-failed "$@" -c "$SRC" -o "$OBJ"
+    -Wno-unused-value -Wno-pass-failed $EXTRA "$@" -c "$SRC" -o "$OBJ"
 mkdir -p ../../build_ab
 OBJS=""
 for f in orbx_api match_kernels orb_kernels ba_kernels bow_kernels euroc_io keyframe; do

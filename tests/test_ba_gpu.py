@@ -377,6 +377,14 @@ def test_ba_observations_from_pinned_memory_equal_staged(gpu_handle, pkg):
         for w in (wins[i], packed[i]):
             s = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
             assert np.array_equal(s["poses_wc"], a[i]["poses_wc"]) and np.array_equal(s["points"], a[i]["points"]), i
+    # the prepared form (api.BaBatch: the windows kept in the ABI's layout) gives the same bits, call after call
+    prepared = gpu_handle.prepare_ba_batch(wins)
+    for _ in range(2):
+        c = prepared.solve(cam, cfg)
+        assert c[11] is None
+        for i, (x, y) in enumerate(zip(a, c)):
+            if x is not None:
+                assert x["iterations"] == y["iterations"] and np.array_equal(x["poses_wc"], y["poses_wc"]) and np.array_equal(x["points"], y["points"]), i
     # an index out of range inside pinned memory is found by the device-side check and named
     o = packed[15]["obs"]; keep = int(o["mp_idx"][7]); o["mp_idx"][7] = len(packed[15]["points"]) + 3
     with pytest.raises(pkg.OrbxError) as e:
