@@ -41,6 +41,16 @@ def two_cycle_share(kernel):
         return None, None, None
 
 
+def mfma_share(kernel):
+    """MFMA instructions as a share of the kernel's vector instructions (same file).  An MFMA holds its SIMD's vector issue port for 8 cycles
+    (MI355X_MICROARCH.md, per-instruction constants) = two slots of the 4-cycle class."""
+    try:
+        w = json.load(open(os.path.join(ROOT, "profiles", "valu_class_mix.json")))["kernels"][kernel]["valu_weighted_per_wave"]
+        return w.get("mfma", 0.0) / w["total"] if w.get("total") else 0.0
+    except Exception:
+        return 0.0
+
+
 def make_batches(P, torch, dev, seed, batch, n_batches, w, h):
     """n_batches distinct [batch,2,h,w] u8 device tensors, EVERY pair unique (no flips / brightness copies of 32
     pairs): the scene generator of synth.stereo_pair (canvas 128, 600 rectangles + 300 discs per 752x480 of area, each at
@@ -265,7 +275,8 @@ def main():
         "fast_kernel": n_img * (sum(px) + 4 * 2 * args.features),          # read every level once, write candidates
         "blur_kernel": n_img * 2 * sum(px),                                # read + write every level
         "resize_kernel": n_img * (sum(px[:-1]) + sum(px[1:])) / 7.0,       # 7 launches: read l-1, write l
-        "describe_kernel": n_img * args.features * (43 * 43 + 28 + 32),  # one 43 x 43 window of the level per keypoint (centroid disc + the 37 x 37 patch's blur support), the keypoint record, the descriptor
+        "describe_fused_kernel": n_img * args.features * (43 * 43 + 28 + 32),  # one 43 x 43 window of the level per keypoint (centroid disc + the 37 x 37 patch's blur support), the keypoint record, the descriptor
+        "describe_kernel": n_img * args.features * (31 * 31 + 37 * 37 + 28 + 32),      # (ORBX_DESC_UNFUSED=1: the two-kernel form)
         "harris_select_kernel": n_img * 2 * args.features * (81 + 4 + 8),
         "rank_select_kernel": n_img * 2 * args.features * 16,
         "stereo_bucket_kernel": args.batch * args.features * (8 + 12),
@@ -296,10 +307,13 @@ def main():
                 rate = kd["valu_wave_instr_per_launch"] / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9
                 share2, share2_bounds, model_vs_pmc = two_cycle_share(dom_name)
                 sh = share2 if share2 is not None else 0.0
+                ms_ = mfma_share(dom_name)                       # MFMAs among the counted vector instructions: 8 cycles of the issue port each
+                slots = (1.0 - ms_) * (sh / VALU_PEAK_2CYC + (1.0 - sh) / VALU_PEAK_4CYC) + ms_ * 2.0 / VALU_PEAK_4CYC
                 valu = dict(wave_instr_per_launch=kd["valu_wave_instr_per_launch"], achieved=round(rate, 1), peak=VALU_PEAK_4CYC,
                             peak_simple_ops=VALU_PEAK_2CYC, unit="G wave-instr/s", two_cycle_share=share2, two_cycle_share_bounds=share2_bounds,
                             class_mix_model_vs_pmc=model_vs_pmc,
-                            frac=round(rate * (sh / VALU_PEAK_2CYC + (1.0 - sh) / VALU_PEAK_4CYC), 4),
+                            mfma_share=round(ms_, 4),
+                            frac=round(rate * slots, 4),
                             frac_of_4cycle_class_rate=round(rate / VALU_PEAK_4CYC, 4),
                             source="scripts/valu_class_mix.py -> profiles/valu_class_mix.json (class mix from the code object); "
                                    "profiles/r02_valu_issue_probe.txt + profiles/r03_valu_issue_probe2.txt (class rates); profiles/pmc_traffic.json "
@@ -671,7 +685,7 @@ def bench_ba_c_abi(P, wins, reps=8):
         subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "ba_batch_driver.cpp"),
                         "-o", exe, "-L", libdir, "-lorbx_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True)
         P.synth.write_ba_batch_file(os.path.join(tmp, "batch.bin"), wins, P.BA_OBS)
-        for mode in ("pinned", "pageable"):
+        for mode in ("pinned32", "pinned", "pageable"):
             r = subprocess.run([exe, os.path.join(tmp, "batch.bin"), os.path.join(tmp, "out.bin"), str(reps), mode], check=True, capture_output=True, text=True, timeout=300)
             line = json.loads(r.stdout.strip().splitlines()[-1])
             its = sum(x["iterations"] for x in P.synth.read_ba_batch_results(os.path.join(tmp, "out.bin"), wins))
@@ -767,11 +781,14 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         out["concurrent_windows"] = dict(windows=nwin, lm_iters_per_s=round(sum(counts) / dtc, 2), note="8 independent windows, one handle and host thread each")
         # many windows per launch (SURVEY §8d "batched problems (>= 32 windows per launch)"): orbx_ba_solve_visual_batch
         nb = 32
-        bw_pageable = [P.synth.ba_window(200 + i, 20, 2000, P.BA_OBS) for i in range(nb)]
+        # pixel coordinates at keypoint precision (f32 widened to f64), as the reference's observations are (kp.pt() is a cv::Point2f,
+        # local_ba_lm.rs:870-872): the 16-byte wire format orbx_ba_obs32 then carries them exactly
+        bw_pageable = [P.synth.keypoint_precision(P.synth.ba_window(200 + i, 20, 2000, P.BA_OBS)) for i in range(nb)]
         # the caller's observation storage: one page-locked buffer (orbx.h: the copy engine then reads it where it lies, one copy per half);
         # the pageable form (the library stages it through its own pinned blob) is timed beside it
         bw = P.Handle.pack_ba_windows(bw_pageable)
-        batch = h.prepare_ba_batch(bw_pageable)      # api.BaBatch: the windows kept in the ABI's own layout, as a host that owns its window storage would
+        batch = h.prepare_ba_batch(bw_pageable, obs32=True)   # api.BaBatch: the windows kept in the ABI's own layout (observations: orbx_ba_obs32), as a host that owns its window storage would
+        batch64 = h.prepare_ba_batch(bw_pageable)             # ... and with the 32-byte observations
         rb = batch.solve(cam, cfg)
         nrep = 8
         # the rate: as a caller sees it (a batch of this size runs as two halves on two streams inside the call, see orbx.h)
@@ -799,11 +816,20 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
                               schur_executed_TFLOPs=round(flop / (sch_ms * 1e-3) / 1e12, 2) if sch_ms > 0 else None,
                               mfma_frac=round(flop / (sch_ms * 1e-3) / 78.6e12, 4) if sch_ms > 0 else None,
                               note="orbx_ba_solve_visual_batch on a prepared api.BaBatch (the windows kept in the ABI's layout; per call: refresh of the in/out points, the C "
-                                   "call, result views): upload of the caller's observations (one pinned buffer) + device-side CSR build + 10 LM iterations of all windows + "
+                                   "call, result views): upload of the caller's observations (one pinned buffer, the 16-byte form orbx_ba_obs32: f32 pixel coordinates as the "
+                                   "reference's keypoints are, widened on the device) + device-side CSR build + 10 LM iterations of all windows + "
                                    "download per call, the batch as two halves on two streams inside the call; device_ms / "
                                    "kernel_ms from a second set of calls with per-kernel events (one stream); every window equals its single-window result bit for bit "
                                    "(tests/test_ba_gpu.py)")
         out["batched"]["call_vs_device_only"] = round(out["batched"]["lm_iters_per_s"] / out["batched"]["lm_iters_per_s_device_only"], 3) if dev_ms > 0 else None
+        batch64.solve(cam, cfg)
+        t0 = time.perf_counter()
+        it64 = 0
+        for _ in range(nrep):
+            it64 += sum(x["iterations"] for x in batch64.solve(cam, cfg))
+        dt64 = time.perf_counter() - t0
+        out["batched"]["obs_32_bytes"] = dict(lm_iters_per_s=round(it64 / dt64, 1), ms_per_call=round(dt64 / nrep * 1e3, 3),
+                                              note="the same prepared batch with the observations as orbx_ba_obs (f64 coordinates): twice the upload")
         t0 = time.perf_counter()
         ita = 0
         for _ in range(nrep):
@@ -827,13 +853,14 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         # two such batches in flight (two handles = two HIP streams, one host thread each): the host preprocessing, upload and
         # download of one batch run under the kernels of the other
         h2 = [P.Handle(cam, 100, device=dev.index if dev is not None else 0) for _ in range(2)]
-        for x in h2:
-            x.ba_solve_visual_batch(cam, cfg, bw)
+        b2 = [x.prepare_ba_batch(bw_pageable, obs32=True) for x in h2]
+        for x in b2:
+            x.solve(cam, cfg)
         cnt2 = [0, 0]
 
         def work2(i):
             for _ in range(nrep + 1):
-                cnt2[i] += sum(r_["iterations"] for r_ in h2[i].ba_solve_visual_batch(cam, cfg, bw))
+                cnt2[i] += sum(r_["iterations"] for r_ in b2[i].solve(cam, cfg))
 
         th2 = [threading.Thread(target=work2, args=(i,)) for i in range(2)]
         t0 = time.perf_counter()
@@ -845,7 +872,7 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
         for x in h2:
             x.close()
         out["batched"]["two_batches_in_flight"] = dict(lm_iters_per_s=round(sum(cnt2) / dt2, 1), vs_single_window=round(sum(cnt2) / dt2 / out["lm_iters_per_s"], 2),
-                                                       note="2 handles x 32 windows, one host thread each, no per-kernel events")
+                                                       note="2 handles x 32 windows (prepared batches, orbx_ba_obs32), one host thread each, no per-kernel events")
         # configs[4]'s BA: 50 keyframes / 8000 map points (synth_ba(seed=43, K=50, M=8000)); the reduced system (n = 294)
         # no longer fits LDS, so the factorisation is the multi-kernel form
         try:

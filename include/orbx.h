@@ -444,6 +444,16 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
  * memory (orbx_host_alloc, hipHostMalloc or a registered range — the library asks the runtime) the copy engine reads it where it lies;
  * windows whose `obs` arrays follow each other in memory travel as ONE copy.  Pageable `obs` is first copied into the handle's pinned
  * staging blob (a plain copy, on worker threads when large).  The same holds for the one-window entry points. */
+/* The same observation in 16 bytes, for callers whose pixel coordinates ARE f32 — the reference's always are: collect_visual_ba_data
+ * widens `kp.pt()` (cv::Point2f) to f64 per observation (local_ba_lm.rs:870-872).  The library widens on the device instead, the same
+ * exact conversion, so results are bit-identical to handing over the widened orbx_ba_obs — and half the bytes cross PCIe (the upload of
+ * the observations is a fifth of a 32-window batch call).  kf_idx >= 0: optimised keyframe; kf_idx < 0: fixed observer -1 - kf_idx
+ * (F = the identity pose, as fixed_idx -1 of orbx_ba_obs). */
+typedef struct {
+  int32_t kf_idx, mp_idx;
+  float u, v;
+} orbx_ba_obs32;
+
 typedef struct {
   int K;                        /* in: optimised keyframes                         */
   const double* poses_cw;       /* in: [K][7]                                      */
@@ -452,11 +462,12 @@ typedef struct {
   int M;
   double* points;               /* in/out: [M][3]                                  */
   int N;
-  const orbx_ba_obs* obs;       /* in: [N]                                         */
+  const orbx_ba_obs* obs;       /* in: [N] (or NULL when obs32 is given)           */
   double* poses_wc_out;         /* out: [K][7]                                     */
   int status;                   /* out                                             */
   int iterations;               /* out                                             */
   double initial_error, final_error;   /* out                                      */
+  const orbx_ba_obs32* obs32;   /* in: [N], optional: used instead of obs when not NULL */
 } orbx_ba_window;
 int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int n_windows,
                                orbx_ba_window* windows, orbx_should_stop_fn should_stop, void* user);

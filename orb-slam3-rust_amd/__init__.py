@@ -6,7 +6,7 @@ Import as `orb_slam3_rust_amd` (the shim at the repo root maps the hyphenated di
 """
 from . import dist, synth  # noqa: F401
 from .api import (  # noqa: F401
-    ABI_SYMBOLS, BA_OBS, DMATCH, KEYPOINT, NN_RATIO, TH_HIGH, TH_LOW, CameraModel, FeatureSet, GlobalBAConfig, Handle,
+    ABI_SYMBOLS, BA_OBS, BA_OBS32, ba_obs_to_obs32, DMATCH, KEYPOINT, NN_RATIO, TH_HIGH, TH_LOW, CameraModel, FeatureSet, GlobalBAConfig, Handle,
     LocalBAConfigLM, OrbxError, StereoFrame, StereoProcessor, VisualBAProblemData, VisualBAResultData,
     VisualObservation, bf_match_crosscheck, descriptor_distance, flatten_ba_problem, load_library,
     solve_visual_ba, GlobalBAObservation, GlobalBAProblemData, GlobalBAResult, flatten_global_ba_problem, se3_inverse,

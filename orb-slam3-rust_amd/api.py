@@ -35,6 +35,23 @@ DMATCH = np.dtype([("query_idx", "<i4"), ("train_idx", "<i4"), ("img_idx", "<i4"
                    ("distance", "<f4")])
 BA_OBS = np.dtype([("kf_idx", "<i4"), ("fixed_idx", "<i4"), ("mp_idx", "<i4"), ("_pad", "<i4"),
                    ("u", "<f8"), ("v", "<f8")])
+# orbx_ba_obs32 (include/orbx.h): the same observation in 16 bytes — kf_idx >= 0 optimised keyframe, < 0 fixed observer -1 - kf_idx (F = identity); u, v f32
+BA_OBS32 = np.dtype([("kf_idx", "<i4"), ("mp_idx", "<i4"), ("u", "<f4"), ("v", "<f4")])
+
+
+def ba_obs_to_obs32(obs, n_fixed):
+    """orbx_ba_obs -> orbx_ba_obs32, or None if a coordinate is not exactly an f32 (the reference's always are: kp.pt() widened, local_ba_lm.rs:870-872)."""
+    obs = np.ascontiguousarray(obs, BA_OBS)
+    u32, v32 = obs["u"].astype(np.float32), obs["v"].astype(np.float32)
+    if not (np.array_equal(u32.astype(np.float64), obs["u"]) and np.array_equal(v32.astype(np.float64), obs["v"])):
+        return None
+    out = np.zeros(len(obs), BA_OBS32)
+    fixed = np.where(obs["fixed_idx"] >= 0, obs["fixed_idx"], n_fixed)
+    out["kf_idx"] = np.where(obs["kf_idx"] >= 0, obs["kf_idx"], -1 - fixed)
+    out["mp_idx"] = obs["mp_idx"]; out["u"] = u32; out["v"] = v32
+    return out
+
+
 
 ORBX_OK, ORBX_ERR_INVALID, ORBX_ERR_NO_DEVICE, ORBX_ERR_HIP = 0, -1, -2, -3
 ORBX_ERR_CAPACITY, ORBX_ERR_NUMERIC, ORBX_ERR_EMPTY = -4, -5, -6
@@ -112,7 +129,7 @@ class _BaWindow(C.Structure):
     """orbx_ba_window (include/orbx.h)"""
     _fields_ = [("K", C.c_int), ("poses_cw", C.c_void_p), ("F", C.c_int), ("fixed_poses_cw", C.c_void_p), ("M", C.c_int),
                 ("points", C.c_void_p), ("N", C.c_int), ("obs", C.c_void_p), ("poses_wc_out", C.c_void_p), ("status", C.c_int),
-                ("iterations", C.c_int), ("initial_error", C.c_double), ("final_error", C.c_double)]
+                ("iterations", C.c_int), ("initial_error", C.c_double), ("final_error", C.c_double), ("obs32", C.c_void_p)]
 
 
 SHOULD_STOP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -699,9 +716,9 @@ class Handle:
                             final_error=a.final_error))
         return res
 
-    def prepare_ba_batch(self, windows):
+    def prepare_ba_batch(self, windows, obs32=False):
         """A BaBatch: the windows laid out once the way orbx_ba_solve_visual_batch takes them (see BaBatch)."""
-        return BaBatch(self, windows)
+        return BaBatch(self, windows, obs32=obs32)
 
     def debug_ba_blocks(self, camera, cfg, poses_cw, fixed_cw, points, obs, global_mode=False):
         """orbx_debug_ba_blocks: (residual [N,2], A [N,2,6], B [N,2,3]) of every observation, from the solver's device functions."""
@@ -990,12 +1007,21 @@ class BaBatch:
     poses / fixed poses / points / output poses each one array.  solve() refreshes the in/out points from the initial ones and makes the
     call; Handle.ba_solve_visual_batch(list of dicts) is the ad-hoc form that builds all of this per call."""
 
-    def __init__(self, handle, windows):
+    def __init__(self, handle, windows, obs32=False):
+        """obs32: carry the observations in the 16-byte form orbx_ba_obs32 (half the upload; bit-identical results).  Needs every pixel
+        coordinate to be exactly an f32, as the reference's are; raises ValueError otherwise."""
         import torch
         self._handle = handle
-        obs = [np.ascontiguousarray(w["obs"], BA_OBS) for w in windows]
-        self._obs_buf = torch.empty(max(sum(len(a) for a in obs), 1) * BA_OBS.itemsize, dtype=torch.uint8).pin_memory()
-        self.obs = self._obs_buf.numpy().view(BA_OBS)
+        dt = BA_OBS32 if obs32 else BA_OBS
+        if obs32:
+            obs = [ba_obs_to_obs32(w["obs"], len(np.asarray(w["fixed_cw"]).reshape(-1, 7))) for w in windows]
+            if any(a is None for a in obs):
+                raise ValueError("BaBatch(obs32=True): a pixel coordinate is not exactly representable as f32")
+        else:
+            obs = [np.ascontiguousarray(w["obs"], BA_OBS) for w in windows]
+        self.obs32 = bool(obs32)
+        self._obs_buf = torch.empty(max(sum(len(a) for a in obs), 1) * dt.itemsize, dtype=torch.uint8).pin_memory()
+        self.obs = self._obs_buf.numpy().view(dt)
         self.poses = [np.ascontiguousarray(w["poses_cw"], np.float64).reshape(-1, 7) for w in windows]
         self.fixed = [np.ascontiguousarray(w["fixed_cw"], np.float64).reshape(-1, 7) for w in windows]
         pts = [np.asarray(w["points"], np.float64).reshape(-1, 3) for w in windows]
@@ -1011,7 +1037,11 @@ class BaBatch:
             a = self.arr[i]
             a.K, a.F, a.M, a.N = K, len(self.fixed[i]), M, n
             a.poses_cw = self.poses[i].ctypes.data; a.fixed_poses_cw = self.fixed[i].ctypes.data
-            a.points = self.points.ctypes.data + 24 * o_pts; a.obs = self.obs.ctypes.data + BA_OBS.itemsize * o_obs
+            a.points = self.points.ctypes.data + 24 * o_pts
+            if obs32:
+                a.obs = None; a.obs32 = self.obs.ctypes.data + BA_OBS32.itemsize * o_obs
+            else:
+                a.obs = self.obs.ctypes.data + BA_OBS.itemsize * o_obs; a.obs32 = None
             a.poses_wc_out = self.out.ctypes.data + 56 * o_out
             self._views.append((self.out[o_out:o_out + K], self.points[o_pts:o_pts + M]))
             o_obs += n; o_pts += M; o_out += max(K, 1)

@@ -109,7 +109,9 @@ struct BaWin {
   double *Sg, *bvec, *ginv;   // global-memory factorisation (n > ~135 and the inertial system)
   double *res;           // [16] result block, see ba_decide_kernel
   // the observation CSR is built on the device once per call (ba_prep_*_kernel) from the caller's observations as they were handed over
-  const orbx_ba_obs* obs_raw;   // [N], input order
+  const orbx_ba_obs* obs_raw;   // [N], input order (obs32 == 0), or
+  int obs32;             // ... the same array in the 16-byte form orbx_ba_obs32 (kf_idx < 0: fixed observer -1 - kf_idx; u, v as f32)
+  int pad_;
   int *pt_fill;          // [M] per-point counters: observations of the point (count pass), then its fill position (place pass)
   int *obs_tmp;          // [N] observation indices grouped by map point, in arrival order within a point (sorted by ba_prep_order_kernel)
   int *o_flag;           // [N] inertial: orbx_ba_obs::_pad (bit 0 = stereo) in point-major order, else null
@@ -143,6 +145,7 @@ struct BaWinView {
   BA_AS1 double *Sg, *bvec, *ginv;
   BA_AS1 double *res;
   BA_AS1 const orbx_ba_obs* obs_raw;
+  int obs32, pad_;
   BA_AS1 int *pt_fill;
   BA_AS1 int *obs_tmp;
   BA_AS1 int *o_flag;
@@ -161,7 +164,7 @@ __device__ __forceinline__ BaWin ba_win_global(const BaWin* __restrict__ wins, i
   g.oP = (double*)v.oP; g.Rt_cur = (double*)v.Rt_cur; g.slot_first = (int*)v.slot_first; g.obs_next = (int*)v.obs_next;
   g.kfpart = (double*)v.kfpart; g.part = (double*)v.part; g.rb = (double*)v.rb; g.dp = (double*)v.dp;
   g.Sg = (double*)v.Sg; g.bvec = (double*)v.bvec; g.ginv = (double*)v.ginv; g.res = (double*)v.res;
-  g.obs_raw = (const orbx_ba_obs*)v.obs_raw; g.pt_fill = (int*)v.pt_fill; g.obs_tmp = (int*)v.obs_tmp; g.o_flag = (int*)v.o_flag;
+  g.obs_raw = (const orbx_ba_obs*)v.obs_raw; g.obs32 = v.obs32; g.pad_ = 0; g.pt_fill = (int*)v.pt_fill; g.obs_tmp = (int*)v.obs_tmp; g.o_flag = (int*)v.o_flag;
   return g;
 }
 
@@ -256,6 +259,15 @@ __global__ void ba_iter_kernel(const BaWin* __restrict__ wins, int iter) {
 //   place: observation index -> its point's segment of obs_tmp
 //   order: per point, sort the segment; gather the observations into o_kf / o_uv / o_flag
 constexpr int BA_PREP_OPB = 1024;   // observations per block of the count / place passes (256 threads x 4)
+// (kf_idx, fixed_idx, mp_idx, _pad) of observation i in either wire format; the 16-byte form carries the fixed observer in kf_idx
+__device__ __forceinline__ int4 ba_obs_ids(const BaWin& win, int i) {
+  if (win.obs32) {
+    const int2 q = *reinterpret_cast<const int2*>(reinterpret_cast<const orbx_ba_obs32*>(win.obs_raw) + i);
+    const int f = -1 - q.x;                                                // fixed observer f; f == F: the identity pose (= fixed_idx -1 of orbx_ba_obs)
+    return make_int4(q.x >= 0 ? q.x : -1, (q.x >= 0 || f == win.d.F) ? -1 : f, q.y, 0);
+  }
+  return *reinterpret_cast<const int4*>(&win.obs_raw[i]);
+}
 __global__ __launch_bounds__(256) void ba_prep_count_kernel(const BaWin* __restrict__ wins) {
   __shared__ int s_kf[BA_MAX_K];
   const BaWin win = ba_win_global(wins, blockIdx.y);
@@ -265,13 +277,12 @@ __global__ __launch_bounds__(256) void ba_prep_count_kernel(const BaWin* __restr
   const int tid = threadIdx.x;
   for (int k = tid; k < K; k += 256) s_kf[k] = 0;
   __syncthreads();
-  const orbx_ba_obs* __restrict__ obs = win.obs_raw;
   int* __restrict__ pt_fill = win.pt_fill;
 #pragma unroll
   for (int r = 0; r < BA_PREP_OPB / 256; ++r) {
     const int i = i0 + r * 256 + tid;
     if (i >= N) break;
-    const int4 q = *reinterpret_cast<const int4*>(&obs[i]);              // kf_idx, fixed_idx, mp_idx, _pad
+    const int4 q = ba_obs_ids(win, i);                                    // kf_idx, fixed_idx, mp_idx, _pad
     if (q.z < 0 || q.z >= M || q.x >= K || (q.x < 0 && q.y >= F)) { atomicMax(&win.S->bad, 0x7fffffff - i); continue; }
     atomicAdd(&pt_fill[q.z], 1);
     if (q.x >= 0) atomicAdd(&s_kf[q.x], 1);
@@ -328,13 +339,12 @@ __global__ __launch_bounds__(256) void ba_prep_place_kernel(const BaWin* __restr
   const int N = win.d.N;
   const int i0 = blockIdx.x * BA_PREP_OPB;
   if (win.S->done || i0 >= N) return;
-  const orbx_ba_obs* __restrict__ obs = win.obs_raw;
   const int* __restrict__ pt_start = win.pt_start;
 #pragma unroll
   for (int r = 0; r < BA_PREP_OPB / 256; ++r) {
     const int i = i0 + r * 256 + threadIdx.x;
     if (i >= N) break;
-    const int mp = obs[i].mp_idx;
+    const int mp = win.obs32 ? reinterpret_cast<const orbx_ba_obs32*>(win.obs_raw)[i].mp_idx : win.obs_raw[i].mp_idx;
     win.obs_tmp[pt_start[mp] + atomicAdd(&win.pt_fill[mp], 1)] = i;
   }
 }
@@ -356,8 +366,12 @@ __global__ __launch_bounds__(256) void ba_prep_order_kernel(const BaWin* __restr
     const int idx = tmp[e];
     int rank = 0;
     for (int k = 0; k < n; ++k) rank += tmp[k] < idx ? 1 : 0;
-    const int4 q = *reinterpret_cast<const int4*>(&obs[idx]);
-    const double2_t uv = *reinterpret_cast<const double2_t*>(&obs[idx].u);
+    const int4 q = ba_obs_ids(win, idx);
+    double2_t uv;
+    if (win.obs32) {                                                       // f32 -> f64: exact, what the host's `as f64` (local_ba_lm.rs:870-872) does
+      const float2 f = *reinterpret_cast<const float2*>(&reinterpret_cast<const orbx_ba_obs32*>(win.obs_raw)[idx].u);
+      uv[0] = (double)f.x; uv[1] = (double)f.y;
+    } else uv = *reinterpret_cast<const double2_t*>(&obs[idx].u);
     const size_t t = (size_t)(s + rank);
     o_kf[t] = q.x >= 0 ? q.x : -1 - (q.y >= 0 ? q.y : F);                 // a fixed observer f as -1 - f; slot F = identity (:569)
     *reinterpret_cast<double2_t*>(&o_uv[2 * t]) = uv;
@@ -3119,6 +3133,7 @@ struct WinPlan {
 };
 static_assert(sizeof(orbx_ba_obs) == 32 && offsetof(orbx_ba_obs, mp_idx) == 8 && offsetof(orbx_ba_obs, u) == 16,
               "ba_prep_*_kernel read an observation as one int4 (kf_idx, fixed_idx, mp_idx, _pad) and one double2 (u, v)");
+static_assert(sizeof(orbx_ba_obs32) == 16 && offsetof(orbx_ba_obs32, mp_idx) == 4 && offsetof(orbx_ba_obs32, u) == 8, "... or one int2 and one float2");
 
 // Is [p, p + bytes) pinned (hipHostMalloc / hipHostRegister) host memory — something the copy engine can read where it lies?
 bool host_is_pinned(const void* p, size_t bytes) {
@@ -3238,7 +3253,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.i_state = cin.take(sizeof(BaState));
     pl.i_params = cin.take(8 * std::max<size_t>(pl.np, 1));
     pl.i_rtfix = cin.take(8 * 12 * (size_t)(F + 1));
-    pl.i_obs = obs_bytes; obs_bytes += sizeof(orbx_ba_obs) * (size_t)(pl.skip ? 0 : N);   // (relative to the observation region, packed)
+    pl.i_obs = obs_bytes; obs_bytes += (ww.obs32 ? sizeof(orbx_ba_obs32) : sizeof(orbx_ba_obs)) * (size_t)(pl.skip ? 0 : N);   // (relative to the observation region, packed; multiples of 16)
     pl.c_fill = ccnt.take(4 * m1); pl.c_kfstart = ccnt.take(4 * (k1 + 1));
     pl.a_ptstart = car.take(4 * (m1 + 1)); pl.a_okf = car.take(4 * n1); pl.a_ouv = car.take(16 * n1);
     pl.a_oflag = inertial ? car.take(4 * n1) : 0; pl.a_tmp = car.take(4 * n1);
@@ -3268,10 +3283,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   bool any_stage = false;
   for (int w = 0; w < W; ++w) {
     if (plan[w].skip || win[w].N == 0) continue;
-    const size_t bytes = sizeof(orbx_ba_obs) * (size_t)win[w].N;
-    if (!runs.empty() && (const char*)runs.back().src + runs.back().bytes == (const char*)win[w].obs && runs.back().off + runs.back().bytes == plan[w].i_obs) {
+    const void* src = win[w].obs32 ? (const void*)win[w].obs32 : (const void*)win[w].obs;
+    const size_t bytes = (win[w].obs32 ? sizeof(orbx_ba_obs32) : sizeof(orbx_ba_obs)) * (size_t)win[w].N;
+    if (!runs.empty() && (const char*)runs.back().src + runs.back().bytes == (const char*)src && runs.back().off + runs.back().bytes == plan[w].i_obs) {
       runs.back().bytes += bytes; runs.back().w1 = w + 1;
-    } else runs.push_back(Run{w, w + 1, plan[w].i_obs, bytes, win[w].obs, false});
+    } else runs.push_back(Run{w, w + 1, plan[w].i_obs, bytes, src, false});
   }
   for (Run& r : runs) {
     r.direct = !force_stage && host_is_pinned(r.src, r.bytes);
@@ -3334,7 +3350,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     size_t staged = 0;
     std::vector<int> stage_w;
     for (const Run& r : runs) if (!r.direct) { staged += r.bytes; for (int w = r.w0; w < r.w1; ++w) if (!plan[w].skip && win[w].N > 0) stage_w.push_back(w); }
-    auto stage = [&](int i) { const int w = stage_w[(size_t)i]; memcpy(hobs + plan[w].i_obs, win[w].obs, sizeof(orbx_ba_obs) * (size_t)win[w].N); };
+    auto stage = [&](int i) {
+      const int w = stage_w[(size_t)i];
+      if (win[w].obs32) memcpy(hobs + plan[w].i_obs, win[w].obs32, sizeof(orbx_ba_obs32) * (size_t)win[w].N);
+      else memcpy(hobs + plan[w].i_obs, win[w].obs, sizeof(orbx_ba_obs) * (size_t)win[w].N);
+    };
     int nthr = (int)std::min<size_t>({stage_w.size(), (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16, staged / (1u << 20) + 1});
     if (h->ba_pool_cap > 0) nthr = std::min(nthr, h->ba_pool_cap);
     if (nthr > 1 && !h->ba_pool) {
@@ -3377,7 +3397,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.pt_start = (const int*)(dar + pl.a_ptstart); b.o_kf = (const int*)(dar + pl.a_okf);
     b.o_uv = (const double*)(dar + pl.a_ouv);
     b.kf_start = (const int*)(dar + a_cnt + pl.c_kfstart); b.kf_obs = (int*)(dar + pl.a_kfobs); b.kf_pt = (int*)(dar + pl.a_kfpt);
-    b.obs_raw = (const orbx_ba_obs*)(dobs + pl.i_obs); b.pt_fill = (int*)(dar + a_cnt + pl.c_fill); b.obs_tmp = (int*)(dar + pl.a_tmp);
+    b.obs_raw = (const orbx_ba_obs*)(dobs + pl.i_obs); b.obs32 = win[w].obs32 ? 1 : 0; b.pt_fill = (int*)(dar + a_cnt + pl.c_fill); b.obs_tmp = (int*)(dar + pl.a_tmp);
     b.o_flag = inertial ? (int*)(dar + pl.a_oflag) : nullptr;
     b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl); b.vg = (double*)(dar + pl.a_vg);
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
@@ -3659,9 +3679,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     const int code = (int)hout[plan[w].o_out / 8 + 5];
     if (code == 0) continue;
     const int i = 0x7fffffff - code;
-    const orbx_ba_obs& o = win[w].obs[i];
-    return orbx_fail(h, ORBX_ERR_INVALID, "window %d observation %d: index out of range (kf %d/%d, fixed %d/%d, mp %d/%d)", w, i, o.kf_idx,
-                     win[w].K, o.fixed_idx, win[w].F, o.mp_idx, win[w].M);
+    int kf, fx, mp;
+    if (win[w].obs32) { const orbx_ba_obs32& o = win[w].obs32[i]; kf = o.kf_idx >= 0 ? o.kf_idx : -1; fx = o.kf_idx >= 0 ? -1 : -1 - o.kf_idx; mp = o.mp_idx; }
+    else { const orbx_ba_obs& o = win[w].obs[i]; kf = o.kf_idx; fx = o.fixed_idx; mp = o.mp_idx; }
+    return orbx_fail(h, ORBX_ERR_INVALID, "window %d observation %d: index out of range (kf %d/%d, fixed %d/%d, mp %d/%d)", w, i, kf,
+                     win[w].K, fx, win[w].F, mp, win[w].M);
   }
   for (int w = 0; w < W; ++w) {
     if (plan[w].skip) continue;

@@ -1895,7 +1895,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     }
     if (fork) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
     {
-      ProfScope ps(h, "describe_kernel", nullptr, true);
+      ProfScope ps(h, unfused ? "describe_kernel" : "describe_fused_kernel", nullptr, true);
       const int blocks_x16 = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block and round
       const int blocks_x = unfused ? blocks_x16 : (blocks_x16 + ORBX_DF_ITERS - 1) / ORBX_DF_ITERS;
       if (unfused)

@@ -979,10 +979,10 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
     for (int i = 0; i < n_windows; ++i) {
       orbx_ba_window& q = windows[i];
       if (q.K < 0 || q.F < 0 || q.M < 0 || q.N < 0 || (q.K > 0 && (!q.poses_cw || !q.poses_wc_out)) || (q.F > 0 && !q.fixed_poses_cw) ||
-          (q.M > 0 && !q.points) || (q.N > 0 && !q.obs))
+          (q.M > 0 && !q.points) || (q.N > 0 && !q.obs && !q.obs32))
         return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_batch: window %d: bad argument", i);
       w[i] = BaWinHost{q.K, q.F, q.M, q.N, q.poses_cw, q.fixed_poses_cw, q.points, q.obs, q.poses_wc_out, &q.iterations,
-                       &q.initial_error, &q.final_error, ORBX_OK};
+                       &q.initial_error, &q.final_error, ORBX_OK, q.obs32};
     }
     ORBX_HIP(h, hipSetDevice(h->device));
     orbx_prof_begin_call(h);

@@ -292,6 +292,7 @@ struct BaWinHost {
   const double* poses_cw; const double* fixed_poses_cw; double* points; const orbx_ba_obs* obs;
   double* poses_wc_out; int* iterations; double* initial_error; double* final_error;
   int status;
+  const orbx_ba_obs32* obs32 = nullptr;       // the 16-byte form of the observations (orbx.h): used instead of obs when given
 };
 int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int W, BaWinHost* win,
                    orbx_should_stop_fn should_stop, void* user, bool global_mode = false, const struct BaInertialHost* inr = nullptr,

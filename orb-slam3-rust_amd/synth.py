@@ -439,6 +439,16 @@ def inertial_window(seed, K, M, obs_dtype, n_fixed=2, dt=0.25, w=752, h=480, cam
                 gt_poses_wc=gt_poses, gt_velocities=gt_vel, gt_points=pts)
 
 
+def keypoint_precision(window):
+    """The window with its pixel coordinates rounded to f32 and widened again — what the reference's observations are: kp.pt() is a
+    cv::Point2f, widened to f64 when the problem is collected (local_ba_lm.rs:870-872)."""
+    w = dict(window)
+    o = np.array(window["obs"], copy=True)
+    o["u"] = o["u"].astype(np.float32).astype(np.float64); o["v"] = o["v"].astype(np.float32).astype(np.float64)
+    w["obs"] = o
+    return w
+
+
 def write_ba_batch_file(path, windows, obs_dtype):
     """`windows` (dicts of ba_window) in the layout tests/cpp/ba_batch_driver.cpp reads: int32 W, then per window int32 K, F, M, N |
     poses_cw [K][7] | fixed_cw [F][7] | points [M][3] | obs [N] (orbx_ba_obs)."""

@@ -385,6 +385,19 @@ def test_ba_observations_from_pinned_memory_equal_staged(gpu_handle, pkg):
         for i, (x, y) in enumerate(zip(a, c)):
             if x is not None:
                 assert x["iterations"] == y["iterations"] and np.array_equal(x["poses_wc"], y["poses_wc"]) and np.array_equal(x["points"], y["points"]), i
+    # the 16-byte wire format (orbx_ba_obs32: f32 coordinates, widened on the device) on windows whose coordinates are f32, as the reference's:
+    # the same bits as the 32-byte form of the same windows; coordinates that are not f32 are refused by the mirror
+    w32 = [pkg.synth.keypoint_precision(w) for w in wins]
+    ref32 = gpu_handle.ba_solve_visual_batch(cam, cfg, w32)
+    got32 = gpu_handle.prepare_ba_batch(w32, obs32=True).solve(cam, cfg)
+    for i, (x, y) in enumerate(zip(ref32, got32)):
+        if x is None:
+            assert y is None
+            continue
+        assert x["iterations"] == y["iterations"] and x["initial_error"] == y["initial_error"] and x["final_error"] == y["final_error"], i
+        assert np.array_equal(x["poses_wc"], y["poses_wc"]) and np.array_equal(x["points"], y["points"]), i
+    with pytest.raises(ValueError):
+        gpu_handle.prepare_ba_batch(wins, obs32=True)
     # an index out of range inside pinned memory is found by the device-side check and named
     o = packed[15]["obs"]; keep = int(o["mp_idx"][7]); o["mp_idx"][7] = len(packed[15]["points"]) + 3
     with pytest.raises(pkg.OrbxError) as e:
@@ -409,7 +422,10 @@ def test_ba_batch_through_the_c_abi_from_a_compiled_caller(gpu_handle, pkg, tmp_
     wins = [pkg.synth.ba_window(2300 + i, *shapes[i % 4], pkg.BA_OBS, n_fixed_extra=i % 2) for i in range(20)]
     want = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
     pkg.synth.write_ba_batch_file(str(tmp_path / "batch.bin"), wins, pkg.BA_OBS)
-    for mode in ("pinned", "pageable"):
+    wins = [pkg.synth.keypoint_precision(w) for w in wins]                    # f32 pixel coordinates, as the reference's: the 16-byte wire format applies
+    want = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
+    pkg.synth.write_ba_batch_file(str(tmp_path / "batch.bin"), wins, pkg.BA_OBS)
+    for mode in ("pinned", "pageable", "pinned32"):
         r = subprocess.run([exe, str(tmp_path / "batch.bin"), str(tmp_path / "out.bin"), "2", mode], check=True, capture_output=True, text=True)
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["windows"] == 20 and line["reps"] == 2 and len(line["ms_per_call"]) == 2
