@@ -408,14 +408,17 @@ def bench_extras(P, h, torch, batches, out, args, W, H):
     hout = P.Handle.alloc_host_outputs(args.batch, out["cap_kp"])
     h.process_stereo_batch_host(host_in, hout)
     reps = 4
+    per_call = []
     t0 = time.perf_counter()
     for _ in range(reps):
+        t1 = time.perf_counter()
         h.process_stereo_batch_host(host_in, hout)
+        per_call.append(round((time.perf_counter() - t1) * 1e3, 3))
     dt = time.perf_counter() - t0
     bytes_in = host_in.numel()
     bytes_out = sum(v.numel() * v.element_size() for k, v in hout.items() if hasattr(v, "numel"))
     r["pcie_inclusive"] = dict(value=round(args.batch * reps / dt, 1), unit="stereo frames/s", pairs_per_call=args.batch,
-                               h2d_MB_per_call=round(bytes_in / 1e6, 1), d2h_MB_per_call=round(bytes_out / 1e6, 1),
+                               h2d_MB_per_call=round(bytes_in / 1e6, 1), d2h_MB_per_call=round(bytes_out / 1e6, 1), ms_per_call=per_call,
                                note="orbx_process_stereo_batch: host images in, host results out (pinned), H2D + kernels + D2H pipelined; never `value`")
     # the one-pair drop-in call (StereoProcessor::process): H2D of two images, ~20 kernels replayed from a hipGraph, one D2H block
     L = host_in[0, 0].numpy(); R = host_in[0, 1].numpy()
@@ -554,7 +557,7 @@ def schur_executed_flop(K_opt, M):
 def bench_ba_inertial(P, h, cam, K=10, M=2000, seed=42):
     """solve_inertial_ba (local_inertial_ba.rs:1074-1275; LocalInertialBAConfig::window_size = 10): what the local mapper runs once the
     IMU is initialised.  15-d keyframe states, 9-d preintegration + 6-d bias-walk edges beside the reprojection residuals."""
-    w = P.synth.inertial_window(seed, K, M, P.BA_OBS)
+    w = P.Handle.pack_ba_windows([P.synth.inertial_window(seed, K, M, P.BA_OBS)])[0]   # (observations in page-locked memory)
     icfg = P.LocalInertialBAConfig()
     args = (cam, icfg, w["poses_wc"], w["velocities"], w["biases"], w["fixed_cw"], w["points"], w["obs"], w["edge_kf"], w["preint"])
     r = h.ba_solve_inertial(*args)
@@ -576,7 +579,7 @@ def bench_ba_inertial(P, h, cam, K=10, M=2000, seed=42):
 
 
 def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
-    win = P.synth.ba_window(seed, K, M, P.BA_OBS)
+    win = P.Handle.pack_ba_windows([P.synth.ba_window(seed, K, M, P.BA_OBS)])[0]      # (observations in page-locked memory, as in bench_ba)
     args = (cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
     r = h.ba_solve_visual(*args)
     reps = 5
@@ -701,6 +704,8 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
     whole window on this GPU.  N GPUs (configs[3]): the SAME window with its map points partitioned
     over the ranks and the reduced normal equations all-reduced over RCCL every iteration."""
     win = P.synth.ba_window(42, 20, 2000, P.BA_OBS)
+    if world == 1:
+        win = P.Handle.pack_ba_windows([win])[0]       # the caller's observation storage is page-locked (orbx.h): the copy engine reads it where it lies
     cfg = P.LocalBAConfigLM()
     hook = None
     native = False

@@ -68,8 +68,9 @@ def _gpu(gpu_handle, w, cfg=None, **kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,K,M,fixed", [(1, 3, 60, 1), (2, 5, 150, 2), (3, 10, 400, 2), (4, 8, 300, 0)])
+@pytest.mark.parametrize("seed,K,M,fixed", [(1, 3, 60, 1), (2, 5, 150, 2), (3, 10, 400, 2), (4, 8, 300, 0), (6, 11, 250, 1)])
 def test_gpu_inertial_ba_matches_oracle(gpu_handle, seed, K, M, fixed):
+    """(K = 11: 15 K = 165 unknowns, the largest system of the tiled LDS solve — 66 tiles = 135 168 B of dynamic LDS beside the kernel's static arrays)"""
     w = P.synth.inertial_window(seed, K, M, P.BA_OBS, n_fixed=fixed)
     o = _oracle(w)
     g = _gpu(gpu_handle, w)
@@ -83,9 +84,10 @@ def test_gpu_inertial_ba_matches_oracle(gpu_handle, seed, K, M, fixed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,K,M", [(11, 13, 300), (12, 22, 400)])
+@pytest.mark.parametrize("seed,K,M", [(11, 13, 300), (12, 22, 400), (13, 21, 300)])
 def test_gpu_inertial_ba_beyond_the_lds_tiles(gpu_handle, seed, K, M):
-    """15 K = 195 unknowns: the one-launch factorisation in global memory; 15 K = 330: one launch per panel (inertial windows of the
+    """15 K = 195 unknowns: the one-launch factorisation in global memory; 15 K = 315: the same with an ODD row stride, two rows per
+    thread below the first panels and a short (11-column) last panel; 15 K = 330: one launch per panel (inertial windows of the
     reference hold 10 keyframes; these sizes are the same code paths a 50-keyframe visual window takes)."""
     w = P.synth.inertial_window(seed, K, M, P.BA_OBS, n_fixed=1)
     o = _oracle(w)
