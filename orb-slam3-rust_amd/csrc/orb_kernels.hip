@@ -880,6 +880,9 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
   return r;
 }
 
+// (Round 4: the same response on packed i16 pairs — v_perm_b32 widening, packed column sums / differences, v_dot2_i32_i16 for the three sums
+// of products — was written and compiled: 665 vector instructions in the kernel against 777, the compiler already shares the column sums of this
+// scalar form; at 45 % VALU share of a 0.15 ms kernel that is below 1 % of the step.  Not kept.)
 // float -> u32 whose unsigned order is the float order
 __device__ __forceinline__ unsigned orderable(float f) {
   const unsigned u = __float_as_uint(f);
@@ -1494,7 +1497,10 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
 #pragma unroll
       for (int it = 0; it < 17; ++it) {
         const int ph = it % 3, k = it / 3;
-        if (it < 16 || li < 2) *reinterpret_cast<unsigned long long*>(mywin + st_l[ph] + (unsigned)k * (8u * DF_WP)) = v[it];
+        // stored as p - 128 (xor 0x80 per byte): the signed bytes the matrix pipe multiplies; the centroid below takes signed dot products of
+        // the same bytes — the disc is symmetric about its centre, so the offset drops out of both moments (sum of (u - 15) and of (r - 15)
+        // over the disc are zero).  34 xors per wave and group of 4 keypoints here instead of 48 on the blur's operands
+        if (it < 16 || li < 2) *reinterpret_cast<unsigned long long*>(mywin + st_l[ph] + (unsigned)k * (8u * DF_WP)) = v[it] ^ 0x8080808080808080ull;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1511,14 +1517,14 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
         const int t0 = row * 8 + 2 * (li & 3);
         const uint2 w1 = *reinterpret_cast<const uint2*>(&s_ones[t0]);
         const uint2 wc = *reinterpret_cast<const uint2*>(&s_col[t0]);
-        const unsigned sI = __builtin_amdgcn_udot4((unsigned)(px >> 32), w1.y, __builtin_amdgcn_udot4((unsigned)px, w1.x, 0u, false), false);
-        sA += (int)__builtin_amdgcn_udot4((unsigned)(px >> 32), wc.y, __builtin_amdgcn_udot4((unsigned)px, wc.x, 0u, false), false);
-        sB += (int)sI;
-        sC += (r - 15) * (int)sI;
+        const int sI = __builtin_amdgcn_sdot4((int)(px >> 32), (int)w1.y, __builtin_amdgcn_sdot4((int)px, (int)w1.x, 0, false), false);
+        sA += __builtin_amdgcn_sdot4((int)(px >> 32), (int)wc.y, __builtin_amdgcn_sdot4((int)px, (int)wc.x, 0, false), false);
+        sB += sI;
+        sC += (r - 15) * sI;
       }
     }
     sA = row16_sum(sA); sB = row16_sum(sB); sC = row16_sum(sC);
-    const int m10 = sA - 15 * sB, m01 = sC;
+    const int m10 = sA - 15 * sB, m01 = sC;   // (of p - 128: equal to the moments of p, see the staging)
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     float ca, sa;
     sincos_deg(angle, ca, sa);
@@ -1532,8 +1538,7 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
         df_i4 a1[3];
 #pragma unroll
         for (int mb = 0; mb < 3; ++mb) {
-          a1[mb] = *reinterpret_cast<const df_i4*>(win + (16 * mb + m16) * DF_WP + 16 * q);
-          a1[mb] ^= (int)0x80808080;                                           // p - 128 as a signed byte
+          a1[mb] = *reinterpret_cast<const df_i4*>(win + (16 * mb + m16) * DF_WP + 16 * q);   // (p - 128 as signed bytes: flipped when staged)
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0): the window is in registers — its bytes may be overwritten
         __builtin_amdgcn_wave_barrier();

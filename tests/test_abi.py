@@ -31,6 +31,30 @@ def test_struct_layouts_match_header(pkg):
     assert pkg.DMATCH.names == ("query_idx", "train_idx", "img_idx", "distance")
 
 
+def test_ba_window_and_obs32_layouts_match_header(pkg, tmp_path):
+    """orbx_ba_window / orbx_ba_obs32 as a C compiler lays them out (gcc on include/orbx.h) against the ctypes / numpy mirrors, and the
+    orbx_ba_obs -> orbx_ba_obs32 mapping (fixed observer f as kf_idx = -1 - f, the identity pose as -1 - F; coordinates that are not f32 refused)."""
+    import ctypes as C
+    import subprocess
+    from orb_slam3_rust_amd.api import _BaWindow
+    src = tmp_path / "lay.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "orbx.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(orbx_ba_window), '
+                   'offsetof(orbx_ba_window, obs), offsetof(orbx_ba_window, obs32), sizeof(orbx_ba_obs32), offsetof(orbx_ba_obs32, u), sizeof(orbx_ba_obs)); return 0; }\n')
+    exe = tmp_path / "lay"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [C.sizeof(_BaWindow), _BaWindow.obs.offset, _BaWindow.obs32.offset, pkg.BA_OBS32.itemsize, pkg.BA_OBS32.fields["u"][1], pkg.BA_OBS.itemsize]
+    assert pkg.BA_OBS32.itemsize == 16
+    o = np.zeros(4, pkg.BA_OBS)
+    o["kf_idx"] = [3, -1, -1, 0]; o["fixed_idx"] = [-1, 1, -1, -1]; o["mp_idx"] = [7, 8, 9, 10]
+    o["u"] = [1.5, 2.25, 640.125, 0.0]; o["v"] = [3.0, 4.5, 100.0625, 479.5]
+    c = pkg.ba_obs_to_obs32(o, 2)
+    assert list(c["kf_idx"]) == [3, -2, -3, 0] and list(c["mp_idx"]) == [7, 8, 9, 10]          # fixed 1 -> -2; identity (fixed_idx -1) -> -1 - F = -3
+    assert np.array_equal(c["u"].astype(np.float64), o["u"]) and np.array_equal(c["v"].astype(np.float64), o["v"])
+    o["u"][2] = 640.1                                                                           # not an f32
+    assert pkg.ba_obs_to_obs32(o, 2) is None
+
+
 def test_defaults_mirror_reference(pkg):
     import ctypes as C
     from orb_slam3_rust_amd.api import _BaConfig, _OrbParams
