@@ -115,6 +115,7 @@ struct BaWin {
   int *pt_fill;          // [M] per-point counters: observations of the point (count pass), then its fill position (place pass)
   int *obs_tmp;          // [N] observation indices grouped by map point, in arrival order within a point (sorted by ba_prep_order_kernel)
   int *o_flag;           // [N] inertial: orbx_ba_obs::_pad (bit 0 = stereo) in point-major order, else null
+  double *Mz;            // [M][6] per point: the inverse of the Cholesky factor of V* (lower: m00, m10, m11, m20, m21, m22) — V*^-1 = M^T M, the one-operand Schur product's Z = W M^T
 };
 
 // The pointers a kernel takes out of its window descriptor are generic to the compiler (loaded from memory, not kernel arguments): every
@@ -149,9 +150,10 @@ struct BaWinView {
   BA_AS1 int *pt_fill;
   BA_AS1 int *obs_tmp;
   BA_AS1 int *o_flag;
+  BA_AS1 double *Mz;
 };
 static_assert(sizeof(BaWinView) == sizeof(BaWin) && offsetof(BaWinView, S) == offsetof(BaWin, S) && offsetof(BaWinView, oP) == offsetof(BaWin, oP) &&
-              offsetof(BaWinView, res) == offsetof(BaWin, res) && offsetof(BaWinView, o_flag) == offsetof(BaWin, o_flag),
+              offsetof(BaWinView, res) == offsetof(BaWin, res) && offsetof(BaWinView, o_flag) == offsetof(BaWin, o_flag) && offsetof(BaWinView, Mz) == offsetof(BaWin, Mz),
               "BaWinView is BaWin with its pointers in the global address space");
 __device__ __forceinline__ BaWin ba_win_global(const BaWin* __restrict__ wins, int i) {
   const BaWinView& v = ((const BaWinView*)wins)[i];
@@ -165,6 +167,7 @@ __device__ __forceinline__ BaWin ba_win_global(const BaWin* __restrict__ wins, i
   g.kfpart = (double*)v.kfpart; g.part = (double*)v.part; g.rb = (double*)v.rb; g.dp = (double*)v.dp;
   g.Sg = (double*)v.Sg; g.bvec = (double*)v.bvec; g.ginv = (double*)v.ginv; g.res = (double*)v.res;
   g.obs_raw = (const orbx_ba_obs*)v.obs_raw; g.obs32 = v.obs32; g.pad_ = 0; g.pt_fill = (int*)v.pt_fill; g.obs_tmp = (int*)v.obs_tmp; g.o_flag = (int*)v.o_flag;
+  g.Mz = (double*)v.Mz;
   return g;
 }
 
@@ -498,6 +501,26 @@ __device__ __forceinline__ void obs_w_from_stored(const BaCam& cam, const double
   }
 }
 
+// The one-operand form of the Schur product (round 4).  S_red = sum_j W_j V_j*^-1 W_j^T, and with V* = L L^T, M = L^-1 (lower triangular):
+// V*^-1 = M^T M, so W V*^-1 W^T = Z Z^T with Z = W M^T — ONE operand tile instead of Y = W V*^-1 and W, and Z = A^T (B M^T) never forms W:
+// per slot the 2 x 3 block B M^T (18 operations) and A^T of it (54) where Y and W took 54 + 90.  z[c * 6 + a], M = (m00, m10, m11, m20, m21, m22).
+#ifndef ORBX_BA_SCHUR_Z
+#define ORBX_BA_SCHUR_Z 1
+#endif
+template <bool ACC>
+__device__ __forceinline__ void obs_z_from_stored(const BaCam& cam, const double* Rt, const double* __restrict__ q, const double* __restrict__ M, double* __restrict__ z) {
+  double A[12], B[6];
+  obs_jac_from_proj(cam, Rt, q[0], q[1], q[2], q[3], A, B);
+  const double t00 = B[0] * M[0], t01 = B[0] * M[1] + B[1] * M[2], t02 = B[0] * M[3] + B[1] * M[4] + B[2] * M[5];
+  const double t10 = B[3] * M[0], t11 = B[3] * M[1] + B[4] * M[2], t12 = B[3] * M[3] + B[4] * M[4] + B[5] * M[5];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double z0 = A[a] * t00 + A[6 + a] * t10, z1 = A[a] * t01 + A[6 + a] * t11, z2 = A[a] * t02 + A[6 + a] * t12;
+    if (ACC) { z[a] += z0; z[6 + a] += z1; z[12 + a] += z2; }
+    else { z[a] = z0; z[6 + a] = z1; z[12 + a] = z2; }
+  }
+}
+
 // error (:192-212), Huber (:291-297), and with want_jac the Jacobian blocks and the four numbers they follow from
 __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, const double* X, double u, double v,
                                           bool want_jac, ObsOut& o, int flag = 0) {
@@ -658,6 +681,18 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
   I[3] = I[1]; I[4] = (a_ * f_ - c_ * c_) * id; I[5] = (b_ * c_ - a_ * e_) * id;
   I[6] = I[2]; I[7] = I[5]; I[8] = (a_ * d_ - b_ * b_) * id;
   if (lane32 == 0) {
+#if ORBX_BA_SCHUR_Z
+    {
+      // V* = L L^T (V* is positive definite: V is a sum of B^T B and every diagonal entry is damped), M = L^-1
+      const double l00 = sqrt(a_), l10 = b_ / l00, l20 = c_ / l00;
+      const double l11 = sqrt(fmax(d_ - l10 * l10, 0.0)), l21 = (e_ - l20 * l10) / l11;
+      const double l22 = sqrt(fmax(f_ - l20 * l20 - l21 * l21, 0.0));
+      const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+      const double m10 = -(l10 * m00) * m11, m21 = -(l21 * m11) * m22, m20 = -(l20 * m00 + l21 * m10) * m22;
+      double* mz = win.Mz + 6 * (size_t)j;
+      mz[0] = m00; mz[1] = m10; mz[2] = m11; mz[3] = m20; mz[4] = m21; mz[5] = m22;
+    }
+#endif
 #pragma unroll
     for (int a = 0; a < 9; ++a) Vinv[9 * (size_t)j + a] = I[a];
     gl[3 * (size_t)j] = g[0]; gl[3 * (size_t)j + 1] = g[1]; gl[3 * (size_t)j + 2] = g[2];
@@ -791,7 +826,11 @@ __device__ __forceinline__ void ba_schur_gen_mfma(double4_t (&acc)[2][8], const 
     const double a1 = sY[row * SCH_PITCH + (7 - Q) * 16 + (lane & 15)];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
+#if ORBX_BA_SCHUR_Z
+      const double bv = (DG ? sY : sW)[row * SCH_PITCH + c * 16 + (lane & 15)];     // (a diagonal pair multiplies its one Z tile with itself)
+#else
       const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
+#endif
       if (!DG || c >= Q) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][c], 0, 0, 0);
       if (!DG || c >= 7 - Q) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][c], 0, 0, 0);
     }
@@ -869,6 +908,22 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
 #pragma unroll
       for (int t = 0; t < 18; ++t) w[t] = 0.0;
       const double* Rk = Rt_cur + 12 * (size_t)k;                     // (read where used: 16 accumulator tiles leave no registers to park it in)
+#if ORBX_BA_SCHUR_Z
+      {
+        double Mj[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) Mj[t] = j < d.M ? win.Mz[6 * (size_t)j + t] : 0.0;
+        for (int i = cur[q]; i >= 0; i = obs_next[i]) obs_z_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, Mj, w);   // Z of the slot (0 + Z for the first)
+        double* __restrict__ dstT = side == 0 ? sY : sW;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const int col = 6 * k + a - cb;
+          if (col < 0 || col >= 128) continue;
+          dstT[(3 * pj + 0) * SCH_PITCH + col] = w[a]; dstT[(3 * pj + 1) * SCH_PITCH + col] = w[6 + a]; dstT[(3 * pj + 2) * SCH_PITCH + col] = w[12 + a];
+        }
+        continue;
+      }
+#endif
       for (int i = cur[q]; i >= 0; i = obs_next[i])                 // usually once: W = A^T B rebuilt from the observation's stored numbers
         obs_w_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, w);    // (0 + W for the first: the stored-W form summed the same way)
       if (side == 0) {
@@ -994,6 +1049,7 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
   for (int T = 0; T < nT; ++T) {
     const double* __restrict__ sY = lds + (size_t)(T & 1) * 2 * TILE;
     const double* __restrict__ sW = sY + TILE;
+    (void)sW;
 #pragma unroll
     for (int kq = 0; kq < SCH_R / 4; ++kq) {
       const int row = 4 * kq + (lane >> 4);
@@ -1001,7 +1057,11 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
       const double a1 = sY[row * SCH_PITCH + (7 - Q) * 16 + (lane & 15)];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
+#if ORBX_BA_SCHUR_Z
+        const double bv = sY[row * SCH_PITCH + c * 16 + (lane & 15)];
+#else
         const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
+#endif
         if (c >= Q) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[c], 0, 0, 0);              // tile (Q, c)
         if (c > 7 - Q) acc[7 - c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[7 - c], 0, 0, 0);  // tile (7-Q, c) in slot 7-c < Q
         if (c == 7 - Q) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accx, 0, 0, 0);              // tile (7-Q, 7-Q)
@@ -1070,10 +1130,15 @@ __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaW
     const int f = tid - 256, pj = f / 23, k = f - pj * 23;
     const bool slot = pj < NPT && k < d.K && 6 * k < 128;
     const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv;
+    (void)Vinv;
     const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
     // (the slot index runs two tiles ahead, the stored numbers one; a second register set — numbers two tiles ahead — measured no
     // difference: the producers wait for the double-precision pipe, not for memory)
+#if ORBX_BA_SCHUR_Z
+    struct SlotData { double pq[4], I[6]; bool have; int chain, idx; } sd;    // I: the point's M (6 numbers)
+#else
     struct SlotData { double pq[4], I[9]; bool have; int chain, idx; } sd;
+#endif
     double Rk[12];
 #pragma unroll
     for (int t = 0; t < 12; ++t) Rk[t] = slot ? win.Rt_cur[12 * (size_t)k + t] : 0.0;
@@ -1086,13 +1151,34 @@ __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaW
       q.have = i >= 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) q.pq[t] = i >= 0 ? oP[6 * (size_t)i + t] : 0.0;
+#if ORBX_BA_SCHUR_Z
+#pragma unroll
+      for (int t = 0; t < 6; ++t) q.I[t] = (slot && T < nT && j < d.M) ? win.Mz[6 * (size_t)j + t] : 0.0;
+#else
 #pragma unroll
       for (int t = 0; t < 9; ++t) q.I[t] = (slot && T < nT && j < d.M) ? Vinv[9 * (size_t)j + t] : 0.0;
+#endif
       q.chain = i >= 0 ? obs_next[i] : -1;
     };
     auto fill = [&](const SlotData& q, double* __restrict__ sY, double* __restrict__ sW) {
       if (!slot) return;
       double w[18];
+#if ORBX_BA_SCHUR_Z
+      if (q.have) obs_z_from_stored<false>(cam, Rk, q.pq, q.I, w);    // Z = A^T (B M^T) of the slot's observation
+      else {
+#pragma unroll
+        for (int t = 0; t < 18; ++t) w[t] = 0.0;
+      }
+      for (int i = q.chain; i >= 0; i = obs_next[i]) obs_z_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, q.I, w);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int col = 6 * k + a;
+        if (col >= 128) continue;
+        sY[(3 * pj + 0) * SCH_PITCH + col] = w[a]; sY[(3 * pj + 1) * SCH_PITCH + col] = w[6 + a]; sY[(3 * pj + 2) * SCH_PITCH + col] = w[12 + a];
+      }
+      (void)sW;
+      return;
+#endif
       if (q.have) obs_w_from_stored<false>(cam, Rk, q.pq, w);         // W = A^T B of the slot's observation: ~90 multiply-adds, no division
       else {
 #pragma unroll
@@ -3126,7 +3212,7 @@ struct WinPlan {
   size_t i_state, i_params, i_rtfix, i_obs;
   size_t c_fill, c_kfstart;
   size_t a_p1, a_oP, a_rtcur, a_slot, a_next, a_kfobs, a_kfpt, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
-  size_t a_ptstart, a_okf, a_ouv, a_oflag, a_tmp;
+  size_t a_ptstart, a_okf, a_ouv, a_oflag, a_tmp, a_mz;
   size_t o_out;
   int n_kfobs = 0;
   double n_res = 0.0;
@@ -3260,6 +3346,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
     pl.a_oP = car.take(48 * n1); pl.a_rtcur = car.take(96 * k1);
     pl.a_slot = car.take(4 * m1 * k1); pl.a_next = car.take(4 * n1); pl.a_kfobs = car.take(4 * n1); pl.a_kfpt = car.take(4 * n1);
+    pl.a_mz = car.take(48 * m1);
     pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_vg = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
     pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
     pl.a_part = car.take(8 * pl.n_upper * d.ksplit * 256);
@@ -3399,6 +3486,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.kf_start = (const int*)(dar + a_cnt + pl.c_kfstart); b.kf_obs = (int*)(dar + pl.a_kfobs); b.kf_pt = (int*)(dar + pl.a_kfpt);
     b.obs_raw = (const orbx_ba_obs*)(dobs + pl.i_obs); b.obs32 = win[w].obs32 ? 1 : 0; b.pt_fill = (int*)(dar + a_cnt + pl.c_fill); b.obs_tmp = (int*)(dar + pl.a_tmp);
     b.o_flag = inertial ? (int*)(dar + pl.a_oflag) : nullptr;
+    b.Mz = (double*)(dar + pl.a_mz);
     b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl); b.vg = (double*)(dar + pl.a_vg);
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
     b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
