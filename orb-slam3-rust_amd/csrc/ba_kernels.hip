@@ -56,7 +56,7 @@ struct BaDims {
   int rows;     // 3 * pps * ksplit: the k dimension of the Schur product, padded
   int ksplit;
   int ntile;    // P/16
-  int pps;      // map points per k-split, a multiple of 8 (= 24 rows = one LDS operand tile)
+  int pps;      // map points per k-split, a multiple of 16 (= 48 rows = one LDS operand tile of the producer / consumer body, two of the general body)
   int ncb;      // 128-column blocks of the reduced system: ceil(ntile / 8)
 };
 
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void ba_kflist_kernel(const BaWin* __restrict_
   }
 }
 
-struct ObsOut { double r0, r1, A[12], B[6]; double px, py, piz, psw; };
+struct ObsOut { double r0, r1, A[12], B[6]; double px, py, piz, psw; double chi; };
 
 // The 2x6 pose block A and the 2x3 point block B of one observation (both * sqrt(w)) from its four "projective" numbers —
 // x, y of the point in the camera frame, 1/z, and the square root of the Huber weight — and the keyframe's R|t: no division, no
@@ -449,118 +449,101 @@ struct ObsOut { double r0, r1, A[12], B[6]; double px, py, piz, psw; };
 // inertial forms).  obs_terms itself goes through this function, so every kernel that rebuilds the blocks from the stored
 // (x, y, 1/z, sqrt w) gets the same bits the build kernel used for V and g_l.
 // J_pose (:239-254), J_point (:281-287); inertial: local_inertial_ba.rs:735-804.
+// Round 4: the entries as products of six shared factors (f_x sqrt w, f_y sqrt w, those times 1/z, x/z, y/z) instead of each entry's own
+// chain of four or five multiplications as the reference writes them — 28 double-precision operations where there were 70, in every
+// per-observation kernel (these kernels issue f64 operations and little else).  The values agree with the literal form to rounding.
+// The inertial form's point block is the same expression; its pose block is the visual one with the opposite sign (the perturbation
+// is applied on the other side), so one body serves both.  A[4] and A[9] are structurally zero: the callers skip their products.
 __device__ __forceinline__ void obs_jac_from_proj(const BaCam& cam, const double* Rt, double x, double y, double piz, double sw,
                                                   double* __restrict__ A, double* __restrict__ B) {
-  if (piz == 0.0) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) A[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) B[i] = 0.0;
-    return;
-  }
-  const double fx = cam.fx, fy = cam.fy;
-  if (cam.inertial) {
-    const double zi = piz, zi2 = zi * zi;
-    const double du0 = fx * zi, du2 = -fx * x * zi2, dv1 = fy * zi, dv2 = -fy * y * zi2;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {                      // -(R_cw^T d(u,v)/dp_cam) (:760-771)
-      B[c] = -(Rt[c] * du0 + Rt[3 + c] * 0.0 + Rt[6 + c] * du2) * sw;
-      B[3 + c] = -(Rt[c] * 0.0 + Rt[3 + c] * dv1 + Rt[6 + c] * dv2) * sw;
-    }
-    const double xy = x * y, xs = x * x, ys = y * y;    // :774-803 (the caller drops A for a fixed keyframe)
-    A[0] = -fx * xy * zi2 * sw; A[1] = fx * (1.0 + xs * zi2) * sw; A[2] = -fx * y * zi * sw;
-    A[3] = fx * zi * sw; A[4] = 0.0; A[5] = -fx * x * zi2 * sw;
-    A[6] = -fy * (1.0 + ys * zi2) * sw; A[7] = fy * xy * zi2 * sw; A[8] = fy * x * zi * sw;
-    A[9] = 0.0; A[10] = fy * zi * sw; A[11] = -fy * y * zi2 * sw;
-    return;
-  }
-  const double invz = piz, invz2 = invz * invz;
-  A[0] = x * y * invz2 * fx * sw;         A[1] = -(1.0 + x * x * invz2) * fx * sw; A[2] = y * invz * fx * sw;
-  A[3] = -invz * fx * sw;                 A[4] = 0.0;                              A[5] = x * invz2 * fx * sw;
-  A[6] = (1.0 + y * y * invz2) * fy * sw; A[7] = -x * y * invz2 * fy * sw;         A[8] = -x * invz * fy * sw;
-  A[9] = 0.0;                             A[10] = -invz * fy * sw;                 A[11] = y * invz2 * fy * sw;
-  const double t0 = fx, t2 = -fx * x * invz, t4 = fy, t5 = -fy * y * invz;
+  // (piz == 0 comes with sw == 0 — obs_terms sets both or neither, an empty Schur slot is all zeros — and then every entry below is
+  // 0 * finite: no test, no branch, so that two observations' blocks can be scheduled into each other)
+  const double fs = cam.fx * sw, gs = cam.fy * sw, fz = fs * piz, gz = gs * piz, xz = x * piz, yz = y * piz;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    B[c] = (-invz) * (t0 * Rt[c] + t2 * Rt[6 + c]) * sw;
-    B[3 + c] = (-invz) * (t4 * Rt[3 + c] + t5 * Rt[6 + c]) * sw;
+    B[c] = fz * fma(xz, Rt[6 + c], -Rt[c]);                // -(1/z) (f_x R_0c - f_x (x/z) R_2c) sqrt w
+    B[3 + c] = gz * fma(yz, Rt[6 + c], -Rt[3 + c]);
   }
+  const double sg = cam.inertial ? -1.0 : 1.0;
+  const double fa = sg * fs, ga = sg * gs, fza = sg * fz, gza = sg * gz;
+  A[2] = yz * fa;                    A[0] = xz * A[2];                  A[1] = -(fma(xz, xz, 1.0) * fa);
+  A[3] = -fza;                       A[4] = 0.0;                        A[5] = xz * fza;
+  A[8] = -(xz * ga);                 A[7] = yz * A[8];                  A[6] = fma(yz, yz, 1.0) * ga;
+  A[9] = 0.0;                        A[10] = -gza;                      A[11] = yz * gza;
 }
-
-// W = A^T B (6x3, w[c * 6 + a]) of the observation stored at q = oP + 6 i, for the keyframe with R|t `Rt`
-// ACC: add to w (a point seen twice by one keyframe: the slot holds the sum of its observations' W blocks, first + second + ...)
-template <bool ACC>
-__device__ __forceinline__ void obs_w_from_stored(const BaCam& cam, const double* Rt, const double* __restrict__ q, double* __restrict__ w) {
-  double A[12], B[6];
-  obs_jac_from_proj(cam, Rt, q[0], q[1], q[2], q[3], A, B);
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    const double w0 = A[a] * B[0] + A[6 + a] * B[3], w1 = A[a] * B[1] + A[6 + a] * B[4], w2 = A[a] * B[2] + A[6 + a] * B[5];
-    if (ACC) { w[a] += w0; w[6 + a] += w1; w[12 + a] += w2; }
-    else { w[a] = w0; w[6 + a] = w1; w[12 + a] = w2; }
-  }
+// (the pose block's structural zeros: column 4 of the u row, column 3 of the v row)
+__device__ __forceinline__ constexpr bool ba_a0_zero(int a) { return a == 4; }
+__device__ __forceinline__ constexpr bool ba_a1_zero(int a) { return a == 3; }
+// A[a] p + A[6 + a] q without the products of the structural zeros
+__device__ __forceinline__ double ba_arow(const double* A, int a, double p, double q) {
+  if (ba_a0_zero(a)) return A[6 + a] * q;
+  if (ba_a1_zero(a)) return A[a] * p;
+  return fma(A[a], p, A[6 + a] * q);
+}
+// acc + A[a] p + A[6 + a] q
+__device__ __forceinline__ double ba_arow_acc(double acc, const double* A, int a, double p, double q) {
+  if (ba_a0_zero(a)) return fma(A[6 + a], q, acc);
+  if (ba_a1_zero(a)) return fma(A[a], p, acc);
+  return fma(A[a], p, fma(A[6 + a], q, acc));
 }
 
 // The one-operand form of the Schur product (round 4).  S_red = sum_j W_j V_j*^-1 W_j^T, and with V* = L L^T, M = L^-1 (lower triangular):
 // V*^-1 = M^T M, so W V*^-1 W^T = Z Z^T with Z = W M^T — ONE operand tile instead of Y = W V*^-1 and W, and Z = A^T (B M^T) never forms W:
-// per slot the 2 x 3 block B M^T (18 operations) and A^T of it (54) where Y and W took 54 + 90.  z[c * 6 + a], M = (m00, m10, m11, m20, m21, m22).
-#ifndef ORBX_BA_SCHUR_Z
-#define ORBX_BA_SCHUR_Z 1
-#endif
+// per slot the 2 x 3 block B M^T (12 operations) and A^T of it (32) where Y and W took 54 + 90.  z[c * 6 + a], M = (m00, m10, m11, m20, m21, m22).
 template <bool ACC>
 __device__ __forceinline__ void obs_z_from_stored(const BaCam& cam, const double* Rt, const double* __restrict__ q, const double* __restrict__ M, double* __restrict__ z) {
   double A[12], B[6];
   obs_jac_from_proj(cam, Rt, q[0], q[1], q[2], q[3], A, B);
-  const double t00 = B[0] * M[0], t01 = B[0] * M[1] + B[1] * M[2], t02 = B[0] * M[3] + B[1] * M[4] + B[2] * M[5];
-  const double t10 = B[3] * M[0], t11 = B[3] * M[1] + B[4] * M[2], t12 = B[3] * M[3] + B[4] * M[4] + B[5] * M[5];
+  double t[6];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const double* b = B + 3 * r;
+    t[3 * r] = b[0] * M[0]; t[3 * r + 1] = fma(b[0], M[1], b[1] * M[2]); t[3 * r + 2] = fma(b[0], M[3], fma(b[1], M[4], b[2] * M[5]));
+  }
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
-    const double z0 = A[a] * t00 + A[6 + a] * t10, z1 = A[a] * t01 + A[6 + a] * t11, z2 = A[a] * t02 + A[6 + a] * t12;
-    if (ACC) { z[a] += z0; z[6 + a] += z1; z[12 + a] += z2; }
-    else { z[a] = z0; z[6 + a] = z1; z[12 + a] = z2; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) z[6 * c + a] = ACC ? ba_arow_acc(z[6 * c + a], A, a, t[c], t[3 + c]) : ba_arow(A, a, t[c], t[3 + c]);
   }
 }
 
-// error (:192-212), Huber (:291-297), and with want_jac the Jacobian blocks and the four numbers they follow from
+// error (:192-212), Huber (:291-297), and with want_jac the Jacobian blocks and the four numbers they follow from.
+// o.chi = w |e|^2 = |e|^2 inside the Huber threshold, threshold * |e| beyond it — every sum of squared residuals (the build kernel's and
+// the trial's) takes this one expression, which needs neither the weight's division nor its square root; r0, r1 (= sqrt w e, for g_l)
+// only exist with want_jac.  The projection divides once (1/z) and multiplies twice where the reference writes x / z, y / z: a
+// double-precision division is ~30 issue slots of a kernel that does little else.
 __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, const double* X, double u, double v,
                                           bool want_jac, ObsOut& o, int flag = 0) {
   // X_c = R X + t.  (The reference rotates with the quaternion form v + w t + q x t; R X is the same
   // rotation — agreement is to rounding, well inside the stated tolerance.)
-  const double x = Rt[0] * X[0] + Rt[1] * X[1] + Rt[2] * X[2] + Rt[9];
-  const double y = Rt[3] * X[0] + Rt[4] * X[1] + Rt[5] * X[2] + Rt[10];
-  const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+  const double x = fma(Rt[0], X[0], fma(Rt[1], X[1], fma(Rt[2], X[2], Rt[9])));
+  const double y = fma(Rt[3], X[0], fma(Rt[4], X[1], fma(Rt[5], X[2], Rt[10])));
+  const double z = fma(Rt[6], X[0], fma(Rt[7], X[1], fma(Rt[8], X[2], Rt[11])));
   o.px = x; o.py = y; o.piz = 0.0; o.psw = 0.0;
-  if (cam.inertial) {   // local_inertial_ba.rs:633-659 (residual), :735-804 (Jacobian rows)
-    if (!(z > 0.001)) {
-      o.r0 = 100.0; o.r1 = 100.0;
-      if (want_jac) obs_jac_from_proj(cam, Rt, x, y, 0.0, 0.0, o.A, o.B);
-      return;
-    }
-    const double thr = (flag & 1) ? cam.huber_stereo : cam.huber, fx = cam.fx, fy = cam.fy;
-    {
-      const double e0 = u - (fx * x / z + cam.cx), e1 = v - (fy * y / z + cam.cy);
-      const double en = sqrt(e0 * e0 + e1 * e1);
-      const double sw = sqrt(en <= thr ? 1.0 : thr / en);
-      o.r0 = e0 * sw; o.r1 = e1 * sw;
-    }
-    if (!want_jac) return;
-    const double zi = 1.0 / z;
-    const double e0 = u - (fx * x * zi + cam.cx), e1 = v - (fy * y * zi + cam.cy);   // :743-745 (x * z_inv, not x / z)
-    const double en = sqrt(e0 * e0 + e1 * e1);
-    const double sw = en <= thr ? 1.0 : sqrt(thr / en);
-    o.piz = zi; o.psw = sw;
-    obs_jac_from_proj(cam, Rt, x, y, zi, sw, o.A, o.B);
+  // local_inertial_ba.rs:633-659 (residual), :735-804 (Jacobian rows): behind the camera -> (100, 100), no Jacobian; the visual form
+  // (:192-212) takes the same residual there and keeps the Jacobian unless |z| < 1e-6 (or zero_behind: the global form)
+  const bool behind = cam.inertial ? !(z > 0.001) : z <= 0.001;
+  const double thr = cam.inertial && (flag & 1) ? cam.huber_stereo : cam.huber;
+  if (cam.inertial && behind) {                       // (its (100, 100) is returned before the Huber weight: :640-642)
+    o.r0 = 100.0; o.r1 = 100.0; o.chi = 20000.0;
+    if (want_jac) obs_jac_from_proj(cam, Rt, x, y, 0.0, 0.0, o.A, o.B);
     return;
   }
-  double e0, e1;
-  if (z <= 0.001) { e0 = 100.0; e1 = 100.0; }
-  else { e0 = u - (cam.fx * x / z + cam.cx); e1 = v - (cam.fy * y / z + cam.cy); }
-  const double en = sqrt(e0 * e0 + e1 * e1);
-  const double w = (en <= cam.huber) ? 1.0 : cam.huber / en;
-  const double sw = sqrt(w);
-  o.r0 = e0 * sw; o.r1 = e1 * sw;
+  const double zi = 1.0 / z;
+  double e0 = 100.0, e1 = 100.0;
+  if (!behind) { e0 = u - fma(cam.fx * x, zi, cam.cx); e1 = v - fma(cam.fy * y, zi, cam.cy); }
+  const double s2 = fma(e0, e0, e1 * e1);
+  double sw = 1.0;
+  if (s2 <= thr * thr) o.chi = s2;
+  else {
+    const double en = sqrt(s2);
+    o.chi = thr * en;
+    if (want_jac) sw = sqrt(thr / en);
+  }
   if (!want_jac) return;
-  if (!(fabs(z) < 1e-6 || (cam.zero_behind && z <= 0.001))) { o.piz = 1.0 / z; o.psw = sw; }
+  o.r0 = e0 * sw; o.r1 = e1 * sw;
+  const bool no_jac = !cam.inertial && (fabs(z) < 1e-6 || (cam.zero_behind && behind));
+  if (!no_jac) { o.piz = zi; o.psw = sw; }
   obs_jac_from_proj(cam, Rt, x, y, o.piz, o.psw, o.A, o.B);
 }
 
@@ -580,9 +563,10 @@ template <int LANES> __device__ __forceinline__ double group_sum(double a, doubl
 }
 
 // One 32-lane group per point (2 points per wave).  Observations are stored point-major (CSR).
-// (115 VGPRs; caps for 3 / 5 blocks per CU: 103.3 -> 102.5 / 134 us per batch iteration)
+// (round 3: 115 VGPRs; caps for 3 / 5 blocks per CU: 103.3 -> 102.5 / 134 us per batch iteration.  Round 4, 16 lanes per point with the
+// residual's Huber branch: 178 VGPRs uncapped = 2 waves per SIMD, 53.6 us per 32-window launch; capped at 3 blocks (168): 40.1; at 4 (128, spills): 56.9)
 #ifndef ORBX_BUILD_MINBLOCKS
-#define ORBX_BUILD_MINBLOCKS 1
+#define ORBX_BUILD_MINBLOCKS 3
 #endif
 template <int LANES>
 __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(const BaWin* __restrict__ wins, BaCam cam, int iter) {
@@ -648,16 +632,16 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
       double* q = oP + 6 * (size_t)i;
       q[0] = o.px; q[1] = o.py; q[2] = o.piz; q[3] = o.psw; q[4] = o.r0; q[5] = o.r1;
     }
-    chi += o.r0 * o.r0 + o.r1 * o.r1;
-    V[0] += o.B[0] * o.B[0] + o.B[3] * o.B[3];
-    V[1] += o.B[0] * o.B[1] + o.B[3] * o.B[4];
-    V[2] += o.B[0] * o.B[2] + o.B[3] * o.B[5];
-    V[3] += o.B[1] * o.B[1] + o.B[4] * o.B[4];
-    V[4] += o.B[1] * o.B[2] + o.B[4] * o.B[5];
-    V[5] += o.B[2] * o.B[2] + o.B[5] * o.B[5];
-    g[0] += o.B[0] * o.r0 + o.B[3] * o.r1;
-    g[1] += o.B[1] * o.r0 + o.B[4] * o.r1;
-    g[2] += o.B[2] * o.r0 + o.B[5] * o.r1;
+    chi += o.chi;
+    V[0] = fma(o.B[0], o.B[0], fma(o.B[3], o.B[3], V[0]));
+    V[1] = fma(o.B[0], o.B[1], fma(o.B[3], o.B[4], V[1]));
+    V[2] = fma(o.B[0], o.B[2], fma(o.B[3], o.B[5], V[2]));
+    V[3] = fma(o.B[1], o.B[1], fma(o.B[4], o.B[4], V[3]));
+    V[4] = fma(o.B[1], o.B[2], fma(o.B[4], o.B[5], V[4]));
+    V[5] = fma(o.B[2], o.B[2], fma(o.B[5], o.B[5], V[5]));
+    g[0] = fma(o.B[0], o.r0, fma(o.B[3], o.r1, g[0]));
+    g[1] = fma(o.B[1], o.r0, fma(o.B[4], o.r1, g[1]));
+    g[2] = fma(o.B[2], o.r0, fma(o.B[5], o.r1, g[2]));
   };
   for (int i = s + lane32; i < e; i += 32) {
     if (i == s + lane32) one(i, pa.k0, pa.u0, pa.v0, Va, ga, chia);               // (the lane's first observation came with the pipeline)
@@ -670,29 +654,23 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
 #pragma unroll
   for (int a = 0; a < 3; ++a) g[a] = group_sum<LANES>(ga[a], gb[a]);
   const double chi = group_sum<LANES>(chia, chib);
-  // damped V* = V + lambda*max(diag,1e-6) (:1031-1034), closed-form symmetric inverse
+  // damped V* = V + lambda*max(diag,1e-6) (:1031-1034)
   const double a_ = V[0] + lambda * fmax(V[0], 1e-6), b_ = V[1], c_ = V[2];
   const double d_ = V[3] + lambda * fmax(V[3], 1e-6), e_ = V[4], f_ = V[5] + lambda * fmax(V[5], 1e-6);
-  const double c00 = d_ * f_ - e_ * e_, c01 = c_ * e_ - b_ * f_, c02 = b_ * e_ - c_ * d_;
-  const double det = a_ * c00 + b_ * c01 + c_ * c02;
-  const double id = 1.0 / det;
   double I[9];
-  I[0] = c00 * id; I[1] = c01 * id; I[2] = c02 * id;
-  I[3] = I[1]; I[4] = (a_ * f_ - c_ * c_) * id; I[5] = (b_ * c_ - a_ * e_) * id;
-  I[6] = I[2]; I[7] = I[5]; I[8] = (a_ * d_ - b_ * b_) * id;
+  // V* = L L^T (V* is positive definite: V is a sum of B^T B and every diagonal entry is damped), M = L^-1, V*^-1 = M^T M.  The three
+  // pivots' reciprocal square roots are the only transcendental steps.  (First form: three square roots and five divisions for M beside
+  // the closed-form inverse's one division: 47.2 us per 32-window launch against 42.8, profiles/r04_ba_mz_rsqrt_ab.txt.)
+  const double m00 = rsqrt(a_), l10 = b_ * m00, l20 = c_ * m00;
+  const double m11 = rsqrt(fmax(d_ - l10 * l10, 0.0)), l21 = (e_ - l20 * l10) * m11;
+  const double m22 = rsqrt(fmax(f_ - l20 * l20 - l21 * l21, 0.0));
+  const double m10 = -(l10 * m00) * m11, m21 = -(l21 * m11) * m22, m20 = -(l20 * m00 + l21 * m10) * m22;
+  I[0] = m00 * m00 + m10 * m10 + m20 * m20; I[1] = m10 * m11 + m20 * m21; I[2] = m20 * m22;
+  I[3] = I[1]; I[4] = m11 * m11 + m21 * m21; I[5] = m21 * m22;
+  I[6] = I[2]; I[7] = I[5]; I[8] = m22 * m22;
   if (lane32 == 0) {
-#if ORBX_BA_SCHUR_Z
-    {
-      // V* = L L^T (V* is positive definite: V is a sum of B^T B and every diagonal entry is damped), M = L^-1
-      const double l00 = sqrt(a_), l10 = b_ / l00, l20 = c_ / l00;
-      const double l11 = sqrt(fmax(d_ - l10 * l10, 0.0)), l21 = (e_ - l20 * l10) / l11;
-      const double l22 = sqrt(fmax(f_ - l20 * l20 - l21 * l21, 0.0));
-      const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
-      const double m10 = -(l10 * m00) * m11, m21 = -(l21 * m11) * m22, m20 = -(l20 * m00 + l21 * m10) * m22;
-      double* mz = win.Mz + 6 * (size_t)j;
-      mz[0] = m00; mz[1] = m10; mz[2] = m11; mz[3] = m20; mz[4] = m21; mz[5] = m22;
-    }
-#endif
+    double* mz = win.Mz + 6 * (size_t)j;
+    mz[0] = m00; mz[1] = m10; mz[2] = m11; mz[3] = m20; mz[4] = m21; mz[5] = m22;
 #pragma unroll
     for (int a = 0; a < 9; ++a) Vinv[9 * (size_t)j + a] = I[a];
     gl[3 * (size_t)j] = g[0]; gl[3 * (size_t)j + 1] = g[1]; gl[3 * (size_t)j + 2] = g[2];
@@ -774,13 +752,18 @@ __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-      for (int b = a; b < 6; ++b) acc[qi++] += A[a] * A[b] + A[6 + a] * A[6 + b];
+      for (int b = a; b < 6; ++b) {                                          // U_ab += A_0a A_0b + A_1a A_1b, the structural zeros' products left out
+        double v = acc[qi];
+        if (!ba_a1_zero(a) && !ba_a1_zero(b)) v = fma(A[6 + a], A[6 + b], v);
+        if (!ba_a0_zero(a) && !ba_a0_zero(b)) v = fma(A[a], A[b], v);
+        acc[qi++] = v;
+      }
 #pragma unroll
-    for (int a = 0; a < 6; ++a) acc[21 + a] += A[a] * r0 + A[6 + a] * r1;
+    for (int a = 0; a < 6; ++a) acc[21 + a] = ba_arow_acc(acc[21 + a], A, a, r0, r1);
     // W V*^-1 g_l = A^T (B (V*^-1 g_l)): the 2-vector B vg, then A^T of it
-    const double t0 = B[0] * v0[0] + B[1] * v0[1] + B[2] * v0[2], t1 = B[3] * v0[0] + B[4] * v0[1] + B[5] * v0[2];
+    const double t0 = fma(B[0], v0[0], fma(B[1], v0[1], B[2] * v0[2])), t1 = fma(B[3], v0[0], fma(B[4], v0[1], B[5] * v0[2]));
 #pragma unroll
-    for (int a = 0; a < 6; ++a) acc[27 + a] += A[a] * t0 + A[6 + a] * t1;
+    for (int a = 0; a < 6; ++a) acc[27 + a] = ba_arow_acc(acc[27 + a], A, a, t0, t1);
     have0 = have1;
 #pragma unroll
     for (int a = 0; a < 6; ++a) q0[a] = q1[a];
@@ -826,11 +809,7 @@ __device__ __forceinline__ void ba_schur_gen_mfma(double4_t (&acc)[2][8], const 
     const double a1 = sY[row * SCH_PITCH + (7 - Q) * 16 + (lane & 15)];
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
-#if ORBX_BA_SCHUR_Z
       const double bv = (DG ? sY : sW)[row * SCH_PITCH + c * 16 + (lane & 15)];     // (a diagonal pair multiplies its one Z tile with itself)
-#else
-      const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
-#endif
       if (!DG || c >= Q) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][c], 0, 0, 0);
       if (!DG || c >= 7 - Q) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][c], 0, 0, 0);
     }
@@ -861,7 +840,7 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
   const int bj = bi + rem;
   const bool diag = bi == bj;
   const int j_begin = ks * d.pps;                                   // first map point of this k-split
-  const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv; const double* __restrict__ Rt_cur = win.Rt_cur;
+  const double* __restrict__ oP = win.oP; const double* __restrict__ Rt_cur = win.Rt_cur;
   const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
   double4_t acc[2][8];
 #pragma unroll
@@ -908,45 +887,16 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
 #pragma unroll
       for (int t = 0; t < 18; ++t) w[t] = 0.0;
       const double* Rk = Rt_cur + 12 * (size_t)k;                     // (read where used: 16 accumulator tiles leave no registers to park it in)
-#if ORBX_BA_SCHUR_Z
-      {
-        double Mj[6];
+      double Mj[6];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) Mj[t] = j < d.M ? win.Mz[6 * (size_t)j + t] : 0.0;
-        for (int i = cur[q]; i >= 0; i = obs_next[i]) obs_z_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, Mj, w);   // Z of the slot (0 + Z for the first)
-        double* __restrict__ dstT = side == 0 ? sY : sW;
+      for (int t = 0; t < 6; ++t) Mj[t] = j < d.M ? win.Mz[6 * (size_t)j + t] : 0.0;
+      for (int i = cur[q]; i >= 0; i = obs_next[i]) obs_z_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, Mj, w);   // Z of the slot (0 + Z for the first)
+      double* __restrict__ dstT = side == 0 ? sY : sW;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const int col = 6 * k + a - cb;
-          if (col < 0 || col >= 128) continue;
-          dstT[(3 * pj + 0) * SCH_PITCH + col] = w[a]; dstT[(3 * pj + 1) * SCH_PITCH + col] = w[6 + a]; dstT[(3 * pj + 2) * SCH_PITCH + col] = w[12 + a];
-        }
-        continue;
-      }
-#endif
-      for (int i = cur[q]; i >= 0; i = obs_next[i])                 // usually once: W = A^T B rebuilt from the observation's stored numbers
-        obs_w_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, w);    // (0 + W for the first: the stored-W form summed the same way)
-      if (side == 0) {
-        double I[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) I[t] = j < d.M ? Vinv[9 * (size_t)j + t] : 0.0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const int col = 6 * k + a - cb;
-          if (col < 0 || col >= 128) continue;
-          const double w0 = w[a], w1 = w[6 + a], w2 = w[12 + a];
-          sY[(3 * pj + 0) * SCH_PITCH + col] = w0 * I[0] + w1 * I[3] + w2 * I[6];       // Y = W V*^-1
-          sY[(3 * pj + 1) * SCH_PITCH + col] = w0 * I[1] + w1 * I[4] + w2 * I[7];
-          sY[(3 * pj + 2) * SCH_PITCH + col] = w0 * I[2] + w1 * I[5] + w2 * I[8];
-          if (diag) { sW[(3 * pj + 0) * SCH_PITCH + col] = w0; sW[(3 * pj + 1) * SCH_PITCH + col] = w1; sW[(3 * pj + 2) * SCH_PITCH + col] = w2; }
-        }
-      } else {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const int col = 6 * k + a - cb;
-          if (col < 0 || col >= 128) continue;
-          sW[(3 * pj + 0) * SCH_PITCH + col] = w[a]; sW[(3 * pj + 1) * SCH_PITCH + col] = w[6 + a]; sW[(3 * pj + 2) * SCH_PITCH + col] = w[12 + a];
-        }
+      for (int a = 0; a < 6; ++a) {
+        const int col = 6 * k + a - cb;
+        if (col < 0 || col >= 128) continue;
+        dstT[(3 * pj + 0) * SCH_PITCH + col] = w[a]; dstT[(3 * pj + 1) * SCH_PITCH + col] = w[6 + a]; dstT[(3 * pj + 2) * SCH_PITCH + col] = w[12 + a];
       }
     }
     __syncthreads();
@@ -1013,10 +963,26 @@ extern "C" int orbx_debug_schur_stamps(unsigned long long* out16, int reset) {
 // tiles ahead) nor halving the producers' instruction stream moved the launch: 39 % of the f64 MFMA peak is what a product whose
 // operands take a third as much f64 arithmetic to BUILD as to multiply can reach on this datapath; the remaining lever is the
 // arithmetic of the fill itself.
+#ifndef ORBX_SCHW_PRODUCER_PRIO
+#define ORBX_SCHW_PRODUCER_PRIO 1
+#endif
+#ifndef ORBX_SCHW_ROWS
+#define ORBX_SCHW_ROWS 48
+#endif
+constexpr int SCHW_THREADS = 512;      // 4 consumer + 4 producer waves
+constexpr int SCHW_R = ORBX_SCHW_ROWS;                                 // rows of a tile of the producer / consumer body: 16 map points, 12 MFMA k-steps
+constexpr int SCHW_NPT = SCHW_R / 3, SCHW_SPT = SCHW_NPT / 8;          // points per tile; slots per producer thread (8 points x 23 keyframes of threads)
+constexpr int SCHW_TILE = SCHW_R * SCH_PITCH;
+static_assert(SCHW_R % 24 == 0 && SCHW_R <= 48, "whole passes of the producers' 8 x 23 slot threads; two tiles of 48 rows are 104 KB");
+#ifndef ORBX_BA_GATHER_MAX_BLOCKS
+#define ORBX_BA_GATHER_MAX_BLOCKS 2048
+#endif
+constexpr int BA_GATHER_MAX_BLOCKS = ORBX_BA_GATHER_MAX_BLOCKS;   // blocks per window of the gather launch (256 / 1024 / 2048: configs[4] 23.0 / 21.3 / 19.8 us; a 20-keyframe window needs 203)
+constexpr int BA_GATHER_LANES = 8;     // shares of a window's k-splits (ba_gather_kernel's lanes per element = the Schur launch's workgroups per window in a large batch)
+constexpr size_t SCHW_LDS_BYTES = 2 * (size_t)SCHW_TILE * sizeof(double);      // two Z buffers: 104 448 B at 48 rows
 template <int Q>
 __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const double* __restrict__ lds, int ks0, int nT, int tps, bool sums) {
   const BaDims& d = win.d;
-  constexpr int TILE = SCH_R * SCH_PITCH;
   const int lane = threadIdx.x & 63;
 #ifdef ORBX_SCHUR_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0};
@@ -1047,26 +1013,22 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
   __syncthreads();                                                    // tile 0 is in buffer 0
   SCHUR_STAMP(0);
   for (int T = 0; T < nT; ++T) {
-    const double* __restrict__ sY = lds + (size_t)(T & 1) * 2 * TILE;
-    const double* __restrict__ sW = sY + TILE;
-    (void)sW;
+    const double* __restrict__ sZ = lds + (size_t)(T & 1) * SCHW_TILE;
+#ifndef ORBX_SCHW_NO_MFMA          // (timing experiments only: the producers alone)
 #pragma unroll
-    for (int kq = 0; kq < SCH_R / 4; ++kq) {
+    for (int kq = 0; kq < SCHW_R / 4; ++kq) {
       const int row = 4 * kq + (lane >> 4);
-      const double a0 = sY[row * SCH_PITCH + Q * 16 + (lane & 15)];
-      const double a1 = sY[row * SCH_PITCH + (7 - Q) * 16 + (lane & 15)];
+      const double a0 = sZ[row * SCH_PITCH + Q * 16 + (lane & 15)];
+      const double a1 = sZ[row * SCH_PITCH + (7 - Q) * 16 + (lane & 15)];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-#if ORBX_BA_SCHUR_Z
-        const double bv = sY[row * SCH_PITCH + c * 16 + (lane & 15)];
-#else
-        const double bv = sW[row * SCH_PITCH + c * 16 + (lane & 15)];
-#endif
+        const double bv = sZ[row * SCH_PITCH + c * 16 + (lane & 15)];
         if (c >= Q) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[c], 0, 0, 0);              // tile (Q, c)
         if (c > 7 - Q) acc[7 - c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[7 - c], 0, 0, 0);  // tile (7-Q, c) in slot 7-c < Q
         if (c == 7 - Q) accx = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, accx, 0, 0, 0);              // tile (7-Q, 7-Q)
       }
     }
+#endif
     SCHUR_STAMP(4);
     if ((T + 1) % tps == 0) {                                         // the k-split is complete
       const int ks = ks0 + T / tps;
@@ -1101,114 +1063,88 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
 #endif
 }
 
-constexpr int SCHW_THREADS = 512;      // 4 consumer + 4 producer waves
-#ifndef ORBX_BA_GATHER_MAX_BLOCKS
-#define ORBX_BA_GATHER_MAX_BLOCKS 2048
-#endif
-constexpr int BA_GATHER_MAX_BLOCKS = ORBX_BA_GATHER_MAX_BLOCKS;   // blocks per window of the gather launch (256 / 1024 / 2048: configs[4] 23.0 / 21.3 / 19.8 us; a 20-keyframe window needs 203)
-constexpr int BA_GATHER_LANES = 8;     // shares of a window's k-splits (ba_gather_kernel's lanes per element = the Schur launch's workgroups per window in a large batch)
-constexpr size_t SCHW_LDS_BYTES = 4 * (size_t)SCH_R * SCH_PITCH * sizeof(double);      // two buffers x (Y, W): 104 448 B
 __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaWin& win, const BaCam& cam, double* __restrict__ lds) {
   const BaDims& d = win.d;
   if (win.part_sums) spb = (d.ksplit + BA_GATHER_LANES - 1) / BA_GATHER_LANES;   // one workgroup per share of the gather
   const int ks0 = bx * spb, ks1 = min(ks0 + spb, d.ksplit);
   if (ks0 >= d.ksplit) return;                                        // (the whole workgroup, before any barrier)
   const int tid = threadIdx.x;
-  constexpr int NPT = SCH_R / 3, TILE = SCH_R * SCH_PITCH;
-  const int tps = d.pps / NPT;                                        // tiles per k-split (pps is a multiple of 8)
+  const int tps = d.pps / SCHW_NPT;                                   // tiles per k-split (pps is a multiple of 16)
   const int nT = (ks1 - ks0) * tps;
   const int j_begin = ks0 * d.pps;
-  for (int u = tid; u < 4 * TILE; u += SCHW_THREADS) lds[u] = 0.0;    // columns past 6K and slots of absent keyframes stay zero in both buffers
+  for (int u = tid; u < 2 * SCHW_TILE; u += SCHW_THREADS) lds[u] = 0.0;    // columns past 6K and slots of absent keyframes stay zero in both buffers
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);            // (a scalar: the two roles and the consumer's tile rows branch on SGPRs; 108.4 -> 107.2 us per 32-window launch)
   if (wv >= 4) {
 #ifdef ORBX_SCHUR_STAMPS
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0};
 #endif
-    // ---- producers: thread f fills slot (point j0 + pj, keyframe k) of every tile.  (Two threads of different waves per slot, one per
-    // half of the keyframe's six columns — 768-thread workgroups, 8 producer waves — measured the same 117 us per 32-window launch as
-    // this form: the producers do not wait for their instruction stream, see the note at the top.)
+    // ---- producers: thread (pj, k) fills the slots (point j0 + pj + 8 h, keyframe k), h = 0 .. SCHW_SPT - 1, of every tile: 8 x 23
+    // threads of the four waves.  The waves dispatched second lose every arbitration for the SIMD's issue slots to the consumers on age
+    // (MI355X_MICROARCH.md, "two waves per SIMD"), and these are the waves the tile waits for: one s_setprio for the whole loop.
+#if ORBX_SCHW_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(ORBX_SCHW_PRODUCER_PRIO);
+#endif
     const int f = tid - 256, pj = f / 23, k = f - pj * 23;
-    const bool slot = pj < NPT && k < d.K && 6 * k < 128;
-    const double* __restrict__ oP = win.oP; const double* __restrict__ Vinv = win.Vinv;
-    (void)Vinv;
+    const bool slot = pj < 8 && k < d.K && 6 * k < 128;
+    const double* __restrict__ oP = win.oP;
     const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
     // (the slot index runs two tiles ahead, the stored numbers one; a second register set — numbers two tiles ahead — measured no
-    // difference: the producers wait for the double-precision pipe, not for memory)
-#if ORBX_BA_SCHUR_Z
-    struct SlotData { double pq[4], I[6]; bool have; int chain, idx; } sd;    // I: the point's M (6 numbers)
-#else
-    struct SlotData { double pq[4], I[9]; bool have; int chain, idx; } sd;
-#endif
+    // difference in round 3 and again in round 4, 86.1-88.9 against 86.3-87.0 us: the loads are not what the producers wait for)
+    struct SlotData { double pq[SCHW_SPT][4], M[SCHW_SPT][6]; int chain[SCHW_SPT], idx[SCHW_SPT]; } sd;    // per slot: (x, y, 1/z, sqrt w) and the point's M; empty slot: zeros
     double Rk[12];
 #pragma unroll
     for (int t = 0; t < 12; ++t) Rk[t] = slot ? win.Rt_cur[12 * (size_t)k + t] : 0.0;
-    auto slot_of = [&](int T) -> int {                                // first observation of (point of tile T, keyframe k), or -1
-      const int j0 = j_begin + T * NPT, j = j0 + pj;
+    auto slot_of = [&](int T, int h) -> int {                         // first observation of (point of tile T, keyframe k), or -1
+      const int j = j_begin + T * SCHW_NPT + pj + 8 * h;
       return (slot && T < nT && j < d.M) ? slot_first[(size_t)j * d.K + k] : -1;
     };
-    auto fetch = [&](SlotData& q, int T) {                             // tile T's stored numbers (32 B) and V*^-1 -> registers, by q.idx
-      const int j = j_begin + T * NPT + pj, i = q.idx;
-      q.have = i >= 0;
+    auto fetch = [&](int T) {                                          // tile T's stored numbers (32 B) and M (48 B) -> registers, by sd.idx
 #pragma unroll
-      for (int t = 0; t < 4; ++t) q.pq[t] = i >= 0 ? oP[6 * (size_t)i + t] : 0.0;
-#if ORBX_BA_SCHUR_Z
+      for (int h = 0; h < SCHW_SPT; ++h) {
+        const int j = j_begin + T * SCHW_NPT + pj + 8 * h, i = sd.idx[h];
 #pragma unroll
-      for (int t = 0; t < 6; ++t) q.I[t] = (slot && T < nT && j < d.M) ? win.Mz[6 * (size_t)j + t] : 0.0;
-#else
+        for (int t = 0; t < 4; ++t) sd.pq[h][t] = i >= 0 ? oP[6 * (size_t)i + t] : 0.0;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) q.I[t] = (slot && T < nT && j < d.M) ? Vinv[9 * (size_t)j + t] : 0.0;
-#endif
-      q.chain = i >= 0 ? obs_next[i] : -1;
+        for (int t = 0; t < 6; ++t) sd.M[h][t] = (slot && T < nT && j < d.M) ? win.Mz[6 * (size_t)j + t] : 0.0;
+        sd.chain[h] = i >= 0 ? obs_next[i] : -1;
+      }
     };
-    auto fill = [&](const SlotData& q, double* __restrict__ sY, double* __restrict__ sW) {
+    auto fill = [&](double* __restrict__ sZ) {
       if (!slot) return;
-      double w[18];
-#if ORBX_BA_SCHUR_Z
-      if (q.have) obs_z_from_stored<false>(cam, Rk, q.pq, q.I, w);    // Z = A^T (B M^T) of the slot's observation
-      else {
-#pragma unroll
-        for (int t = 0; t < 18; ++t) w[t] = 0.0;
-      }
-      for (int i = q.chain; i >= 0; i = obs_next[i]) obs_z_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, q.I, w);
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const int col = 6 * k + a;
-        if (col >= 128) continue;
-        sY[(3 * pj + 0) * SCH_PITCH + col] = w[a]; sY[(3 * pj + 1) * SCH_PITCH + col] = w[6 + a]; sY[(3 * pj + 2) * SCH_PITCH + col] = w[12 + a];
-      }
-      (void)sW;
+#ifdef ORBX_SCHW_NO_FILL           // (timing experiments only: the consumers alone)
       return;
 #endif
-      if (q.have) obs_w_from_stored<false>(cam, Rk, q.pq, w);         // W = A^T B of the slot's observation: ~90 multiply-adds, no division
-      else {
+      // Z = A^T (B M^T) of each of the thread's slots: straight-line code (an empty slot's zeros go through the same arithmetic), so
+      // the slots' dependent chains are scheduled into each other; then the rare second observation of a point by this keyframe
+      double w[SCHW_SPT][18];
 #pragma unroll
-        for (int t = 0; t < 18; ++t) w[t] = 0.0;
-      }
-      for (int i = q.chain; i >= 0; i = obs_next[i])                  // a point seen twice by this keyframe: rare, fetched on the spot
-        obs_w_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, w);
+      for (int h = 0; h < SCHW_SPT; ++h) obs_z_from_stored<false>(cam, Rk, sd.pq[h], sd.M[h], w[h]);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const int col = 6 * k + a;
-        if (col >= 128) continue;
-        const double w0 = w[a], w1 = w[6 + a], w2 = w[12 + a];
-        sY[(3 * pj + 0) * SCH_PITCH + col] = w0 * q.I[0] + w1 * q.I[3] + w2 * q.I[6];
-        sY[(3 * pj + 1) * SCH_PITCH + col] = w0 * q.I[1] + w1 * q.I[4] + w2 * q.I[7];
-        sY[(3 * pj + 2) * SCH_PITCH + col] = w0 * q.I[2] + w1 * q.I[5] + w2 * q.I[8];
-        sW[(3 * pj + 0) * SCH_PITCH + col] = w0; sW[(3 * pj + 1) * SCH_PITCH + col] = w1; sW[(3 * pj + 2) * SCH_PITCH + col] = w2;
-      }
+      for (int h = 0; h < SCHW_SPT; ++h)
+        for (int i = sd.chain[h]; i >= 0; i = obs_next[i]) obs_z_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, sd.M[h], w[h]);
+      // (columns 6 k + a <= 125 for k <= 20: no bounds test; the stores pair up into ds_write_b128)
+#pragma unroll
+      for (int h = 0; h < SCHW_SPT; ++h)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const int col = 6 * k + a, r0 = 3 * (pj + 8 * h);
+          sZ[(r0 + 0) * SCH_PITCH + col] = w[h][a]; sZ[(r0 + 1) * SCH_PITCH + col] = w[h][6 + a]; sZ[(r0 + 2) * SCH_PITCH + col] = w[h][12 + a];
+        }
     };
-    // build tile T into buffer T & 1, then request tile T + 1's numbers and tile T + 2's slot index
+    // build tile T into buffer T & 1, then request tile T + 1's numbers and tile T + 2's slot indices
     auto step = [&](int T) {
-      double* b = lds + (size_t)(T & 1) * 2 * TILE;
-      fill(sd, b, b + TILE);
+      fill(lds + (size_t)(T & 1) * SCHW_TILE);
       SCHUR_STAMP(8);
-      fetch(sd, T + 1);                                                // (by the index loaded a step ago; past the last tile: zeros)
-      sd.idx = slot_of(T + 2);
+      fetch(T + 1);                                                    // (by the indices loaded a step ago; past the last tile: zeros)
+#pragma unroll
+      for (int h = 0; h < SCHW_SPT; ++h) sd.idx[h] = slot_of(T + 2, h);
       SCHUR_STAMP(9);
     };
-    sd.idx = slot_of(0);
-    fetch(sd, 0);
-    sd.idx = slot_of(1);
+#pragma unroll
+    for (int h = 0; h < SCHW_SPT; ++h) sd.idx[h] = slot_of(0, h);
+    fetch(0);
+#pragma unroll
+    for (int h = 0; h < SCHW_SPT; ++h) sd.idx[h] = slot_of(1, h);
     __syncthreads();                                                  // zero fill done
     step(0);                                                          // tile 0 -> buffer 0
     __syncthreads();
@@ -2710,9 +2646,13 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     obs_jac_from_proj(cam, sRt0 + 12 * k, q[0], q[1], q[2], q[3], A, B);
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) { const double dk = dp[6 * (size_t)k + a]; s0 += A[a] * dk; s1 += A[6 + a] * dk; }
+    for (int a = 0; a < 6; ++a) {
+      const double dk = dp[6 * (size_t)k + a];
+      if (!ba_a0_zero(a)) s0 = fma(A[a], dk, s0);
+      if (!ba_a1_zero(a)) s1 = fma(A[6 + a], dk, s1);
+    }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) acc[c] += B[c] * s0 + B[3 + c] * s1;
+    for (int c = 0; c < 3; ++c) acc[c] = fma(B[c], s0, fma(B[3 + c], s1, acc[c]));
   };
   for (int i = s + lane32; i < e; i += 32) {
     wtdp(i, acca);
@@ -2745,7 +2685,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
     }
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
-    chi += o.r0 * o.r0 + o.r1 * o.r1;
+    chi += o.chi;
   };
   for (int i = s + lane32; i < e; i += 32) {
     trial_chi(i, chia);
@@ -2799,7 +2739,7 @@ __global__ __launch_bounds__(256) void ba_chi2_kernel(const BaWin* __restrict__ 
     }
     ObsOut o;
     obs_terms(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], false, o, cam.o_flag ? cam.o_flag[i] : 0);
-    chi += o.r0 * o.r0 + o.r1 * o.r1;
+    chi += o.chi;
   };
   for (int i = pt_start[j] + lane32; i < pt_start[j + 1]; i += 32) trial_chi(i, chia);
   const double chi = group_sum<32>(chia, chib);
@@ -3321,7 +3261,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     d.ksplit = std::max(1, std::min(128, (M + BA_PPS_TARGET - 1) / BA_PPS_TARGET));
     // (configs[4], 6 column-block pairs x 128 splits = 768 workgroups at 2 per CU: capping the splits at 100 / 85 / 64 / 48 / 32 to fit one
     // round of workgroups measured 95.7 / 99.2 / 102.8 / 120.7 / 180.0 us against 94.1 — many short workgroups it stays)
-    d.pps = std::max(8, (((M + d.ksplit - 1) / d.ksplit) + 7) & ~7);
+    d.pps = std::max(16, (((M + d.ksplit - 1) / d.ksplit) + 15) & ~15);   // (whole tiles of both Schur bodies: 8 and 16 points)
     d.rows = 3 * d.pps * d.ksplit;
     pl.n = 6 * K;
     pl.np = 6 * (size_t)K + 3 * (size_t)M + (inertial ? 9 * (size_t)K : 0);
