@@ -2787,7 +2787,7 @@ __global__ __launch_bounds__(256) void ba_sum3_kernel(const BaWin* __restrict__ 
 #endif
 constexpr int BA_DECIDE_THREADS = ORBX_BA_DECIDE_THREADS;   // (the thread count fixes the order of the three sums; 256 / 512 / 1024: one window 7.5 / 6.6 / 6.3 us, configs[4] 15.1 / 10.6 / 8.6, 32-window batch 9.4 / 8.8 / 9.8)
 __global__ __launch_bounds__(BA_DECIDE_THREADS) void ba_decide_kernel(const BaWin* __restrict__ wins, int reduce_here, const double* __restrict__ imu_buf, int E,
-                                                        const volatile int* __restrict__ abort_flag, int stop_vote) {
+                                                        const volatile int* __restrict__ abort_flag, int stop_vote, int first_is_initial) {
   __shared__ double sh[3][BA_DECIDE_THREADS];
   const BaWin win = ba_win_global(wins, blockIdx.y);
   BaState* S = win.S;
@@ -2817,6 +2817,7 @@ __global__ __launch_bounds__(BA_DECIDE_THREADS) void ba_decide_kernel(const BaWi
     res[5] = c; res[6] = sh[1][0]; res[7] = sh[2][0];
   }
   const double cur_sq = res[0];
+  if (first_is_initial && S->iters == 1) res[12] = cur_sq;                        // the initial error (:1000-1001) is the first iteration's current error: no pass of its own
   S->cur_sq = cur_sq;
   S->final_sq = cur_sq;
   if (res[1] < S->gtol) { S->done = 1; return; }                                  // :1027-1029
@@ -3587,18 +3588,26 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
 
   if (maxM > 0 && maxK > 0) hipLaunchKernelGGL(ba_slots_kernel, dim3((maxM + 255) / 256, W), dim3(256), 0, st, d_wins);
   if (maxM > 0 && maxK > 0) hipLaunchKernelGGL(ba_kflist_kernel, dim3(maxK, W), dim3(256), 0, st, d_wins);
-  // initial error (:1000-1001) -> res[12]
-  {
+  // initial error (:1000-1001) -> res[12].  The visual solve on one GPU takes it from its first iteration (the current error the gather
+  // assembles from the build kernel's per-point sums, ba_decide_kernel) — a pass over every observation and a reduction less per call;
+  // a call that enqueues no iteration, the partitioned solve (the sum is a collective) and the inertial one (IMU terms) compute it here.
+  const bool init_from_first = !dist && !inertial;
+  auto initial_error_pass = [&]() {
     ProfScope ps(h, "ba_chi2");
     if (maxM > 0) hipLaunchKernelGGL(ba_chi2_kernel, dim3((maxM * 32 + 255) / 256, W), dim3(256), 0, st, d_wins, bc, 0);
     chi2_sum(0, 0);
+  };
+  if (!init_from_first) {
+    initial_error_pass();
+    if (int rc = allreduce(res0 + 12, 1)) return rc;
   }
-  if (int rc = allreduce(res0 + 12, 1)) return rc;
+  bool any_iteration = false;
 
   // The loop only polls should_stop (:1013) and enqueues; nothing below waits for the GPU.
   bool stopped = my_stop;
   for (int iter = 0; iter < cfg->max_iterations && !(dist && iter == 0 && my_stop); ++iter) {           // :1012
     if (!dist && should_stop && should_stop(user)) { stopped = true; break; }                           // :1013
+    any_iteration = true;
     {
       ProfScope ps(h, "ba_build_kernel");
       if (maxM > 0) {
@@ -3674,14 +3683,15 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       ORBX_HIP(h, hipMemcpyAsync(res0 + 8, &votes[(size_t)iter], 8, hipMemcpyHostToDevice, st));
       if (int rc = allreduce(res0 + 5, 4)) return rc;
       ProfScope ps(h, "ba_decide_kernel");
-      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(BA_DECIDE_THREADS), 0, st, d_wins, 0, (const double*)nullptr, 0, (const volatile int*)nullptr, 1);
+      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(BA_DECIDE_THREADS), 0, st, d_wins, 0, (const double*)nullptr, 0, (const volatile int*)nullptr, 1, 0);
     } else {
       ProfScope ps(h, "ba_decide_kernel");
       const int E = inertial ? inr->E : 0;
       if (E > 0) hipLaunchKernelGGL(ba_imu_kernel, dim3(E), dim3(64), 0, st, w0.S, w0.P0, w0.P1, 1, 0, ind, imu_buf);
-      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(BA_DECIDE_THREADS), 0, st, d_wins, 1, (const double*)imu_buf, E, (const volatile int*)h->d_abort, 0);
+      hipLaunchKernelGGL(ba_decide_kernel, gW1, dim3(BA_DECIDE_THREADS), 0, st, d_wins, 1, (const double*)imu_buf, E, (const volatile int*)h->d_abort, 0, init_from_first ? 1 : 0);
     }
   }
+  if (init_from_first && !any_iteration) initial_error_pass();
   {
     size_t np_max = 1;
     for (int w = 0; w < W; ++w) np_max = std::max(np_max, plan[w].np);
