@@ -136,7 +136,9 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
   // So: the keypoints, descriptors and bucket bounds of ALL of a wave's rounds are requested before the first is used; a candidate's
   // index travels with its position (both are functions of t), not after the gates; and two candidates per lane (t, t + 16) are in
   // flight at a time, their descriptors requested together.  (Round 2's form took 8 round trips per round of 4 keypoints, two rounds
-  // per wave in turn: 0.130 ms per 256 pairs.)
+  // per wave in turn: 0.130 ms per 256 pairs.  Round 4: the right descriptors copied into bucket order by stereo_bucket_kernel, so that a
+  // group's sixteen lanes read adjacent descriptors and the index leaves the address chain: this kernel 0.0895 -> 0.0865 ms, the bucket
+  // kernel 0.011 -> 0.022 — withdrawn.)
   constexpr int NR = SM_LEFT_PER_WAVE / 4;
   if (nL <= 0) return;
   int li_[NR]; bool live[NR]; float ul_[NR], vl_[NR]; Desc256 dl_[NR]; int lo_[NR], hi_[NR];

@@ -838,7 +838,8 @@ __device__ __forceinline__ unsigned ld_u32(const uint8_t* p) {   // unaligned dw
 // ---- A.6 Harris response (blockSize 7, k 0.04) of one candidate, one thread ------------------------------
 __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img, int pitch, int x0, int y0) {
   int a = 0, b = 0, c = 0;
-  // 9x9 window as 9 rows x 3 unaligned dwords (27 loads instead of 81 byte loads)
+  // 9x9 window as 9 rows x 3 unaligned dwords (27 loads instead of 81 byte loads; one unaligned global_load_dwordx3 per row — 9 loads —
+  // measured 0.159 against 0.150 ms per 256 pairs, round 4: the 12-byte form does not go through the address coalescer as three dwords do)
   int rowm[9], row0[9], rowp[9];
   const uint8_t* p = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
   unsigned w[9][3];
