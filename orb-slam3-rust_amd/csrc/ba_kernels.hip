@@ -24,7 +24,8 @@
 //                        branch-free backward substitution over the zeroed upper triangle, delta_p
 //                        (128 < n <= 176, inertial windows: ba_solve_tiled_kernel / ba_solve_inertial_tiled_kernel, lower tiles in LDS)
 //                        (176 < n <= 320, S in global memory: ba_big_assemble_kernel + ba_big_factor_kernel — one workgroup, left-looking,
-//                        one panel of look-ahead — + ba_big_back_kernel; beyond 320: one ba_big_step_kernel per panel instead of the factor kernel)
+//                        one panel of look-ahead, the backward substitution in the same launch; beyond 320: one ba_big_step_kernel per panel
+//                        + ba_big_back_kernel)
 //   ba_backsub_kernel    delta_l = V*^-1 (-g_l - W^T delta_p), trial parameters and trial residuals
 //   ba_decide_kernel     sums, accept / reject, lambda, stop tests — the LM state lives on the device
 //
@@ -2234,6 +2235,10 @@ constexpr int BF_LROWS = BF_MAX_N + 16;                                   // row
 constexpr int BF_BPITCH = 290;                                            // doubles per row of the B operand (>= BF_MAX_N - 32; = 2 mod 32)
 constexpr int BF_BQ = (BF_MAX_N - 2 * 16 + 127) / 128;                         // slices of 64 column pairs in a row of Bp
 constexpr int BF_TILE_WAVES = 12, BF_TILES = 2;                           // tile ti of a panel: slot ti / 12 of the ti % 12-th wave that is not on wave 0's SIMD
+// (Round 4: the four row waves, all on wave 0's SIMD, take 4-5 k cycles per panel for what is one wave's 1.2 k — so the rows were spread over
+// waves 0-3, one per SIMD, nine tile waves with three slots each on SIMDs 1-3, waves 4 / 8 / 12 staging Bp only: 128.8-129.4 -> 135.4-135.8 us
+// per solve at n = 294.  The stamps say why: the phase ends when the tile waves' look-ahead does — 9 waves x 3 tiles need longer than
+// 12 x 2 — not when the rows are solved.  Withdrawn; profiles/r04_ba_big_factor_ab.txt.)
 static_assert((BF_MAX_N + 1 + 15) / 16 <= BF_TILES * BF_TILE_WAVES, "every tile of a panel needs an owner");
 static_assert(BF_MAX_N + 1 - 16 <= 2 * 256, "the rows below a panel: at most two per thread of the four row waves");
 constexpr size_t BF_LDS_BYTES = (size_t)(16 * BF_CPITCH + BF_LROWS * BF_LPITCH + 16 * BF_BPITCH) * 8;
@@ -2260,11 +2265,13 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
   const int n = win.n;
   if (win.use_lds || n > BF_MAX_N || win.S->done) return;
   double* Sg = win.Sg; double* ginv = win.ginv; double* bvec = win.bvec; double* res = win.res;
+  double* Linv = ginv + 2 * ((n + 15) & ~15);                               // [panel][16][16] rows of the diagonal blocks' L11^-T (behind 1/L_jj and the inertial system's gradient)
   double* Cs = dyn;
   double* Lp = Cs + 16 * BF_CPITCH;
   double* Bp = Lp + BF_LROWS * BF_LPITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;   // (the wave index as a scalar — the roles and tiles derived from it branch on SGPRs: 138.1 -> 136.0 us)
-  const int widx = (wave & 3) ? wave - 1 - (wave >> 2) : -1;                // 0 .. 11 among the tile waves
+  const bool row_role = (wave & 3) == 0;
+  const int widx = (wave & 3) ? wave - 1 - (wave >> 2) : 1000;              // 0 .. 11 among the tile waves
   if (tid == 0) s_ok = 1;
   auto rowp = [&](int r) -> double* { return r < n ? Sg + (size_t)r * n : bvec; };    // row n (and the clamped rows past it): the right-hand side
   auto mfma4 = [](double4_t a, double2_t a0, double2_t a1, double2_t b0, double2_t b1) {
@@ -2347,7 +2354,7 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
 #endif
   // Two roles, two loops, the same three barriers per panel: what a tile wave keeps in registers from one panel to the next (its tiles'
   // sums and entries of S) is not live in the code of the waves that factor and solve rows, and the other way round.
-  if (widx >= 0) {
+  if (!row_role) {
     // ---- the tile waves
     ahead_factor(-BB_NB);                                                  // panel 0: its entries of S
     // Bp for the look-ahead two panels on — rows c0 + 32 .. + 47 of L, the columns before c0 — is requested beside a panel's row solves and
@@ -2384,7 +2391,7 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
       __syncthreads();
       if (c0 + BB_NB < n) ahead_factor(c0);                                // under the factor: the first part of the next panel's sum over the columns before this panel
       __syncthreads();
-      if (!s_ok) return;
+      if (!s_ok) break;
       // (every panel and every lane, at clamped addresses: a conditional load would keep the old value alive through the whole next panel)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -2428,13 +2435,18 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
       }
       __syncthreads();
       BF_STAMP(3);
-      if (!s_ok) { if (tid == 0) res[2] = 0.0; return; }
+      if (!s_ok) break;
       if (tid < nb) ginv[c0 + tid] = rinv[tid];
-      // rows below the block, r = c0 + nb .. n (a short last panel: the right-hand side only)
-      for (int lr = nb + ridx; c0 + lr <= n; lr += 256) {
+      // rows below the block, r = c0 + nb .. n (a short last panel: the right-hand side only), and behind them the sixteen rows of the
+      // identity: e_r L11^-T = row r of L11^-T, which turns the backward substitution's panel step (below) into a 16 x 16 matrix-vector
+      // product — no dependent chain there
+      const int nreal = n - c0 - nb + 1;
+      for (int qr = ridx; qr < nreal + BB_NB; qr += 256) {
+        const bool pseudo = qr >= nreal;
+        const int lr = nb + qr;
         double xr[BB_NB];
 #pragma unroll
-        for (int j = 0; j < BB_NB; ++j) xr[j] = Cs[j * BF_CPITCH + lr];
+        for (int j = 0; j < BB_NB; ++j) xr[j] = pseudo ? (j == qr - nreal ? 1.0 : 0.0) : Cs[j * BF_CPITCH + lr];
 #pragma unroll
         for (int t = 0; t < BB_NB; t += 2) {
           double la[BB_NB], lb[BB_NB];
@@ -2454,6 +2466,12 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
           asm volatile("" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]), "+v"(xr[8]), "+v"(xr[9]),
                        "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15]) :: "memory");
         }
+        if (pseudo) {
+          double* li = Linv + ((size_t)(c0 >> 4) * BB_NB + (qr - nreal)) * BB_NB;
+#pragma unroll
+          for (int j = 0; j < BB_NB; j += 2) { const double2_t v2 = {xr[j], xr[j + 1]}; *(double2_t*)(li + j) = v2; }
+          continue;
+        }
         double* dst = rowp(c0 + lr) + c0;
         if (nb == BB_NB) {
           double* lp = Lp + (lr - BB_NB) * BF_LPITCH;                        // the next panel numbers its rows from c0 + 16
@@ -2468,6 +2486,94 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
       BF_STAMP(4);
     }
   }
+  // ---- backward substitution L^T x = y, |dp|^2, |p|^2 (until round 4 a launch of its own, ba_big_back_kernel: 31 us at n = 294 — a
+  // 16-step dependent chain per panel on one wave).  Every wave arrives here behind the same barrier (a failed pivot leaves both loops
+  // after a panel's second one).  Per panel: x_p = L11^-T v_p by sixteen lanes of the last wave from the rows the row solves left in
+  // Linv, then v_i -= sum_j L[c0 + j][i] x_j for the rows above, one thread each; both read what they need of the NEXT panel from
+  // global memory before this panel's barriers.
+  const bool ok = s_ok != 0;
+  // Six waves stay: one thread per row of v (n <= 320: five waves) and the first sixteen lanes of the sixth for the panel's product;
+  // the other ten leave — a block barrier costs by the waves that must arrive, and the loop below has two per panel.
+  constexpr int BK_THREADS = 384;
+  if (tid >= BK_THREADS) return;
+  double* sb = Cs;                                                         // v, then x (n <= BF_MAX_N entries)
+  double* yv = Cs + BF_MAX_N + 16;                                         // the panel's x
+  double* red = yv + BB_NB;                                                // per-wave partial sums
+  static_assert(BF_MAX_N <= BK_THREADS - 64 && BF_MAX_N + 16 + BB_NB + 2 * (BK_THREADS / 64) <= 16 * BF_CPITCH, "a thread per row, a wave for the panel's product; the epilogue's vectors fit the panel buffer");
+  const BaState* St = win.S;
+  const double* params = ba_cur(St, win.P0, win.P1);
+  double* __restrict__ dp = win.dp;
+  if (tid == 0 && !ok) res[2] = 0.0;
+  if (ok) {
+    const int c_last = ((n - 1) / BB_NB) * BB_NB;
+    const int mt = tid - (BK_THREADS - 64);                                // 0 .. 15: this lane's row of the panel's L11^-T (lanes of the sixth wave — never a row of v)
+    const bool mv = mt >= 0 && mt < BB_NB;
+    // (FULL: a 16-column panel — everything but, possibly, the last one; a compile-time flag, because a run-time `j < nb` around every load
+    // and multiply-add of the unrolled loops became a scalar branch each: some sixty basic blocks per panel, 2.7 k cycles)
+    auto load_panel = [&](int c0, double (&a)[BB_NB], auto full_) {
+      constexpr bool FULL = decltype(full_)::value;
+      if (c0 < 0) return;
+      const int nb = FULL ? BB_NB : min(BB_NB, n - c0);
+      if (mv) {
+#pragma unroll
+        for (int j = 0; j < BB_NB; j += 2) { const double2_t v2 = bf_ldg2(Linv + ((size_t)(c0 >> 4) * BB_NB + mt) * BB_NB + j); a[j] = v2[0]; a[j + 1] = v2[1]; }
+      } else if (tid < c0) {
+#pragma unroll
+        for (int j = 0; j < BB_NB; ++j) a[j] = (FULL || j < nb) ? bf_ldg1(Sg + (size_t)(c0 + j) * n + tid) : 0.0;
+      }
+    };
+    // (a third register set — a panel's numbers requested TWO panels ahead, nothing copied — does not fit the 128 VGPRs of a 1024-thread
+    // workgroup: 25 spills)
+    double cur[BB_NB], nxt[BB_NB];
+#pragma unroll
+    for (int j = 0; j < BB_NB; ++j) { cur[j] = 0.0; nxt[j] = 0.0; }
+    auto panel = [&](int c0, auto full_) {
+      constexpr bool FULL = decltype(full_)::value;
+      const int nb = FULL ? BB_NB : min(BB_NB, n - c0);
+      load_panel(c0 - BB_NB, nxt, std::true_type{});                       // (the panels below the last are full)
+      if (mv) {
+        // four partial sums (the row's sixteen products, every fourth to one sum), then (s0 + s1) + (s2 + s3): four dependent steps instead of sixteen
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < BB_NB; ++j) s4[j & 3] = fma(cur[j], (FULL || j < nb) ? sb[c0 + j] : 0.0, s4[j & 3]);   // (row mt of L11^-T is zero left of its diagonal; rows >= nb of a short panel are not used)
+        yv[mt] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      }
+      __syncthreads();
+      if (tid < c0) {
+        double v0 = sb[tid], v1 = 0.0;                                     // two chains of eight
+#pragma unroll
+        for (int j = 0; j < BB_NB; j += 2) {
+          v0 = fma(-cur[j], (FULL || j < nb) ? yv[j] : 0.0, v0);
+          v1 = fma(-cur[j + 1], (FULL || j + 1 < nb) ? yv[j + 1] : 0.0, v1);
+        }
+        sb[tid] = v0 + v1;
+      } else if (tid < c0 + nb) sb[tid] = yv[tid - c0];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < BB_NB; ++j) cur[j] = nxt[j];
+    };
+    if (tid < n) sb[tid] = bf_ldg1(bvec + tid);                            // y: the row solves left it in the right-hand side's row
+    load_panel(c_last, cur, std::false_type{});
+    __syncthreads();
+    panel(c_last, std::false_type{});
+    for (int c0 = c_last - BB_NB; c0 >= 0; c0 -= BB_NB) panel(c0, std::true_type{});
+  }
+  double dsq = 0.0, psq = 0.0;
+  if (tid < n) {
+    const double v = ok ? sb[tid] : 0.0, pv = params[tid];
+    dp[tid] = v;
+    dsq = v * v; psq = pv * pv;
+  }
+  dsq = wave_sum(dsq); psq = wave_sum(psq);
+  if ((tid & 63) == 0) { red[tid >> 6] = dsq; red[BK_THREADS / 64 + (tid >> 6)] = psq; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = red[0], c = red[BK_THREADS / 64];
+#pragma unroll
+    for (int w2 = 1; w2 < BK_THREADS / 64; ++w2) { a += red[w2]; c += red[BK_THREADS / 64 + w2]; }
+    res[3] = a; res[4] = c;
+  }
+  BF_STAMP(5);
 #ifdef ORBX_BF_DEBUG
   if (tid == 0) for (int k = 0; k < 8; ++k) g_bf_stamps[k] = bf_acc_[k];
 #endif
@@ -2478,10 +2584,10 @@ __global__ __launch_bounds__(BF_THREADS) void ba_big_factor_kernel(const BaWin* 
 extern "C" int orbx_debug_big_factor(double* S, double* b, double* ginv_out, int n) {
   double* d = nullptr; BaWin* dw = nullptr; BaState* ds = nullptr;
   const size_t nn = (size_t)n * n;
-  if (hipMalloc(&d, (nn + 2 * (size_t)n + 16) * 8) != hipSuccess || hipMalloc(&dw, sizeof(BaWin)) != hipSuccess || hipMalloc(&ds, sizeof(BaState)) != hipSuccess) return -1;
+  if (hipMalloc(&d, (nn + 21 * (size_t)n + 700) * 8) != hipSuccess || hipMalloc(&dw, sizeof(BaWin)) != hipSuccess || hipMalloc(&ds, sizeof(BaState)) != hipSuccess) return -1;
   hipMemset(ds, 0, sizeof(BaState));
   BaWin w; memset(&w, 0, sizeof(w));
-  w.n = n; w.use_lds = 0; w.S = ds; w.Sg = d; w.bvec = d + nn; w.ginv = w.bvec + n; w.res = w.ginv + n;
+  w.n = n; w.use_lds = 0; w.S = ds; w.Sg = d; w.bvec = d + nn; w.ginv = w.bvec + n; w.res = w.ginv + 19 * (size_t)n + 600; w.dp = w.res + 16; w.P0 = w.P1 = w.bvec;   // (Linv behind ginv; the epilogue's dp and |p|^2 go to scratch)
   hipMemcpy(d, S, nn * 8, hipMemcpyHostToDevice); hipMemcpy(w.bvec, b, (size_t)n * 8, hipMemcpyHostToDevice);
   const double one[3] = {0, 0, 1.0}; hipMemcpy(w.res, one, 24, hipMemcpyHostToDevice);
   hipMemcpy(dw, &w, sizeof(w), hipMemcpyHostToDevice);
@@ -2496,19 +2602,19 @@ extern "C" int orbx_debug_big_factor(double* S, double* b, double* ginv_out, int
   hipFree(d); hipFree(dw); hipFree(ds);
   unsigned long long st[8];
   if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_bf_stamps), 64) == hipSuccess)
-    fprintf(stderr, "  ticks: first loads %llu | last chunk + barrier %llu | factor %llu | look-ahead past the factor %llu | row solves + barrier %llu\n", st[0], st[1], st[2], st[3], st[4]);
+    fprintf(stderr, "  ticks: first loads %llu | last chunk + barrier %llu | factor %llu | look-ahead past the factor %llu | row solves + barrier %llu | backward substitution + norms %llu\n", st[0], st[1], st[2], st[3], st[4], st[5]);
   return r3[2] != 0.0 ? 0 : 1;
 }
 #endif
 
 // backward substitution L^T x = y (y = bvec after the last ba_big_step_kernel), |dp|^2, |p|^2: one block
-__global__ __launch_bounds__(256) void ba_big_back_kernel(const BaWin* __restrict__ wins) {
+__global__ __launch_bounds__(256) void ba_big_back_kernel(const BaWin* __restrict__ wins, int one_launch_max_n) {
   __shared__ double sb[BA_MAX_N];
   __shared__ double y[BB_NB];
   __shared__ double red[256];
   const BaWin win = ba_win_global(wins, blockIdx.y);
   const BaState* St = win.S;
-  if (win.use_lds || St->done) return;
+  if (win.use_lds || St->done || win.n <= one_launch_max_n) return;      // (the one-launch factorisation substitutes backward itself)
   const int n = win.n;
   const double* __restrict__ Sg = win.Sg; const double* __restrict__ ginv = win.ginv; const double* __restrict__ bvec = win.bvec;
   double* __restrict__ dp = win.dp; double* __restrict__ res = win.res;
@@ -3292,7 +3398,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
     pl.a_part = car.take(8 * pl.n_upper * d.ksplit * 256);
     pl.a_rb = car.take(8 * (pl.rb_len + 8));
-    pl.a_solve = car.take(8 * ((size_t)pl.n * pl.n + 4 * (size_t)pl.n + 64 + BA_SOLVE_THREADS));   // dp [n pad 16] | S [n*n] | b [n] | 1/L_jj [n]
+    pl.a_solve = car.take(8 * ((size_t)pl.n * pl.n + 21 * (size_t)pl.n + 640 + BA_SOLVE_THREADS));   // dp [n pad 16] | S [n*n] | b [n] | 1/L_jj [n pad 16] | (gradient slot [n pad 16]) | L11^-T rows [n / 16 + 1][256]
     pl.a_res = car.take(8 * 16);
     pl.o_out = cout.take(8 * (8 + pl.np));
   }
@@ -3330,7 +3436,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   if (int rc = orbx_reserve(h, h->ws_ba[B_OUT], cout.off)) return rc;
   // inertial: edges (int [E][2]) | preint [E][11] | per-edge J^T J records;  dp15 [n15 pad 16] | S [n15^2] | b | 1/L_jj | gradient
   if (int rc = orbx_reserve(h, h->ws_ba[B_IMU], inertial ? 8 * ((size_t)inr->E * (1 + 11 + IMU_REC) + 8) : 8)) return rc;
-  if (int rc = orbx_reserve(h, h->ws_ba[B_S15], inertial ? 8 * ((size_t)n15 * n15 + 4 * (size_t)n15 + 64) : 8)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_ba[B_S15], inertial ? 8 * ((size_t)n15 * n15 + 21 * (size_t)n15 + 640) : 8)) return rc;
   if (int rc = pinned_reserve(h, &h->h_ba_in, &h->h_ba_in_bytes, small_bytes + (any_stage ? obs_bytes : 0))) return rc;
   if (int rc = pinned_reserve(h, &h->h_ba_out, &h->h_ba_out_bytes, cout.off)) return rc;
   if (!h->h_abort) {
@@ -3648,7 +3754,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
           const int nt = (n15 - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
           hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + BB_STEP_WAVES - 1) / BB_STEP_WAVES, 1), dim3(BB_STEP_THREADS), 0, st, d_wins15, c0, one_launch_max_n);
         }
-        hipLaunchKernelGGL(ba_big_back_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15);
+        if (n15 > one_launch_max_n) hipLaunchKernelGGL(ba_big_back_kernel, dim3(1, 1), dim3(256), 0, st, d_wins15, one_launch_max_n);
       }
       hipLaunchKernelGGL(ba_inertial_scatter_kernel, dim3(1), dim3(256), 0, st, w0.S, w0.P0, w0.P1, K0, M0, dp15, w0.dp);
     } else {
@@ -3662,7 +3768,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
           const int nt = (n_big_max - c0 + 15) / 16, units = c0 > 0 ? nt * (nt - 1) / 2 : 0;
           hipLaunchKernelGGL(ba_big_step_kernel, dim3(1 + (units + BB_STEP_WAVES - 1) / BB_STEP_WAVES, W), dim3(BB_STEP_THREADS), 0, st, d_wins, c0, one_launch_max_n);
         }
-        hipLaunchKernelGGL(ba_big_back_kernel, gW1, dim3(256), 0, st, d_wins);
+        if (n_big_max > 0) hipLaunchKernelGGL(ba_big_back_kernel, gW1, dim3(256), 0, st, d_wins, one_launch_max_n);
       }
     }
     {
