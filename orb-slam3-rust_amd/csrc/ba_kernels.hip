@@ -2905,6 +2905,8 @@ __global__ __launch_bounds__(BA_DECIDE_THREADS) void ba_decide_kernel(const BaWi
   if (M >= 0) {
     double x = 0.0, y = 0.0, z = 0.0;
     for (int j = tid; j < M; j += BA_DECIDE_THREADS) { x += pt_chi2[j]; y += pt_dsq[j]; z += pt_psq[j]; }
+    // (shuffle trees inside the waves and the wave totals in wave order — one barrier instead of log2(threads) — measured 9.2 -> 12.5 us
+    // per 32-window launch, 6.0 -> 7.0 for one window: three f64 shuffle trees cost more than the LDS tree's barriers.  Round 4, withdrawn.)
     sh[0][tid] = x; sh[1][tid] = y; sh[2][tid] = z;
     __syncthreads();
     for (int s2 = BA_DECIDE_THREADS / 2; s2 >= 1; s2 >>= 1) {
@@ -3739,7 +3741,10 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     }
     {
       ProfScope ps(h, "ba_gather_kernel");
-      hipLaunchKernelGGL(ba_gather_kernel, dim3(max_gather, W), dim3(256), 0, st, d_wins);
+      // (with the shares already summed by the Schur launch a lane reads ONE pair per element: a block per 32 element pairs was 7 200 blocks of a
+      // few hundred cycles each for 32 windows; ORBX_BA_GATHER_DIV elements per thread: 1 / 2 / 4 / 8 / 16 measured 14.7 / 13.4 / 12.8 / 15.1 / 18.5 us)
+      static const int gather_div = [] { const char* e = getenv("ORBX_BA_GATHER_DIV"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+      hipLaunchKernelGGL(ba_gather_kernel, dim3(schur_sums ? std::max(1, max_gather / gather_div) : max_gather, W), dim3(256), 0, st, d_wins);
     }
     if (int rc = allreduce(w0.rb, plan[0].rb_len)) return rc;
     if (inertial) {
