@@ -133,6 +133,27 @@ def test_ba_noise_free_and_golden(gpu_handle, oracle, pkg, golden):
     assert abs(r["initial_error"] - want) < 1e-12 * want and r["iterations"] == 0
 
 
+def test_ba_failed_factorisation_ends_the_solve_on_every_reduced_system_path(gpu_handle, pkg):
+    """local_ba_lm.rs:1036-1039: when the reduced system cannot be factored the loop ends and the parameters stay as they are.  One
+    observation with a NaN pixel makes every pivot fail; each path of the reduced solve — LDS square (n = 114), LDS tiles (n = 150), the
+    one-launch global factorisation with its folded backward substitution (n = 192, 294) and the multi-launch one (n = 330) — must stop
+    after that iteration and hand back exactly what a zero-iteration call returns, alone and inside a batch."""
+    cam = pkg.CameraModel(**pkg.synth.EUROC_CAMERA)
+    wins = []
+    for seed, K, M in ((61, 20, 300), (62, 26, 350), (63, 33, 400), (64, 50, 600), (65, 56, 600)):
+        w = pkg.synth.ba_window(seed, K, M, pkg.BA_OBS)
+        w["obs"] = w["obs"].copy(); w["obs"]["u"][7] = np.nan
+        wins.append(w)
+    cfg, cfg0 = pkg.LocalBAConfigLM(), pkg.LocalBAConfigLM(max_iterations=0)
+    batch = gpu_handle.ba_solve_visual_batch(cam, cfg, wins)
+    for w, b in zip(wins, batch):
+        r = gpu_handle.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+        z = gpu_handle.ba_solve_visual(cam, cfg0, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+        for got in (r, b):
+            assert got["iterations"] == 1, len(w["poses_cw"])
+            assert np.array_equal(np.asarray(got["poses_wc"]), np.asarray(z["poses_wc"])) and np.array_equal(got["points"], z["points"])
+
+
 def test_ba_abort_and_none(gpu_handle, oracle, pkg):
     w = pkg.synth.ba_window(3, 4, 40, pkg.BA_OBS)
     cam = pkg.CameraModel(**w["camera"])
