@@ -78,6 +78,9 @@ struct BaState {
   double lambda, cur_sq, final_sq, gtol, ptol;
   int done, iters, sel;
   int bad;      // 0, or INT_MAX - (index of the first observation with an index out of range): ba_prep_count_kernel; such a window never runs
+  // the fused step (ba_step_kernel, BaWin::dbl): which of the two sets of per-observation / per-point build results belongs to the
+  // current parameters, and whether the current set's lambda-dependent point matrices are the ones of the last REJECTED step (BaWin::rej)
+  int bsel, psel;
 };
 __device__ __forceinline__ double* ba_cur(const BaState* S, double* P0, double* P1) { return S->sel ? P1 : P0; }
 __device__ __forceinline__ double* ba_trial(const BaState* S, double* P0, double* P1) { return S->sel ? P0 : P1; }
@@ -117,6 +120,11 @@ struct BaWin {
   int *obs_tmp;          // [N] observation indices grouped by map point, in arrival order within a point (sorted by ba_prep_order_kernel)
   int *o_flag;           // [N] inertial: orbx_ba_obs::_pad (bit 0 = stereo) in point-major order, else null
   double *Mz;            // [M][6] per point: the inverse of the Cholesky factor of V* (lower: m00, m10, m11, m20, m21, m22) — V*^-1 = M^T M, the one-operand Schur product's Z = W M^T
+  // dbl: oP, Rt_cur, Mz, Vinv, gl, vg, pt_chi2, pt_glsq and Vraw exist twice, set 1 right behind set 0 (ba_set): the step kernel writes
+  // the build results of the TRIAL parameters into the set that is not current while the current one is still being read
+  double *Vraw;          // [M][6] per point: V before damping (dbl only: the rejected step's matrices are rebuilt from it)
+  double *rej;           // [M][18] per point: Mz (6) | Vinv (9) | vg (3) of the CURRENT set for the lambda a rejection leaves (dbl only)
+  int dbl, pad2_;
 };
 
 // The pointers a kernel takes out of its window descriptor are generic to the compiler (loaded from memory, not kernel arguments): every
@@ -152,9 +160,13 @@ struct BaWinView {
   BA_AS1 int *obs_tmp;
   BA_AS1 int *o_flag;
   BA_AS1 double *Mz;
+  BA_AS1 double *Vraw;
+  BA_AS1 double *rej;
+  int dbl, pad2_;
 };
 static_assert(sizeof(BaWinView) == sizeof(BaWin) && offsetof(BaWinView, S) == offsetof(BaWin, S) && offsetof(BaWinView, oP) == offsetof(BaWin, oP) &&
-              offsetof(BaWinView, res) == offsetof(BaWin, res) && offsetof(BaWinView, o_flag) == offsetof(BaWin, o_flag) && offsetof(BaWinView, Mz) == offsetof(BaWin, Mz),
+              offsetof(BaWinView, res) == offsetof(BaWin, res) && offsetof(BaWinView, o_flag) == offsetof(BaWin, o_flag) && offsetof(BaWinView, Mz) == offsetof(BaWin, Mz) &&
+              offsetof(BaWinView, rej) == offsetof(BaWin, rej) && offsetof(BaWinView, dbl) == offsetof(BaWin, dbl),
               "BaWinView is BaWin with its pointers in the global address space");
 __device__ __forceinline__ BaWin ba_win_global(const BaWin* __restrict__ wins, int i) {
   const BaWinView& v = ((const BaWinView*)wins)[i];
@@ -168,7 +180,7 @@ __device__ __forceinline__ BaWin ba_win_global(const BaWin* __restrict__ wins, i
   g.kfpart = (double*)v.kfpart; g.part = (double*)v.part; g.rb = (double*)v.rb; g.dp = (double*)v.dp;
   g.Sg = (double*)v.Sg; g.bvec = (double*)v.bvec; g.ginv = (double*)v.ginv; g.res = (double*)v.res;
   g.obs_raw = (const orbx_ba_obs*)v.obs_raw; g.obs32 = v.obs32; g.pad_ = 0; g.pt_fill = (int*)v.pt_fill; g.obs_tmp = (int*)v.obs_tmp; g.o_flag = (int*)v.o_flag;
-  g.Mz = (double*)v.Mz;
+  g.Mz = (double*)v.Mz; g.Vraw = (double*)v.Vraw; g.rej = (double*)v.rej; g.dbl = v.dbl; g.pad2_ = 0;
   return g;
 }
 
@@ -548,6 +560,64 @@ __device__ __forceinline__ void obs_terms(const BaCam& cam, const double* Rt, co
   obs_jac_from_proj(cam, Rt, x, y, o.piz, o.psw, o.A, o.B);
 }
 
+// The arrays that exist once per SET of build results (BaWin::dbl): set s of a window.  Without dbl there is one set and s is 0.
+struct BaSet { double *oP, *Rt_cur, *Mz, *Vinv, *gl, *vg, *pt_chi2, *pt_glsq, *Vraw; };
+__device__ __forceinline__ BaSet ba_set(const BaWin& w, int s) {
+  const size_t n1 = (size_t)max(w.d.N, 1), m1 = (size_t)max(w.d.M, 1), k1 = (size_t)max(w.d.K, 1), q = w.dbl ? (size_t)s : 0;
+  BaSet b;
+  b.oP = w.oP + q * 6 * n1; b.Rt_cur = w.Rt_cur + q * 12 * k1; b.Mz = w.Mz + q * 6 * m1; b.Vinv = w.Vinv + q * 9 * m1;
+  b.gl = w.gl + q * 3 * m1; b.vg = w.vg + q * 3 * m1; b.pt_chi2 = w.pt_chi2 + q * m1; b.pt_glsq = w.pt_glsq + q * m1;
+  b.Vraw = w.Vraw ? w.Vraw + q * 6 * m1 : nullptr;
+  return b;
+}
+// The lambda-dependent point matrices the consumers read: the current set's own, or — after a rejected step — the ones the step kernel
+// left for the lambda of the rejection (BaWin::rej: Mz | Vinv | vg)
+struct BaPointMats { const double *Mz, *Vinv, *vg; };
+__device__ __forceinline__ BaPointMats ba_point_mats(const BaWin& w, const BaState* S, const BaSet& cur) {
+  BaPointMats m;
+  if (w.dbl && S->psel) { const size_t m1 = (size_t)max(w.d.M, 1); m.Mz = w.rej; m.Vinv = w.rej + 6 * m1; m.vg = w.rej + 15 * m1; }
+  else { m.Mz = cur.Mz; m.Vinv = cur.Vinv; m.vg = cur.vg; }
+  return m;
+}
+
+// One observation of the build pass: residual + Jacobian at (Rt, X), its six numbers stored, chi2 / V / g_l accumulated
+__device__ __forceinline__ void ba_build_obs(const BaCam& cam, const double* Rt, const double (&X)[3], double u, double v, int flag,
+                                             double* __restrict__ q, double (&V)[6], double (&g)[3], double& chi) {
+  ObsOut o;
+  obs_terms(cam, Rt, X, u, v, true, o, flag);
+  q[0] = o.px; q[1] = o.py; q[2] = o.piz; q[3] = o.psw; q[4] = o.r0; q[5] = o.r1;
+  chi += o.chi;
+  V[0] = fma(o.B[0], o.B[0], fma(o.B[3], o.B[3], V[0]));
+  V[1] = fma(o.B[0], o.B[1], fma(o.B[3], o.B[4], V[1]));
+  V[2] = fma(o.B[0], o.B[2], fma(o.B[3], o.B[5], V[2]));
+  V[3] = fma(o.B[1], o.B[1], fma(o.B[4], o.B[4], V[3]));
+  V[4] = fma(o.B[1], o.B[2], fma(o.B[4], o.B[5], V[4]));
+  V[5] = fma(o.B[2], o.B[2], fma(o.B[5], o.B[5], V[5]));
+  g[0] = fma(o.B[0], o.r0, fma(o.B[3], o.r1, g[0]));
+  g[1] = fma(o.B[1], o.r0, fma(o.B[4], o.r1, g[1]));
+  g[2] = fma(o.B[2], o.r0, fma(o.B[5], o.r1, g[2]));
+}
+// damped V* = V + lambda*max(diag,1e-6) (:1031-1034); V* = L L^T (V* is positive definite: V is a sum of B^T B and every diagonal entry is
+// damped), M = L^-1 (m00, m10, m11, m20, m21, m22), I = V*^-1 = M^T M, vg = V*^-1 g.  The three pivots' reciprocal square roots are the only
+// transcendental steps.  (First form: three square roots and five divisions for M beside the closed-form inverse's one division: 47.2 us
+// per 32-window launch against 42.8, profiles/r04_ba_mz_rsqrt_ab.txt.)
+__device__ __forceinline__ void ba_point_matrices(const double (&V)[6], const double (&g)[3], double lambda, double (&M)[6], double (&I)[9], double (&vgo)[3]) {
+  const double a_ = V[0] + lambda * fmax(V[0], 1e-6), b_ = V[1], c_ = V[2];
+  const double d_ = V[3] + lambda * fmax(V[3], 1e-6), e_ = V[4], f_ = V[5] + lambda * fmax(V[5], 1e-6);
+  const double m00 = rsqrt(a_), l10 = b_ * m00, l20 = c_ * m00;
+  const double m11 = rsqrt(fmax(d_ - l10 * l10, 0.0)), l21 = (e_ - l20 * l10) * m11;
+  const double m22 = rsqrt(fmax(f_ - l20 * l20 - l21 * l21, 0.0));
+  const double m10 = -(l10 * m00) * m11, m21 = -(l21 * m11) * m22, m20 = -(l20 * m00 + l21 * m10) * m22;
+  M[0] = m00; M[1] = m10; M[2] = m11; M[3] = m20; M[4] = m21; M[5] = m22;
+  I[0] = m00 * m00 + m10 * m10 + m20 * m20; I[1] = m10 * m11 + m20 * m21; I[2] = m20 * m22;
+  I[3] = I[1]; I[4] = m11 * m11 + m21 * m21; I[5] = m21 * m22;
+  I[6] = I[2]; I[7] = I[5]; I[8] = m22 * m22;
+  // V*^-1 g_l: what the keyframe partials need of this point for b_red = sum W V*^-1 g_l = sum A^T (B V*^-1 g_l)
+  vgo[0] = I[0] * g[0] + I[1] * g[1] + I[2] * g[2];
+  vgo[1] = I[3] * g[0] + I[4] * g[1] + I[5] * g[2];
+  vgo[2] = I[6] * g[0] + I[7] * g[1] + I[8] * g[2];
+}
+
 // Lanes per map point in the per-observation kernels: 32 for one window (twice the blocks for its latency chains), 16 in a batch of
 // >= 8 windows (points average 16 observations: in a 32-lane group half the lanes idle through the Jacobian arithmetic, and these
 // kernels are f64-VALU-bound there).  The group size must not enter the sums, so the 16-lane form keeps TWO accumulators per sum —
@@ -580,14 +650,15 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
   const double* __restrict__ Rt_fix = win.Rt_fix;
   const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf;
   const double* __restrict__ o_uv = win.o_uv;
-  double* __restrict__ Vinv = win.Vinv /*M*9*/; double* __restrict__ gl = win.gl /*M*3*/; double* __restrict__ vg = win.vg /*M*3*/;
-  double* __restrict__ pt_chi2 = win.pt_chi2 /*M*/; double* __restrict__ pt_glsq = win.pt_glsq /*M*/;
-  double* __restrict__ oP = win.oP;
+  const BaSet out = ba_set(win, S->bsel);                                // (the fused loop launches this kernel for iteration 0 only: set 0)
+  double* __restrict__ Vinv = out.Vinv /*M*9*/; double* __restrict__ gl = out.gl /*M*3*/; double* __restrict__ vg = out.vg /*M*3*/;
+  double* __restrict__ pt_chi2 = out.pt_chi2 /*M*/; double* __restrict__ pt_glsq = out.pt_glsq /*M*/;
+  double* __restrict__ oP = out.oP;
   const double lambda = S->lambda;
   const double* params = ba_cur(S, P0, P1);
   if (blockIdx.x == 0 && threadIdx.x == 0) S->iters = iter + 1;          // local_ba_lm.rs:1017
   block_poses(params, d.K, cam.inertial, sRt);
-  if (blockIdx.x == 0) for (int a = threadIdx.x; a < 12 * d.K; a += blockDim.x) win.Rt_cur[a] = sRt[a];   // for the kernels that rebuild the blocks
+  if (blockIdx.x == 0) for (int a = threadIdx.x; a < 12 * d.K; a += blockDim.x) out.Rt_cur[a] = sRt[a];   // for the kernels that rebuild the blocks
   const int lane32 = threadIdx.x & (LANES - 1);
   // a group takes the points g0, g0 + (groups of the launch), ...: one point per group for a single window (as many short blocks as
   // possible for its latency chain), several in a large batch, where the block's prologue (K poses) is then paid once for all of
@@ -627,22 +698,7 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
 #pragma unroll
       for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)(-1 - k) + a];
     }
-    ObsOut o;
-    obs_terms(cam, Rt, X, u, v, true, o, cam.o_flag ? cam.o_flag[i] : 0);
-    {
-      double* q = oP + 6 * (size_t)i;
-      q[0] = o.px; q[1] = o.py; q[2] = o.piz; q[3] = o.psw; q[4] = o.r0; q[5] = o.r1;
-    }
-    chi += o.chi;
-    V[0] = fma(o.B[0], o.B[0], fma(o.B[3], o.B[3], V[0]));
-    V[1] = fma(o.B[0], o.B[1], fma(o.B[3], o.B[4], V[1]));
-    V[2] = fma(o.B[0], o.B[2], fma(o.B[3], o.B[5], V[2]));
-    V[3] = fma(o.B[1], o.B[1], fma(o.B[4], o.B[4], V[3]));
-    V[4] = fma(o.B[1], o.B[2], fma(o.B[4], o.B[5], V[4]));
-    V[5] = fma(o.B[2], o.B[2], fma(o.B[5], o.B[5], V[5]));
-    g[0] = fma(o.B[0], o.r0, fma(o.B[3], o.r1, g[0]));
-    g[1] = fma(o.B[1], o.r0, fma(o.B[4], o.r1, g[1]));
-    g[2] = fma(o.B[2], o.r0, fma(o.B[5], o.r1, g[2]));
+    ba_build_obs(cam, Rt, X, u, v, cam.o_flag ? cam.o_flag[i] : 0, oP + 6 * (size_t)i, V, g, chi);
   };
   for (int i = s + lane32; i < e; i += 32) {
     if (i == s + lane32) one(i, pa.k0, pa.u0, pa.v0, Va, ga, chia);               // (the lane's first observation came with the pipeline)
@@ -655,30 +711,19 @@ __global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_build_kernel(con
 #pragma unroll
   for (int a = 0; a < 3; ++a) g[a] = group_sum<LANES>(ga[a], gb[a]);
   const double chi = group_sum<LANES>(chia, chib);
-  // damped V* = V + lambda*max(diag,1e-6) (:1031-1034)
-  const double a_ = V[0] + lambda * fmax(V[0], 1e-6), b_ = V[1], c_ = V[2];
-  const double d_ = V[3] + lambda * fmax(V[3], 1e-6), e_ = V[4], f_ = V[5] + lambda * fmax(V[5], 1e-6);
-  double I[9];
-  // V* = L L^T (V* is positive definite: V is a sum of B^T B and every diagonal entry is damped), M = L^-1, V*^-1 = M^T M.  The three
-  // pivots' reciprocal square roots are the only transcendental steps.  (First form: three square roots and five divisions for M beside
-  // the closed-form inverse's one division: 47.2 us per 32-window launch against 42.8, profiles/r04_ba_mz_rsqrt_ab.txt.)
-  const double m00 = rsqrt(a_), l10 = b_ * m00, l20 = c_ * m00;
-  const double m11 = rsqrt(fmax(d_ - l10 * l10, 0.0)), l21 = (e_ - l20 * l10) * m11;
-  const double m22 = rsqrt(fmax(f_ - l20 * l20 - l21 * l21, 0.0));
-  const double m10 = -(l10 * m00) * m11, m21 = -(l21 * m11) * m22, m20 = -(l20 * m00 + l21 * m10) * m22;
-  I[0] = m00 * m00 + m10 * m10 + m20 * m20; I[1] = m10 * m11 + m20 * m21; I[2] = m20 * m22;
-  I[3] = I[1]; I[4] = m11 * m11 + m21 * m21; I[5] = m21 * m22;
-  I[6] = I[2]; I[7] = I[5]; I[8] = m22 * m22;
+  double Mm[6], I[9], vgo[3];
+  ba_point_matrices(V, g, lambda, Mm, I, vgo);
   if (lane32 == 0) {
-    double* mz = win.Mz + 6 * (size_t)j;
-    mz[0] = m00; mz[1] = m10; mz[2] = m11; mz[3] = m20; mz[4] = m21; mz[5] = m22;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) out.Mz[6 * (size_t)j + a] = Mm[a];
 #pragma unroll
     for (int a = 0; a < 9; ++a) Vinv[9 * (size_t)j + a] = I[a];
-    gl[3 * (size_t)j] = g[0]; gl[3 * (size_t)j + 1] = g[1]; gl[3 * (size_t)j + 2] = g[2];
-    // V*^-1 g_l: what the keyframe partials need of this point for b_red = sum W V*^-1 g_l = sum A^T (B V*^-1 g_l)
-    vg[3 * (size_t)j] = I[0] * g[0] + I[1] * g[1] + I[2] * g[2];
-    vg[3 * (size_t)j + 1] = I[3] * g[0] + I[4] * g[1] + I[5] * g[2];
-    vg[3 * (size_t)j + 2] = I[6] * g[0] + I[7] * g[1] + I[8] * g[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { gl[3 * (size_t)j + a] = g[a]; vg[3 * (size_t)j + a] = vgo[a]; }
+    if (out.Vraw) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) out.Vraw[6 * (size_t)j + a] = V[a];
+    }
     pt_chi2[j] = chi;
     pt_glsq[j] = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
   }
@@ -708,12 +753,13 @@ template <int NT>
 __device__ __forceinline__ void ba_kf_body(int bx, const BaWin& win, const BaCam& cam) {
   __shared__ double red[NT / 64][33];
   const int* __restrict__ kf_start = win.kf_start; const int* __restrict__ kf_obs = win.kf_obs; const int* __restrict__ kf_pt = win.kf_pt;
-  const double* __restrict__ oP = win.oP; const double* __restrict__ vg = win.vg;
+  const BaSet cset = ba_set(win, win.S->bsel);
+  const double* __restrict__ oP = cset.oP; const double* __restrict__ vg = ba_point_mats(win, win.S, cset).vg;
   double* __restrict__ kfpart = win.kfpart;   /*[K][BA_KFSPLIT][33]*/
   const int k = bx / BA_KFSPLIT, sp = bx % BA_KFSPLIT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double Rt[12];                                                          // this block's keyframe, as the build kernel derived it
 #pragma unroll
-  for (int a = 0; a < 12; ++a) Rt[a] = win.Rt_cur[12 * (size_t)k + a];
+  for (int a = 0; a < 12; ++a) Rt[a] = cset.Rt_cur[12 * (size_t)k + a];
   const int s0 = kf_start[k], len = kf_start[k + 1] - s0;
   const int s = s0 + (int)((long long)len * sp / BA_KFSPLIT), e = s0 + (int)((long long)len * (sp + 1) / BA_KFSPLIT);
   double acc[33];   // 21 unique U entries, 6 g_p, 6 b_red
@@ -841,7 +887,8 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
   const int bj = bi + rem;
   const bool diag = bi == bj;
   const int j_begin = ks * d.pps;                                   // first map point of this k-split
-  const double* __restrict__ oP = win.oP; const double* __restrict__ Rt_cur = win.Rt_cur;
+  const BaSet cset = ba_set(win, win.S->bsel);
+  const double* __restrict__ oP = cset.oP; const double* __restrict__ Rt_cur = cset.Rt_cur; const double* __restrict__ Mzp = ba_point_mats(win, win.S, cset).Mz;
   const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
   double4_t acc[2][8];
 #pragma unroll
@@ -890,7 +937,7 @@ __device__ __forceinline__ void ba_schur_body(int bx, const BaWin& win, const Ba
       const double* Rk = Rt_cur + 12 * (size_t)k;                     // (read where used: 16 accumulator tiles leave no registers to park it in)
       double Mj[6];
 #pragma unroll
-      for (int t = 0; t < 6; ++t) Mj[t] = j < d.M ? win.Mz[6 * (size_t)j + t] : 0.0;
+      for (int t = 0; t < 6; ++t) Mj[t] = j < d.M ? Mzp[6 * (size_t)j + t] : 0.0;
       for (int i = cur[q]; i >= 0; i = obs_next[i]) obs_z_from_stored<true>(cam, Rk, oP + 6 * (size_t)i, Mj, w);   // Z of the slot (0 + Z for the first)
       double* __restrict__ dstT = side == 0 ? sY : sW;
 #pragma unroll
@@ -1087,14 +1134,15 @@ __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaW
 #endif
     const int f = tid - 256, pj = f / 23, k = f - pj * 23;
     const bool slot = pj < 8 && k < d.K && 6 * k < 128;
-    const double* __restrict__ oP = win.oP;
+    const BaSet cset = ba_set(win, win.S->bsel);
+    const double* __restrict__ oP = cset.oP; const double* __restrict__ Mzp = ba_point_mats(win, win.S, cset).Mz;
     const int* __restrict__ slot_first = win.slot_first; const int* __restrict__ obs_next = win.obs_next;
     // (the slot index runs two tiles ahead, the stored numbers one; a second register set — numbers two tiles ahead — measured no
     // difference in round 3 and again in round 4, 86.1-88.9 against 86.3-87.0 us: the loads are not what the producers wait for)
     struct SlotData { double pq[SCHW_SPT][4], M[SCHW_SPT][6]; int chain[SCHW_SPT], idx[SCHW_SPT]; } sd;    // per slot: (x, y, 1/z, sqrt w) and the point's M; empty slot: zeros
     double Rk[12];
 #pragma unroll
-    for (int t = 0; t < 12; ++t) Rk[t] = slot ? win.Rt_cur[12 * (size_t)k + t] : 0.0;
+    for (int t = 0; t < 12; ++t) Rk[t] = slot ? cset.Rt_cur[12 * (size_t)k + t] : 0.0;
     auto slot_of = [&](int T, int h) -> int {                         // first observation of (point of tile T, keyframe k), or -1
       const int j = j_begin + T * SCHW_NPT + pj + 8 * h;
       return (slot && T < nT && j < d.M) ? slot_first[(size_t)j * d.K + k] : -1;
@@ -1106,7 +1154,7 @@ __device__ __forceinline__ void ba_schur_diag_ws_body(int bx, int spb, const BaW
 #pragma unroll
         for (int t = 0; t < 4; ++t) sd.pq[h][t] = i >= 0 ? oP[6 * (size_t)i + t] : 0.0;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) sd.M[h][t] = (slot && T < nT && j < d.M) ? win.Mz[6 * (size_t)j + t] : 0.0;
+        for (int t = 0; t < 6; ++t) sd.M[h][t] = (slot && T < nT && j < d.M) ? Mzp[6 * (size_t)j + t] : 0.0;
         sd.chain[h] = i >= 0 ? obs_next[i] : -1;
       }
     };
@@ -1233,12 +1281,14 @@ __global__ __launch_bounds__(DIAG ? SCHW_THREADS : 256, DIAG ? 1 : 2) void ba_sc
 }
 
 // reduce-buffer layout (doubles): [Sred n*n | U 36K | gp n | bred n | chi2 | glsq], n = 6K
-__global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict__ wins) {
+__global__ __launch_bounds__(256) void ba_gather_kernel(const BaWin* __restrict__ wins, int iter_mark) {
   const BaWin win = ba_win_global(wins, blockIdx.y);
   if (win.S->done) return;
+  if (iter_mark >= 0 && blockIdx.x == 0 && threadIdx.x == 0) win.S->iters = iter_mark + 1;   // local_ba_lm.rs:1017 — the fused loop has no build launch to count its iterations 1, 2, ...
   const BaDims d = win.d;
   const double* __restrict__ part = win.part; const double* __restrict__ kfpart = win.kfpart;
-  const double* __restrict__ pt_chi2 = win.pt_chi2; const double* __restrict__ pt_glsq = win.pt_glsq;
+  const BaSet cset = ba_set(win, win.S->bsel);
+  const double* __restrict__ pt_chi2 = cset.pt_chi2; const double* __restrict__ pt_glsq = cset.pt_glsq;
   double* __restrict__ rb = win.rb;
   const int n = 6 * d.K;
   const size_t nn = (size_t)n * n;
@@ -2807,6 +2857,134 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(const BaWin* __restrict
   }
 }
 
+// The back-substitution of iteration i and the build pass of iteration i + 1 in ONE pass over the observations (round 4; the visual
+// solve on one GPU: BaWin::dbl).  An accepted step makes the trial parameters current, and what ba_build_kernel would then compute from them —
+// residuals, the stored numbers of every observation, V, g_l, V*^-1, M — is what the trial's chi2 already needs most of: so the group
+// that back-substitutes a point builds it at its trial position right away, into the set of build results that is NOT current (ba_set),
+// with the lambda an acceptance leaves (lambda / 10).  ba_decide_kernel then only flips BaState::bsel.  A rejected step keeps the current
+// set — same parameters, same residuals and Jacobians — and needs its lambda-dependent point matrices for lambda * 10: the group writes
+// those too (BaWin::rej, from the V and g_l the set keeps), and BaState::psel makes the consumers read them.  Same arithmetic on the same
+// operands in the same order as the two kernels it replaces: same bits.  One launch and one pass over o_kf / o_uv less per iteration.
+template <int LANES>
+__global__ __launch_bounds__(256, ORBX_BUILD_MINBLOCKS) void ba_step_kernel(const BaWin* __restrict__ wins, BaCam cam) {
+  __shared__ double sRt[12 * BA_MAX_K];      // trial poses
+  __shared__ double sRt0[12 * BA_MAX_K];     // current poses (the linearisation point)
+  const BaWin win = ba_win_global(wins, blockIdx.y);
+  const BaDims d = win.d;
+  const BaState* S = win.S;
+  if (S->done || (int)blockIdx.x * 256 >= max(LANES * d.M, 6 * d.K)) return;
+  double *P0 = win.P0, *P1 = win.P1;
+  const double* __restrict__ dp = win.dp;
+  const int* __restrict__ pt_start = win.pt_start; const int* __restrict__ o_kf = win.o_kf;
+  const double* __restrict__ o_uv = win.o_uv; const double* __restrict__ Rt_fix = win.Rt_fix;
+  const int bs = S->bsel;
+  const BaSet cur = ba_set(win, bs), oth = ba_set(win, bs ^ 1);
+  const double* __restrict__ oP = cur.oP; const double* __restrict__ Vinv = ba_point_mats(win, S, cur).Vinv; const double* __restrict__ gl = cur.gl;
+  double* __restrict__ pt_dsq = win.pt_dsq; double* __restrict__ pt_psq = win.pt_psq;
+  const size_t m1 = (size_t)max(d.M, 1);
+  double* __restrict__ rMz = win.rej; double* __restrict__ rVinv = win.rej + 6 * m1; double* __restrict__ rvg = win.rej + 15 * m1;
+  const double lambda = S->lambda, lam_a = fmax(lambda * 0.1, 1e-10), lam_r = fmin(lambda * 10.0, 1e10);   // what ba_decide_kernel will set (:1050-1055)
+  const double* params = ba_cur(S, P0, P1);
+  double* trial = ba_trial(S, P0, P1);
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gtid < 6 * d.K) trial[gtid] = params[gtid] + dp[gtid];
+  for (int k = threadIdx.x; k < d.K; k += blockDim.x) {
+    double p6[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) p6[a] = params[6 * (size_t)k + a] + dp[6 * (size_t)k + a];   // = the trial pose written above
+    pose_to_Rt(p6, cam.inertial, sRt + 12 * k);
+  }
+  for (int a = threadIdx.x; a < 12 * d.K; a += blockDim.x) sRt0[a] = cur.Rt_cur[a];
+  __syncthreads();
+  if (blockIdx.x == 0) for (int a = threadIdx.x; a < 12 * d.K; a += blockDim.x) oth.Rt_cur[a] = sRt[a];
+  const int lane32 = threadIdx.x & (LANES - 1);
+  const int gstride = (int)gridDim.x * (256 / LANES);
+  for (int j = gtid / LANES; j < d.M; j += gstride) {   // group-uniform
+  const double X0[3] = {params[6 * (size_t)d.K + 3 * (size_t)j], params[6 * (size_t)d.K + 3 * (size_t)j + 1], params[6 * (size_t)d.K + 3 * (size_t)j + 2]};
+  const int s = pt_start[j], e = pt_start[j + 1];
+  // ---- the back-substitution of ba_backsub_kernel: delta_l = V*^-1 (-g_l - sum_k W_kj^T delta_p_k)
+  double acca[3] = {0.0, 0.0, 0.0}, accb[3] = {0.0, 0.0, 0.0};
+  auto wtdp = [&](int i, double (&acc)[3]) {
+    const int k = o_kf[i];
+    if (k < 0) return;
+    const double* q = oP + 6 * (size_t)i;
+    double A[12], B[6];
+    obs_jac_from_proj(cam, sRt0 + 12 * k, q[0], q[1], q[2], q[3], A, B);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double dk = dp[6 * (size_t)k + a];
+      if (!ba_a0_zero(a)) s0 = fma(A[a], dk, s0);
+      if (!ba_a1_zero(a)) s1 = fma(A[6 + a], dk, s1);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = fma(B[c], s0, fma(B[3 + c], s1, acc[c]));
+  };
+  for (int i = s + lane32; i < e; i += 32) {
+    wtdp(i, acca);
+    if (LANES == 16 && i + 16 < e) wtdp(i + 16, accb);
+  }
+  double acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) acc[c] = group_sum<LANES>(acca[c], accb[c]);
+  const double rhs[3] = {-gl[3 * (size_t)j] - acc[0], -gl[3 * (size_t)j + 1] - acc[1], -gl[3 * (size_t)j + 2] - acc[2]};
+  const double* Ic = Vinv + 9 * (size_t)j;
+  double X[3], dsq = 0.0, psq = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double dl = Ic[a * 3] * rhs[0] + Ic[a * 3 + 1] * rhs[1] + Ic[a * 3 + 2] * rhs[2];
+    const double p = X0[a];
+    X[a] = p + dl;
+    dsq += dl * dl; psq += p * p;
+  }
+  // ---- the build pass of ba_build_kernel at the trial position and the trial poses, into the other set
+  double Va[6] = {0, 0, 0, 0, 0, 0}, ga[3] = {0, 0, 0}, chia = 0.0, Vb[6] = {0, 0, 0, 0, 0, 0}, gb[3] = {0, 0, 0}, chib = 0.0;
+  auto one = [&](int i, double (&V)[6], double (&g)[3], double& chi) {
+    const int k = o_kf[i];
+    double Rt[12];
+    if (k >= 0) {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Rt[a] = sRt[12 * k + a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Rt[a] = Rt_fix[12 * (size_t)(-1 - k) + a];
+    }
+    ba_build_obs(cam, Rt, X, o_uv[2 * (size_t)i], o_uv[2 * (size_t)i + 1], cam.o_flag ? cam.o_flag[i] : 0, oth.oP + 6 * (size_t)i, V, g, chi);
+  };
+  for (int i = s + lane32; i < e; i += 32) {
+    one(i, Va, ga, chia);
+    if (LANES == 16 && i + 16 < e) one(i + 16, Vb, gb, chib);
+  }
+  double V[6], g[3];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) V[a] = group_sum<LANES>(Va[a], Vb[a]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) g[a] = group_sum<LANES>(ga[a], gb[a]);
+  const double chi = group_sum<LANES>(chia, chib);
+  double Mm[6], I[9], vgo[3];
+  ba_point_matrices(V, g, lam_a, Mm, I, vgo);
+  // the current set's matrices for the lambda a rejection leaves
+  double Vc[6], gc[3], Mr[6], Ir[9], vgr[3];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) Vc[a] = cur.Vraw[6 * (size_t)j + a];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) gc[a] = gl[3 * (size_t)j + a];
+  ba_point_matrices(Vc, gc, lam_r, Mr, Ir, vgr);
+  if (lane32 != 0) continue;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) { oth.Mz[6 * (size_t)j + a] = Mm[a]; oth.Vraw[6 * (size_t)j + a] = V[a]; rMz[6 * (size_t)j + a] = Mr[a]; }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) { oth.Vinv[9 * (size_t)j + a] = I[a]; rVinv[9 * (size_t)j + a] = Ir[a]; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { oth.gl[3 * (size_t)j + a] = g[a]; oth.vg[3 * (size_t)j + a] = vgo[a]; rvg[3 * (size_t)j + a] = vgr[a]; }
+  oth.pt_chi2[j] = chi;
+  oth.pt_glsq[j] = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) trial[6 * (size_t)d.K + 3 * (size_t)j + a] = X[a];
+  pt_dsq[j] = dsq; pt_psq[j] = psq;
+  }
+}
+
 // out[i] = a[i] - b[i]  /  a[i] += b[i]   (merging point updates across ranks)
 __global__ void ba_diff_kernel(size_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] - b[i];
@@ -2900,7 +3078,9 @@ __global__ __launch_bounds__(BA_DECIDE_THREADS) void ba_decide_kernel(const BaWi
   if (S->done) return;
   double* __restrict__ res = win.res;
   const int M = reduce_here ? win.d.M : -1;
-  const double* __restrict__ pt_chi2 = win.pt_chi2; const double* __restrict__ pt_dsq = win.pt_dsq; const double* __restrict__ pt_psq = win.pt_psq;
+  // (the fused loop: the trial's per-point chi2 is the OTHER set's, written by ba_step_kernel)
+  const double* __restrict__ pt_chi2 = win.dbl ? ba_set(win, S->bsel ^ 1).pt_chi2 : win.pt_chi2;
+  const double* __restrict__ pt_dsq = win.pt_dsq; const double* __restrict__ pt_psq = win.pt_psq;
   const int tid = threadIdx.x;
   if (M >= 0) {
     double x = 0.0, y = 0.0, z = 0.0;
@@ -2936,8 +3116,10 @@ __global__ __launch_bounds__(BA_DECIDE_THREADS) void ba_decide_kernel(const BaWi
     S->sel ^= 1;
     S->final_sq = res[5];
     S->lambda = fmax(S->lambda * 0.1, 1e-10);
+    if (win.dbl) { S->bsel ^= 1; S->psel = 0; }                                   // the build results of the trial parameters are current now
   } else {
     S->lambda = fmin(S->lambda * 10.0, 1e10);
+    if (win.dbl) S->psel = 1;                                                     // same set, the point matrices of the larger lambda (BaWin::rej)
   }
   // should_stop at the top of the next iteration (:1013)
   if ((abort_flag && *abort_flag) || (stop_vote && res[8] > 0.0)) S->done = 1;
@@ -3260,7 +3442,7 @@ struct WinPlan {
   // scratch arena, output blob
   size_t i_state, i_params, i_rtfix, i_obs;
   size_t c_fill, c_kfstart;
-  size_t a_p1, a_oP, a_rtcur, a_slot, a_next, a_kfobs, a_kfpt, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res;
+  size_t a_p1, a_oP, a_rtcur, a_slot, a_next, a_kfobs, a_kfpt, a_vinv, a_gl, a_vg, a_pt, a_kfpart, a_part, a_rb, a_solve, a_res, a_vraw, a_rej;
   size_t a_ptstart, a_okf, a_ouv, a_oflag, a_tmp, a_mz;
   size_t o_out;
   int n_kfobs = 0;
@@ -3343,6 +3525,15 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // ---- plan: dimensions and the layout of the buffers
   std::vector<WinPlan> plan(W);
   Carve cin, car, cout, ccnt;
+  // the fused loop (ba_step_kernel: back-substitution + the next iteration's build pass in one launch): the visual solve on one GPU.
+  // ORBX_BA_FUSED=0 keeps the six-launch iteration (A/B runs); the partitioned solve (its trial chi2 is a collective) and the inertial
+  // one (15-d steps scattered into the pose steps, IMU terms in the decision) keep it always.
+  static const bool fused_off = [] { const char* e = getenv("ORBX_BA_FUSED"); return e && e[0] == '0'; }();
+  // In a batch of 8 windows or more (16 lanes per point, several points per lane group) the two separate kernels stay: the fused pass
+  // measured 79.1 us per 32-window launch against 28.3 + 37.6 (it has no room for the build kernel's software pipeline over a group's points:
+  // 168 VGPRs, 10 spilled); for one window it is 10.4 us against 6.1 + 7.7 and a launch less.  Same bits either way (tests).
+  const bool fused = !fused_off && !dist && !inertial && W < 8;
+  const size_t dbl = fused ? 2 : 1;
   const size_t i_wins = cin.take(sizeof(BaWin) * (size_t)W);
   const size_t i_wins15 = cin.take(sizeof(BaWin));                      // inertial: the same window seen by the 15-d solve
   const size_t i_outoff = cin.take(sizeof(size_t) * (size_t)W);
@@ -3393,10 +3584,12 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     pl.a_ptstart = car.take(4 * (m1 + 1)); pl.a_okf = car.take(4 * n1); pl.a_ouv = car.take(16 * n1);
     pl.a_oflag = inertial ? car.take(4 * n1) : 0; pl.a_tmp = car.take(4 * n1);
     pl.a_p1 = car.take(8 * std::max<size_t>(pl.np, 1));
-    pl.a_oP = car.take(48 * n1); pl.a_rtcur = car.take(96 * k1);
+    pl.a_oP = car.take(48 * n1 * dbl); pl.a_rtcur = car.take(96 * k1 * dbl);
     pl.a_slot = car.take(4 * m1 * k1); pl.a_next = car.take(4 * n1); pl.a_kfobs = car.take(4 * n1); pl.a_kfpt = car.take(4 * n1);
-    pl.a_mz = car.take(48 * m1);
-    pl.a_vinv = car.take(72 * m1); pl.a_gl = car.take(24 * m1); pl.a_vg = car.take(24 * m1); pl.a_pt = car.take(8 * 4 * m1);
+    pl.a_mz = car.take(48 * m1 * dbl);
+    pl.a_vinv = car.take(72 * m1 * dbl); pl.a_gl = car.take(24 * m1 * dbl); pl.a_vg = car.take(24 * m1 * dbl);
+    pl.a_pt = car.take(8 * (2 * dbl + 2) * m1);                            // pt_chi2 [dbl][m1] | pt_glsq [dbl][m1] | pt_dsq [m1] | pt_psq [m1]
+    pl.a_vraw = fused ? car.take(48 * m1 * dbl) : 0; pl.a_rej = fused ? car.take(8 * 18 * m1) : 0;
     pl.a_kfpart = car.take(8 * 33 * BA_KFSPLIT * k1);
     pl.a_part = car.take(8 * pl.n_upper * d.ksplit * 256);
     pl.a_rb = car.take(8 * (pl.rb_len + 8));
@@ -3538,7 +3731,9 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     b.Mz = (double*)(dar + pl.a_mz);
     b.Vinv = (double*)(dar + pl.a_vinv); b.gl = (double*)(dar + pl.a_gl); b.vg = (double*)(dar + pl.a_vg);
     const size_t m1 = (size_t)std::max(pl.d.M, 1);
-    b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + m1; b.pt_dsq = b.pt_glsq + m1; b.pt_psq = b.pt_dsq + m1;
+    b.pt_chi2 = (double*)(dar + pl.a_pt); b.pt_glsq = b.pt_chi2 + dbl * m1; b.pt_dsq = b.pt_glsq + dbl * m1; b.pt_psq = b.pt_dsq + m1;
+    b.dbl = fused ? 1 : 0; b.pad2_ = 0;
+    b.Vraw = fused ? (double*)(dar + pl.a_vraw) : nullptr; b.rej = fused ? (double*)(dar + pl.a_rej) : nullptr;
     b.oP = (double*)(dar + pl.a_oP); b.Rt_cur = (double*)(dar + pl.a_rtcur);
     b.slot_first = (int*)(dar + pl.a_slot); b.obs_next = (int*)(dar + pl.a_next);
     b.kfpart = (double*)(dar + pl.a_kfpart); b.part = (double*)(dar + pl.a_part); b.rb = (double*)(dar + pl.a_rb);
@@ -3716,7 +3911,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   for (int iter = 0; iter < cfg->max_iterations && !(dist && iter == 0 && my_stop); ++iter) {           // :1012
     if (!dist && should_stop && should_stop(user)) { stopped = true; break; }                           // :1013
     any_iteration = true;
-    {
+    const bool fused_loop = fused && maxM > 0;                               // (iterations 1, 2, ...: the step kernel of the iteration before has built them)
+    if (!fused_loop || iter == 0) {
       ProfScope ps(h, "ba_build_kernel");
       if (maxM > 0) {
         const dim3 g((pt_groups * ptl + 255) / 256, W);
@@ -3744,7 +3940,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       // (with the shares already summed by the Schur launch a lane reads ONE pair per element: a block per 32 element pairs was 7 200 blocks of a
       // few hundred cycles each for 32 windows; ORBX_BA_GATHER_DIV elements per thread: 1 / 2 / 4 / 8 / 16 measured 14.7 / 13.4 / 12.8 / 15.1 / 18.5 us)
       static const int gather_div = [] { const char* e = getenv("ORBX_BA_GATHER_DIV"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
-      hipLaunchKernelGGL(ba_gather_kernel, dim3(schur_sums ? std::max(1, max_gather / gather_div) : max_gather, W), dim3(256), 0, st, d_wins);
+      hipLaunchKernelGGL(ba_gather_kernel, dim3(schur_sums ? std::max(1, max_gather / gather_div) : max_gather, W), dim3(256), 0, st, d_wins, fused_loop && iter > 0 ? iter : -1);
     }
     if (int rc = allreduce(w0.rb, plan[0].rb_len)) return rc;
     if (inertial) {
@@ -3776,7 +3972,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
         if (n_big_max > 0) hipLaunchKernelGGL(ba_big_back_kernel, gW1, dim3(256), 0, st, d_wins, one_launch_max_n);
       }
     }
-    {
+    if (fused_loop) {
+      ProfScope ps(h, "ba_step_kernel");
+      if (ptl == 16) hipLaunchKernelGGL(ba_step_kernel<16>, dim3(max_back, W), dim3(256), 0, st, d_wins, bc);
+      else hipLaunchKernelGGL(ba_step_kernel<32>, dim3(max_back, W), dim3(256), 0, st, d_wins, bc);
+    } else {
       ProfScope ps(h, "ba_backsub_kernel");
       if (ptl == 16) hipLaunchKernelGGL(ba_backsub_kernel<16>, dim3(max_back, W), dim3(256), 0, st, d_wins, bc, (const double*)nullptr, dist ? 1 : 0);
       else hipLaunchKernelGGL(ba_backsub_kernel<32>, dim3(max_back, W), dim3(256), 0, st, d_wins, bc, (const double*)nullptr, dist ? 1 : 0);
