@@ -1088,15 +1088,26 @@ __device__ __forceinline__ void ba_schur_ws_consume(const BaWin& win, const doub
       } else {
         // this workgroup owns one of the gather's shares: it adds the share's partials itself, in the order the gather would (running
         // sum + next partial, starting from the first), and leaves the ONE sum in the first k-split's slot — 1/spb of the bytes
+        // (the three cases around the whole set of nine, not inside it: as a test per accumulator this was eighteen scalar branches
+        // per k-split, 2.1 k cycles of a consumer's 20 k per k-split)
         const bool first = T + 1 == tps, last = T + 1 == nT;
+        if (first) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-          double4_t& a = c < 8 ? acc[c] : accx;
-          double4_t& r = run[c];
-          if (first) r = a;
-          else { r[0] = r[0] + a[0]; r[1] = r[1] + a[1]; r[2] = r[2] + a[2]; r[3] = r[3] + a[3]; }
-          a = double4_t{0.0, 0.0, 0.0, 0.0};
-          if (last) store(ks0, tofs[c], r);
+          for (int c = 0; c < 9; ++c) run[c] = c < 8 ? acc[c] : accx;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) {
+            const double4_t& a = c < 8 ? acc[c] : accx;
+            double4_t& r = run[c];
+            r[0] = r[0] + a[0]; r[1] = r[1] + a[1]; r[2] = r[2] + a[2]; r[3] = r[3] + a[3];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+        accx = double4_t{0.0, 0.0, 0.0, 0.0};
+        if (last) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) store(ks0, tofs[c], run[c]);
         }
       }
       SCHUR_STAMP(5);
