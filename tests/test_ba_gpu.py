@@ -457,6 +457,46 @@ def test_ba_batch_through_the_c_abi_from_a_compiled_caller(gpu_handle, pkg, tmp_
             assert np.array_equal(g["poses_wc"], w_["poses_wc"]) and np.array_equal(g["points"], w_["points"]), (mode, i)
 
 
+def test_ba_fused_step_equals_the_two_kernels_bit_for_bit(pkg, tmp_path):
+    """Calls of up to seven windows run the back-substitution and the next iteration's build pass as ONE launch (ba_step_kernel: two sets of
+    build results, the rejected step's point matrices beside them); ORBX_BA_FUSED=0 keeps the two kernels.  Same arithmetic, same order:
+    the results of the two forms must be the same bits — windows of every reduced-system path, a point seen twice, a call of three
+    windows, and a window with a poor start whose first steps are rejected (the lambda * 10 branch).  Two child processes: the switch is
+    read once per process."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import orb_slam3_rust_amd as P
+        cam = P.CameraModel(**P.synth.EUROC_CAMERA); cfg = P.LocalBAConfigLM()
+        h = P.Handle(cam, 100)
+        out = {}
+        shapes = [(71, 5, 80), (72, 20, 600), (73, 26, 350), (74, 33, 400), (75, 56, 500)]
+        wins = [P.synth.ba_window(s, K, M, P.BA_OBS) for s, K, M in shapes]
+        bad = P.synth.ba_window(76, 12, 300, P.BA_OBS)
+        bad["points"] = bad["points"] + 0.6 * np.random.default_rng(5).standard_normal(bad["points"].shape)     # far off: rejected steps
+        wins.append(bad)
+        for i, w in enumerate(wins):
+            r = h.ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+            out["p%%d" %% i] = np.asarray(r["poses_wc"]); out["x%%d" %% i] = np.asarray(r["points"])
+            out["e%%d" %% i] = np.array([r["iterations"], r["initial_error"], r["final_error"]])
+        for i, r in enumerate(h.ba_solve_visual_batch(cam, cfg, wins[:3])):
+            out["bp%%d" %% i] = np.asarray(r["poses_wc"]); out["bx%%d" %% i] = np.asarray(r["points"])
+        np.savez(sys.argv[1], **out)
+    """ % root)
+    res = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / ("fused%s.npz" % mode))
+        env = dict(os.environ, ORBX_BA_FUSED=mode)
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=env, timeout=300)
+        res[mode] = np.load(path)
+    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 24
+    for k in res["1"].files:
+        assert np.array_equal(res["1"][k], res["0"][k]), k
+    assert res["1"]["e5"][0] >= 2                                             # (the poor start did iterate)
+
+
 def test_ba_large_batch_share_sums_mixed_sizes(gpu_handle, pkg):
     """A batch large enough that every Schur workgroup owns one share of its window's k-splits and writes the share's sum instead of
     the partials (BaWin::part_sums; 32 windows x 8 shares = one workgroup per CU): windows of very different sizes in one call — 1 to 63
