@@ -3540,9 +3540,12 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // ORBX_BA_FUSED=0 keeps the six-launch iteration (A/B runs); the partitioned solve (its trial chi2 is a collective) and the inertial
   // one (15-d steps scattered into the pose steps, IMU terms in the decision) keep it always.
   static const bool fused_off = [] { const char* e = getenv("ORBX_BA_FUSED"); return e && e[0] == '0'; }();
-  // In a batch of 8 windows or more (16 lanes per point, several points per lane group) the two separate kernels stay: the fused pass
-  // measured 79.1 us per 32-window launch against 28.3 + 37.6 (it has no room for the build kernel's software pipeline over a group's points:
-  // 168 VGPRs, 10 spilled); for one window it is 10.4 us against 6.1 + 7.7 and a launch less.  Same bits either way (tests).
+  // In a batch of 8 windows or more (16 lanes per point, several points per lane group) the two separate kernels stay.  Two fused forms
+  // were measured there, both the same bits: point by point (no room for the build kernel's software pipeline over a group's points at
+  // the 168 VGPRs three blocks per CU allow: 10 spilled) 79.1 us per 32-window launch against 28.3 + 37.6; and as two sweeps over a
+  // group's points inside one launch (back-substitution of all of them, trial positions parked in LDS, then the build kernel's own
+  // pipelined loop; 161 VGPRs, no spills) 67.0 against 28.8 + 37.8 — the trial-chi2 pass it drops is what the second set's footprint
+  // and the rejected step's matrices cost.  For one window the fused pass is 10.4 us against 6.1 + 7.7 and a launch less.
   const bool fused = !fused_off && !dist && !inertial && W < 8;
   const size_t dbl = fused ? 2 : 1;
   const size_t i_wins = cin.take(sizeof(BaWin) * (size_t)W);

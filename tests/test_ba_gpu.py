@@ -460,8 +460,8 @@ def test_ba_batch_through_the_c_abi_from_a_compiled_caller(gpu_handle, pkg, tmp_
 def test_ba_fused_step_equals_the_two_kernels_bit_for_bit(pkg, tmp_path):
     """Calls of up to seven windows run the back-substitution and the next iteration's build pass as ONE launch (ba_step_kernel: two sets of
     build results, the rejected step's point matrices beside them); ORBX_BA_FUSED=0 keeps the two kernels.  Same arithmetic, same order:
-    the results of the two forms must be the same bits — windows of every reduced-system path, a point seen twice, a call of three
-    windows, and a window with a poor start whose first steps are rejected (the lambda * 10 branch).  Two child processes: the switch is
+    the results of the two forms must be the same bits — windows of every reduced-system path, a call of three windows, one of nine
+    (which keeps the two kernels either way), and a window with a poor start whose first steps are rejected (the lambda * 10 branch).  Two child processes: the switch is
     read once per process."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -483,6 +483,8 @@ def test_ba_fused_step_equals_the_two_kernels_bit_for_bit(pkg, tmp_path):
             out["e%%d" %% i] = np.array([r["iterations"], r["initial_error"], r["final_error"]])
         for i, r in enumerate(h.ba_solve_visual_batch(cam, cfg, wins[:3])):
             out["bp%%d" %% i] = np.asarray(r["poses_wc"]); out["bx%%d" %% i] = np.asarray(r["points"])
+        for i, r in enumerate(h.ba_solve_visual_batch(cam, cfg, wins + wins[:3])):      # nine windows: 16 lanes per point
+            out["cp%%d" %% i] = np.asarray(r["poses_wc"]); out["cx%%d" %% i] = np.asarray(r["points"])
         np.savez(sys.argv[1], **out)
     """ % root)
     res = {}
@@ -491,7 +493,7 @@ def test_ba_fused_step_equals_the_two_kernels_bit_for_bit(pkg, tmp_path):
         env = dict(os.environ, ORBX_BA_FUSED=mode)
         subprocess.run([sys.executable, "-c", script, path], check=True, env=env, timeout=300)
         res[mode] = np.load(path)
-    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 24
+    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 42
     for k in res["1"].files:
         assert np.array_equal(res["1"][k], res["0"][k]), k
     assert res["1"]["e5"][0] >= 2                                             # (the poor start did iterate)
