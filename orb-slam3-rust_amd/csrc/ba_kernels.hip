@@ -3537,8 +3537,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   std::vector<WinPlan> plan(W);
   Carve cin, car, cout, ccnt;
   // the fused loop (ba_step_kernel: back-substitution + the next iteration's build pass in one launch): the visual solve on one GPU.
-  // ORBX_BA_FUSED=0 keeps the six-launch iteration (A/B runs); the partitioned solve (its trial chi2 is a collective) and the inertial
-  // one (15-d steps scattered into the pose steps, IMU terms in the decision) keep it always.
+  // ORBX_BA_FUSED=0 keeps the six-launch iteration (A/B runs); the partitioned solve (its trial chi2 is a collective) keeps it always.
+  // (The inertial solve scatters its 15-d steps into the pose steps before this pass and adds its IMU terms in the decision: both outside it.)
   static const bool fused_off = [] { const char* e = getenv("ORBX_BA_FUSED"); return e && e[0] == '0'; }();
   // In a batch of 8 windows or more (16 lanes per point, several points per lane group) the two separate kernels stay.  Two fused forms
   // were measured there, both the same bits: point by point (no room for the build kernel's software pipeline over a group's points at
@@ -3546,7 +3546,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // group's points inside one launch (back-substitution of all of them, trial positions parked in LDS, then the build kernel's own
   // pipelined loop; 161 VGPRs, no spills) 67.0 against 28.8 + 37.8 — the trial-chi2 pass it drops is what the second set's footprint
   // and the rejected step's matrices cost.  For one window the fused pass is 10.4 us against 6.1 + 7.7 and a launch less.
-  const bool fused = !fused_off && !dist && !inertial && W < 8;
+  const bool fused = !fused_off && !dist && W < 8;
   const size_t dbl = fused ? 2 : 1;
   const size_t i_wins = cin.take(sizeof(BaWin) * (size_t)W);
   const size_t i_wins15 = cin.take(sizeof(BaWin));                      // inertial: the same window seen by the 15-d solve
