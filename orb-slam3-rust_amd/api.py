@@ -77,7 +77,7 @@ ABI_SYMBOLS = [
     "orbx_bow_transform", "orbx_bow_transform_device", "orbx_bow_vectors", "orbx_bow_vectors_device", "orbx_bow_score",
     "orbx_png_decode_gray8", "orbx_euroc_open", "orbx_euroc_close", "orbx_euroc_len", "orbx_euroc_last_error",
     "orbx_euroc_frame_timestamp", "orbx_euroc_calibration", "orbx_euroc_read_pairs",
-    "orbx_set_profiling", "orbx_get_kernel_times", "orbx_debug_read_level",
+    "orbx_set_profiling", "orbx_set_profiling_only", "orbx_get_kernel_times", "orbx_debug_read_level",
     "orbx_debug_read_candidates",
 ]
 
@@ -349,8 +349,12 @@ class Handle:
         self._keep = []
         self._check(rc)
 
-    def set_profiling(self, on=True):
-        self._check(self._L.orbx_set_profiling(self._h, C.c_int(1 if on else 0)))
+    def set_profiling(self, on=True, only=None):
+        """HIP events around every launch (on), or around the launches of the one kernel `only` names."""
+        if on and only:
+            self._check(self._L.orbx_set_profiling_only(self._h, C.c_char_p(only.encode())))
+        else:
+            self._check(self._L.orbx_set_profiling(self._h, C.c_int(1 if on else 0)))
 
     def kernel_times(self):
         arr = (_KernelTime * 64)()

@@ -57,6 +57,7 @@ static hipEvent_t prof_event(orbx_handle* h) {
 ProfScope::ProfScope(orbx_handle* h_, const char* name, hipStream_t stream_, bool chained)
     : h(h_), idx(-1), stream(stream_ ? stream_ : h_->stream) {
   if (!h->profiling) return;
+  if (!h->prof_only.empty() && h->prof_only != name) { h->prof_tail = nullptr; return; }   // (launches follow that no scope brackets: the next bracketed one records its own start)
   for (size_t i = 0; i < h->timers.size(); ++i)
     if (h->timers[i].name == name) { idx = (int)i; break; }
   if (idx < 0) {
@@ -203,9 +204,18 @@ int orbx_check_status(orbx_handle* h) {
 int orbx_set_profiling(orbx_handle* h, int on) {
   if (!h) return ORBX_ERR_INVALID;
   h->profiling = on != 0;
+  h->prof_only.clear();
   h->event_next = 0;
   h->prof_tail = nullptr;
   for (auto& t : h->timers) t.ev.clear();
+  return ORBX_OK;
+}
+
+int orbx_set_profiling_only(orbx_handle* h, const char* kernel_name) {
+  if (!h) return ORBX_ERR_INVALID;
+  const int rc = orbx_set_profiling(h, 1);
+  if (rc != ORBX_OK) return rc;
+  try { h->prof_only = kernel_name ? kernel_name : ""; } catch (...) { return orbx_fail(h, ORBX_ERR_HIP, "orbx_set_profiling_only: out of host memory"); }
   return ORBX_OK;
 }
 

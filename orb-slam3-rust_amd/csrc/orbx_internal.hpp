@@ -224,6 +224,7 @@ struct orbx_handle {
   hipEvent_t ba_gate_event = nullptr;
   // profiling
   bool profiling = false;
+  std::string prof_only;   // non-empty: only this kernel's launches are bracketed (orbx_set_profiling_only)
   std::vector<KernelTimer> timers;
   std::vector<hipEvent_t> event_pool;
   size_t event_next = 0;

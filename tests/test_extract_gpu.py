@@ -300,3 +300,21 @@ def test_graph_replay_survives_geometry_change(oracle, pkg):
     for r in big0[1:]:
         assert all(a.tobytes() == b.tobytes() for a, b in zip(big0[0], r))
     h.close()
+
+
+def test_profiling_of_one_kernel_only(h2000, frame0):
+    """orbx_set_profiling_only: HIP events around the launches of one kernel — the per-kernel table then holds that kernel alone, with
+    as many launches as the calls made; orbx_set_profiling(on) brackets every launch again; results do not depend on either."""
+    L, R, a = frame0
+    h2000.set_profiling(True, only="fast_kernel")
+    b = [h2000.process_stereo(L, R) for _ in range(3)]
+    kt = h2000.kernel_times()
+    assert list(kt) == ["fast_kernel"] and kt["fast_kernel"][1] == 3 and kt["fast_kernel"][0] > 0.0
+    only_ms = kt["fast_kernel"][0] / 3
+    h2000.set_profiling(True)
+    h2000.process_stereo(L, R)
+    kt = h2000.kernel_times()
+    assert "fast_kernel" in kt and "describe_fused_kernel" in kt and len(kt) >= 5
+    assert only_ms < 3.0 * kt["fast_kernel"][0] + 0.02                            # the kernel's own duration, not the span between two of its launches
+    h2000.set_profiling(False)
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b[-1]))
