@@ -245,9 +245,12 @@ def main():
     # K steps with no events at all).
     n_pre = max(3, min(args.steps, 10))
     h.set_profiling(True)
+    h.synchronize()
+    t_pre = time.perf_counter()
     for i in range(n_pre):
         h.process_stereo_batch_device(batches[i % len(batches)], out)
     h.synchronize()
+    elapsed_pre = time.perf_counter() - t_pre            # rounds 1-3 measured `value` this way (events around every launch)
     acc_pre = {k: [v[0], v[1]] for k, v in h.kernel_times().items()}
     h.set_profiling(False)
     dom_pre = max(acc_pre.items(), key=lambda kv: kv[1][0])[0]
@@ -286,19 +289,30 @@ def main():
     sc = [float(np.float32(np.float64(np.float32(1.2)) ** l)) for l in range(8)]       # level sizes as orb.cpp
     lv = [(int(np.rint(np.float32(W) / np.float32(s))), int(np.rint(np.float32(H) / np.float32(s)))) for s in sc]
     px = [a * b for a, b in lv]
+    # pixels of a level that a keypoint's 43-row x 48-byte window can reach (keypoints sit in [31, w-31) x [31, h-31): columns 8 .. w-7,
+    # rows 10 .. h-11): what describe_fused_kernel must fetch from HBM ONCE per image — neighbouring keypoints' windows overlap 3.3-fold,
+    # and all but the first read of a line come out of L2 (the XCD-aware block map keeps an image on one XCD)
+    px_win = [max(0, a - 14) * max(0, b - 20) for a, b in lv]
+    # HBM bytes each kernel must move per launch (compulsory: every input byte once, every output byte once), x images per launch
     per_launch = {
         "fast_kernel": n_img * (sum(px) + 4 * 2 * args.features),          # read every level once, write candidates
         "blur_kernel": n_img * 2 * sum(px),                                # read + write every level
         "resize_kernel": n_img * (sum(px[:-1]) + sum(px[1:])) / 7.0,       # 7 launches: read l-1, write l
-        "describe_fused_kernel": n_img * args.features * (43 * 43 + 28 + 32),  # one 43 x 43 window of the level per keypoint (centroid disc + the 37 x 37 patch's blur support), the keypoint record, the descriptor
-        "describe_kernel": n_img * args.features * (31 * 31 + 37 * 37 + 28 + 32),      # (ORBX_DESC_UNFUSED=1: the two-kernel form)
+        "describe_fused_kernel": n_img * (sum(px_win) + args.features * (28 + 32)),    # the reachable part of every level once, the keypoint records and descriptors out
+        "describe_kernel": n_img * (2 * sum(px_win) + args.features * (28 + 32)),      # (ORBX_DESC_UNFUSED=1: the level and the blurred level)
         "harris_select_kernel": n_img * 2 * args.features * (81 + 4 + 8),
         "rank_select_kernel": n_img * 2 * args.features * 16,
         "stereo_bucket_kernel": args.batch * args.features * (8 + 12),
         "stereo_match_kernel": args.batch * (2 * args.features * (32 + 8) + args.features * 8),
         "stereo_compact_kernel": args.batch * args.features * (8 + 16 + 25),
     }
-    ach = per_launch.get(dom_name, 0) / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # what the kernel REQUESTS from the memory hierarchy (L2 and below), overlap counted every time — not an HBM figure, never `achieved`
+    l2_requests = {
+        "describe_fused_kernel": n_img * args.features * (43 * 43 + 28 + 32),
+        "describe_kernel": n_img * args.features * (31 * 31 + 37 * 37 + 28 + 32),
+    }
+    launch_s = dom_ms / max(dom_launches, 1) * 1e-3
+    ach = per_launch.get(dom_name, 0) / launch_s / 1e9 if dom_ms > 0 else 0.0
     # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run
     # separately: scripts/pmc_summary.py -> profiles/*_pmc_traffic.json); counters cannot be read live here
     traffic = None
@@ -319,13 +333,13 @@ def main():
             # frac = rate x (share_2cycle / peak_2cycle + (1 - share_2cycle) / peak_4cycle), the share from scripts/valu_class_mix.py
             # (disassembly of the shipped code object, loop trip counts stated in profiles/valu_loop_weights.json).
             if kd.get("valu_wave_instr_per_launch") and dom_ms > 0:
-                rate = kd["valu_wave_instr_per_launch"] / (dom_ms / max(dom_launches, 1) * 1e-3) / 1e9
+                rate = kd["valu_wave_instr_per_launch"] / launch_s / 1e9
                 share2, share2_bounds, model_vs_pmc = two_cycle_share(dom_name)
                 sh = share2 if share2 is not None else 0.0
                 ms_ = mfma_share(dom_name)                       # MFMAs among the counted vector instructions: 8 cycles of the issue port each
                 slots = (1.0 - ms_) * (sh / VALU_PEAK_2CYC + (1.0 - sh) / VALU_PEAK_4CYC) + ms_ * 2.0 / VALU_PEAK_4CYC
                 valu = dict(wave_instr_per_launch=kd["valu_wave_instr_per_launch"], achieved=round(rate, 1), peak=VALU_PEAK_4CYC,
-                            peak_simple_ops=VALU_PEAK_2CYC, unit="G wave-instr/s", two_cycle_share=share2, two_cycle_share_bounds=share2_bounds,
+                            peak_simple_ops=VALU_PEAK_2CYC, peak_for_this_mix=round(1.0 / slots, 1), unit="G wave-instr/s", two_cycle_share=share2, two_cycle_share_bounds=share2_bounds,
                             class_mix_model_vs_pmc=model_vs_pmc,
                             mfma_share=round(ms_, 4),
                             frac=round(rate * slots, 4),
@@ -344,14 +358,28 @@ def main():
             per_step_bytes = per_launch[kname] * (7 if kname == "resize_kernel" else 1)
             gbs = per_step_bytes / (acc[kname][0] / args.steps * 1e-3) / 1e9
             streaming[kname.replace("_kernel", "")] = dict(GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
-    roofline = dict(bound="hbm", kernel=dom_name, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, valu_issue=valu, streaming=streaming,
-                    binding_limit=("valu_issue" if valu and valu["frac"] > ach / HBM_PEAK_GBS else "hbm"),
+    # The block names the limit that BINDS the dominant kernel.  hbm: compulsory bytes / launch time / 8 TB/s (cross-checked by the counter
+    # bytes of the PMC pass, `traffic`).  When the kernel's VALU issue fraction (above) exceeds its HBM fraction the kernel is issue-bound and
+    # achieved / peak / frac are the issue figures — wave-instructions per second against the rate this chip issues THIS kernel's opcode mix
+    # at — with the HBM side kept beside them as `hbm` / `hbm_frac`.
+    hbm_frac = ach / HBM_PEAK_GBS
+    hbm = dict(achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 5), compulsory_bytes_per_launch=int(per_launch.get(dom_name, 0)),
+               counter_bytes_per_launch=traffic,
+               frac_from_counter_bytes=round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 5) if traffic and dom_ms > 0 else None,
+               l2_request_bytes_per_launch=(int(l2_requests[dom_name]) if dom_name in l2_requests else None))
+    issue_bound = bool(valu and valu["frac"] > hbm_frac)
+    if issue_bound:
+        head = dict(bound="valu_issue", achieved=valu["achieved"], peak=valu["peak_for_this_mix"], unit="G wave-instr/s", frac=valu["frac"])
+    else:
+        head = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 5))
+    roofline = dict(head, kernel=dom_name, traffic=traffic, hbm_frac=round(hbm_frac, 5), hbm=hbm, valu_issue=valu, streaming=streaming,
+                    binding_limit=head["bound"],
                     algorithmic_bytes_per_launch=int(per_launch.get(dom_name, 0)),
-                    avg_launch_us=round(dom_ms / max(dom_launches, 1) * 1e3, 2),
+                    avg_launch_us=round(launch_s * 1e6, 2),
                     kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in sorted(acc.items())},
                     kernel_ms_per_step_source="%s: HIP events over the timed region; the other kernels: an untimed pass of %d steps with events around every launch" % (dom_pre, n_pre),
-                    path_algorithmic_GBps=round(algo_bytes_per_frame(W, H, args.features) * args.batch * world * args.steps / elapsed / 1e9, 3))
+                    path_algorithmic_GBps=round(algo_bytes_per_frame(W, H, args.features) * args.batch * world * args.steps / elapsed / 1e9, 3),
+                    path_hbm_frac=round(algo_bytes_per_frame(W, H, args.features) * args.batch * world * args.steps / elapsed / 1e9 / HBM_PEAK_GBS / world, 5))
 
     frames = args.batch * args.steps * world
     value = frames / elapsed
@@ -364,7 +392,10 @@ def main():
                            distinct_batches=args.n_batches, unique_pairs=(min(32, args.batch * args.n_batches) if args.small_gen else args.batch * args.n_batches),
                            parallelism="frames sharded, %d rank(s), no collective%s" % (world, " (REHEARSAL: ranks share GPUs, gloo)" if rehearse else ""),
                            mean_keypoints_per_image=round(n_kp, 1), mean_matches_per_frame=round(n_matches, 1)),
-               roofline=roofline, value_unprofiled=round(args.batch * args.steps * world / elapsed_np, 2))
+               roofline=roofline, value_unprofiled=round(args.batch * args.steps * world / elapsed_np, 2),
+               value_all_kernel_events=dict(value=round(args.batch * n_pre / elapsed_pre, 2), steps=n_pre,
+                                            note="rank 0's untimed pass with HIP events around EVERY launch: how `value` was measured until round 3 "
+                                                 "(since round 4 the timed region brackets the dominant kernel only)"))
 
     if rank == 0 and world == 1 and not args.no_extras:
         try:
@@ -699,13 +730,16 @@ def bench_ba_c_abi(P, wins, reps=8):
     import tempfile
     libdir = os.path.join(ROOT, "orb-slam3-rust_amd")
     out = {}
+    # the children must not inherit a profiler's preload (bench.py itself may run under rocprofv3: its tool library initialises the GPU in
+    # every process it is loaded into, and the compiled driver is a separate GPU process that the profile is not about)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX"))}
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "ba_batch_driver")
         subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "ba_batch_driver.cpp"),
-                        "-o", exe, "-L", libdir, "-lorbx_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True)
+                        "-o", exe, "-L", libdir, "-lorbx_hip", "-Wl,-rpath," + libdir], check=True, capture_output=True, env=env)
         P.synth.write_ba_batch_file(os.path.join(tmp, "batch.bin"), wins, P.BA_OBS)
         for mode in ("pinned32", "pinned", "pageable"):
-            r = subprocess.run([exe, os.path.join(tmp, "batch.bin"), os.path.join(tmp, "out.bin"), str(reps), mode], check=True, capture_output=True, text=True, timeout=300)
+            r = subprocess.run([exe, os.path.join(tmp, "batch.bin"), os.path.join(tmp, "out.bin"), str(reps), mode], check=True, capture_output=True, text=True, timeout=300, env=env)
             line = json.loads(r.stdout.strip().splitlines()[-1])
             its = sum(x["iterations"] for x in P.synth.read_ba_batch_results(os.path.join(tmp, "out.bin"), wins))
             out[mode] = dict(ms_per_call_median=line["ms_per_call_median"], ms_per_call_min=line["ms_per_call_min"],

@@ -42,8 +42,6 @@
 extern "C" {
 #endif
 
-#define ORBX_ABI_VERSION 1
-
 enum {
   ORBX_OK = 0,
   ORBX_ERR_INVALID = -1,   /* bad argument (null pointer, size out of range)        */
@@ -87,6 +85,12 @@ typedef struct {
 typedef struct orbx_handle orbx_handle;
 
 const char* orbx_version(void);
+/* Layout version of this header's structs and entry points: bumped whenever a struct grows or a signature changes (2: orbx_ba_window
+ * gained `obs32`, so its array stride changed).  orbx_abi_version() is what the loaded library was built with; a caller compiled against
+ * another ORBX_ABI_VERSION must not call it (the C++ and Python mirrors check at handle creation / load time, and the Rust shim of
+ * INTEGRATION.md does the same in StereoProcessor::new). */
+#define ORBX_ABI_VERSION 2
+int orbx_abi_version(void);
 const char* orbx_last_error(const orbx_handle* h);
 
 /* Fills *p with the reference's ORB configuration (stereo.rs:38-48) for n_features. */

@@ -65,6 +65,8 @@ struct StereoFrame {   // stereo.rs:21-29
 class Handle {
  public:
   Handle(const CameraModel& cam, int n_features, int device = 0, int max_w = 1920, int max_h = 1080, int max_batch = 1) {
+    if (orbx_abi_version() != ORBX_ABI_VERSION)       // the library on the loader's path was built from another orbx.h: struct strides differ
+      throw Error(ORBX_ERR_INVALID, "liborbx_hip.so has ABI version " + std::to_string(orbx_abi_version()) + ", this caller was compiled against " + std::to_string(ORBX_ABI_VERSION));
     orbx_orb_params p;
     orbx_default_orb_params(n_features, &p);
     const orbx_camera c = cam.c();

@@ -60,8 +60,9 @@ ORBX_ERR_CAPACITY, ORBX_ERR_NUMERIC, ORBX_ERR_EMPTY = -4, -5, -6
 TH_HIGH, TH_LOW, NN_RATIO = 100, 50, 0.75
 
 # every symbol include/orbx.h declares
+ABI_VERSION = 2      # = ORBX_ABI_VERSION of include/orbx.h, whose struct layouts the ctypes mirrors below restate
 ABI_SYMBOLS = [
-    "orbx_version", "orbx_last_error", "orbx_default_orb_params", "orbx_create", "orbx_destroy",
+    "orbx_version", "orbx_abi_version", "orbx_last_error", "orbx_default_orb_params", "orbx_create", "orbx_destroy",
     "orbx_stream", "orbx_synchronize", "orbx_process_stereo", "orbx_process_stereo_batch_device",
     "orbx_process_stereo_batch", "orbx_host_alloc", "orbx_host_free",
     "orbx_extract_batch_device", "orbx_check_status", "orbx_stereo_match",
@@ -168,6 +169,9 @@ def load_library():
                 pass
         L = C.CDLL(LIB_PATH)
         L.orbx_version.restype = C.c_char_p
+        if L.orbx_abi_version() != ABI_VERSION:
+            raise RuntimeError("liborbx_hip.so was built from an orbx.h of ABI version %d, this mirror restates version %d: rebuild with "
+                               "__graft_entry__.build()" % (L.orbx_abi_version(), ABI_VERSION))
         L.orbx_last_error.restype = C.c_char_p
         L.orbx_last_error.argtypes = [C.c_void_p]
         L.orbx_stream.restype = C.c_void_p

@@ -3640,6 +3640,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   const int K0 = win[0].K, M0 = win[0].M;                               // inertial / partitioned: the one window
   const int n15 = 15 * K0;
   if (inertial && n15 > BA_MAX_N) return orbx_fail(h, ORBX_ERR_INVALID, "at most %d keyframes per inertial window", BA_MAX_N / 15);
+  // (pure host validation comes before the first byte of the caller's memory is handed to the copy engine: ADVICE r4)
+  if (inertial)
+    for (int e = 0; e < inr->E; ++e)
+      if (inr->edge_kf[2 * e] < 0 || inr->edge_kf[2 * e] >= K0 || inr->edge_kf[2 * e + 1] < 0 || inr->edge_kf[2 * e + 1] >= K0)
+        return orbx_fail(h, ORBX_ERR_INVALID, "IMU edge %d: keyframe index out of range", e);
   if (int rc = orbx_reserve(h, h->ws_ba[B_IN], small_bytes + obs_bytes + 256)) return rc;
   if (int rc = orbx_reserve(h, h->ws_ba[B_ARENA], car.off)) return rc;
   if (int rc = orbx_reserve(h, h->ws_ba[B_OUT], cout.off)) return rc;
@@ -3663,15 +3668,19 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   // The second half of a batch (orbx_ba_solve_visual_batch) orders its uploads behind the first half's: both share one PCIe link, and the
   // first half's kernels start when ITS bytes have arrived.  Whatever happens below, the first half opens the gate when it leaves.
   struct GateOpen { std::atomic<int>* g; ~GateOpen() { if (g) g->store(1, std::memory_order_release); } } gate_open{h->ba_gate_signal};
-  bool direct_sent = false;
+  bool direct_sent = false, drained = false;
+  // Once the copy engine has been pointed at the caller's page-locked observations, no return path may leave them in flight: an error
+  // return below (a HIP failure, the pool, the attribute check, the collective) first drains the stream, so the caller may reuse or free
+  // its buffer the moment the call is back, whatever it answered.
+  struct DrainOnLeave { hipStream_t st; const bool* sent; const bool* done; ~DrainOnLeave() { if (*sent && !*done) (void)hipStreamSynchronize(st); } } drain_on_leave{st, &direct_sent, &drained};
   auto send_direct = [&]() -> int {
     if (h->ba_gate_wait) {
       while (h->ba_gate_wait->load(std::memory_order_acquire) == 0) std::this_thread::yield();
       if (h->ba_gate_event) ORBX_HIP(h, hipStreamWaitEvent(st, h->ba_gate_event, 0));
     }
+    direct_sent = true;                                                  // (set first: a failure part-way has already enqueued the earlier runs)
     for (const Run& r : runs)
       if (r.direct) ORBX_HIP(h, hipMemcpyAsync(dobs + r.off, r.src, r.bytes, hipMemcpyHostToDevice, st));
-    direct_sent = true;
     return ORBX_OK;
   };
   mark(1);
@@ -3788,9 +3797,6 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
   BaWin* d_wins15 = (BaWin*)(din + i_wins15);
   double *dp15 = nullptr, *gfull = nullptr;
   if (inertial) {
-    for (int e = 0; e < inr->E; ++e)
-      if (inr->edge_kf[2 * e] < 0 || inr->edge_kf[2 * e] >= K0 || inr->edge_kf[2 * e + 1] < 0 || inr->edge_kf[2 * e + 1] >= K0)
-        return orbx_fail(h, ORBX_ERR_INVALID, "IMU edge %d: keyframe index out of range", e);
     bc.o_flag = hw[0].o_flag;
     int* d_edges = (int*)h->ws_ba[B_IMU].p;
     double* d_pre = (double*)h->ws_ba[B_IMU].p + inr->E;               // 2 ints per edge = 1 double slot per edge
@@ -4034,6 +4040,7 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
       if (should_stop(user)) { *(volatile int*)h->h_abort = 1; break; }
   }
   ORBX_HIP(h, hipStreamSynchronize(st));
+  drained = true;
   ORBX_HIP(h, hipGetLastError());
   mark(5);
 

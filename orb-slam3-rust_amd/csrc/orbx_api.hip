@@ -89,7 +89,10 @@ void orbx_prof_end_call(orbx_handle* h) { (void)h; }
 
 extern "C" {
 
-const char* orbx_version(void) { return "orbx-mi355x 0.1 (gfx950, abi 1)"; }
+#define ORBX_STR2(x) #x
+#define ORBX_STR(x) ORBX_STR2(x)
+const char* orbx_version(void) { return "orbx-mi355x 0.1 (gfx950, abi " ORBX_STR(ORBX_ABI_VERSION) ")"; }
+int orbx_abi_version(void) { return ORBX_ABI_VERSION; }
 
 const char* orbx_last_error(const orbx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -163,6 +166,7 @@ void orbx_destroy(orbx_handle* h) {
   for (int i = 0; i < 2; ++i) { if (h->ev_in[i]) hipEventDestroy(h->ev_in[i]); if (h->ev_comp[i]) hipEventDestroy(h->ev_comp[i]); if (h->ev_out[i]) hipEventDestroy(h->ev_out[i]); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
+  if (h->ba_up_event) hipEventDestroy(h->ba_up_event);
   if (h->s_aux) hipStreamDestroy(h->s_aux);
   if (h->s_in) hipStreamDestroy(h->s_in);
   if (h->s_out) hipStreamDestroy(h->s_out);
@@ -1052,7 +1056,7 @@ int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orb
         gate.store(1, std::memory_order_release);                              // (however the first half ended, the second must not wait for it)
         h->ba_helper->wait();
       } else {                                                              // no thread: the whole batch here, on one stream
-        h->ba_gate_signal = nullptr; h->ba_peer_windows = 0;
+        h->ba_gate_signal = nullptr; h->ba_peer_windows = 0; h->ba_pool_cap = 0;
         rc = ba_solve_batch(h, cam, cfg, n_windows, w.data(), nullptr, nullptr);
       }
       if (rc == ORBX_OK && rc1 != ORBX_OK) rc = orbx_fail(h, rc1, "(windows %d..%d, numbered from %d) %s", n0, n_windows - 1, n0, orbx_last_error(h->ba_aux));
