@@ -626,8 +626,13 @@ def bench_ba_inertial(P, h, cam, K=10, M=2000, seed=42):
 
 
 def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
-    win = P.Handle.pack_ba_windows([P.synth.ba_window(seed, K, M, P.BA_OBS)])[0]      # (observations in page-locked memory, as in bench_ba)
+    # observations at keypoint precision (f32 widened, as the reference's are: local_ba_lm.rs:870-872) in page-locked memory, handed over in the
+    # 16-byte form (orbx_ba_solve_visual_obs32: 3.2 MB up per solve instead of 6.5); the 32-byte form of the same window is timed beside it
+    base = P.synth.keypoint_precision(P.synth.ba_window(seed, K, M, P.BA_OBS))
+    win = P.Handle.pack_ba_windows([base], obs32=True)[0]
+    win64 = P.Handle.pack_ba_windows([base])[0]
     args = (cam, cfg, win["poses_cw"], win["fixed_cw"], win["points"], win["obs"])
+    args64 = (cam, cfg, win64["poses_cw"], win64["fixed_cw"], win64["points"], win64["obs"])
     r = h.ba_solve_visual(*args)
     reps = 5
     t0 = time.perf_counter()
@@ -635,6 +640,12 @@ def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
     for _ in range(reps):
         its += h.ba_solve_visual(*args)["iterations"]
     dt = time.perf_counter() - t0
+    r64 = h.ba_solve_visual(*args64)
+    t0 = time.perf_counter()
+    its64 = 0
+    for _ in range(reps):
+        its64 += h.ba_solve_visual(*args64)["iterations"]
+    dt64 = time.perf_counter() - t0
     h.set_profiling(True)
     h.ba_solve_visual(*args)
     kt = h.kernel_times()
@@ -644,18 +655,22 @@ def bench_ba_config5(P, h, cam, cfg, K=50, M=8000, seed=43):
     flop = schur_executed_flop(k_opt, M)
     fused = kt.get("ba_kf_schur_kernel", (0.0, 1))
     fused_ms = fused[0] / max(fused[1], 1)
-    res = dict(workload="synth_ba(seed=%d, K=%d, M=%d), %d observations, %d optimised keyframes (reduced system n = %d, one-launch Cholesky in global memory)"
-                        % (seed, K, M, len(win["obs"]), k_opt, 6 * k_opt),
+    kernel_ms = sum(v[0] for k, v in kt.items() if k.startswith("ba_"))
+    res = dict(workload="synth_ba(seed=%d, K=%d, M=%d) at keypoint precision, %d observations (16-byte form, %.1f MB up per solve), %d optimised keyframes (reduced system n = %d, one-launch Cholesky in global memory)"
+                        % (seed, K, M, len(win["obs"]), win["obs"].nbytes / 1e6, k_opt, 6 * k_opt),
                lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3), iterations=r["iterations"],
                initial_error_px=round(r["initial_error"], 4), final_error_px=round(r["final_error"], 4),
                kernel_ms_per_iteration={k: round(v[0] / n_it, 4) for k, v in sorted(kt.items()) if k.startswith("ba_")},
+               kernel_ms_per_solve=round(kernel_ms, 3), wall_over_kernels=round(dt / reps * 1e3 / kernel_ms, 3) if kernel_ms > 0 else None,
+               obs_32_bytes=dict(lm_iters_per_s=round(its64 / dt64, 2), ms_per_solve=round(dt64 / reps * 1e3, 3), MB_up_per_solve=round(win64["obs"].nbytes / 1e6, 1),
+                                 same_result_bit_for_bit=bool(np.array_equal(r["poses_wc"], r64["poses_wc"]) and np.array_equal(r["points"], r64["points"]))),
                algorithmic_GFLOP_per_iteration=round(ba_algorithmic_flop(k_opt, M, len(win["obs"])) / 1e9, 3),   # SURVEY §8(d)'s formula at this window's K, M, N
                schur=dict(executed_GFLOP_per_launch=round(flop / 1e9, 3), fused_launch_ms=round(fused_ms, 4),
                           executed_TFLOPs_fused_launch=round(flop / (fused_ms * 1e-3) / 1e12, 2) if fused_ms > 0 else None,
                           mfma_frac_fused_launch=round(flop / (fused_ms * 1e-3) / 78.6e12, 4) if fused_ms > 0 else None,
                           note="one window: the keyframe partials share the Schur launch, so this fraction is a lower bound for the MFMA part"))
     # the Schur product alone: 4 such windows through the batch call, where it is its own launch
-    wins = [win] + [P.synth.ba_window(seed + 1 + i, K, M, P.BA_OBS) for i in range(3)]
+    wins = [win64] + [P.synth.ba_window(seed + 1 + i, K, M, P.BA_OBS) for i in range(3)]
     h.ba_solve_visual_batch(cam, cfg, wins)
     h.set_profiling(True)
     rb = h.ba_solve_visual_batch(cam, cfg, wins)
@@ -748,6 +763,18 @@ def bench_ba_c_abi(P, wins, reps=8):
     return out
 
 
+def ba_transport_text(world, native, comm, rehearse):
+    """What carried the all-reduces of the point-partitioned BA solve, for the bench line (`local_ba.transport`, and appended to
+    `config.parallelism`): with the library's own communicator the rank count is the communicator's own answer (ncclCommCount)."""
+    if world == 1:
+        return "one GPU, no collective"
+    if native and isinstance(comm, tuple):
+        return "native RCCL: communicator of %s ranks (ncclCommCount), this is rank %s" % (comm[0], comm[1])
+    if native:
+        return "native RCCL (ncclCommCount unavailable: %s)" % (comm,)
+    return "all-reduce hook over torch.distributed (%s)" % ("gloo, REHEARSAL" if rehearse else "nccl = RCCL")
+
+
 def bench_ba(P, h, cam, rank=0, world=1, dev=None):
     import torch
     """configs[2]: local BA, 20 keyframes / 2000 map points, LM iterations per second.  One GPU: the
@@ -802,10 +829,7 @@ def bench_ba(P, h, cam, rank=0, world=1, dev=None):
             comm = repr(e)
     out = dict(workload="synth_ba(seed=42, K=20, M=2000), %d observations%s" % (
                    len(win["obs"]), ", points partitioned over %d ranks + %s" % (world, "native RCCL all-reduce (ncclAllReduce issued by the library)" if native else "all-reduce hook") if world > 1 else ""),
-               transport=("one GPU, no collective" if world == 1 else
-                          ("native RCCL: communicator of %s ranks (ncclCommCount), this is rank %s" % (comm[0], comm[1]) if native and isinstance(comm, tuple)
-                           else "native RCCL (ncclCommCount unavailable: %s)" % (comm,) if native
-                           else "all-reduce hook over torch.distributed (%s)" % ("gloo, REHEARSAL" if os.environ.get("ORBX_DIST_REHEARSE") == "1" else "nccl = RCCL"))),
+               transport=ba_transport_text(world, native, comm, os.environ.get("ORBX_DIST_REHEARSE") == "1"),
                lm_iters_per_s=round(its / dt, 2), ms_per_solve=round(dt / reps * 1e3, 3),
                iterations=r["iterations"], initial_error_px=round(r["initial_error"], 4),
                final_error_px=round(r["final_error"], 4))

@@ -424,6 +424,26 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
                          int* iterations, double* initial_error, double* final_error);
 
+/* The same observation in 16 bytes, for callers whose pixel coordinates ARE f32 — the reference's always are: collect_visual_ba_data
+ * widens `kp.pt()` (cv::Point2f) to f64 per observation (local_ba_lm.rs:870-872).  The library widens on the device instead, the same
+ * exact conversion, so results are bit-identical to handing over the widened orbx_ba_obs — and half the bytes cross PCIe (the upload of
+ * the observations is a fifth of a 32-window batch call).  kf_idx >= 0: optimised keyframe; kf_idx < 0: fixed observer -1 - kf_idx
+ * (F = the identity pose, as fixed_idx -1 of orbx_ba_obs). */
+typedef struct {
+  int32_t kf_idx, mp_idx;
+  float u, v;
+} orbx_ba_obs32;
+/* orbx_ba_solve_visual with the observations in the 16-byte form orbx_ba_obs32: f32 pixel coordinates — what the reference's are,
+ * `kp.pt()` widened per observation at collect time (local_ba_lm.rs:870-872) — widened on the device, the same exact conversion, so the
+ * result equals orbx_ba_solve_visual's on the widened observations bit for bit while half the bytes cross the host link (a 50-keyframe
+ * window carries 2*10^5 observations: 3.2 MB instead of 6.5).  Not with an all-reduce hook / communicator installed: the partitioned
+ * solve takes orbx_ba_obs. */
+int orbx_ba_solve_visual_obs32(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+                               const double* poses_cw, int F, const double* fixed_poses_cw, int M,
+                               double* points, int N, const orbx_ba_obs32* obs32,
+                               orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
+                               int* iterations, double* initial_error, double* final_error);
+
 /* Many independent windows in ONE call ("many BA windows": one map per stream / per robot).  Each
  * window is exactly one orbx_ba_solve_visual problem (same arguments, same LM loop, local_ba_lm.rs:1012-1056) with its own
  * LM state on the device; all windows share every kernel launch — the window is the second grid dimension — so W reduced
@@ -448,15 +468,6 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
  * memory (orbx_host_alloc, hipHostMalloc or a registered range — the library asks the runtime) the copy engine reads it where it lies;
  * windows whose `obs` arrays follow each other in memory travel as ONE copy.  Pageable `obs` is first copied into the handle's pinned
  * staging blob (a plain copy, on worker threads when large).  The same holds for the one-window entry points. */
-/* The same observation in 16 bytes, for callers whose pixel coordinates ARE f32 — the reference's always are: collect_visual_ba_data
- * widens `kp.pt()` (cv::Point2f) to f64 per observation (local_ba_lm.rs:870-872).  The library widens on the device instead, the same
- * exact conversion, so results are bit-identical to handing over the widened orbx_ba_obs — and half the bytes cross PCIe (the upload of
- * the observations is a fifth of a 32-window batch call).  kf_idx >= 0: optimised keyframe; kf_idx < 0: fixed observer -1 - kf_idx
- * (F = the identity pose, as fixed_idx -1 of orbx_ba_obs). */
-typedef struct {
-  int32_t kf_idx, mp_idx;
-  float u, v;
-} orbx_ba_obs32;
 
 typedef struct {
   int K;                        /* in: optimised keyframes                         */
@@ -490,6 +501,12 @@ int orbx_ba_solve_global(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
                          const double* poses_cw, const double* fixed_pose_cw, int M, double* points, int N,
                          const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user,
                          double* poses_wc_out, int* iterations, double* initial_error, double* final_error);
+
+/* orbx_ba_solve_global with 16-byte observations (see orbx_ba_solve_visual_obs32): kf_idx -1 marks the fixed keyframe. */
+int orbx_ba_solve_global_obs32(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+                               const double* poses_cw, const double* fixed_pose_cw, int M, double* points, int N,
+                               const orbx_ba_obs32* obs32, orbx_should_stop_fn should_stop, void* user,
+                               double* poses_wc_out, int* iterations, double* initial_error, double* final_error);
 
 /* LocalInertialBAConfig (src/optimizer/local_inertial_ba.rs:109-141); orbx_default_inertial_ba_config = its Default:
  * 10 iterations, window 10, sqrt(5.991), sqrt(7.815), lambda 1e-2, gyro random-walk information 1e6, accel 1e4. */

@@ -265,6 +265,11 @@ inline std::optional<VisualBAResultData> solve_visual_ba(Handle& h, const Visual
     points.insert(points.end(), p.begin(), p.end());
   }
   std::vector<orbx_ba_obs> obs;
+  // the reference's observed_uv are keypoint coordinates widened from f32 (:870-872): when every one of them is an f32 value — always, for
+  // a problem collect_visual_ba_data made — the observations travel in the 16-byte form (orbx_ba_obs32: same result, half the upload)
+  std::vector<orbx_ba_obs32> obs32;
+  bool all_f32 = true;
+  const int F = (int)problem.fixed_kf_poses.size();
   for (const VisualObservation& o : problem.observations) {              // :943-961
     auto m = mp_idx.find(o.mp_id);
     if (m == mp_idx.end()) continue;                                     // :947
@@ -274,8 +279,12 @@ inline std::optional<VisualBAResultData> solve_visual_ba(Handle& h, const Visual
     if (k != kf_idx.end()) { b.kf_idx = k->second; b.fixed_idx = -1; }
     else { auto f = fixed_idx.find(o.kf_id); b.kf_idx = -1; b.fixed_idx = f != fixed_idx.end() ? f->second : -1; }   // :569 identity
     obs.push_back(b);
+    const float uf = (float)b.u, vf = (float)b.v;
+    if ((double)uf != b.u || (double)vf != b.v) all_f32 = false;
+    obs32.push_back(orbx_ba_obs32{b.kf_idx >= 0 ? b.kf_idx : -1 - (b.fixed_idx >= 0 ? b.fixed_idx : F), b.mp_idx, uf, vf});
   }
-  const int K = (int)problem.optimized_kf_ids.size(), F = (int)fixed_idx.size(), M = (int)problem.mp_ids.size();
+  const int K = (int)problem.optimized_kf_ids.size(), M = (int)problem.mp_ids.size();
+  all_f32 = all_f32 && orbx_ba_has_collective(h.get()) == 0;             // (the point-partitioned solve takes orbx_ba_obs)
   std::vector<double> out((size_t)std::max(K, 1) * 7);
   int it = 0;
   double e0 = 0, e1 = 0;
@@ -283,9 +292,11 @@ inline std::optional<VisualBAResultData> solve_visual_ba(Handle& h, const Visual
   const orbx_ba_config cfg{config.max_iterations, config.param_tolerance, config.gradient_tolerance, config.huber_threshold,
                            config.max_covisible_keyframes};
   auto tramp = [](void* user) -> int { return (*static_cast<const std::function<bool()>*>(user))() ? 1 : 0; };
-  const int rc = orbx_ba_solve_visual(h.get(), &c, &cfg, K, poses.data(), F, fixed.data(), M, points.data(), (int)obs.size(),
-                                      obs.data(), should_stop ? +tramp : nullptr, const_cast<std::function<bool()>*>(&should_stop),
-                                      out.data(), &it, &e0, &e1);
+  void* user = const_cast<std::function<bool()>*>(&should_stop);
+  const int rc = all_f32 ? orbx_ba_solve_visual_obs32(h.get(), &c, &cfg, K, poses.data(), F, fixed.data(), M, points.data(), (int)obs32.size(),
+                                                      obs32.data(), should_stop ? +tramp : nullptr, user, out.data(), &it, &e0, &e1)
+                         : orbx_ba_solve_visual(h.get(), &c, &cfg, K, poses.data(), F, fixed.data(), M, points.data(), (int)obs.size(),
+                                                obs.data(), should_stop ? +tramp : nullptr, user, out.data(), &it, &e0, &e1);
   if (rc != ORBX_OK) return std::nullopt;                                // :923-925 and every failure -> None
   VisualBAResultData r;
   for (int i = 0; i < K; ++i) {

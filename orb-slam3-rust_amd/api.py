@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "orbx_keyframe_create", "orbx_keyframe_destroy", "orbx_keyframe_info", "orbx_keyframe_set_pose", "orbx_keyframe_set_map_points",
     "orbx_keyframe_get_map_points", "orbx_keyframe_download", "orbx_keyframe_device_keypoints", "orbx_keyframe_device_descriptors",
     "orbx_keyframe_guided_match", "orbx_keyframe_search_for_triangulation", "orbx_keyframe_fuse_search",
-    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_has_collective", "orbx_ba_rccl_world", "orbx_ba_solve_visual", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_debug_imu_residual", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
+    "orbx_default_ba_config", "orbx_ba_set_allreduce", "orbx_rccl_unique_id", "orbx_ba_init_rccl", "orbx_ba_set_rccl_comm", "orbx_ba_has_collective", "orbx_ba_rccl_world", "orbx_ba_solve_visual", "orbx_ba_solve_visual_obs32", "orbx_ba_solve_global_obs32", "orbx_ba_solve_visual_batch", "orbx_debug_ba_blocks", "orbx_debug_imu_residual", "orbx_ba_solve_global", "orbx_default_inertial_ba_config", "orbx_ba_solve_inertial",
     "orbx_guided_match", "orbx_guided_match_device", "orbx_search_for_triangulation", "orbx_search_for_triangulation_device", "orbx_search_for_triangulation_bow",
     "orbx_fuse_search", "orbx_fuse_search_device",
     "orbx_vocab_load_text", "orbx_vocab_create", "orbx_vocab_destroy", "orbx_vocab_info", "orbx_vocab_nodes",
@@ -655,15 +655,19 @@ class Handle:
         poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)
         fixed_cw = np.ascontiguousarray(fixed_cw, np.float64).reshape(-1, 7)
         pts = np.array(points, np.float64, copy=True).reshape(-1, 3)
-        obs = np.ascontiguousarray(obs, BA_OBS)
+        # observations of dtype BA_OBS32 (ba_obs_to_obs32: the 16-byte form, f32 pixel coordinates as the reference's keypoints are) go through
+        # orbx_ba_solve_visual_obs32: the same result bit for bit, half the upload
+        o32 = getattr(obs, "dtype", None) == BA_OBS32
+        obs = np.ascontiguousarray(obs, BA_OBS32 if o32 else BA_OBS)
         K, F, M, N = len(poses_cw), len(fixed_cw), len(pts), len(obs)
         out_wc = np.zeros((max(K, 1), 7))
         it = C.c_int(); e0 = C.c_double(); e1 = C.c_double()
         cb = SHOULD_STOP_FN((lambda user: 1 if should_stop() else 0)) if should_stop else C.cast(None, SHOULD_STOP_FN)
         cam = camera._c(); c = cfg._c()
-        rc = self._L.orbx_ba_solve_visual(self._h, C.byref(cam), C.byref(c), C.c_int(K), _vp(poses_cw),
-                                          C.c_int(F), _vp(fixed_cw), C.c_int(M), _vp(pts), C.c_int(N),
-                                          _vp(obs), cb, None, _vp(out_wc), C.byref(it), C.byref(e0), C.byref(e1))
+        fn = self._L.orbx_ba_solve_visual_obs32 if o32 else self._L.orbx_ba_solve_visual
+        rc = fn(self._h, C.byref(cam), C.byref(c), C.c_int(K), _vp(poses_cw),
+                C.c_int(F), _vp(fixed_cw), C.c_int(M), _vp(pts), C.c_int(N),
+                _vp(obs), cb, None, _vp(out_wc), C.byref(it), C.byref(e0), C.byref(e1))
         if rc in (ORBX_ERR_EMPTY,):
             return None                      # reference returns None, local_ba_lm.rs:923-925
         self._check(rc)
@@ -671,15 +675,21 @@ class Handle:
                     final_error=e1.value)
 
     @staticmethod
-    def pack_ba_windows(windows):
+    def pack_ba_windows(windows, obs32=False):
         """The same windows with every `obs` array a consecutive slice of ONE page-locked host buffer (window order): what a caller that
         owns its observation storage would hand to orbx_ba_solve_visual_batch — the copy engine then reads the observations where they lie
         and each half of the batch travels as one copy (orbx.h).  The buffer is a pinned torch tensor kept alive by the returned dicts."""
         import torch
-        arrs = [np.ascontiguousarray(w["obs"], BA_OBS) for w in windows]
+        dt = BA_OBS32 if obs32 else BA_OBS
+        if obs32:       # (coordinates that are not f32 values cannot take the 16-byte form: ba_obs_to_obs32 answers None)
+            arrs = [w["obs"] if getattr(w["obs"], "dtype", None) == BA_OBS32 else ba_obs_to_obs32(np.ascontiguousarray(w["obs"], BA_OBS), len(np.asarray(w["fixed_cw"]).reshape(-1, 7))) for w in windows]
+            if any(a is None for a in arrs):
+                raise ValueError("pack_ba_windows(obs32=True): an observation's pixel coordinates are not f32 values")
+        else:
+            arrs = [np.ascontiguousarray(w["obs"], BA_OBS) for w in windows]
         total = sum(len(a) for a in arrs)
-        buf = torch.empty(max(total, 1) * BA_OBS.itemsize, dtype=torch.uint8).pin_memory()
-        flat = buf.numpy().view(BA_OBS)
+        buf = torch.empty(max(total, 1) * dt.itemsize, dtype=torch.uint8).pin_memory()
+        flat = buf.numpy().view(dt)
         out, o = [], 0
         for w, a in zip(windows, arrs):
             flat[o:o + len(a)] = a
@@ -782,15 +792,17 @@ class Handle:
         poses_cw = np.ascontiguousarray(poses_cw, np.float64).reshape(-1, 7)
         fixed = np.ascontiguousarray(fixed_pose_cw, np.float64).reshape(7)
         pts = np.array(points, np.float64, copy=True).reshape(-1, 3)
-        obs = np.ascontiguousarray(obs, BA_OBS)
+        o32 = getattr(obs, "dtype", None) == BA_OBS32       # (as ba_solve_visual)
+        obs = np.ascontiguousarray(obs, BA_OBS32 if o32 else BA_OBS)
         K, M, N = len(poses_cw), len(pts), len(obs)
         out_wc = np.zeros((max(K, 1), 7))
         it = C.c_int(); e0 = C.c_double(); e1 = C.c_double()
         cb = SHOULD_STOP_FN((lambda user: 1 if should_stop() else 0)) if should_stop else C.cast(None, SHOULD_STOP_FN)
         cam = camera._c(); c = cfg._c()
-        rc = self._L.orbx_ba_solve_global(self._h, C.byref(cam), C.byref(c), C.c_int(K), _vp(poses_cw), _vp(fixed), C.c_int(M),
-                                          _vp(pts), C.c_int(N), _vp(obs), cb, None, _vp(out_wc), C.byref(it), C.byref(e0),
-                                          C.byref(e1))
+        fn = self._L.orbx_ba_solve_global_obs32 if o32 else self._L.orbx_ba_solve_global
+        rc = fn(self._h, C.byref(cam), C.byref(c), C.c_int(K), _vp(poses_cw), _vp(fixed), C.c_int(M),
+                _vp(pts), C.c_int(N), _vp(obs), cb, None, _vp(out_wc), C.byref(it), C.byref(e0),
+                C.byref(e1))
         if rc in (ORBX_ERR_EMPTY,):
             return None                      # reference returns None, global_ba.rs:194-196
         self._check(rc)

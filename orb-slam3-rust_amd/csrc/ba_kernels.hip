@@ -4118,8 +4118,8 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
 int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
                     const double* poses_cw, int F, const double* fixed_poses_cw, int M, double* points, int N,
                     const orbx_ba_obs* obs, orbx_should_stop_fn should_stop, void* user, double* poses_wc_out,
-                    int* iterations, double* initial_error, double* final_error, bool global_mode, const BaInertialHost* inr) {
-  BaWinHost w{K, F, M, N, poses_cw, fixed_poses_cw, points, obs, poses_wc_out, iterations, initial_error, final_error, ORBX_OK};
+                    int* iterations, double* initial_error, double* final_error, bool global_mode, const BaInertialHost* inr, const orbx_ba_obs32* obs32) {
+  BaWinHost w{K, F, M, N, poses_cw, fixed_poses_cw, points, obs, poses_wc_out, iterations, initial_error, final_error, ORBX_OK, obs32};
   return ba_solve_batch(h, cam, cfg, 1, &w, should_stop, user, global_mode, inr, true);
 }
 

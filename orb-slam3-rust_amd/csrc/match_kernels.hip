@@ -748,39 +748,54 @@ __global__ __launch_bounds__(256) void hamming_batch_kernel(const uint8_t* __res
 
 }  // namespace
 
-int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, const uint8_t* d_desc,
-                        const int* d_nkp, int cap_kp, orbx_dmatch* d_matches, int* d_nmatches,
-                        double* d_points, uint8_t* d_has_point) {
-  if (batch <= 0) return ORBX_OK;
+// `batch_total` pairs size the workspace; this call matches the `batch` pairs that start at pair `pair0` of the caller's arrays on stream
+// `st` (nullptr = the handle's).  Pairs are independent and every array — the workspace's too — is indexed by pair, so a batch processed
+// as several ranges (orbx_process_stereo_batch_device's two-stream form) gives the bits of one call over the whole batch.
+int launch_stereo_match_range(orbx_handle* h, hipStream_t st, int batch_total, int pair0, int batch, const orbx_keypoint* d_kp, const uint8_t* d_desc,
+                              const int* d_nkp, int cap_kp, orbx_dmatch* d_matches, int* d_nmatches,
+                              double* d_points, uint8_t* d_has_point) {
+  if (batch_total <= 0) return ORBX_OK;
+  if (!st) st = h->stream;
   // workspace: tmp int2[batch*cap] | bstart int[batch*(SB_ROWS+1)] | sidx int[batch*cap] | sxy float2[batch*cap]
-  const size_t n_tmp = (size_t)batch * cap_kp;
-  const size_t bytes = sizeof(int2) * n_tmp + sizeof(int) * (size_t)batch * (SB_ROWS + 1) + sizeof(int) * n_tmp +
+  const size_t n_tmp = (size_t)batch_total * cap_kp;
+  const size_t bytes = sizeof(int2) * n_tmp + sizeof(int) * (size_t)batch_total * (SB_ROWS + 1) + sizeof(int) * n_tmp +
                        sizeof(float2) * n_tmp + 64;
   if (int rc = orbx_reserve(h, h->ws_match, bytes)) return rc;
+  if (batch <= 0) return ORBX_OK;                      // (a call that only sizes the workspace)
+  const size_t o = (size_t)pair0 * cap_kp;
   int2* tmp = (int2*)h->ws_match.p;
   float2* sxy = (float2*)(tmp + n_tmp);
   int* sidx = (int*)(sxy + n_tmp);
-  int* bstart = sidx + n_tmp;
+  int* bstart = sidx + n_tmp + (size_t)pair0 * (SB_ROWS + 1);
+  tmp += o; sxy += o; sidx += o;
+  d_kp += 2 * o; d_desc += 64 * o; d_nkp += 2 * (size_t)pair0;
+  d_matches += o; d_nmatches += pair0; d_points += 3 * o; d_has_point += o;
   // stereo.rs:84-90: f64 product/quotient, then `as f32`
   const float max_disp = (float)(h->cam.fx * h->cam.baseline / 0.1);
   const float min_disp = (float)(h->cam.fx * h->cam.baseline / 40.0);
   {
-    ProfScope ps(h, "stereo_bucket_kernel");
-    hipLaunchKernelGGL(stereo_bucket_kernel, dim3(batch), dim3(SB_THREADS), 0, h->stream, d_kp, d_nkp, cap_kp, bstart, sidx, sxy);
+    ProfScope ps(h, "stereo_bucket_kernel", st);
+    hipLaunchKernelGGL(stereo_bucket_kernel, dim3(batch), dim3(SB_THREADS), 0, st, d_kp, d_nkp, cap_kp, bstart, sidx, sxy);
   }
   {
-    ProfScope ps(h, "stereo_match_kernel", nullptr, true);
+    ProfScope ps(h, "stereo_match_kernel", st, true);
     dim3 grid((cap_kp + SM_LEFT_PER_BLOCK - 1) / SM_LEFT_PER_BLOCK, batch);
-    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(SM_THREADS), 0, h->stream, d_kp, d_desc, d_nkp,
+    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(SM_THREADS), 0, st, d_kp, d_desc, d_nkp,
                        cap_kp, max_disp, min_disp, bstart, sidx, sxy, tmp);
   }
   {
-    ProfScope ps(h, "stereo_compact_kernel", nullptr, true);
-    hipLaunchKernelGGL(stereo_compact_kernel, dim3(batch), dim3(256), 0, h->stream, d_kp, d_nkp, cap_kp,
+    ProfScope ps(h, "stereo_compact_kernel", st, true);
+    hipLaunchKernelGGL(stereo_compact_kernel, dim3(batch), dim3(256), 0, st, d_kp, d_nkp, cap_kp,
                        (const int2*)tmp, h->cam, d_matches, d_nmatches, d_points, d_has_point);
   }
   ORBX_HIP(h, hipGetLastError());
   return ORBX_OK;
+}
+
+int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, const uint8_t* d_desc,
+                        const int* d_nkp, int cap_kp, orbx_dmatch* d_matches, int* d_nmatches,
+                        double* d_points, uint8_t* d_has_point) {
+  return launch_stereo_match_range(h, nullptr, batch, 0, batch, d_kp, d_desc, d_nkp, cap_kp, d_matches, d_nmatches, d_points, d_has_point);
 }
 
 int launch_crosscheck(orbx_handle* h, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,

@@ -790,8 +790,14 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
     unsigned P[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) P[k] = r[k] | (r[k + 8] << 16);
+#ifdef ORBX_FAST_NO_LADDER
+    // measurement build (NOT the specification): the 16 ring reads and their packing stay, the min / max ladder of the arc score is replaced by
+    // two instructions — what ANY cheaper test in front of the ladder (a contiguity bit-mask) could save at the very most
+    int b = (int)((P[0] ^ P[1] ^ P[2] ^ P[3] ^ P[4] ^ P[5] ^ P[6] ^ P[7]) & 0xffu) + (brighter ? 1 : 0);
+#else
     int b = fast_arc_score_h(v, P, brighter);
     if (brighter && darker) b = max(b, fast_arc_score_h(v, P, false));    // both passed (rare)
+#endif
     const int sc = b > t ? b - 1 : 0;
     ss[j][i] = (uint8_t)sc;
   }
@@ -894,18 +900,23 @@ __device__ __forceinline__ float from_orderable(unsigned o) {
   return __uint_as_float(u);
 }
 
+// blocks of harris_select_kernel per image: level l owns blocks start[l] .. start[l + 1] - 1, each a contiguous share of the level's candidates
+struct HarrisPlan { int start[ORBX_MAX_LEVELS + 1]; };
 // retainBest(2*n_l) by FAST score (threshold from the histogram), then Harris of each survivor.
 // key = (~orderable(response) << 32) | y << 16 | x : ascending key = canonical order.
 __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ cand,
                                                             const unsigned* __restrict__ cand_count,
                                                             const unsigned* __restrict__ hist,
                                                             unsigned long long* __restrict__ sel,
-                                                            unsigned* __restrict__ sel_count, int chunk_shift) {
+                                                            unsigned* __restrict__ sel_count, HarrisPlan hp) {
   __shared__ unsigned sh[256];
   __shared__ int s_thr;
   int img, bb;
   if (!xcd_decode(xm, n_img, img, bb)) return;
-  const int l = bb >> chunk_shift, chunk = bb & ((1 << chunk_shift) - 1), n_chunks = 1 << chunk_shift;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < ORBX_MAX_LEVELS; ++k) l += (bb >= hp.start[k]) ? 1 : 0;             // (start[] is non-decreasing; levels beyond n_levels start at the total)
+  const int chunk = bb - hp.start[l], n_chunks = hp.start[l + 1] - hp.start[l];
   const int il = img * g.n_levels + l;
   const int tid = threadIdx.x;
   const unsigned count = min(cand_count[il], g.lv[l].cand_cap);   // (fast_kernel never writes beyond the level's list)
@@ -937,7 +948,7 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
   __shared__ unsigned s_pass[1024];
   __shared__ unsigned s_np;
   const int lane = tid & 63;
-  const unsigned per = (count + n_chunks - 1) >> chunk_shift;                          // this block's contiguous share
+  const unsigned per = (count + (unsigned)n_chunks - 1u) / (unsigned)n_chunks;         // this block's contiguous share
   const unsigned lim = min(count, (chunk + 1) * per);
   for (unsigned base = chunk * per; base < lim; base += 1024u) {                       // block-uniform bounds
     if (tid == 0) s_np = 0;
@@ -1788,13 +1799,11 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
   return ORBX_OK;
 }
 
-int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px, size_t stride,
-                       orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp, int cap_kp) {
+int orb_extract_prepare(orbx_handle* h, int n_images, int w, int h_px) {
   if (n_images <= 0) return ORBX_OK;
   if (int rc = orb_prepare_geometry(h, w, h_px)) return rc;
   const OrbGeom& g = h->geom;
-  const int nl = g.n_levels;
-  const size_t n_il = (size_t)n_images * nl;
+  const size_t n_il = (size_t)n_images * g.n_levels;
   if (int rc = orbx_reserve(h, h->ws_pyr, (size_t)g.slot_bytes * n_images)) return rc;
   static const bool unfused_ws = getenv("ORBX_DESC_UNFUSED") != nullptr;
   if (unfused_ws) { if (int rc = orbx_reserve(h, h->ws_blur, (size_t)g.slot_bytes * n_images)) return rc; }
@@ -1804,15 +1813,23 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
   // counters: cand_count[n_il], sel_count[n_il], kept[n_il], hist[n_il*256]
   const size_t n_cnt = n_il * (3 + 256);
   if (int rc = orbx_reserve(h, h->ws_counters, sizeof(unsigned) * n_cnt)) return rc;
+  ORBX_HIP(h, hipMemsetAsync(h->ws_counters.p, 0, sizeof(unsigned) * n_cnt, h->stream));
+  return ORBX_OK;
+}
+
+int orb_extract_range(orbx_handle* h, hipStream_t st, const uint8_t* d_images, int n_images, int img0, int n, int w, int h_px, size_t stride,
+                      orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp, int cap_kp, hipEvent_t after_resize) {
+  if (n <= 0) return ORBX_OK;
+  const OrbGeom& g = h->geom;
+  const int nl = g.n_levels;
+  const size_t n_il = (size_t)n_images * nl;
   unsigned* cand_count = (unsigned*)h->ws_counters.p;
   unsigned* sel_count = cand_count + n_il;
   unsigned* kept = sel_count + n_il;
   unsigned* hist = kept + n_il;
-  ORBX_HIP(h, hipMemsetAsync(h->ws_counters.p, 0, sizeof(unsigned) * n_cnt, h->stream));
-
   const bool aligned = ((uintptr_t)d_images % 4 == 0) && (stride % 4 == 0) && (((size_t)h_px * stride) % 4 == 0);
   const unsigned* tab = (const unsigned*)h->resize_tab.p;
-  auto run = [&](hipStream_t st, int img0, int n) -> int {
+  {
     OrbSrc s{};
     s.pyr = (uint8_t*)h->ws_pyr.p + (size_t)img0 * g.slot_bytes;
     s.blur = (uint8_t*)h->ws_blur.p + (size_t)img0 * g.slot_bytes;
@@ -1820,12 +1837,12 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     if (aligned) {
       s.l0 = imgs; s.l0_img_stride = (size_t)h_px * stride; s.l0_pitch = (int)stride;
     } else {
-      ProfScope ps(h, "copy_l0_kernel");
+      ProfScope ps(h, "copy_l0_kernel", st);
       hipLaunchKernelGGL(copy_l0_kernel, dim3(1, h_px, n), dim3(256), 0, st, imgs, (size_t)h_px * stride, stride, w, h_px, s.pyr,
                          g.slot_bytes, g.lv[0].pitch);
       s.l0 = s.pyr; s.l0_img_stride = g.slot_bytes; s.l0_pitch = g.lv[0].pitch;
     }
-    h->last_src = s; h->last_n_images = n;
+    if (img0 == 0) { h->last_src = s; h->last_n_images = n_images; }     // (orbx_debug_read_level addresses the whole call's images)
     unsigned* cc = cand_count + (size_t)img0 * nl;
     unsigned* sc = sel_count + (size_t)img0 * nl;
     unsigned* kp = kept + (size_t)img0 * nl;
@@ -1834,7 +1851,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     unsigned long long* sel = (unsigned long long*)h->ws_sel.p + (size_t)img0 * g.cand_total;
     unsigned long long* sel2 = (unsigned long long*)h->ws_sel2.p + (size_t)img0 * g.cand_total;
     {
-      ProfScope ps(h, "resize_kernel");
+      ProfScope ps(h, "resize_kernel", st);
       for (int l = 1; l < nl; ++l) {
         const bool small = n < 64;                       // up to 32 pairs: latency counts, keep the blocks short and many (4 / 8 / 16 pairs: 1-2 % over the 6-row form)
         // (rows chosen per level to waste least of its last tile row, among 3..6: 0.262 against 0.258 ms with 6 everywhere)
@@ -1849,6 +1866,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
                              tab + h->resize_tab_off[2 * l], tab + h->resize_tab_off[2 * l + 1]);
       }
     }
+    if (after_resize) ORBX_HIP(h, hipEventRecord(after_resize, st));
     // blur (latency-bound, ~50 % VALU-busy) and the FAST -> Harris -> ordering chain (issue-bound) both depend only on the
     // pyramid and meet again at describe: with ORBX_FORK_BLUR=1 in the environment the blur runs beside the chain on a
     // second stream (+2-3 % frames/s).  Off by default and never while per-kernel profiling is on: two kernels sharing the
@@ -1874,7 +1892,7 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
     }
     if (fork) ORBX_HIP(h, hipEventRecord(h->ev_join, h->s_aux));
     if (g.ftiles_total > 0) {
-      ProfScope ps(h, "fast_kernel", nullptr, true);
+      ProfScope ps(h, "fast_kernel", st, true);
       // chains of FAST_CHAIN tiles per block once there are blocks to spare (each CU holds 8): for a pair one tile per block
       const int chain_len = (size_t)g.ftiles_total * n >= (size_t)4 * 8 * h->n_cu ? FAST_CHAIN : 1;
       const int chains = (g.ftiles_total + chain_len - 1) / chain_len;
@@ -1884,24 +1902,37 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
         hipLaunchKernelGGL(fast_kernel<false>, xcd_grid(chains, n), dim3(FT_THREADS), 0, st, s, g, n, xcd_map(chains), tab + h->ftile_tab_off, cand, cc, hs, g.ftiles_total, chain_len, h->d_status);
     }
     {
-      ProfScope ps(h, "harris_select_kernel", nullptr, true);
+      ProfScope ps(h, "harris_select_kernel", st, true);
       // (round 3: the first round's candidates requested before the histogram, which they do not depend on — one round trip less on the
       // block's chain —: 0.152 -> 0.165 ms per 256 pairs; not kept)
       // 8 blocks per (image, level).  1 / 2 / 4 / 8 / 16 / 32 blocks: 0.210 / 0.169 / 0.153 / 0.150 / 0.204 / 0.375 ms per 256 pairs:
       // a level's 2 x quota survivors are a few hundred, so a block is one latency chain (histogram -> candidates -> 27 loads per
       // response -> store) and the kernel lives on how many of them are in flight
-      constexpr int cshift = 3;
-      hipLaunchKernelGGL(harris_select_kernel, xcd_grid(nl << cshift, n), dim3(256), 0, st, s, g, n, xcd_map(nl << cshift),
-                         (const unsigned*)cand, cc, hs, sel, sc, cshift);
+      // Round 5: the blocks dealt to the levels in proportion to their area (candidates follow the area: level 0 holds 12.8 x level 7's, and
+      // with 8 blocks each a level-7 block held ~10 candidates for its 256 threads), at least one each.  Same box, ms per 256 pairs: 8 per
+      // level 0.153; 64 / 40 / 24 / 16 blocks per image by area: 0.146 / 0.141 / 0.144 / 0.149 (profiles/r05_harris_blocks_by_area_ab.txt).
+      // ORBX_HARRIS_BLOCKS=<total per image> overrides, ORBX_HARRIS_BLOCKS=0 keeps 8 per level (A/B runs).
+      HarrisPlan hp{};
+      static const int hb_total = [] { const char* e = getenv("ORBX_HARRIS_BLOCKS"); const int v = e ? atoi(e) : 40; return v >= 8 && v <= 512 ? v : 0; }();
+      if (hb_total) {
+        double area = 0;
+        for (int l = 0; l < nl; ++l) area += (double)g.lv[l].w * g.lv[l].h;
+        for (int l = 0; l < nl; ++l) hp.start[l + 1] = hp.start[l] + std::max(1, (int)lrint(hb_total * ((double)g.lv[l].w * g.lv[l].h) / area));
+      } else
+        for (int l = 0; l < nl; ++l) hp.start[l + 1] = hp.start[l] + 8;
+      for (int l = nl; l < ORBX_MAX_LEVELS; ++l) hp.start[l + 1] = hp.start[nl];
+      const int hblocks = hp.start[nl];
+      hipLaunchKernelGGL(harris_select_kernel, xcd_grid(hblocks, n), dim3(256), 0, st, s, g, n, xcd_map(hblocks),
+                         (const unsigned*)cand, cc, hs, sel, sc, hp);
     }
     {
-      ProfScope ps(h, "rank_select_kernel", nullptr, true);
+      ProfScope ps(h, "rank_select_kernel", st, true);
       hipLaunchKernelGGL(rank_select_kernel, xcd_grid(nl, n), dim3(RK_NT), 0, st, g, n, xcd_map(nl), sel, sc,
                          sel2, kp);
     }
     if (fork) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
     {
-      ProfScope ps(h, unfused ? "describe_kernel" : "describe_fused_kernel", nullptr, true);
+      ProfScope ps(h, unfused ? "describe_kernel" : "describe_fused_kernel", st, true);
       const int blocks_x16 = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block and round
       const int blocks_x = unfused ? blocks_x16 : (blocks_x16 + ORBX_DF_ITERS - 1) / ORBX_DF_ITERS;
       if (unfused)
@@ -1913,16 +1944,22 @@ int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, in
                            (const unsigned long long*)sel2, (const unsigned long long*)sel, kp, d_kp + (size_t)img0 * cap_kp, d_desc + (size_t)img0 * cap_kp * 32,
                            d_nkp + img0, cap_kp, (float)h->orb.patch_size, h->d_status);
     }
-    return ORBX_OK;
-  };
+  }
+  ORBX_HIP(h, hipGetLastError());
+  return ORBX_OK;
+}
+
+int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px, size_t stride,
+                       orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp, int cap_kp) {
+  if (n_images <= 0) return ORBX_OK;
+  if (int rc = orb_extract_prepare(h, n_images, w, h_px)) return rc;
   // (Round 3: the previous batch's stereo matcher on a stream of its own, so that its latency-bound launches run under this batch's resize
   // launches — describe waiting for it, since it rewrites what the matcher reads —: both stretch by what the other takes (resize 0.264 ->
   // 0.360, matcher 0.091 -> 0.155 ms per 256 pairs), frames/s unchanged; withdrawn.)
   // (Two half-batches on two streams were measured: +0.3 % in round 1; again at the end of round 2, when FAST's 7 blocks per CU leave wave
-  // slots free: 2 / 3 / 4 / 6 / 8 chunks alternating over two streams: +0.5 ... +2 % / -3 % / 0 / -3 % / -5 % without per-kernel events — so one stream.)
-  if (int rc = run(h->stream, 0, n_images)) return rc;
-  ORBX_HIP(h, hipGetLastError());
-  return ORBX_OK;
+  // slots free: 2 / 3 / 4 / 6 / 8 chunks alternating over two streams: +0.5 ... +2 % / -3 % / 0 / -3 % / -5 % without per-kernel events — so one stream.
+  // Round 5: the same with the second stream STAGGERED by a phase, orbx_process_stereo_batch_device.)
+  return orb_extract_range(h, h->stream, d_images, n_images, 0, n_images, w, h_px, stride, d_kp, d_desc, d_nkp, cap_kp, nullptr);
 }
 
 // ---- stage inspection --------------------------------------------------------------------------------------

@@ -167,6 +167,7 @@ void orbx_destroy(orbx_handle* h) {
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->ba_up_event) hipEventDestroy(h->ba_up_event);
+  for (hipEvent_t e : h->ev_stag) if (e) hipEventDestroy(e);
   if (h->s_aux) hipStreamDestroy(h->s_aux);
   if (h->s_in) hipStreamDestroy(h->s_in);
   if (h->s_out) hipStreamDestroy(h->s_out);
@@ -675,6 +676,47 @@ int orbx_process_stereo_batch_device(orbx_handle* h, const uint8_t* d_images, in
     return orbx_fail(h, ORBX_ERR_INVALID, "batch %d outside 0..max_batch %d", batch, h->max_batch);
   if (!d_matches || !d_nmatches || !d_points || !d_has_point)
     return orbx_fail(h, ORBX_ERR_INVALID, "orbx_process_stereo_batch_device: bad argument");
+  // Two-stream form (ORBX_STAGGER=<chunks>, 2..8; experimental, round 5): the batch as `chunks` ranges of pairs dealt alternately to the
+  // handle's stream and a second one, chunk c + 1 starting behind chunk c's pyramid launches, so that one range's latency-bound
+  // launches (resize chain, Harris, ordering, the matcher's three) are in flight while the other range is in its issue-bound FAST /
+  // describe kernels.  Pairs are independent and every workspace is indexed by image or pair: the results are those of one range over
+  // the whole batch, bit for bit.  The handle's stream waits for the second one before the call returns (work the caller enqueues on
+  // orbx_stream() afterwards sees every result).  MEASURED NEGATIVE (profiles/r05_stagger_two_streams_negative.txt): 145.2 k frames/s on one
+  // stream, 144.6 k as 2 ranges, 139.5 k as 4 — under overlap every kernel stretches by what the other stream takes (describe x 2.1, FAST
+  // x 1.6, Harris x 1.5, resize x 1.8): the latency-bound launches do not hide under the issue-bound ones, the chip is shared.  Off by default.
+  const int stagger = [] { const char* e = getenv("ORBX_STAGGER"); const int v = e ? atoi(e) : 0; return v >= 2 && v <= 8 ? v : 0; }();   // (read per call, as ORBX_FORK_BLUR)
+  static const bool stagger_prof = getenv("ORBX_STAGGER_PROFILE") != nullptr;    // (per-kernel events on both streams: they then time the overlap, not the kernels)
+  static const bool desc_unfused = getenv("ORBX_DESC_UNFUSED") != nullptr;
+  if (stagger && batch >= 2 * stagger && (!h->profiling || stagger_prof) && !desc_unfused) {
+    if (!d_images || !d_kp || !d_desc || !d_nkp || cap_kp < 1)
+      return orbx_fail(h, ORBX_ERR_INVALID, "orbx_process_stereo_batch_device: bad argument");
+    if (w < 64 || h_px < 64 || w > h->max_w || h_px > h->max_h || stride < (size_t)w)
+      return orbx_fail(h, ORBX_ERR_INVALID, "image %dx%d (stride %zu) outside the handle's bounds %dx%d", w, h_px, stride, h->max_w, h->max_h);
+    ORBX_HIP(h, hipSetDevice(h->device));
+    if (!h->s_aux) {
+      ORBX_HIP(h, hipStreamCreateWithFlags(&h->s_aux, hipStreamNonBlocking));
+      ORBX_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      ORBX_HIP(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    for (auto& e : h->ev_stag) if (!e) ORBX_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (int rc = orb_extract_prepare(h, 2 * batch, w, h_px)) return rc;
+    // (the matcher's workspace is sized before the streams fork: orbx_reserve may synchronise)
+    if (int rc = launch_stereo_match_range(h, h->stream, batch, 0, 0, d_kp, d_desc, d_nkp, cap_kp, d_matches, d_nmatches, d_points, d_has_point)) return rc;
+    ORBX_HIP(h, hipEventRecord(h->ev_fork, h->stream));
+    ORBX_HIP(h, hipStreamWaitEvent(h->s_aux, h->ev_fork, 0));
+    int p0 = 0;
+    for (int c = 0; c < stagger; ++c) {
+      const int p1 = (int)((long long)batch * (c + 1) / stagger);
+      hipStream_t st = (c & 1) ? h->s_aux : h->stream;
+      if (c > 0) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_stag[(c - 1) & 3], 0));     // behind the previous chunk's pyramid
+      if (int rc = orb_extract_range(h, st, d_images, 2 * batch, 2 * p0, 2 * (p1 - p0), w, h_px, stride, d_kp, d_desc, d_nkp, cap_kp, h->ev_stag[c & 3])) return rc;
+      if (int rc = launch_stereo_match_range(h, st, batch, p0, p1 - p0, d_kp, d_desc, d_nkp, cap_kp, d_matches, d_nmatches, d_points, d_has_point)) return rc;
+      p0 = p1;
+    }
+    ORBX_HIP(h, hipEventRecord(h->ev_join, h->s_aux));
+    ORBX_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    return ORBX_OK;
+  }
   if (int rc = orbx_extract_batch_device(h, d_images, 2 * batch, w, h_px, stride, d_kp, d_desc, d_nkp, cap_kp))
     return rc;
   return launch_stereo_match(h, batch, d_kp, d_desc, d_nkp, cap_kp, d_matches, d_nmatches, d_points, d_has_point);
@@ -981,6 +1023,29 @@ int orbx_ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
   }
 }
 
+int orbx_ba_solve_visual_obs32(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
+                               const double* poses_cw, int F, const double* fixed_poses_cw, int M,
+                               double* points, int N, const orbx_ba_obs32* obs32, orbx_should_stop_fn should_stop,
+                               void* user, double* poses_wc_out, int* iterations, double* initial_error,
+                               double* final_error) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || !cfg || K < 0 || F < 0 || M < 0 || N < 0 || !iterations || !initial_error || !final_error ||
+      (K > 0 && (!poses_cw || !poses_wc_out)) || (F > 0 && !fixed_poses_cw) || (M > 0 && !points) ||
+      (N > 0 && !obs32))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_obs32: bad argument");
+  if (h->allreduce || h->rccl_comm) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_visual_obs32: the partitioned solve takes orbx_ba_obs (orbx_ba_solve_visual)");
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  try {
+    return ba_solve_visual(h, cam, cfg, K, poses_cw, F, fixed_poses_cw, M, points, N, nullptr, should_stop, user,
+                           poses_wc_out, iterations, initial_error, final_error, false, nullptr, obs32);
+  } catch (const std::bad_alloc&) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_obs32: out of host memory");
+  } catch (...) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_visual_obs32: unexpected C++ exception");
+  }
+}
+
 int orbx_ba_solve_visual_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int n_windows,
                                orbx_ba_window* windows, orbx_should_stop_fn should_stop, void* user) {
   if (!h) return ORBX_ERR_INVALID;
@@ -1143,6 +1208,29 @@ int orbx_ba_solve_global(orbx_handle* h, const orbx_camera* cam, const orbx_ba_c
     return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_global: out of host memory");
   } catch (...) {
     return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_global: unexpected C++ exception");
+  }
+}
+
+int orbx_ba_solve_global_obs32(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K, const double* poses_cw,
+                               const double* fixed_pose_cw, int M, double* points, int N, const orbx_ba_obs32* obs32,
+                               orbx_should_stop_fn should_stop, void* user, double* poses_wc_out, int* iterations,
+                               double* initial_error, double* final_error) {
+  if (!h) return ORBX_ERR_INVALID;
+  if (!cam || !cfg || K < 0 || M < 0 || N < 0 || !iterations || !initial_error || !final_error || !fixed_pose_cw ||
+      (K > 0 && (!poses_cw || !poses_wc_out)) || (M > 0 && !points) || (N > 0 && !obs32))
+    return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_global_obs32: bad argument");
+  if (h->allreduce || h->rccl_comm) return orbx_fail(h, ORBX_ERR_INVALID, "orbx_ba_solve_global_obs32: the partitioned solve takes orbx_ba_obs (orbx_ba_solve_global)");
+  *iterations = 0; *initial_error = 0.0; *final_error = 0.0;
+  if (K < 1 || M == 0) return orbx_fail(h, ORBX_ERR_EMPTY, "global BA needs two keyframes and a map point");   // global_ba.rs:194-196
+  ORBX_HIP(h, hipSetDevice(h->device));
+  orbx_prof_begin_call(h);
+  try {
+    return ba_solve_visual(h, cam, cfg, K, poses_cw, 1, fixed_pose_cw, M, points, N, nullptr, should_stop, user, poses_wc_out,
+                           iterations, initial_error, final_error, true, nullptr, obs32);
+  } catch (const std::bad_alloc&) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_global_obs32: out of host memory");
+  } catch (...) {
+    return orbx_fail(h, ORBX_ERR_HIP, "orbx_ba_solve_global_obs32: unexpected C++ exception");
   }
 }
 

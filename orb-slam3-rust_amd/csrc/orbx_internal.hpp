@@ -202,6 +202,7 @@ struct orbx_handle {
   // second stream of the extractor: the blur runs beside the FAST -> Harris -> ordering chain (launch_orb_extract)
   hipStream_t s_aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_stag[4] = {nullptr, nullptr, nullptr, nullptr};   // two-stream form of orbx_process_stereo_batch_device: chunk c + 1 starts behind chunk c's pyramid
   // BA
   orbx_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -259,6 +260,9 @@ void orbx_prof_end_call(orbx_handle* h);
 int launch_stereo_match(orbx_handle* h, int batch, const orbx_keypoint* d_kp, const uint8_t* d_desc,
                         const int* d_nkp, int cap_kp, orbx_dmatch* d_matches, int* d_nmatches,
                         double* d_points, uint8_t* d_has_point);
+int launch_stereo_match_range(orbx_handle* h, hipStream_t st, int batch_total, int pair0, int batch, const orbx_keypoint* d_kp,
+                              const uint8_t* d_desc, const int* d_nkp, int cap_kp, orbx_dmatch* d_matches, int* d_nmatches,
+                              double* d_points, uint8_t* d_has_point);
 int launch_crosscheck(orbx_handle* h, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                       orbx_dmatch* d_out, int* d_n_out);
 int launch_hamming_batch(orbx_handle* h, const uint8_t* d_a, const uint8_t* d_b, int n, uint32_t* d_out);
@@ -281,12 +285,19 @@ int launch_fuse_search(orbx_handle* h, const orbx_camera* cam, const double* d_p
 int orb_prepare_geometry(orbx_handle* h, int w, int h_px);
 int launch_orb_extract(orbx_handle* h, const uint8_t* d_images, int n_images, int w, int h_px,
                        size_t stride, orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp, int cap_kp);
+// The same over the images [img0, img0 + n) of a call that carries n_images in all, on stream `st`: orb_extract_prepare sizes the
+// workspaces for the whole call and clears its counters (on the handle's stream), orb_extract_range then runs one range of it; `after_resize`
+// (optional) is recorded on `st` behind the range's pyramid launches.
+int orb_extract_prepare(orbx_handle* h, int n_images, int w, int h_px);
+int orb_extract_range(orbx_handle* h, hipStream_t st, const uint8_t* d_images, int n_images, int img0, int n, int w, int h_px, size_t stride,
+                      orbx_keypoint* d_kp, uint8_t* d_desc, int* d_nkp, int cap_kp, hipEvent_t after_resize);
 // BA (ba_kernels.hip)
 int ba_solve_visual(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config* cfg, int K,
                     const double* poses_cw, int F, const double* fixed_poses_cw, int M,
                     double* points, int N, const orbx_ba_obs* obs, orbx_should_stop_fn should_stop,
                     void* user, double* poses_wc_out, int* iterations, double* initial_error,
-                    double* final_error, bool global_mode = false, const struct BaInertialHost* inr = nullptr);
+                    double* final_error, bool global_mode = false, const struct BaInertialHost* inr = nullptr,
+                    const orbx_ba_obs32* obs32 = nullptr);   // obs32: the 16-byte form of the observations, used instead of obs when given
 // one window of a batch as the caller hands it over (orbx_ba_solve_visual_batch); status: ORBX_OK or ORBX_ERR_EMPTY
 struct BaWinHost {
   int K, F, M, N;

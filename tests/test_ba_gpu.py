@@ -187,16 +187,13 @@ def test_solve_visual_ba_mirror(gpu_handle, oracle, pkg):
     assert _rel(got, o["poses_wc"]) < POSE_TOL
 
 
-def test_ba_point_partition_two_ranks_one_gpu(oracle, pkg):
-    """Point-partitioned BA on the real kernels: two 'ranks' = two handles driven by two
-    threads in this process, the all-reduce hook sums their device buffers in place.  The result must
-    match the single-handle solve to rounding (summation order differs) and be identical on both."""
+def _solve_partitioned_on_one_gpu(pkg, w, world):
+    """`world` ranks = `world` handles driven by `world` host threads of this process on ONE GPU; the all-reduce hook sums their device
+    buffers in place (every rank adds the slots in rank order, so all ranks hold the same bits).  Returns (per-rank results, handles)."""
     import threading
     import torch
-    w = pkg.synth.ba_window(21, 10, 400, pkg.BA_OBS, n_fixed_extra=1)
     cam = pkg.CameraModel(**w["camera"]); cfg = pkg.LocalBAConfigLM()
     dev = torch.device("cuda", 0)
-    world = 2
     hs = [pkg.Handle(cam, 100, device=0) for _ in range(world)]
     bar = threading.Barrier(world)
     slots = [None] * world
@@ -208,7 +205,9 @@ def test_ba_point_partition_two_ranks_one_gpu(oracle, pkg):
             torch.cuda.synchronize()
             slots[rank] = pkg.dist.device_tensor(ptr, n, dev)
             bar.wait()
-            total = slots[0] + slots[1]
+            total = slots[0].clone()
+            for r in range(1, world):
+                total += slots[r]
             torch.cuda.synchronize()
             bar.wait()
             slots[rank].copy_(total)
@@ -225,15 +224,38 @@ def test_ba_point_partition_two_ranks_one_gpu(oracle, pkg):
 
     ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in ts: t.start()
-    for t in ts: t.join(120)
+    for t in ts: t.join(300)
     assert not errs, errs
+    return out, hs
+
+
+@pytest.mark.parametrize("world,seed,K,M,extra", [(2, 21, 10, 400, 1),                       # a small window with a second fixed observer
+                                                  (2, 42, 20, 2000, 0), (4, 42, 20, 2000, 0), (8, 42, 20, 2000, 0),   # configs[2] / configs[3]: synth_ba(42, 20, 2000)
+                                                  (8, 43, 50, 8000, 0)])                     # configs[4]: synth_ba(43, 50, 8000) over 8 ranks
+def test_ba_point_partition_ranks_on_one_gpu(oracle, pkg, world, seed, K, M, extra):
+    """Point-partitioned BA on the real kernels at the sizes and rank counts configs[3] / configs[4] name: the map points dealt
+    round-robin to `world` ranks, each rank building complete V_j / W_j for its points and partial U, g_p, S_red, b_red, chi2; one all-reduce of
+    (6K)^2 + 48K + 2 doubles before the solve and one of 4 after the back-substitution, per iteration.  Against the ORACLE's structured
+    solve of the whole problem (iteration counts, errors, poses and points within the 1e-6 bar of every other BA test), against the
+    library's own single-handle solve (rounding only: the summation order differs), and identical bits on every rank."""
+    w = pkg.synth.ba_window(seed, K, M, pkg.BA_OBS, n_fixed_extra=extra)
+    out, hs = _solve_partitioned_on_one_gpu(pkg, w, world)
+    cam = pkg.CameraModel(**w["camera"]); cfg = pkg.LocalBAConfigLM()
     single = hs[0].ba_solve_visual(cam, cfg, w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+    o = oracle.ba_solve_schur(oracle.Camera(**w["camera"]), oracle.ba_config(), w["poses_cw"], w["fixed_cw"], w["points"], w["obs"])
+    sizes = [len(pkg.dist.partition_observations(w["obs"], r, world)) for r in range(world)]
+    assert sum(sizes) == len(w["obs"]) and min(sizes) > 0
     for r in range(world):
-        assert out[r]["iterations"] == single["iterations"]
+        assert out[r]["iterations"] == single["iterations"] == o["iterations"]
         assert _rel(out[r]["poses_wc"], single["poses_wc"]) < 1e-9
         assert _rel(out[r]["points"], single["points"]) < 1e-9
         assert abs(out[r]["final_error"] - single["final_error"]) < 1e-10 * single["final_error"]
-    assert np.array_equal(out[0]["poses_wc"], out[1]["poses_wc"]) and np.array_equal(out[0]["points"], out[1]["points"])
+        ang, dt = pose_errors(out[r]["poses_wc"], o["poses_wc"])
+        assert ang < POSE_TOL and dt < POSE_TOL, (r, ang, dt)
+        assert _rel(out[r]["points"], o["points"]) < POSE_TOL
+        assert abs(out[r]["initial_error"] - o["initial_error"]) < 1e-8 * o["initial_error"]
+        assert abs(out[r]["final_error"] - o["final_error"]) < 1e-8 * o["final_error"]
+        assert np.array_equal(out[r]["poses_wc"], out[0]["poses_wc"]) and np.array_equal(out[r]["points"], out[0]["points"])
     for h in hs: h.close()
 
 
@@ -419,6 +441,20 @@ def test_ba_observations_from_pinned_memory_equal_staged(gpu_handle, pkg):
         assert np.array_equal(x["poses_wc"], y["poses_wc"]) and np.array_equal(x["points"], y["points"]), i
     with pytest.raises(ValueError):
         gpu_handle.prepare_ba_batch(wins, obs32=True)
+    # ... and through the single-window entry points (orbx_ba_solve_visual_obs32 / orbx_ba_solve_global_obs32, round 5): pageable and pinned
+    p32 = pkg.Handle.pack_ba_windows(w32, obs32=True)
+    assert p32[0]["obs"].dtype == pkg.BA_OBS32 and p32[0]["obs"].itemsize == 16
+    for i in (0, 4, 17):
+        for o in (pkg.ba_obs_to_obs32(w32[i]["obs"], len(w32[i]["fixed_cw"])), p32[i]["obs"]):
+            s = gpu_handle.ba_solve_visual(cam, cfg, w32[i]["poses_cw"], w32[i]["fixed_cw"], w32[i]["points"], o)
+            assert s["iterations"] == ref32[i]["iterations"] and s["initial_error"] == ref32[i]["initial_error"] and s["final_error"] == ref32[i]["final_error"], i
+            assert np.array_equal(s["poses_wc"], ref32[i]["poses_wc"]) and np.array_equal(s["points"], ref32[i]["points"]), i
+    gw = pkg.synth.keypoint_precision(pkg.synth.ba_window(2177, 7, 300, pkg.BA_OBS))        # global BA: one fixed keyframe, kf_idx -1 - 0
+    g64 = gpu_handle.ba_solve_global(cam, cfg, gw["poses_cw"], gw["fixed_cw"][0], gw["points"], gw["obs"])
+    g32 = gpu_handle.ba_solve_global(cam, cfg, gw["poses_cw"], gw["fixed_cw"][0], gw["points"], pkg.ba_obs_to_obs32(gw["obs"], 1))
+    assert g64["iterations"] == g32["iterations"] and np.array_equal(g64["poses_wc"], g32["poses_wc"]) and np.array_equal(g64["points"], g32["points"])
+    with pytest.raises(ValueError):
+        pkg.Handle.pack_ba_windows(wins, obs32=True)
     # an index out of range inside pinned memory is found by the device-side check and named
     o = packed[15]["obs"]; keep = int(o["mp_idx"][7]); o["mp_idx"][7] = len(packed[15]["points"]) + 3
     with pytest.raises(pkg.OrbxError) as e:

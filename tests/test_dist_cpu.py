@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the N>1 host logic: stream sharding, the BA point partition and
+"""gloo tests on the CPU (world 2, and world 8 = the rank count configs[3] / configs[4] name) of the N>1 host logic: stream sharding, the BA point partition and
 the all-reduce of the reduced normal equations.  The compute under the collective is
 the oracle's reduced-system builder; the partition / reduce code is the product's (dist.py)."""
 import os
@@ -30,7 +30,8 @@ def _worker(rank, world, port, q):
         dist.all_gather_object(allv, mine)
         assert sorted(sum(allv, [])) == list(range(8))
         # 2) BA: partial reduced systems of the point partition, summed over ranks == full system
-        w = P.synth.ba_window(11, 6, 120, P.BA_OBS, n_fixed_extra=1)
+        # (world 8: 203 points = 25 or 26 per rank — not a multiple of the Schur product's 16-point k-split tiles, nor equal across ranks)
+        w = P.synth.ba_window(11, 6, 120 if world == 2 else 203, P.BA_OBS, n_fixed_extra=1)
         cam = O.Camera(**w["camera"]); cfg = O.ba_config()
         pp = np.concatenate([O.se3_to_params(p) for p in w["poses_cw"]])
         local = P.dist.partition_observations(w["obs"], rank, world)
@@ -55,7 +56,14 @@ def _worker(rank, world, port, q):
         dp = np.linalg.solve(H, rhs)
         gathered = [None] * world
         dist.all_gather_object(gathered, dp.tolist())
-        assert np.array_equal(np.array(gathered[0]), np.array(gathered[1]))
+        assert all(np.array_equal(np.array(gathered[0]), np.array(g)) for g in gathered[1:])
+        # ... and the partition covers every observation exactly once, every rank holding ALL observations of the points it owns
+        counts = [None] * world
+        dist.all_gather_object(counts, (len(local), sorted(set(local["mp_idx"].tolist()))))
+        assert sum(c[0] for c in counts) == len(w["obs"])
+        owned = [set(c[1]) for c in counts]
+        assert all(not (owned[a] & owned[b]) for a in range(world) for b in range(a + 1, world))
+        assert set().union(*owned) == set(w["obs"]["mp_idx"].tolist())
         # 4) the bench's max-over-ranks timing helper
         assert P.dist.allreduce_max_seconds(1.0 + rank) == float(world)
         q.put((rank, "ok"))
@@ -66,18 +74,34 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_partition_and_reduce():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_partition_and_reduce(world):
+    """world 2, and world 8 = the rank count configs[3] / configs[4] name (gloo on the CPU: the host side of the partitioned solve)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=400) for _ in procs]
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_bench_line_names_the_communicator_and_both_ba_shardings():
+    """bench.py --gpus N (N > 1): `local_ba.transport` carries the rank count the library's own communicator reports (ncclCommCount), and the
+    line holds both shardings of BA — one window partitioned over the ranks (lm_iters_per_s) and one window per rank (independent_windows).
+    Parsed here from the source and its helper; the N = 2 rehearsal on one GPU runs the whole path (tests/test_properties_gpu.py)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    t = bench.ba_transport_text(8, True, (8, 3), False)
+    assert "ncclCommCount" in t and "8 ranks" in t and "rank 3" in t
+    assert "REHEARSAL" in bench.ba_transport_text(2, False, None, True) and "nccl = RCCL" in bench.ba_transport_text(8, False, None, False)
+    assert bench.ba_transport_text(1, False, None, False) == "one GPU, no collective"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'out["independent_windows"]' in src and "ba_solve_partitioned" in src and "h.rccl_world()" in src
 
 
 def test_partition_properties():

@@ -123,6 +123,31 @@ def test_gpu_inertial_ba_config_abort_and_none(gpu_handle):
 
 
 @pytest.mark.gpu
+def test_gpu_inertial_ba_failed_call_leaves_no_copy_of_caller_memory_in_flight(gpu_handle):
+    """page-locked observations are read by the copy engine where they lie, so a call that FAILS must not return while that
+    read is pending.  An inertial call with a bad IMU edge index (validated on the host before anything is enqueued) and one with a bad
+    observation index (found on the device; the call drains before it answers): the buffer is scribbled over the moment each call is back,
+    restored, and the next valid solve gives the bits of the first."""
+    w = P.Handle.pack_ba_windows([P.synth.inertial_window(8, 6, 4000, P.BA_OBS, n_fixed=1)])[0]
+    ref = _gpu(gpu_handle, w)
+    keep = w["obs"].copy()
+    bad = dict(w); bad["edge_kf"] = w["edge_kf"].copy(); bad["edge_kf"][2, 0] = -1
+    with pytest.raises(P.OrbxError) as e:
+        _gpu(gpu_handle, bad)
+    assert "IMU edge 2" in str(e.value)
+    w["obs"]["u"][:] = -1.0e9; w["obs"]["mp_idx"][:] = 0            # reuse at once
+    w["obs"][:] = keep
+    w["obs"]["mp_idx"][5] = len(w["points"]) + 1
+    with pytest.raises(P.OrbxError) as e:
+        _gpu(gpu_handle, w)
+    assert "observation 5" in str(e.value)
+    w["obs"]["u"][:] = -1.0e9
+    w["obs"][:] = keep
+    again = _gpu(gpu_handle, w)
+    assert again["iterations"] == ref["iterations"] and all(np.array_equal(again[k], ref[k]) for k in ("poses_wc", "velocities", "biases", "points"))
+
+
+@pytest.mark.gpu
 def test_gpu_solve_inertial_ba_keyed_by_ids(gpu_handle):
     """The reference-shaped entry: InertialBAProblemData keyed by ids; the first keyframe of the window is not reported."""
     w = P.synth.inertial_window(6, 4, 90, P.BA_OBS, n_fixed=2)

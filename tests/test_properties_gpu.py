@@ -118,6 +118,30 @@ def test_optional_blur_fork_gives_identical_results(full_batch):
         assert torch.equal(out["matches"][b, :nm[b]], snap["matches"][b, :nm[b]])
 
 
+def test_two_stream_ranges_give_identical_results(full_batch):
+    """ORBX_STAGGER=<n> (read at call time): the batch as n ranges of pairs on two streams, each range started behind the previous one's
+    pyramid launches (a measured negative for throughput, kept opt-in): same bytes out as the one-stream call."""
+    import os
+    import torch
+    h, imgs, out, snap, B, cap = full_batch
+    nk = snap["nkp"].cpu().numpy(); nm = snap["nmatches"].cpu().numpy()
+    for n in ("2", "3"):
+        os.environ["ORBX_STAGGER"] = n
+        try:
+            for _ in range(2):
+                h.process_stereo_batch_device(imgs, out)
+            h.check_status()
+        finally:
+            del os.environ["ORBX_STAGGER"]
+        assert torch.equal(out["nkp"], snap["nkp"]) and torch.equal(out["nmatches"], snap["nmatches"])
+        for b in range(0, B, 7):
+            for s in range(2):
+                assert torch.equal(out["kp"][b, s, :nk[b, s]].view(torch.int32), snap["kp"][b, s, :nk[b, s]].view(torch.int32))
+                assert torch.equal(out["desc"][b, s, :nk[b, s]], snap["desc"][b, s, :nk[b, s]])
+            assert torch.equal(out["matches"][b, :nm[b]], snap["matches"][b, :nm[b]])
+            assert torch.equal(out["has_point"][b, :nk[b, 0]], snap["has_point"][b, :nk[b, 0]])
+
+
 def test_pair_result_independent_of_batch_position(full_batch, pkg):
     """reversing the batch order permutes the results and nothing else (no cross-talk through shared workspaces,
     the XCD-aware block mapping or the atomically appended candidate lists)"""
@@ -186,3 +210,31 @@ def test_large_odd_image(oracle, pkg):
     ok, od = oracle.orb_extract(L, oracle.orb_params(n))
     assert kpL.tobytes() == ok.tobytes() and np.array_equal(dL, od)
     h.close()
+
+
+def test_bench_two_rank_rehearsal_line(tmp_path):
+    """bench.py as the driver launches it for N > 1 (python -m torch.distributed.run, one rank per GPU), rehearsed on this one-GPU box with
+    N = 2 (ORBX_DIST_REHEARSE=1: the ranks share the card, gloo carries the all-reduce hook — RCCL refuses two ranks on one device):
+    ONE JSON line from rank 0 with the whole-job value, weak scaling, and BOTH shardings of local BA — one window's map points
+    partitioned over the ranks with the normal equations all-reduced (lm_iters_per_s + transport), and one window per rank
+    (independent_windows).  Small sizes: this checks the N > 1 path end to end, not its speed."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ORBX_DIST_REHEARSE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline", "--no-files", "--no-extras"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["batch_pairs_per_gpu"] == 8
+    ba = d["local_ba"]
+    assert ba["iterations"] == 10 and ba["lm_iters_per_s"] > 0 and "points partitioned over 2 ranks" in ba["workload"]
+    assert "REHEARSAL" in ba["transport"] and "REHEARSAL" in d["config"]["parallelism"] and "all-reduced" in d["config"]["parallelism"]
+    assert ba["independent_windows"]["windows"] == 2 and ba["independent_windows"]["lm_iters_per_s"] > 0
