@@ -342,11 +342,19 @@ __global__ __launch_bounds__(1024) void ba_prep_scan_kernel(const BaWin* __restr
     if (tid == 1023) s_carry = base + inc;
     __syncthreads();
   }
-  if (tid == 0) {
-    pt_start[M] = s_carry;
-    int* kf_start = const_cast<int*>(win.kf_start);
-    int run = 0;
-    for (int k = 0; k < K; ++k) { run += kf_start[k + 1]; kf_start[k + 1] = run; }   // (kf_start[0] = 0: zeroed with the counters)
+  if (tid == 0) pt_start[M] = s_carry;
+  if (wave == 0) {
+    // kf_start[k + 1] = observations of the keyframes 0 .. k: a wave scan, two keyframes per lane (K <= 128) — one thread's loop of K
+    // dependent read-modify-writes was most of this launch at 49 keyframes (16 us)
+    int* kf_start = const_cast<int*>(win.kf_start);                      // (kf_start[0] = 0: zeroed with the counters)
+    static_assert(BA_MAX_K <= 128, "two keyframes per lane of one wave");
+    const int k0 = 2 * lane, c0 = k0 < K ? kf_start[k0 + 1] : 0, c1 = k0 + 1 < K ? kf_start[k0 + 2] : 0;
+    int inc = c0 + c1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+    const int before = inc - c0 - c1;
+    if (k0 < K) kf_start[k0 + 1] = before + c0;
+    if (k0 + 1 < K) kf_start[k0 + 2] = before + c0 + c1;
   }
 }
 
@@ -400,16 +408,42 @@ __global__ __launch_bounds__(256) void ba_prep_order_kernel(const BaWin* __restr
 // keyframe k; a point seen twice by one keyframe (two features of it carry the same map point) has its observations chained in
 // order through obs_next — the tile slot then holds the sum of their W blocks, as J^T J does.  Built here once per call instead of
 // on the host: 4 (M K + N) bytes per window less to prepare and to upload (a fifth of the input blob at 20 keyframes / 2000 points).
+// Round 5: sixteen lanes per point instead of one thread walking its ~16-50 observations through dependent global round trips (2000
+// points = 8 workgroups, 15 us per call; 8000 points 38 us).  The lanes take the point's observations in turn and note the smallest
+// observation index per keyframe in LDS (atomicMin); a keyframe that comes up twice — rare: two features of one keyframe on one map
+// point — sends the whole point down the serial walk below, by one lane, exactly as before.  Same slot map, same chains.
+constexpr int BA_SLOT_LANES = 16, BA_SLOT_PPB = 256 / BA_SLOT_LANES;
 __global__ __launch_bounds__(256) void ba_slots_kernel(const BaWin* __restrict__ wins) {
+  __shared__ int s_first[BA_SLOT_PPB][BA_MAX_K];
   const BaWin win = ba_win_global(wins, blockIdx.y);
   const int K = win.d.K, M = win.d.M;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (win.S->done || j >= M || K <= 0) return;        // (a window the reference answers None for was never prepared: its index arrays hold nothing)
-  int* __restrict__ slot = win.slot_first + (size_t)j * K;
+  const int grp = threadIdx.x / BA_SLOT_LANES, li = threadIdx.x % BA_SLOT_LANES;
+  const int j = blockIdx.x * BA_SLOT_PPB + grp;
+  if (win.S->done || K <= 0 || K > BA_MAX_K) return;  // (a window the reference answers None for was never prepared: its index arrays hold nothing; K is checked by the host)
+  const bool live = j < M;
+  int* __restrict__ slot = win.slot_first + (size_t)(live ? j : 0) * K;
   int* __restrict__ nxt = win.obs_next;
   const int* __restrict__ o_kf = win.o_kf;
+  int* first = s_first[grp];
+  const int t0 = live ? win.pt_start[j] : 0, t1 = live ? win.pt_start[j + 1] : 0;
+  for (int k = li; k < K; k += BA_SLOT_LANES) first[k] = 0x7fffffff;
+  // (a group is part of one wave: its LDS operations are performed in issue order, no barrier between these steps)
+  bool dup = false;
+  for (int t = t0 + li; t < t1; t += BA_SLOT_LANES) {
+    const int k = o_kf[t];
+    if (k >= 0 && atomicMin(&first[k], t) != 0x7fffffff) dup = true;     // somebody noted this keyframe before: a second observation of (point, keyframe)
+  }
+  const unsigned long long bal = __ballot(dup);
+  const bool any_dup = ((bal >> ((threadIdx.x & 63) & ~(BA_SLOT_LANES - 1))) & ((1ull << BA_SLOT_LANES) - 1ull)) != 0ull;
+  if (!live) return;
+  if (!any_dup) {
+    for (int t = t0 + li; t < t1; t += BA_SLOT_LANES) nxt[t] = -1;
+    for (int k = li; k < K; k += BA_SLOT_LANES) { const int f = first[k]; slot[k] = f == 0x7fffffff ? -1 : f; }
+    return;
+  }
+  if (li != 0) return;
   for (int k = 0; k < K; ++k) slot[k] = -1;
-  for (int t = win.pt_start[j]; t < win.pt_start[j + 1]; ++t) {
+  for (int t = t0; t < t1; ++t) {
     nxt[t] = -1;
     const int k = o_kf[t];
     if (k < 0) continue;
@@ -424,8 +458,11 @@ __global__ __launch_bounds__(256) void ba_slots_kernel(const BaWin* __restrict__
 // map: block k walks the points in chunks of 256, a thread counts its point's chain for keyframe k (0, 1, rarely more), a block-wide
 // exclusive scan places them behind the keyframe's host-computed start.  Until round 3's end the host built these 8 bytes per observation
 // and uploaded them with every call.  Same order as the host's pass produced (ascending observation index within a keyframe).
-__global__ __launch_bounds__(256) void ba_kflist_kernel(const BaWin* __restrict__ wins) {
-  __shared__ int s_wave[4];
+// (Round 5: 1024 threads — the block walks the points in chunks of its size with three barriers per chunk; with the sixteen-lane slot kernel
+// the two launches together 27.5 -> 11.8 us per call at 20 keyframes / 2000 points, 82 -> 29.4 us at 50 / 8000: profiles/r05_ba_setup_kernels_ab.txt)
+constexpr int BA_KFL_THREADS = 1024;
+__global__ __launch_bounds__(BA_KFL_THREADS) void ba_kflist_kernel(const BaWin* __restrict__ wins) {
+  __shared__ int s_wave[BA_KFL_THREADS / 64];
   __shared__ int s_base;
   const BaWin win = ba_win_global(wins, blockIdx.y);
   const int K = win.d.K, M = win.d.M, k = blockIdx.x;
@@ -435,7 +472,7 @@ __global__ __launch_bounds__(256) void ba_kflist_kernel(const BaWin* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_base = win.kf_start[k];
   __syncthreads();
-  for (int j0 = 0; j0 < M; j0 += 256) {
+  for (int j0 = 0; j0 < M; j0 += BA_KFL_THREADS) {
     const int j = j0 + tid;
     const int first = j < M ? slot_first[(size_t)j * K + k] : -1;
     int cnt = 0;
@@ -449,7 +486,7 @@ __global__ __launch_bounds__(256) void ba_kflist_kernel(const BaWin* __restrict_
     for (int w2 = 0; w2 < wave; ++w2) pos += s_wave[w2];
     for (int i = first; i >= 0; i = nxt[i]) { kf_obs[pos] = i; kf_pt[pos] = j; ++pos; }
     __syncthreads();
-    if (tid == 255) s_base = pos;                                           // (the last thread's end = the chunk's end)
+    if (tid == BA_KFL_THREADS - 1) s_base = pos;                            // (the last thread's end = the chunk's end)
     __syncthreads();
   }
 }
@@ -3909,8 +3946,11 @@ int ba_solve_batch(orbx_handle* h, const orbx_camera* cam, const orbx_ba_config*
     my_stop = tot[1] > 0.0;                                              // the collective decision for iteration 0
   }
 
-  if (maxM > 0 && maxK > 0) hipLaunchKernelGGL(ba_slots_kernel, dim3((maxM + 255) / 256, W), dim3(256), 0, st, d_wins);
-  if (maxM > 0 && maxK > 0) hipLaunchKernelGGL(ba_kflist_kernel, dim3(maxK, W), dim3(256), 0, st, d_wins);
+  if (maxM > 0 && maxK > 0) {
+    ProfScope ps(h, "ba_slots_kflist");
+    hipLaunchKernelGGL(ba_slots_kernel, dim3((maxM + BA_SLOT_PPB - 1) / BA_SLOT_PPB, W), dim3(256), 0, st, d_wins);
+    hipLaunchKernelGGL(ba_kflist_kernel, dim3(maxK, W), dim3(BA_KFL_THREADS), 0, st, d_wins);
+  }
   // initial error (:1000-1001) -> res[12].  The visual solve on one GPU takes it from its first iteration (the current error the gather
   // assembles from the build kernel's per-point sums, ba_decide_kernel) — a pass over every observation and a reduction less per call;
   // a call that enqueues no iteration, the partitioned solve (the sum is a collective) and the inertial one (IMU terms) compute it here.
