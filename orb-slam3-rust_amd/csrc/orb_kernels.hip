@@ -1032,10 +1032,33 @@ __device__ __forceinline__ void rank_pass(const unsigned long long* __restrict__
 // entry x | y << 16 | slot-in-level << 32.  describe_kernel walks that list, so the 16 keypoints of a block are
 // neighbours in one band and share the cache lines of their patch rows (results go to the keypoint's slot: the order
 // of processing is free).
+// exclusive prefix sum over skey[0..1024) in place (all RK_NT threads; skey[1024..1024+RK_NT/64) is scratch): 1024 / RK_NT counters per
+// thread, scan inside each wave, totals of the waves before
+__device__ __forceinline__ void rank_prefix_1024(unsigned* skey, int tid) {
+  constexpr int CE = 1024 / RK_NT;
+  unsigned cv[CE], tot = 0;
+#pragma unroll
+  for (int q = 0; q < CE; ++q) { cv[q] = skey[CE * tid + q]; tot += cv[q]; }
+  unsigned inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned t = __shfl_up(inc, off);
+    if ((tid & 63) >= off) inc += t;
+  }
+  if ((tid & 63) == 63) skey[1024 + (tid >> 6)] = inc;
+  __syncthreads();
+  unsigned run = inc - tot;
+  for (int w = 0; w < (tid >> 6); ++w) run += skey[1024 + w];
+#pragma unroll
+  for (int q = 0; q < CE; ++q) { skey[CE * tid + q] = run; run += cv[q]; }
+}
+
+// With describe tiles (g.dt_total > 0) the spatial order is by describe tile — cell = tile index inside the level — and the kernel also
+// leaves each tile's (begin, end) range of that list in tile_rng: describe_tile_kernel's blocks own one tile each.
 __global__ __launch_bounds__(RK_NT) void rank_select_kernel(OrbGeom g, int n_img, XcdMap xm, unsigned long long* __restrict__ sel,
                                                            const unsigned* __restrict__ sel_count,
                                                            unsigned long long* __restrict__ sel2,
-                                                           unsigned* __restrict__ kept) {
+                                                           unsigned* __restrict__ kept, uint2* __restrict__ tile_rng) {
   __shared__ unsigned long long chunk[2048];
   __shared__ unsigned skey[1024 + 16];
   __shared__ unsigned s_thr, s_keep;
@@ -1047,9 +1070,18 @@ __global__ __launch_bounds__(RK_NT) void rank_select_kernel(OrbGeom g, int n_img
   const int quota = g.lv[l].quota;
   unsigned long long* in = sel + (size_t)img * g.cand_total + g.lv[l].cand_off;
   unsigned long long* out = sel2 + (size_t)img * g.cand_total + g.lv[l].cand_off;
+  const bool tiled = g.dt_total > 0;
+  const unsigned ntl = tiled ? (unsigned)(g.lv[l].dt_nx * g.lv[l].dt_ny) : 0u;     // at most 1024 (orb_prepare_geometry)
+  uint2* rng = tile_rng + (size_t)img * (size_t)g.dt_total + g.lv[l].dt_start;
+  const unsigned dt_nx = (unsigned)g.lv[l].dt_nx, dt_mx = g.lv[l].dt_mx, dt_my = g.lv[l].dt_my;
+  auto tile_of = [&](unsigned xy) { return __umulhi((xy >> 16) - (unsigned)EDGE, dt_my) * dt_nx + __umulhi((xy & 0xffffu) - (unsigned)EDGE, dt_mx); };
   if (tid == 0) { s_thr = 0xffffffffu; s_keep = 0; }
   __syncthreads();
-  if (M == 0 || quota == 0) { if (tid == 0) kept[il] = 0; return; }
+  if (M == 0 || quota == 0) {
+    if (tid == 0) kept[il] = 0;
+    for (unsigned t = tid; t < ntl; t += RK_NT) rng[t] = uint2{0u, 0u};
+    return;
+  }
   if (M <= 2048) {
     // the usual case (M ~ 2 n_l): bitonic sort of the keys in LDS, padded with ~0 to a power of two.  A thread owns the
     // compare-exchanges c = tid, tid + RK_NT, ... of a step; steps with stride <= 64 stay inside the 128 keys of one
@@ -1097,58 +1129,57 @@ __global__ __launch_bounds__(RK_NT) void rank_select_kernel(OrbGeom g, int n_img
       const unsigned i = tid + (unsigned)RK_NT * e;
       if (i < K) {
         const unsigned xy = (unsigned)chunk[i];
-        mycell[e] = ((xy & 0xffffu) >> 7) * nrb + ((xy >> 16) >> rsh);
+        mycell[e] = tiled ? tile_of(xy) : ((xy & 0xffffu) >> 7) * nrb + ((xy >> 16) >> rsh);
         mypos[e] = atomicAdd(&skey[mycell[e]], 1u);
       }
     }
     __syncthreads();
-    // exclusive prefix over the 1024 counters: 1024 / RK_NT per thread, scan inside each wave, totals of the waves before
-    {
-      constexpr int CE = 1024 / RK_NT;
-      unsigned cv[CE], tot = 0;
-#pragma unroll
-      for (int q = 0; q < CE; ++q) { cv[q] = skey[CE * tid + q]; tot += cv[q]; }
-      unsigned inc = tot;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned t = __shfl_up(inc, off);
-        if ((tid & 63) >= off) inc += t;
-      }
-      if ((tid & 63) == 63) skey[1024 + (tid >> 6)] = inc;
-      __syncthreads();
-      unsigned run = inc - tot;
-      for (int w = 0; w < (tid >> 6); ++w) run += skey[1024 + w];
-#pragma unroll
-      for (int q = 0; q < CE; ++q) { skey[CE * tid + q] = run; run += cv[q]; }
-    }
+    rank_prefix_1024(skey, tid);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < KE; ++e) {
       const unsigned i = tid + (unsigned)RK_NT * e;
       if (i < K) in[skey[mycell[e]] + mypos[e]] = (chunk[i] & 0xffffffffull) | ((unsigned long long)i << 32);
     }
+    for (unsigned t = tid; t < ntl; t += RK_NT) rng[t] = uint2{skey[t], t + 1 < ntl ? skey[t + 1] : K};
     return;
   }
   for (unsigned g0 = 0; g0 < M; g0 += 4 * RK_NT) rank_pass<4>(in, out, M, g0, chunk, quota, &s_thr);
   __syncthreads();
+  unsigned K;
   if (M <= (unsigned)quota) {
     if (tid == 0) kept[il] = M;
-    __threadfence();
+    K = M;
+  } else {
+    const unsigned thr = s_thr;   // ~orderable(response of the n-th best); keep hi <= thr
+    unsigned cnt = 0;
+    for (unsigned i = tid; i < M; i += RK_NT) cnt += ((unsigned)(in[i] >> 32) <= thr) ? 1u : 0u;
+    atomicAdd(&s_keep, cnt);
     __syncthreads();
-    for (unsigned i = tid; i < M; i += RK_NT) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
-    return;
+    if (tid == 0) kept[il] = s_keep;
+    K = min(s_keep, M);
   }
-  const unsigned thr = s_thr;   // ~orderable(response of the n-th best); keep hi <= thr
-  unsigned cnt = 0;
-  for (unsigned i = tid; i < M; i += RK_NT) cnt += ((unsigned)(in[i] >> 32) <= thr) ? 1u : 0u;
-  atomicAdd(&s_keep, cnt);
-  __syncthreads();
-  if (tid == 0) kept[il] = s_keep;
-  // (more than 2048 candidates on one level: no spatial sort, the list is the canonical order)
   __threadfence();
   __syncthreads();
-  const unsigned K = min(s_keep, M);
-  for (unsigned i = tid; i < K; i += RK_NT) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
+  if (!tiled) {
+    // (more than 2048 candidates on one level: no spatial sort, the list is the canonical order)
+    for (unsigned i = tid; i < K; i += RK_NT) in[i] = (out[i] & 0xffffffffull) | ((unsigned long long)i << 32);
+    return;
+  }
+  // the same list by describe tile: counting sort of the K kept entries (canonical order in out[]) with the counters in LDS
+  unsigned* cursor = reinterpret_cast<unsigned*>(chunk);
+  for (int i = tid; i < 1024; i += RK_NT) { skey[i] = 0u; cursor[i] = 0u; }
+  __syncthreads();
+  for (unsigned i = tid; i < K; i += RK_NT) atomicAdd(&skey[tile_of((unsigned)out[i])], 1u);
+  __syncthreads();
+  rank_prefix_1024(skey, tid);
+  __syncthreads();
+  for (unsigned i = tid; i < K; i += RK_NT) {
+    const unsigned long long v = out[i];
+    const unsigned c = tile_of((unsigned)v);
+    in[skey[c] + atomicAdd(&cursor[c], 1u)] = (v & 0xffffffffull) | ((unsigned long long)i << 32);
+  }
+  for (unsigned t = tid; t < ntl; t += RK_NT) rng[t] = uint2{skey[t], t + 1 < ntl ? skey[t + 1] : K};
 }
 
 // ---- A.7 orientation + A.8 descriptor: one wave per keypoint ---------------------------------------------
@@ -1544,8 +1575,11 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
     {
       const int m16 = lane & 15, q = lane >> 4;
       const df_i4* band = reinterpret_cast<const df_i4*>(c_blur_band) + lane;
+#ifndef ORBX_DF_BLUR_KPS
+#define ORBX_DF_BLUR_KPS DG_PER_WAVE     // measurement builds only: fewer than 4 leaves keypoints' patches unblurred (results meaningless)
+#endif
 #pragma unroll 1
-      for (int kp = 0; kp < DG_PER_WAVE; ++kp) {
+      for (int kp = 0; kp < ORBX_DF_BLUR_KPS; ++kp) {
         unsigned char* win = wwin + kp * DF_WIN_BYTES;
         df_i4 a1[3];
 #pragma unroll
@@ -1623,6 +1657,265 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
       kp_out[(size_t)img * cap_kp + slot] = o;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- A.7 + A.8 per TILE (round 5): the patch blur shared by the keypoints of a tile ---------------------------------------------------
+// describe_fused_kernel blurs a 48 x 48 window per keypoint, and the windows of an image's 2000 keypoints cover its pyramid more than three
+// times over (a build without the blur: 0.425 of the kernel's 0.680 ms per 256 pairs).  Here a workgroup owns one describe tile — a rectangle
+// of at most DT_TW_MAX x DT_TH_MAX keypoint positions of one level (orb_prepare_geometry cuts each level's keypoint region into equal tiles;
+// rank_select_kernel orders the kept keypoints by tile and leaves each tile's range) — and
+//   1. blurs the tile's rectangle + 18 px once into LDS, column-major, with the same two banded products on v_mfma_i32_16x16x64_i8
+//      as the per-keypoint form: a window is 64 rows x 64 bytes of the level read straight from global memory as the A operands
+//      (row 16 mb + m, bytes 16 q .. 16 q + 15: no staging) and yields 48 x 48 blurred pixels (30 MFMAs); windows sit 48 apart, the last one
+//      of a row / column pulled back inside the level (it then repeats pixels of its neighbour: same integers);
+//   2. walks the tile's keypoints four per wave as before: intensity centroid from the level (global loads: the level's bytes are not staged),
+//      angle, 256 tests on the LDS tile at (kx - ox + dx) * DT_PITCH + (ky - oy + dy).
+// Same integers as the per-keypoint blur and as the whole-level specification (A.8), so the descriptors are bit-identical; tiles without
+// keypoints return at once.  Levels too small for a 64 x 64 window use describe_fused_kernel (g.dt_total == 0).
+#ifndef ORBX_DT_NWX
+#define ORBX_DT_NWX 4
+#endif
+#ifndef ORBX_DT_NWY
+#define ORBX_DT_NWY 4
+#endif
+constexpr int DT_NWX = ORBX_DT_NWX, DT_NWY = ORBX_DT_NWY;     // windows per tile at most
+#ifndef ORBX_DT_PAD
+#define ORBX_DT_PAD 4
+#endif
+// LDS tile: DT_COLS columns of DT_PITCH bytes (column-major: a lane's four result rows are one dword).  The pitch is an ODD number of dwords:
+// the 16 columns of a result store then fall into 16 different banks (at 48 dwords they share 2)
+constexpr int DT_PITCH = 48 * DT_NWY + ORBX_DT_PAD, DT_COLS = 48 * DT_NWX;
+constexpr int DT_TILE_BYTES = DT_PITCH * DT_COLS;
+// keypoint positions per tile: the blurred rectangle is 36 larger, and the first window starts up to 3 bytes / rows earlier — columns on 4-byte
+// boundaries (a window's 16-byte row loads at an odd address cost 0.15 ms of this kernel's 0.70 per 256 pairs: the unaligned form goes through
+// the address path lane by lane), rows so that every window row is a multiple of 4 below the clamp row
+constexpr int DT_TW_MAX = 48 * DT_NWX - 39;
+constexpr int DT_TH_MAX = 48 * DT_NWY - 39;
+static_assert(DT_NWX >= 1 && DT_NWY >= 1 && DT_TILE_BYTES + 3072 <= 65536, "LDS per workgroup");
+__constant__ __attribute__((aligned(16))) unsigned c_blur_band_t[6 * 64 * 4];   // T1 for output-column block 0..2, T2 for output-row block 0..2 (64 real k-slots)
+
+__global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
+                                                            const uint2* __restrict__ tile_rng,
+                                                            const unsigned long long* __restrict__ sel2,
+                                                            const unsigned long long* __restrict__ spatial,
+                                                            const unsigned* __restrict__ kept,
+                                                            orbx_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
+                                                            int* __restrict__ nkp, int cap_kp, float patch_size,
+                                                            unsigned* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_tile[DT_TILE_BYTES + 1024 + 2 * 1024];
+  int* s_pat = reinterpret_cast<int*>(s_tile + DT_TILE_BYTES);
+  unsigned* s_ones = reinterpret_cast<unsigned*>(s_tile + DT_TILE_BYTES + 1024);
+  unsigned* s_col = s_ones + 256;
+  int img, tile;
+  if (!xcd_decode(xm, n_img, img, tile)) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int l, tx, ty;
+  decode_tile(tile_tab, tile, l, tx, ty);
+  unsigned lbase = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < ORBX_MAX_LEVELS; ++i) {
+    const unsigned k = i < g.n_levels ? kept[img * g.n_levels + i] : 0u;
+    lbase += i < l ? k : 0u;
+    total += k;
+  }
+  const unsigned limit = min(total, (unsigned)cap_kp);
+  if (tile == 0 && tid == 0) {
+    nkp[img] = (int)limit;
+    if (total > (unsigned)cap_kp) atomicOr(status, ORBX_ST_KP_OVERFLOW);
+  }
+  const uint2 rng = tile_rng[(size_t)img * (size_t)g.dt_total + tile];
+  const unsigned n_kp = rng.y - rng.x;
+  if (n_kp == 0) return;
+  s_pat[tid] = reinterpret_cast<const int*>(c_pattern)[tid];
+  s_ones[tid] = c_ic_ones[tid];
+  s_col[tid] = c_ic_col[tid];
+  // ---- the tile's rectangle of the level (block-uniform)
+  int pitch;
+  const uint8_t* src = level_ptr(s, g, img, l, pitch);
+  const int lw = g.lv[l].w, lh = g.lv[l].h;
+  const int X0 = EDGE + tx * g.lv[l].dt_tw, X1 = min(X0 + g.lv[l].dt_tw - 1, lw - EDGE - 1);
+  const int Y0 = EDGE + ty * g.lv[l].dt_th, Y1 = min(Y0 + g.lv[l].dt_th - 1, lh - EDGE - 1);
+  const int xlim = pitch - 64, ylim = lh - 64;                  // last admissible window origin (every byte a window reads lies inside the level's rows)
+  const int ox = min(X0 - 21, xlim) & ~3;                       // origin of the first window: blurred pixel (ox + 3, oy + 3) is byte 0 of the LDS tile; xlim and 48 are multiples of 4
+  int oy = min(Y0 - 21, ylim);
+  oy -= (4 - ((ylim - oy) & 3)) & 3;                            // window rows stay dword-aligned in the tile when the last one is pulled back to ylim
+  const int nwx = min((X1 + 18 - (ox + 3) + 1 + 47) / 48, DT_NWX), nwy = min((Y1 + 18 - (oy + 3) + 1 + 47) / 48, DT_NWY);
+  const int grp = lane >> 4, li = lane & 15;
+  const size_t lofs = (size_t)img * g.cand_total + g.lv[l].cand_off;
+  const unsigned ngrp = (n_kp + DG_PER_WAVE - 1) / DG_PER_WAVE;
+  const unsigned long long* sp0 = spatial + lofs + rng.x;
+  auto entry = [&](unsigned gi) {
+    const unsigned pos_raw = gi * DG_PER_WAVE + (unsigned)grp;
+    return sp0[pos_raw < n_kp ? pos_raw : (gi < ngrp ? gi * DG_PER_WAVE : 0u)];   // idle groups shadow the wave's first keypoint
+  };
+  unsigned long long ent = entry((unsigned)wave), ent_n = entry((unsigned)wave + 4u);   // (requested here: they arrive under the blur)
+  // ---- 1. the blurred rectangle, one 64 x 64 window per wave and round
+  {
+    const int m16 = lane & 15, q = lane >> 4;
+    const df_i4* band = reinterpret_cast<const df_i4*>(c_blur_band_t) + lane;
+#if defined(ORBX_DT_SKIP) && ORBX_DT_SKIP == 1     // measurement builds only (results meaningless): 1 = no blur, 2 = no keypoint phase, 3 = no centroid loads
+    const int nwin = 0;
+#else
+    const int nwin = nwx * nwy;
+#endif
+    // a window's origin and its A operands (the loads of window wi + 4 travel under the products of window wi)
+    const unsigned p16 = 16u * (unsigned)pitch;
+    auto origin = [&](int wi, int& c, int& r) {
+      const int wy = wi / nwx, wx = wi - wy * nwx;              // (scalar)
+      c = min(ox + 48 * wx, xlim); r = min(oy + 48 * wy, ylim);
+    };
+    auto fetch = [&](int wi, df_i4 (&a)[4]) {
+      int c, r;
+      origin(wi, c, r);
+#ifdef ORBX_DT_ALIGN      // measurement builds only (results meaningless): window columns on ORBX_DT_ALIGN-byte boundaries; 0 = no loads at all
+#if ORBX_DT_ALIGN > 0
+      c &= ~(ORBX_DT_ALIGN - 1);
+#endif
+#endif
+      const uint8_t* wp = src + (unsigned)(__umul24((unsigned)(r + m16), (unsigned)pitch) + (unsigned)(c + 16 * q));
+#if defined(ORBX_DT_ALIGN) && ORBX_DT_ALIGN == 0
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) a[mb] = (df_i4){c + mb, r, m16, q};
+#else
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) __builtin_memcpy(&a[mb], wp + (unsigned)mb * p16, 16);
+#endif
+    };
+    df_i4 anx[4];
+    if (wave < nwin) fetch(wave, anx);
+    for (int wi = wave; wi < nwin; wi += 4) {
+      int c, r;
+      origin(wi, c, r);
+      df_i4 a1[4];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) a1[mb] = anx[mb] ^ (df_i4){(int)0x80808080u, (int)0x80808080u, (int)0x80808080u, (int)0x80808080u};   // p - 128: the signed bytes the matrix pipe multiplies
+      if (wi + 4 < nwin) fetch(wi + 4, anx);
+      unsigned char* out0 = s_tile + (unsigned)((c - ox + m16) * DT_PITCH + (r - oy) + 4 * q);
+#pragma unroll
+      for (int nb = 0; nb < 3; ++nb) {
+        const df_i4 t1 = band[64 * nb];
+        df_i4 hh[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) hh[mb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[mb], t1, (df_i4){0, 0, 0, 0}, 0, 0, 0);
+        // split H' = H - 32768 into a signed high byte and a low byte (xor 0x80 -> signed): k-slot (q, j = 4 mb + i) = row 16 mb + 4 q + i = register i of hh[mb]
+        df_i4 bhi, blo;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const unsigned p01 = __builtin_amdgcn_perm((unsigned)hh[mb][1], (unsigned)hh[mb][0], 0x05010400u);
+          const unsigned p23 = __builtin_amdgcn_perm((unsigned)hh[mb][3], (unsigned)hh[mb][2], 0x05010400u);
+          blo[mb] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+          bhi[mb] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
+        }
+#pragma unroll
+        for (int mb2 = 0; mb2 < 3; ++mb2) {
+          const df_i4 t2 = band[64 * (3 + mb2)];
+          const df_i4 shi = __builtin_amdgcn_mfma_i32_16x16x64_i8(t2, bhi, (df_i4){0, 0, 0, 0}, 0, 0, 0);
+          const df_i4 slo = __builtin_amdgcn_mfma_i32_16x16x64_i8(t2, blo, (df_i4){8454144, 8454144, 8454144, 8454144}, 0, 0, 0);   // 2^16 + 2^23
+          const unsigned v0 = ((unsigned)shi[0] << 8) + (unsigned)slo[0], v1 = ((unsigned)shi[1] << 8) + (unsigned)slo[1];
+          const unsigned v2 = ((unsigned)shi[2] << 8) + (unsigned)slo[2], v3 = ((unsigned)shi[3] << 8) + (unsigned)slo[3];
+          const unsigned u01 = __builtin_amdgcn_perm(v1, v0, 0x00000602u), u23 = __builtin_amdgcn_perm(v3, v2, 0x00000602u);
+          *reinterpret_cast<unsigned*>(out0 + (16 * nb) * DT_PITCH + 16 * mb2) = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#if defined(ORBX_DT_SKIP) && ORBX_DT_SKIP == 2
+  if (s_tile[tid] == 1 && s_tile[tid + 256] == 77) return;
+  if (tid >= 0) return;
+#endif
+  // ---- 2. the tile's keypoints, four per wave and round (16 lanes each)
+  // Two keypoint groups ahead: the list entry of group gi + 8 and the centroid pixels of group gi + 4 are requested while group gi is worked on
+  // (list entry -> pixels -> arithmetic is two dependent round trips to L2 per group otherwise, with four waves per SIMD to hide them).
+  // Intensity centroid over the 749-pixel disc straight from the level image (integer, order independent): lane li takes rows
+  // 4 it + (li >> 2), dwords 2 (li & 3) and 2 (li & 3) + 1 of the row as ONE 8-byte load (row 31 does not exist: zero weights, re-reads row 30)
+  const unsigned astep = 4u * (unsigned)pitch;
+  auto pixels = [&](unsigned long long e, unsigned long long (&px)[8]) {
+    const int kx = (int)(e & 0xffffu), ky = (int)((e >> 16) & 0xffffu);
+    const uint8_t* a0 = src + (unsigned)(__umul24((unsigned)(ky - 15 + (li >> 2)), (unsigned)pitch) + (unsigned)(kx - 15 + 8 * (li & 3)));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = 4 * it + (li >> 2);
+#if defined(ORBX_DT_SKIP) && ORBX_DT_SKIP == 3
+      px[it] = (unsigned long long)(kx * 77 + it * ky) * 0x0101010101010101ull;
+#else
+      __builtin_memcpy(&px[it], a0 + ((unsigned)it * astep - (row > 30 ? (unsigned)pitch : 0u)), 8);
+#endif
+    }
+  };
+  unsigned long long px[8], pxn[8];
+  pixels(ent, px);
+  for (unsigned gi = (unsigned)wave; gi < ngrp; gi += 4) {
+    const unsigned long long ent_nn = entry(gi + 8u);
+    pixels(ent_n, pxn);
+    const unsigned pos_raw = gi * DG_PER_WAVE + (unsigned)grp;
+    const int kx = (int)(ent & 0xffffu), ky = (int)((ent >> 16) & 0xffffu);
+    const unsigned j2 = (unsigned)(ent >> 32) & 0xffffu;
+    const unsigned slot = lbase + j2;
+    const bool active = pos_raw < n_kp && slot < limit;
+    const float resp = from_orderable(~(unsigned)(sel2[lofs + j2] >> 32));   // only needed for the output record
+    int sA = 0, sB = 0, sC = 0;
+    {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = 4 * it + (li >> 2);
+        const int r = min(row, 30);
+        const int t0 = row * 8 + 2 * (li & 3);
+        const uint2 w1 = *reinterpret_cast<const uint2*>(&s_ones[t0]);
+        const uint2 wc = *reinterpret_cast<const uint2*>(&s_col[t0]);
+        const unsigned sI = __builtin_amdgcn_udot4((unsigned)(px[it] >> 32), w1.y, __builtin_amdgcn_udot4((unsigned)px[it], w1.x, 0u, false), false);
+        sA += (int)__builtin_amdgcn_udot4((unsigned)(px[it] >> 32), wc.y, __builtin_amdgcn_udot4((unsigned)px[it], wc.x, 0u, false), false);
+        sB += (int)sI;
+        sC += (r - 15) * (int)sI;
+      }
+    }
+    sA = row16_sum(sA); sB = row16_sum(sB); sC = row16_sum(sC);
+    const int m10 = sA - 15 * sB, m01 = sC;
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    float ca, sa;
+    sincos_deg(angle, ca, sa);
+    unsigned long long word[4] = {0ull, 0ull, 0ull, 0ull};
+    const desc_f2 ca2 = {ca, ca}, sa2 = {sa, sa}, magic2 = {12582912.f, 12582912.f};
+    // byte (kx - (ox + 3) + col) * DT_PITCH + (ky - (oy + 3) + row) of the column-major tile from the raw float bits: the 24-bit multiply sees
+    // 0x400000 + col, the row term carries the whole 0x4B400000 + row
+    constexpr unsigned kBias = 0x400000u * DT_PITCH + 0x4B400000u;
+    const unsigned kbase = (unsigned)((kx - (ox + 3)) * DT_PITCH + (ky - (oy + 3))) - kBias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pr = s_pat[r * 16 + li];
+      const desc_f2 X = {(float)(signed char)(pr & 0xff), (float)(signed char)((pr >> 16) & 0xff)};
+      const desc_f2 Y = {(float)(signed char)((pr >> 8) & 0xff), (float)(signed char)((pr >> 24) & 0xff)};
+      const desc_f2 fx = X * ca2 - Y * sa2 + magic2;
+      const desc_f2 fy = X * sa2 + Y * ca2 + magic2;
+      const unsigned a0 = __umul24(__float_as_uint(fx[0]), DT_PITCH) + __float_as_uint(fy[0]) + kbase;
+      const unsigned a1 = __umul24(__float_as_uint(fx[1]), DT_PITCH) + __float_as_uint(fy[1]) + kbase;
+      const int t0 = s_tile[a0];
+      const int t1 = s_tile[a1];
+      const unsigned long long bal = __ballot(t0 < t1);
+      const unsigned chunk = (unsigned)(bal >> (16 * grp)) & 0xffffu;        // this keypoint's bits 16r .. 16r+15
+      word[r >> 2] |= (unsigned long long)chunk << (16 * (r & 3));
+    }
+    if (active && li < 4) {
+      const unsigned long long wv = li == 0 ? word[0] : li == 1 ? word[1] : li == 2 ? word[2] : word[3];
+      reinterpret_cast<unsigned long long*>(desc_out + ((size_t)img * cap_kp + slot) * 32)[li] = wv;
+    }
+    if (active && li == 4) {
+      const float sc = g.lv[l].scale;
+      orbx_keypoint o;
+      o.x = __fmul_rn((float)kx, sc);
+      o.y = __fmul_rn((float)ky, sc);
+      o.size = __fmul_rn(patch_size, sc);
+      o.angle = angle;
+      o.response = resp;
+      o.octave = l;
+      o.class_id = -1;
+      kp_out[(size_t)img * cap_kp + slot] = o;
+    }
+    ent = ent_n; ent_n = ent_nn;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) px[it] = pxn[it];
   }
 }
 
@@ -1722,6 +2015,37 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
   g.cand_total = coff;
   g.btiles_total = bt;
   g.ftiles_total = ft;
+  // describe tiles: each level's keypoint region [31, w-32] x [31, h-32] cut into equal rectangles of at most DT_TW_MAX x DT_TH_MAX positions,
+  // the cut that needs the fewest 48 x 48 blur windows (a tile's blurred rectangle is 36 larger than its keypoint rectangle).  Needs every
+  // level that can hold keypoints to hold a 64 x 64 window, and at most 1024 tiles per level (rank_select_kernel's counters).
+  {
+    static const bool dt_off = [] { const char* e = getenv("ORBX_DESC_TILE"); return e && atoi(e) == 0; }();
+    bool ok = !dt_off;
+    int dt = 0;
+    auto cut = [](int k, int tmax, int margin, int& n_out, int& t_out) {
+      int best = 1 << 30;
+      const int n0 = (k + tmax - 1) / tmax;
+      for (int n = n0; n <= n0 + 4; ++n) {
+        const int t = (k + n - 1) / n;
+        const int wins = n * ((t + margin + 47) / 48);
+        if (wins < best) { best = wins; n_out = n; t_out = t; }
+      }
+    };
+    for (int l = 0; l < p.n_levels; ++l) {
+      OrbLevelGeom& L = g.lv[l];
+      const int kw = L.w - 2 * EDGE, kh = L.h - 2 * EDGE;
+      L.dt_nx = L.dt_ny = 0; L.dt_tw = L.dt_th = 1; L.dt_start = dt; L.dt_mx = L.dt_my = 0;
+      if (kw <= 0 || kh <= 0) continue;
+      if (L.w < 64 || L.h < 64) { ok = false; continue; }
+      cut(kw, DT_TW_MAX, 39, L.dt_nx, L.dt_tw);
+      cut(kh, DT_TH_MAX, 39, L.dt_ny, L.dt_th);
+      if (L.dt_nx * L.dt_ny > 1024) ok = false;
+      L.dt_mx = (unsigned)(0x100000000ull / (unsigned)L.dt_tw) + 1u;     // floor(n / d) = umulhi(n, floor(2^32 / d) + 1) for n, d < 2^16
+      L.dt_my = (unsigned)(0x100000000ull / (unsigned)L.dt_th) + 1u;
+      dt += L.dt_nx * L.dt_ny;
+    }
+    g.dt_total = ok ? dt : 0;
+  }
   // resize tables
   std::vector<unsigned> tab;
   h->resize_tab_off.assign(2 * ORBX_MAX_LEVELS, 0);
@@ -1750,6 +2074,12 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
       for (int tx = 0; tx < L.ftiles_x; ++tx) tab.push_back((unsigned)l | ((unsigned)tx << 3) | ((unsigned)ty << 17));
   }
   if ((int)(tab.size() - h->ftile_tab_off) != ft) return orbx_fail(h, ORBX_ERR_INVALID, "internal: FAST tile table size mismatch");
+  h->dtile_tab_off = (unsigned)tab.size();
+  if (g.dt_total > 0)
+    for (int l = 0; l < p.n_levels; ++l)
+      for (int ty = 0; ty < g.lv[l].dt_ny; ++ty)
+        for (int tx = 0; tx < g.lv[l].dt_nx; ++tx) tab.push_back((unsigned)l | ((unsigned)tx << 3) | ((unsigned)ty << 17));
+  if ((int)(tab.size() - h->dtile_tab_off) != g.dt_total) return orbx_fail(h, ORBX_ERR_INVALID, "internal: describe tile table size mismatch");
   if (int rc = orbx_reserve(h, h->resize_tab, sizeof(unsigned) * (tab.size() + 1))) return rc;
   ORBX_HIP(h, hipMemcpy(h->resize_tab.p, tab.data(), sizeof(unsigned) * tab.size(), hipMemcpyHostToDevice));
   static_assert(sizeof(kPattern31) == 256 * 4 * sizeof(int), "pattern table");
@@ -1792,6 +2122,18 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
           band[((size_t)set * 64 + lane) * 4 + (j >> 2)] |= v << (8 * (j & 3));
         }
     ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_blur_band), band.data(), band.size() * sizeof(unsigned)));
+    // describe_tile_kernel's operands: windows of 64 rows x 64 bytes, output (x, y) from window bytes x .. x + 6 of rows y .. y + 6, all 64 k-slots real:
+    //   sets 0..2  T1: byte j = tap[c - x], c = 16 g + j, x = 16 nb + m;   sets 3..5  T2: byte j = tap[rho - y], rho = 16 (j >> 2) + 4 g + (j & 3), y = 16 mb + m
+    std::vector<unsigned> band_t(6 * 64 * 4, 0u);
+    for (int set = 0; set < 6; ++set)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 16; ++j) {
+          const int m = lane & 15, gq = lane >> 4;
+          const int idx = set < 3 ? (16 * gq + j) - (16 * set + m) : (16 * (j >> 2) + 4 * gq + (j & 3)) - (16 * (set - 3) + m);
+          const unsigned v = (idx >= 0 && idx <= 6) ? (unsigned)tap[idx] : 0u;
+          band_t[((size_t)set * 64 + lane) * 4 + (j >> 2)] |= v << (8 * (j & 3));
+        }
+    ORBX_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(c_blur_band_t), band_t.data(), band_t.size() * sizeof(unsigned)));
   }
   h->geom = g;
   h->geom_w = w;
@@ -1810,6 +2152,7 @@ int orb_extract_prepare(orbx_handle* h, int n_images, int w, int h_px) {
   if (int rc = orbx_reserve(h, h->ws_cand, sizeof(unsigned) * (size_t)g.cand_total * n_images)) return rc;
   if (int rc = orbx_reserve(h, h->ws_sel, sizeof(unsigned long long) * (size_t)g.cand_total * n_images)) return rc;
   if (int rc = orbx_reserve(h, h->ws_sel2, sizeof(unsigned long long) * (size_t)g.cand_total * n_images)) return rc;
+  if (int rc = orbx_reserve(h, h->ws_dtile, sizeof(uint2) * (size_t)std::max(g.dt_total, 1) * n_images)) return rc;
   // counters: cand_count[n_il], sel_count[n_il], kept[n_il], hist[n_il*256]
   const size_t n_cnt = n_il * (3 + 256);
   if (int rc = orbx_reserve(h, h->ws_counters, sizeof(unsigned) * n_cnt)) return rc;
@@ -1850,6 +2193,7 @@ int orb_extract_range(orbx_handle* h, hipStream_t st, const uint8_t* d_images, i
     unsigned* cand = (unsigned*)h->ws_cand.p + (size_t)img0 * g.cand_total;
     unsigned long long* sel = (unsigned long long*)h->ws_sel.p + (size_t)img0 * g.cand_total;
     unsigned long long* sel2 = (unsigned long long*)h->ws_sel2.p + (size_t)img0 * g.cand_total;
+    uint2* dtile = (uint2*)h->ws_dtile.p + (size_t)img0 * (size_t)g.dt_total;
     {
       ProfScope ps(h, "resize_kernel", st);
       for (int l = 1; l < nl; ++l) {
@@ -1928,10 +2272,18 @@ int orb_extract_range(orbx_handle* h, hipStream_t st, const uint8_t* d_images, i
     {
       ProfScope ps(h, "rank_select_kernel", st, true);
       hipLaunchKernelGGL(rank_select_kernel, xcd_grid(nl, n), dim3(RK_NT), 0, st, g, n, xcd_map(nl), sel, sc,
-                         sel2, kp);
+                         sel2, kp, dtile);
     }
     if (fork) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
-    {
+    // Round 5: one workgroup per describe tile, the patch blur shared by the tile's keypoints (describe_tile_kernel); ORBX_DESC_TILE=0 (read when
+    // the geometry is prepared) or a level too small for a 64 x 64 window keeps the per-keypoint form
+    if (g.dt_total > 0 && !unfused) {
+      ProfScope ps(h, "describe_tile_kernel", st, true);
+      // the level's bytes of a window are read where the level lives: level 0 may be the caller's image (row pitch s.l0_pitch >= w >= 64)
+      hipLaunchKernelGGL(describe_tile_kernel, xcd_grid(g.dt_total, n), dim3(256), 0, st, s, g, n, xcd_map(g.dt_total), tab + h->dtile_tab_off,
+                         (const uint2*)dtile, (const unsigned long long*)sel2, (const unsigned long long*)sel, kp, d_kp + (size_t)img0 * cap_kp,
+                         d_desc + (size_t)img0 * cap_kp * 32, d_nkp + img0, cap_kp, (float)h->orb.patch_size, h->d_status);
+    } else {
       ProfScope ps(h, unfused ? "describe_kernel" : "describe_fused_kernel", st, true);
       const int blocks_x16 = (h->orb.n_features + 64 + 15) / 16;   // 16 keypoints per block and round
       const int blocks_x = unfused ? blocks_x16 : (blocks_x16 + ORBX_DF_ITERS - 1) / ORBX_DF_ITERS;

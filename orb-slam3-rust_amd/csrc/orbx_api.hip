@@ -158,7 +158,7 @@ void orbx_destroy(orbx_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->resize_tab, &h->ws_pyr, &h->ws_blur, &h->ws_cand, &h->ws_counters,
-                    &h->ws_sel, &h->ws_sel2, &h->ws_match};
+                    &h->ws_sel, &h->ws_sel2, &h->ws_match, &h->ws_dtile};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (DevBuf& b : h->ws_io) if (b.p) hipFree(b.p);
   for (DevBuf& b : h->ws_ba) if (b.p) hipFree(b.p);

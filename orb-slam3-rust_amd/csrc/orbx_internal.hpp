@@ -130,6 +130,10 @@ struct OrbLevelGeom {
   unsigned cand_cap;   // worst-case number of NMS survivors of the level
   int btiles_x, btile_start;   // blur tiles (64x16 over the whole level)
   int ftiles_x, ftile_start;   // FAST tiles (64x16 over the border-filtered region [31,w-31)x[31,h-31))
+  // describe tiles (describe_tile_kernel): the keypoint region [31, w-32] x [31, h-32] cut into dt_nx x dt_ny rectangles of dt_tw x dt_th
+  // keypoint positions; tile of a keypoint = ((x - 31) / dt_tw, (y - 31) / dt_th), the divisions by __umulhi with dt_mx / dt_my
+  int dt_nx, dt_ny, dt_tw, dt_th, dt_start;
+  unsigned dt_mx, dt_my;
 };
 struct OrbGeom {
   int n_levels;
@@ -137,6 +141,7 @@ struct OrbGeom {
   int fast_threshold;
   unsigned slot_bytes;   // bytes of one image's pyramid (and blur) slot
   unsigned cand_total;   // candidate slots per image (sum of cand_cap)
+  int dt_total;          // describe tiles per image (all levels); 0: the image size does not admit them (describe_fused_kernel then)
   OrbLevelGeom lv[ORBX_MAX_LEVELS];
 };
 // Where level images live: level 0 is the caller's image when it is 4-byte aligned with a pitch
@@ -189,11 +194,12 @@ struct orbx_handle {
   OrbGeom geom{};
   DevBuf resize_tab;                     // per level l>=1: xtab[w_l], ytab[h_l] packed (ofs<<16 | c1)
   std::vector<unsigned> resize_tab_off;  // element offsets: [2*l] x table, [2*l+1] y table
-  unsigned btile_tab_off = 0, ftile_tab_off = 0;   // tile -> (level, tx, ty) tables of the blur / FAST launches, same buffer
+  unsigned btile_tab_off = 0, ftile_tab_off = 0, dtile_tab_off = 0;   // tile -> (level, tx, ty) tables of the blur / FAST / describe launches, same buffer
   OrbSrc last_src{};                               // where the level images of the last extraction live, and how many images it held:
   int last_n_images = 0;                           // orbx_debug_read_level(which = 1) blurs them on demand (the product path keeps no blurred pyramid)
   // grow-only workspaces
   DevBuf ws_pyr, ws_blur, ws_cand, ws_counters, ws_sel, ws_sel2, ws_match, ws_io[12];
+  DevBuf ws_dtile;                       // [image][describe tile] (begin, end) inside the level's spatially ordered keypoint list (rank_select_kernel)
   DevBuf ws_ba[28];
   // pipelined host-batch path: copy streams, events, double-buffered staging
   hipStream_t s_in = nullptr, s_out = nullptr;
