@@ -847,13 +847,31 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ img
   // 9x9 window as 9 rows x 3 unaligned dwords (27 loads instead of 81 byte loads; one unaligned global_load_dwordx3 per row — 9 loads —
   // measured 0.159 against 0.150 ms per 256 pairs, round 4: the 12-byte form does not go through the address coalescer as three dwords do)
   int rowm[9], row0[9], rowp[9];
-  const uint8_t* p = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
+  // Round 5: each row as ONE 12-byte load on a 4-byte boundary (level rows start on 4-byte boundaries and x0 - 4 - sh + 11 < w), the window
+  // shifted into place by v_alignbyte_b32: 9 aligned loads instead of 27 dwords at odd addresses, 0.142 -> 0.139 ms per 256 pairs
+  // (ORBX_HARRIS_UNALIGNED: the three dwords at x0 - 4 as before, A/B builds)
   unsigned w[9][3];
+#ifdef ORBX_HARRIS_UNALIGNED
+  const uint8_t* p = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
 #pragma unroll
   for (int r = 0; r < 9; ++r) {
     const uint8_t* pr = p + (size_t)r * pitch;
     w[r][0] = ld_u32(pr); w[r][1] = ld_u32(pr + 4); w[r][2] = ld_u32(pr + 8);
   }
+#else
+  const unsigned sh = (unsigned)(x0 - 4) & 3u;
+  const uint8_t* p = img + (unsigned)(__umul24((unsigned)(y0 - 4), (unsigned)pitch) + ((unsigned)(x0 - 4) & ~3u));
+  struct alignas(4) Row12 { unsigned d[3]; };
+  Row12 rw[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) rw[r] = *reinterpret_cast<const Row12*>(p + (unsigned)r * (unsigned)pitch);
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    w[r][0] = __builtin_amdgcn_alignbyte(rw[r].d[1], rw[r].d[0], sh);
+    w[r][1] = __builtin_amdgcn_alignbyte(rw[r].d[2], rw[r].d[1], sh);
+    w[r][2] = rw[r].d[2] >> (8u * sh);
+  }
+#endif
 #define ORBX_ROW(dst, r)                                                                    \
   _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                             \
     dst[k] = (int)((w[r][0] >> (8 * k)) & 0xffu);                                             \
@@ -1059,6 +1077,8 @@ __global__ __launch_bounds__(RK_NT) void rank_select_kernel(OrbGeom g, int n_img
                                                            const unsigned* __restrict__ sel_count,
                                                            unsigned long long* __restrict__ sel2,
                                                            unsigned* __restrict__ kept, uint2* __restrict__ tile_rng) {
+  // (Round 5: the Harris responses inside this kernel — survivors compacted into the key array, responses computed densely, sorted in place —
+  // took 0.215-0.218 ms against 0.139 + 0.074 for the two launches: profiles/r05_select_fused_negative.txt.  Withdrawn.)
   __shared__ unsigned long long chunk[2048];
   __shared__ unsigned skey[1024 + 16];
   __shared__ unsigned s_thr, s_keep;
@@ -1575,11 +1595,8 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
     {
       const int m16 = lane & 15, q = lane >> 4;
       const df_i4* band = reinterpret_cast<const df_i4*>(c_blur_band) + lane;
-#ifndef ORBX_DF_BLUR_KPS
-#define ORBX_DF_BLUR_KPS DG_PER_WAVE     // measurement builds only: fewer than 4 leaves keypoints' patches unblurred (results meaningless)
-#endif
 #pragma unroll 1
-      for (int kp = 0; kp < ORBX_DF_BLUR_KPS; ++kp) {
+      for (int kp = 0; kp < DG_PER_WAVE; ++kp) {
         unsigned char* win = wwin + kp * DF_WIN_BYTES;
         df_i4 a1[3];
 #pragma unroll
@@ -1755,11 +1772,7 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
   {
     const int m16 = lane & 15, q = lane >> 4;
     const df_i4* band = reinterpret_cast<const df_i4*>(c_blur_band_t) + lane;
-#if defined(ORBX_DT_SKIP) && ORBX_DT_SKIP == 1     // measurement builds only (results meaningless): 1 = no blur, 2 = no keypoint phase, 3 = no centroid loads
-    const int nwin = 0;
-#else
     const int nwin = nwx * nwy;
-#endif
     // a window's origin and its A operands (the loads of window wi + 4 travel under the products of window wi)
     const unsigned p16 = 16u * (unsigned)pitch;
     auto origin = [&](int wi, int& c, int& r) {
@@ -1769,19 +1782,9 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
     auto fetch = [&](int wi, df_i4 (&a)[4]) {
       int c, r;
       origin(wi, c, r);
-#ifdef ORBX_DT_ALIGN      // measurement builds only (results meaningless): window columns on ORBX_DT_ALIGN-byte boundaries; 0 = no loads at all
-#if ORBX_DT_ALIGN > 0
-      c &= ~(ORBX_DT_ALIGN - 1);
-#endif
-#endif
       const uint8_t* wp = src + (unsigned)(__umul24((unsigned)(r + m16), (unsigned)pitch) + (unsigned)(c + 16 * q));
-#if defined(ORBX_DT_ALIGN) && ORBX_DT_ALIGN == 0
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) a[mb] = (df_i4){c + mb, r, m16, q};
-#else
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) __builtin_memcpy(&a[mb], wp + (unsigned)mb * p16, 16);
-#endif
     };
     df_i4 anx[4];
     if (wave < nwin) fetch(wave, anx);
@@ -1822,28 +1825,38 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
     }
   }
   __syncthreads();
-#if defined(ORBX_DT_SKIP) && ORBX_DT_SKIP == 2
-  if (s_tile[tid] == 1 && s_tile[tid + 256] == 77) return;
-  if (tid >= 0) return;
-#endif
   // ---- 2. the tile's keypoints, four per wave and round (16 lanes each)
   // Two keypoint groups ahead: the list entry of group gi + 8 and the centroid pixels of group gi + 4 are requested while group gi is worked on
   // (list entry -> pixels -> arithmetic is two dependent round trips to L2 per group otherwise, with four waves per SIMD to hide them).
   // Intensity centroid over the 749-pixel disc straight from the level image (integer, order independent): lane li takes rows
   // 4 it + (li >> 2), dwords 2 (li & 3) and 2 (li & 3) + 1 of the row as ONE 8-byte load (row 31 does not exist: zero weights, re-reads row 30)
   const unsigned astep = 4u * (unsigned)pitch;
+  // (each 8-byte piece as ONE 12-byte load on a 4-byte boundary, shifted into place by two v_alignbyte_b32: loads at odd addresses go through
+  // the address path lane by lane — 0.065 of this kernel's 0.55 ms per 256 pairs; ORBX_DT_CENTROID_UNALIGNED keeps the 8-byte form for A/B builds)
+  struct alignas(4) Row12 { unsigned d[3]; };
   auto pixels = [&](unsigned long long e, unsigned long long (&px)[8]) {
     const int kx = (int)(e & 0xffffu), ky = (int)((e >> 16) & 0xffffu);
+#ifdef ORBX_DT_CENTROID_UNALIGNED
     const uint8_t* a0 = src + (unsigned)(__umul24((unsigned)(ky - 15 + (li >> 2)), (unsigned)pitch) + (unsigned)(kx - 15 + 8 * (li & 3)));
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = 4 * it + (li >> 2);
-#if defined(ORBX_DT_SKIP) && ORBX_DT_SKIP == 3
-      px[it] = (unsigned long long)(kx * 77 + it * ky) * 0x0101010101010101ull;
-#else
       __builtin_memcpy(&px[it], a0 + ((unsigned)it * astep - (row > 30 ? (unsigned)pitch : 0u)), 8);
-#endif
     }
+#else
+    const unsigned xb = (unsigned)(kx - 15 + 8 * (li & 3)), sh = xb & 3u;     // (the last piece's 12 bytes end at kx + 20 at most: inside the row)
+    const uint8_t* a0 = src + (unsigned)(__umul24((unsigned)(ky - 15 + (li >> 2)), (unsigned)pitch) + (xb & ~3u));
+    Row12 rw[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = 4 * it + (li >> 2);
+      rw[it] = *reinterpret_cast<const Row12*>(a0 + ((unsigned)it * astep - (row > 30 ? (unsigned)pitch : 0u)));
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      px[it] = (unsigned long long)__builtin_amdgcn_alignbyte(rw[it].d[1], rw[it].d[0], sh) |
+               ((unsigned long long)__builtin_amdgcn_alignbyte(rw[it].d[2], rw[it].d[1], sh) << 32);
+#endif
   };
   unsigned long long px[8], pxn[8];
   pixels(ent, px);
