@@ -318,3 +318,61 @@ def test_profiling_of_one_kernel_only(h2000, frame0):
     assert only_ms < 3.0 * kt["fast_kernel"][0] + 0.02                            # the kernel's own duration, not the span between two of its launches
     h2000.set_profiling(False)
     assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b[-1]))
+
+
+def test_describe_tile_form_equals_per_keypoint_form(pkg, tmp_path):
+    """describe_tile_kernel (one workgroup per describe tile: the tile's rectangle blurred once into LDS, the keypoints ordered by tile by
+    rank_select_kernel) against describe_fused_kernel (a 48 x 48 window blurred per keypoint; ORBX_DESC_TILE=0): the same integers, so
+    keypoints and descriptors must be the same bits.  Sizes: the bench's, 400 x 226 whose level 7 is 63 rows — keypoints but no room for a 64 x 64
+    window: the tile form must step aside by itself (no describe tiles) —, odd widths that pull the last window of a row / column back inside the level, a row
+    pitch that is not a multiple of 4 (level 0 copied), 1920 x 1080, and a batch whose images differ.  Two child processes: the switch is
+    read when the geometry is prepared."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import torch
+        import orb_slam3_rust_amd as P
+        cam = P.CameraModel(**P.synth.EUROC_CAMERA)
+        out = {}
+        rng = np.random.default_rng(77)
+        def scene(w, h, seed):
+            L, R = P.synth.stereo_pair(seed, seed, w=w, h=h)
+            return L, R
+        for i, (w, hh, n) in enumerate([(752, 480, 2000), (333, 259, 500), (400, 226, 500), (641, 479, 1200), (190, 150, 300), (1241, 376, 1500), (1920, 1080, 4000)]):
+            h = P.Handle(cam, n, device=0, max_w=w, max_h=hh, max_batch=1)
+            L, R = scene(w, hh, 40 + i)
+            kpL, dL, kpR, dR, m, pts, has = h.process_stereo(L, R, cap_kp=n + 2048)
+            out["kL%%d" %% i] = np.frombuffer(kpL.tobytes(), np.uint8); out["dL%%d" %% i] = dL
+            out["kR%%d" %% i] = np.frombuffer(kpR.tobytes(), np.uint8); out["dR%%d" %% i] = dR
+            out["m%%d" %% i] = np.frombuffer(m.tobytes(), np.uint8)
+            h.close()
+        # binary dot grid: every FAST score and every Harris response ties, all candidates are kept — more than 2048 on level 0, so the
+        # rank-sort path (which orders by tile too) runs
+        h = P.Handle(cam, 300, device=0, max_w=752, max_h=480, max_batch=1)
+        dots = np.full((480, 752), 20, np.uint8)
+        dots[8::12, 8::12] = 240
+        kpL, dL, kpR, dR, m, pts, has = h.process_stereo(dots, dots, cap_kp=20000)
+        out["kn"] = np.frombuffer(kpL.tobytes(), np.uint8); out["dn"] = dL
+        h.close()
+        # a device batch of different images
+        h = P.Handle(cam, 2000, device=0, max_w=752, max_h=480, max_batch=6)
+        pairs = np.stack([np.stack(P.synth.stereo_pair(3, f)) for f in range(6)])
+        o = h.alloc_batch_outputs(6, 2000 + 1024)
+        h.process_stereo_batch_device(torch.from_numpy(pairs).cuda(), o)
+        h.synchronize()
+        out["bk"] = o["kp"].cpu().numpy().view(np.uint8).reshape(-1); out["bd"] = o["desc"].cpu().numpy().reshape(-1); out["bn"] = o["nkp"].cpu().numpy()
+        h.close()
+        np.savez(sys.argv[1], **out)
+    """ % root)
+    res = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / ("tile%s.npz" % mode))
+        env = dict(os.environ, ORBX_DESC_TILE=mode)
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=env, timeout=600)
+        res[mode] = np.load(path)
+    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 40
+    for k in res["1"].files:
+        assert np.array_equal(res["1"][k], res["0"][k]), k
+    assert len(res["1"]["dn"]) > 1500 and int(res["1"]["bn"].min()) > 1500
