@@ -172,7 +172,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)      # 60 x 2.3 ms: a timed region of ~0.14 s (20 steps = 45 ms was thin)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="stereo pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="stereo pairs per step per GPU (256 until round 4; round 5: 512 — same kernels, the launches' ramps and tails "
+                                                          "over twice the work: +3.7 %, profiles/r05_batch_sweep.txt; the 256-pair figure stays in batch_sweep)")
     ap.add_argument("--n-batches", type=int, default=3)
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--width", type=int, default=752)
@@ -293,12 +294,26 @@ def main():
     # rows 10 .. h-11): what describe_fused_kernel must fetch from HBM ONCE per image — neighbouring keypoints' windows overlap 3.3-fold,
     # and all but the first read of a line come out of L2 (the XCD-aware block map keeps an image on one XCD)
     px_win = [max(0, a - 14) * max(0, b - 20) for a, b in lv]
+    # describe_tile_kernel (round 5): a tile's blur windows cover the keypoint region + 21 px on every side — columns / rows 10 .. w-11 / h-11 of
+    # a level, read ONCE per image from HBM (a tile's 36-px margin is read again by its neighbours, out of L2), and the centroid's 31-row discs
+    # lie inside that rectangle
+    px_tile = [max(0, a - 20) * max(0, b - 20) for a, b in lv]
+    def _cut(k, tmax, margin):       # orb_prepare_geometry's cut of a level's keypoint region into describe tiles: (windows, tiles)
+        best = None
+        n0 = -(-k // tmax)
+        for n in range(n0, n0 + 5):
+            t = -(-k // n); wins = n * (-(-(t + margin) // 48))
+            if best is None or wins < best[0]:
+                best = (wins, n)
+        return best
+    dt_windows = sum(_cut(a - 62, 153, 39)[0] * _cut(b - 62, 153, 39)[0] for a, b in lv if a > 62 and b > 62)
     # HBM bytes each kernel must move per launch (compulsory: every input byte once, every output byte once), x images per launch
     per_launch = {
         "fast_kernel": n_img * (sum(px) + 4 * 2 * args.features),          # read every level once, write candidates
         "blur_kernel": n_img * 2 * sum(px),                                # read + write every level
         "resize_kernel": n_img * (sum(px[:-1]) + sum(px[1:])) / 7.0,       # 7 launches: read l-1, write l
         "describe_fused_kernel": n_img * (sum(px_win) + args.features * (28 + 32)),    # the reachable part of every level once, the keypoint records and descriptors out
+        "describe_tile_kernel": n_img * (sum(px_tile) + args.features * (8 + 8 + 28 + 32)),   # the same rectangle once, list entry + response in, keypoint record + descriptor out
         "describe_kernel": n_img * (2 * sum(px_win) + args.features * (28 + 32)),      # (ORBX_DESC_UNFUSED=1: the level and the blurred level)
         "harris_select_kernel": n_img * 2 * args.features * (81 + 4 + 8),
         "rank_select_kernel": n_img * 2 * args.features * 16,
@@ -309,6 +324,7 @@ def main():
     # what the kernel REQUESTS from the memory hierarchy (L2 and below), overlap counted every time — not an HBM figure, never `achieved`
     l2_requests = {
         "describe_fused_kernel": n_img * args.features * (43 * 43 + 28 + 32),
+        "describe_tile_kernel": n_img * (dt_windows * 64 * 64 + args.features * (31 * 4 * 12 + 8 + 8 + 28 + 32)),   # 64 x 64 bytes per blur window, 4 x 12 bytes per centroid row
         "describe_kernel": n_img * args.features * (31 * 31 + 37 * 37 + 28 + 32),
     }
     launch_s = dom_ms / max(dom_launches, 1) * 1e-3
@@ -433,7 +449,7 @@ def bench_extras(P, h, torch, batches, out, args, W, H):
     r = {}
     # batch sweep: pairs resident in HBM, no per-kernel events
     sweep = {}
-    for b in (1, 8, 64, 256):
+    for b in (1, 8, 64, 256, 512):
         if b > args.batch:
             continue
         sub = [x[:b].contiguous() for x in batches]
