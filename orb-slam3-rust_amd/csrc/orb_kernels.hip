@@ -2293,7 +2293,11 @@ int orb_extract_range(orbx_handle* h, hipStream_t st, const uint8_t* d_images, i
     if (fork) ORBX_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
     // Round 5: one workgroup per describe tile, the patch blur shared by the tile's keypoints (describe_tile_kernel); ORBX_DESC_TILE=0 (read when
     // the geometry is prepared) or a level too small for a 64 x 64 window keeps the per-keypoint form
-    if (g.dt_total > 0 && !unfused) {
+    // Small calls keep the per-keypoint form: a pair is 104 tiles — 104 workgroups that each walk ~4 window rounds and ~3 keypoint rounds one after
+    // the other — against 126 workgroups of 32 keypoints; one pair per call 0.319 against 0.272 ms, 8 pairs 50.9 against 52.7 k frames/s, 64 pairs
+    // 133 against 126 k (profiles/r05_bench_b512_mid.json against round 4's line).  ORBX_DESC_TILE=1 forces the tile form (tests).
+    static const bool dt_force = [] { const char* e = getenv("ORBX_DESC_TILE"); return e && atoi(e) == 1; }();
+    if (g.dt_total > 0 && !unfused && (dt_force || (size_t)g.dt_total * (size_t)n >= (size_t)8 * (size_t)h->n_cu)) {
       ProfScope ps(h, "describe_tile_kernel", st, true);
       // the level's bytes of a window are read where the level lives: level 0 may be the caller's image (row pitch s.l0_pitch >= w >= 64)
       hipLaunchKernelGGL(describe_tile_kernel, xcd_grid(g.dt_total, n), dim3(256), 0, st, s, g, n, xcd_map(g.dt_total), tab + h->dtile_tab_off,

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The extractor describes small calls (a pair, a few pairs) with the per-keypoint kernel and large batches with the tile kernel (bench.py's
+# workload).  The suite's calls are small, so the tile form is forced here: every extractor parity test then checks the kernel the headline is
+# measured on against the oracle; the per-keypoint form is compared with it bit for bit by test_describe_tile_form_equals_per_keypoint_form
+# (child processes with ORBX_DESC_TILE=0 / 1) and runs in smoke() and bench.py's small legs.  Read by the library when it first prepares a geometry.
+os.environ.setdefault("ORBX_DESC_TILE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
