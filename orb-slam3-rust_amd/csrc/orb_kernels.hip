@@ -1785,12 +1785,13 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
     auto fetch = [&](int wi, df_i4 (&a)[4]) {
       int c, r;
       origin(wi, c, r);
-      const uint8_t* wp = src + (unsigned)(__umul24((unsigned)(r + m16), (unsigned)pitch) + (unsigned)(c + 16 * q));
+      unsigned off = __umul24((unsigned)(r + m16), (unsigned)pitch) + (unsigned)(c + 16 * q);
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) __builtin_memcpy(&a[mb], wp + (unsigned)mb * p16, 16);
+      for (int mb = 0; mb < 4; ++mb) { __builtin_memcpy(&a[mb], src + off, 16); off += p16; }
     };
     df_i4 anx[4];
     if (wave < nwin) fetch(wave, anx);
+    // (s_setprio 1 / 3 for the blur phase, 0 for the keypoint phase: 1.07 against 1.047 ms per 512 pairs — profiles/r05_describe_tile_steps.txt)
     for (int wi = wave; wi < nwin; wi += 4) {
       int c, r;
       origin(wi, c, r);
@@ -1848,12 +1849,13 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
     }
 #else
     const unsigned xb = (unsigned)(kx - 15 + 8 * (li & 3)), sh = xb & 3u;     // (the last piece's 12 bytes end at kx + 20 at most: inside the row)
-    const uint8_t* a0 = src + (unsigned)(__umul24((unsigned)(ky - 15 + (li >> 2)), (unsigned)pitch) + (xb & ~3u));
+    // 32-bit offsets from the (uniform) level base, stepped by additions: scalar base + VGPR offset loads, no 64-bit address arithmetic
+    unsigned off = __umul24((unsigned)(ky - 15 + (li >> 2)), (unsigned)pitch) + (xb & ~3u);
     Row12 rw[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int row = 4 * it + (li >> 2);
-      rw[it] = *reinterpret_cast<const Row12*>(a0 + ((unsigned)it * astep - (row > 30 ? (unsigned)pitch : 0u)));
+      rw[it] = *reinterpret_cast<const Row12*>(src + (it == 7 && (li >> 2) == 3 ? off - (unsigned)pitch : off));   // (row 31 does not exist: re-reads row 30)
+      off += astep;
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it)
