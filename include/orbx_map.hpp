@@ -13,6 +13,9 @@
 //   solve_inertial_ba         orbx.hpp (GPU)
 //   apply_inertial_ba_results local_inertial_ba.rs:1289-1330
 //
+// and the host phases of global BA (src/optimizer/global_ba.rs): collect_global_ba_data :100-181, apply_global_ba_results :421-443,
+// run_global_ba :450-500 around solve_global_ba (orbx.hpp, GPU).
+//
 // The reference walks its HashMap-based `Map` under a read lock.  A GPU-side BA wants the same information as a handful
 // of arrays, so the snapshot here is CSR: keyframes with their features (map-point id or none, keypoint position), their
 // covisibility lists, map points with their observer lists.  A Rust shim fills it under the read lock (or keeps it in
@@ -34,6 +37,7 @@
 #define ORBX_MAP_HPP
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <optional>
 #include <unordered_map>
@@ -385,6 +389,87 @@ inline std::optional<size_t> local_bundle_adjustment(Handle& h, MapSnapshot& map
     if (lock_write) lock_write(phase3); else phase3();
   }
   return updated;
+}
+
+// ---- global BA (src/optimizer/global_ba.rs), the host phases around solve_global_ba ---------------------------------------------------
+// PHASE 1, global_ba.rs:100-181.  ORDER: the reference walks map.keyframes() and map.map_points() — HashMap iterations — and sorts only the
+// keyframe ids (:122); the map points keep the HashMap's order (:131-144), which is the parameter order of the solve.  Here: the snapshot's
+// map-point order.  A map point is taken when it is not bad and ANY of its observers is a collected keyframe (:137); observations are walked
+// keyframe by keyframe in ascending id, features in order (:154-170).
+inline std::optional<GlobalBAProblemData> collect_global_ba_data(const MapSnapshot& m) {
+  GlobalBAProblemData p;
+  for (size_t k = 0; k < m.kf_ids.size(); ++k) {                                     // :108-114
+    if (m.kf_bad[k]) continue;
+    p.kf_ids.push_back(m.kf_ids[k]);
+    p.kf_poses[m.kf_ids[k]] = se3_inverse(m.kf_pose((int)k));                        // T_cw
+  }
+  if (p.kf_ids.empty()) return std::nullopt;                                         // :116-118
+  std::sort(p.kf_ids.begin(), p.kf_ids.end());                                       // :121
+  p.fixed_kf_id = p.kf_ids.front();                                                  // :124
+  const std::unordered_set<KeyFrameId> kf_set(p.kf_ids.begin(), p.kf_ids.end());
+  for (size_t j = 0; j < m.mp_ids.size(); ++j) {                                     // :129-144
+    if (m.mp_bad[j]) continue;
+    bool has_valid_obs = false;
+    for (int o = m.mp_obs_start[j]; o < m.mp_obs_start[j + 1] && !has_valid_obs; ++o) has_valid_obs = kf_set.count(m.mp_obs_kf_id[(size_t)o]) != 0;
+    if (!has_valid_obs) continue;
+    p.mp_ids.push_back(m.mp_ids[j]);
+    p.mp_positions[m.mp_ids[j]] = {m.mp_pos[3 * j], m.mp_pos[3 * j + 1], m.mp_pos[3 * j + 2]};
+  }
+  if (p.mp_ids.empty()) return std::nullopt;                                         // :146-148
+  const std::unordered_set<MapPointId> mp_set(p.mp_ids.begin(), p.mp_ids.end());
+  for (KeyFrameId id : p.kf_ids) {                                                   // :153-170
+    const int k = m.kf_index(id);
+    if (k < 0) continue;
+    const int s = m.kf_feat_start[(size_t)k], e = m.kf_feat_start[(size_t)k + 1];
+    for (int f = s; f < e; ++f) {
+      const int64_t mp_id = m.feat_mp_id[(size_t)f];
+      if (mp_id < 0 || !mp_set.count((MapPointId)mp_id)) continue;
+      if (f - s >= m.kf_n_keypoints[(size_t)k]) continue;                            // keypoints.get(feat_idx) is Err
+      p.observations.push_back(GlobalBAObservation{id, (MapPointId)mp_id, {(double)m.feat_uv[2 * (size_t)f], (double)m.feat_uv[2 * (size_t)f + 1]}});
+    }
+  }
+  if (p.observations.empty()) return std::nullopt;                                   // :172-174
+  return p;
+}
+
+// PHASE 3, global_ba.rs:421-443: gone or bad entities are skipped silently (the fixed keyframe's unchanged pose counts as an update too)
+inline size_t apply_global_ba_results(MapSnapshot& m, const GlobalBAResult& r) {
+  size_t updated = 0;
+  for (const auto& kv : r.optimized_poses) {
+    const int k = m.kf_index(kv.first);
+    if (k >= 0 && !m.kf_bad[(size_t)k]) {
+      for (int i = 0; i < 4; ++i) m.kf_pose_wc[7 * (size_t)k + i] = kv.second.rotation[(size_t)i];
+      for (int i = 0; i < 3; ++i) m.kf_pose_wc[7 * (size_t)k + 4 + i] = kv.second.translation[(size_t)i];
+      ++updated;
+    }
+  }
+  for (const auto& kv : r.optimized_points) {
+    const int j = m.mp_index(kv.first);
+    if (j >= 0 && !m.mp_bad[(size_t)j]) {
+      for (int i = 0; i < 3; ++i) m.mp_pos[3 * (size_t)j + i] = kv.second[(size_t)i];
+      ++updated;
+    }
+  }
+  return updated;
+}
+
+// run_global_ba (global_ba.rs:450-500): collect under the read lock, solve with no lock (should_stop = the running flag cleared), apply under the
+// write lock — unconditionally, unlike local BA (:486-489); `running` is set on entry and cleared on every way out (:456, :468, :479, :498).
+inline std::optional<GlobalBAResult> run_global_ba(Handle& h, MapSnapshot& map, const CameraModel& camera, const GlobalBAConfig& config,
+                                                   std::atomic<bool>& running,
+                                                   const std::function<void(const std::function<void()>&)>& lock_read = nullptr,
+                                                   const std::function<void(const std::function<void()>&)>& lock_write = nullptr) {
+  running.store(true);
+  std::optional<GlobalBAProblemData> problem;
+  auto phase1 = [&] { problem = collect_global_ba_data(map); };
+  if (lock_read) lock_read(phase1); else phase1();
+  if (!problem) { running.store(false); return std::nullopt; }
+  std::optional<GlobalBAResult> result = solve_global_ba(h, *problem, camera, config, [&] { return !running.load(); });
+  if (!result) { running.store(false); return std::nullopt; }
+  auto phase3 = [&] { apply_global_ba_results(map, *result); };
+  if (lock_write) lock_write(phase3); else phase3();
+  running.store(false);
+  return result;
 }
 
 }  // namespace orbx

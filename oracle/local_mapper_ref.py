@@ -7,6 +7,7 @@
     collect_temporal_keyframes / collect_map_points / collect_fixed_keyframes      local_inertial_ba.rs:366-429
     collect_inertial_ba_data                                                       local_inertial_ba.rs:933-1072
     apply_inertial_ba_results                                                      local_inertial_ba.rs:1289-1330
+    collect_global_ba_data / apply_global_ba_results / run_global_ba               global_ba.rs:100-181, :421-443, :450-500
 
 over a Map made of Python dicts, written line by line after the Rust.  The reference iterates `HashMap`s and `HashSet`s
 (covisibility weights :675, the map-point set :704, the fixed-keyframe set :725, observations.keys() :718), whose order is
@@ -289,3 +290,72 @@ def local_bundle_adjustment(m: Map, kf_id, solve, max_covisible_keyframes=20, so
     if result["iterations"] > 0:                                           # :396
         return apply_visual_ba_results(m, result["optimized_poses"], result["optimized_points"])
     return 0
+
+
+# ---- global BA: the host phases around solve_global_ba (src/optimizer/global_ba.rs) ---------------------------------------------
+def collect_global_ba_data(m: Map):                                             # :100-181
+    kf_ids = []
+    kf_poses = {}
+    for kf_id, kf in m.keyframes.items():                                       # :108-114
+        if kf.is_bad:
+            continue
+        kf_ids.append(kf_id)
+        kf_poses[kf_id] = se3_inverse(kf.pose)                                  # T_cw
+    if not kf_ids:
+        return None
+    kf_ids.sort()                                                               # :121
+    fixed_kf_id = kf_ids[0]                                                     # :124
+    kf_set = set(kf_ids)
+    mp_ids = []
+    mp_positions = {}
+    for mp_id, mp in m.map_points.items():                                      # :129-144 (HashMap order = insertion order here)
+        if mp.is_bad:
+            continue
+        if not any(k in kf_set for k in mp.observations.keys()):                # :137
+            continue
+        mp_ids.append(mp_id)
+        mp_positions[mp_id] = mp.position
+    if not mp_ids:
+        return None
+    mp_set = set(mp_ids)
+    observations = []
+    for kf_id in kf_ids:                                                        # :153-170
+        kf = m.keyframes.get(kf_id)
+        if kf is None:
+            continue
+        for feat_idx, mp_id in enumerate(kf.map_point_ids):
+            if mp_id is not None and mp_id in mp_set and feat_idx < len(kf.keypoints):
+                observations.append(dict(kf_id=kf_id, mp_id=mp_id, uv=(float(kf.keypoints[feat_idx][0]), float(kf.keypoints[feat_idx][1]))))
+    if not observations:
+        return None
+    return dict(kf_poses=kf_poses, mp_positions=mp_positions, observations=observations, kf_ids=kf_ids, mp_ids=mp_ids, fixed_kf_id=fixed_kf_id)
+
+
+def apply_global_ba_results(m: Map, optimized_poses, optimized_points):          # :421-443
+    updated = 0
+    for kf_id, pose in optimized_poses.items():
+        kf = m.keyframes.get(kf_id)
+        if kf is not None and not kf.is_bad:
+            kf.pose = np.asarray(pose, np.float64).copy()
+            updated += 1
+    for mp_id, pos in optimized_points.items():
+        mp = m.map_points.get(mp_id)
+        if mp is not None and not mp.is_bad:
+            mp.position = np.asarray(pos, np.float64).copy()
+            updated += 1
+    return updated
+
+
+def run_global_ba(m: Map, solve, running):                                       # :450-500; `running` = one-element list (the AtomicBool)
+    running[0] = True
+    problem = collect_global_ba_data(m)
+    if problem is None:
+        running[0] = False
+        return None
+    result = solve(problem, lambda: not running[0])                              # should_stop = the flag cleared
+    if result is None:
+        running[0] = False
+        return None
+    apply_global_ba_results(m, result["optimized_poses"], result["optimized_points"])   # unconditionally (:486-489)
+    running[0] = False
+    return result

@@ -11,5 +11,5 @@ from .api import (  # noqa: F401
     VisualObservation, bf_match_crosscheck, descriptor_distance, flatten_ba_problem, load_library,
     solve_visual_ba, GlobalBAObservation, GlobalBAProblemData, GlobalBAResult, flatten_global_ba_problem, se3_inverse,
     solve_global_ba, OrbVocabulary, EurocDataset, png_decode_gray8, LocalInertialBAConfig, InertialVisualObs, ImuEdgeData, InertialBAProblemData,
-    InertialBAResultData, flatten_inertial_ba_problem, solve_inertial_ba, MapSnapshot, local_bundle_adjustment, KeyFrame, BaBatch)
+    InertialBAResultData, flatten_inertial_ba_problem, solve_inertial_ba, MapSnapshot, local_bundle_adjustment, run_global_ba, KeyFrame, BaBatch)
 from .build import LIB_PATH, build  # noqa: F401

@@ -1294,6 +1294,46 @@ class MapSnapshot:
                 updated += 1
         return updated
 
+    # ---- global_ba.rs:100-181, :421-443 ----------------------------------------------------------------------------
+    def collect_global_ba_data(self) -> Optional["GlobalBAProblemData"]:
+        """PHASE 1 = collect_global_ba_data, global_ba.rs:100-181.  Keyframes: not bad, ids ascending (:121), the first one fixed; map points:
+        not bad and seen by ANY collected keyframe (:137), in the snapshot's order (the reference's is its HashMap's); observations keyframe by
+        keyframe in ascending id, features in order."""
+        kf_ids = sorted(int(k) for k, bad in zip(self.kf_ids, self.kf_bad) if not bad)
+        if not kf_ids:
+            return None
+        kf_poses = {k: se3_inverse(self.kf_pose_wc[self._kf[k]]) for k in kf_ids}
+        kf_set = set(kf_ids)
+        mp_ids, mp_positions = [], {}
+        for j, mid in enumerate(self.mp_ids):
+            if self.mp_bad[j]:
+                continue
+            s, e = int(self.mp_obs_start[j]), int(self.mp_obs_start[j + 1])
+            if not any(int(k) in kf_set for k in self.mp_obs_kf_id[s:e]):
+                continue
+            mp_ids.append(int(mid))
+            mp_positions[int(mid)] = self.mp_pos[j].copy()
+        if not mp_ids:
+            return None
+        mp_set = set(mp_ids)
+        obs = []
+        for kid in kf_ids:
+            k = self._kf[kid]
+            s, e = int(self.kf_feat_start[k]), int(self.kf_feat_start[k + 1])
+            nkp = int(self.kf_n_keypoints[k])
+            for f in range(s, e):
+                mp_id = int(self.feat_mp_id[f])
+                if mp_id >= 0 and mp_id in mp_set and f - s < nkp:
+                    obs.append(GlobalBAObservation(kid, mp_id, (float(self.feat_uv[f, 0]), float(self.feat_uv[f, 1]))))
+        if not obs:
+            return None
+        return GlobalBAProblemData(kf_poses, mp_positions, obs, kf_ids, mp_ids, kf_ids[0])
+
+    def apply_global_ba_results(self, result: "GlobalBAResult") -> int:
+        """PHASE 3 = apply_global_ba_results, global_ba.rs:421-443: the same silent skips as the local one; the fixed keyframe's pose is in the
+        result too and counts."""
+        return self.apply_visual_ba_results(result)
+
     def apply_visual_ba_results(self, result: "VisualBAResultData") -> int:
         """PHASE 3 = apply_visual_ba_results, local_ba_lm.rs:1112-1138: gone or bad entities are skipped silently."""
         updated = 0
@@ -1414,6 +1454,26 @@ def solve_global_ba(problem: GlobalBAProblemData, camera: CameraModel, config: G
     out.update({k: r["poses_wc"][i] for i, k in enumerate(opt_ids)})
     return GlobalBAResult(out, {m: r["points"][i] for i, m in enumerate(problem.mp_ids)}, r["iterations"], r["initial_error"],
                           r["final_error"])
+
+
+def run_global_ba(snapshot: MapSnapshot, camera: CameraModel, config: GlobalBAConfig = None, running: Optional[list] = None,
+                  handle: Handle = None) -> Optional[GlobalBAResult]:
+    """run_global_ba (global_ba.rs:450-500): collect -> solve (should_stop = the running flag cleared by stop_global_ba, loop_closer.rs:285) ->
+    apply, unconditionally (unlike local BA, which applies only when an iteration ran).  `running`: a one-element list standing in for the
+    reference's AtomicBool — set on entry, cleared on every way out."""
+    running = running if running is not None else [False]
+    running[0] = True
+    try:
+        problem = snapshot.collect_global_ba_data()
+        if problem is None:
+            return None
+        result = solve_global_ba(problem, camera, config or GlobalBAConfig(), lambda: not running[0], handle=handle)
+        if result is None:
+            return None
+        snapshot.apply_global_ba_results(result)
+        return result
+    finally:
+        running[0] = False
 
 
 class OrbVocabulary:

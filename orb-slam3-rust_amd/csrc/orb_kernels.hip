@@ -1891,6 +1891,8 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
     }
     sA = row16_sum(sA); sB = row16_sum(sB); sC = row16_sum(sC);
     const int m10 = sA - 15 * sB, m01 = sC;
+    // (the angle and its f64 sin / cos are computed by all 16 lanes of a keypoint; computing them once per FOUR rounds — 16 keypoints, one per lane —
+    // is bounded at 1.030 -> 0.985 ms per 512 pairs by a build that skips three of four evaluations, before the broadcasts it would need: not built)
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     float ca, sa;
     sincos_deg(angle, ca, sa);

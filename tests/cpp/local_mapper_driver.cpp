@@ -6,6 +6,9 @@
 //   driver lba     <snapshot.bin> <current_kf_id> <stop_after_polls> <out.bin>     (the branch follows the snapshot's imu_initialized)
 //   driver icollect <snapshot.bin> <current_kf_id> <window_size> <out.bin>         collect_inertial_ba_data (phase 1 of the inertial branch)
 //   driver iapply   <snapshot.bin> <result.bin> <out.bin>                          apply_inertial_ba_results
+//   driver gcollect <snapshot.bin> 0 0 <out.bin>                                   collect_global_ba_data
+//   driver gapply   <snapshot.bin> <result.bin> <out.bin>                          apply_global_ba_results (result file as for `apply`)
+//   driver gba      <snapshot.bin> <stop_after_polls> 0 <out.bin>                  run_global_ba on the GPU
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -117,6 +120,33 @@ static void write_problem(FILE* f, const std::optional<orbx::VisualBAProblemData
   }
 }
 
+// GlobalBAProblemData: [some] then [fixed id, n_kf, n_mp, n_obs] | kf ids | mp ids | obs (kf, mp, u, v) | per kf id (id, present, pose7) | per mp id (id, present, xyz)
+static void write_global_problem(FILE* f, const std::optional<orbx::GlobalBAProblemData>& p) {
+  const uint64_t some = p ? 1 : 0;
+  put(f, &some, 1);
+  if (!p) return;
+  const uint64_t hdr[4] = {p->fixed_kf_id, p->kf_ids.size(), p->mp_ids.size(), p->observations.size()};
+  put(f, hdr, 4);
+  put(f, p->kf_ids.data(), p->kf_ids.size());
+  put(f, p->mp_ids.data(), p->mp_ids.size());
+  for (const auto& o : p->observations) {
+    const uint64_t ids[2] = {o.kf_id, o.mp_id};
+    put(f, ids, 2); put(f, o.observed_uv.data(), 2);
+  }
+  for (uint64_t id : p->kf_ids) {
+    auto it = p->kf_poses.find(id);
+    const uint64_t present = it != p->kf_poses.end();
+    const orbx::SE3 s = present ? it->second : orbx::SE3{};
+    put(f, &id, 1); put(f, &present, 1); put(f, s.rotation.data(), 4); put(f, s.translation.data(), 3);
+  }
+  for (uint64_t id : p->mp_ids) {
+    auto it = p->mp_positions.find(id);
+    const uint64_t present = it != p->mp_positions.end();
+    const std::array<double, 3> z{0, 0, 0};
+    put(f, &id, 1); put(f, &present, 1); put(f, present ? it->second.data() : z.data(), 3);
+  }
+}
+
 static void write_map_state(FILE* f, const orbx::MapSnapshot& m) {
   put(f, m.kf_pose_wc.data(), m.kf_pose_wc.size());
   put(f, m.mp_pos.data(), m.mp_pos.size());
@@ -184,6 +214,46 @@ int main(int argc, char** argv) {
       const uint64_t updated = orbx::apply_inertial_ba_results(m, r);
       FILE* f = fopen(argv[4], "wb");
       put(f, &updated, 1);
+      write_map_state(f, m);
+      fclose(f);
+    } else if (mode == "gcollect") {
+      FILE* f = fopen(argv[5], "wb");
+      write_global_problem(f, orbx::collect_global_ba_data(m));
+      fclose(f);
+    } else if (mode == "gapply") {
+      const std::vector<uint8_t> b = slurp(argv[3]);                       // [nk, nm] then (id, pose7)*, (id, xyz)*
+      const uint64_t* c = (const uint64_t*)b.data();
+      const uint8_t* p = b.data() + 16;
+      orbx::GlobalBAResult r;
+      for (uint64_t i = 0; i < c[0]; ++i) {
+        uint64_t id; double v[7];
+        memcpy(&id, p, 8); memcpy(v, p + 8, 56); p += 64;
+        orbx::SE3 s; for (int q = 0; q < 4; ++q) s.rotation[q] = v[q]; for (int q = 0; q < 3; ++q) s.translation[q] = v[4 + q];
+        r.optimized_poses[id] = s;
+      }
+      for (uint64_t i = 0; i < c[1]; ++i) {
+        uint64_t id; double v[3];
+        memcpy(&id, p, 8); memcpy(v, p + 8, 24); p += 32;
+        r.optimized_points[id] = {v[0], v[1], v[2]};
+      }
+      const uint64_t updated = orbx::apply_global_ba_results(m, r);
+      FILE* f = fopen(argv[4], "wb");
+      put(f, &updated, 1);
+      write_map_state(f, m);
+      fclose(f);
+    } else if (mode == "gba") {
+      const orbx::CameraModel cam{458.654, 457.296, 367.215, 248.375, 0.11007};   // EuRoC cam0
+      orbx::Handle h(cam, 100, 0, 752, 480, 1);
+      std::atomic<bool> running{false};
+      int locks[2] = {0, 0};
+      const std::optional<orbx::GlobalBAResult> res = orbx::run_global_ba(
+          h, m, cam, orbx::GlobalBAConfig{}, running,
+          [&](const std::function<void()>& body) { ++locks[0]; body(); }, [&](const std::function<void()>& body) { ++locks[1]; body(); });
+      FILE* f = fopen(argv[5], "wb");
+      const int64_t hdr[5] = {res ? 1 : 0, res ? (int64_t)res->iterations : -1, locks[0], locks[1], running.load() ? 1 : 0};
+      put(f, hdr, 5);
+      const double err[2] = {res ? res->initial_error : 0.0, res ? res->final_error : 0.0};
+      put(f, err, 2);
       write_map_state(f, m);
       fclose(f);
     } else if (mode == "lba") {

@@ -545,3 +545,172 @@ def test_cpp_three_phase_driver(pkg, gpu_handle, tmp_path):
     py_updated, ires = pkg.local_bundle_adjustment(isnap, win_ids[-1], pkg.CameraModel(**pkg.synth.EUROC_CAMERA), handle=gpu_handle)
     assert updated == py_updated > 0 and iters == ires.iterations > 0 and rl == 2 and wl == 1
     assert np.array_equal(kf, isnap.kf_pose_wc) and np.array_equal(mp, isnap.mp_pos) and np.array_equal(vel, isnap.kf_velocity)
+
+
+# ---- global BA: collect_global_ba_data / apply_global_ba_results / run_global_ba (global_ba.rs:100-181, :421-443, :450-500) ------------
+def global_problems_equal(o, p):
+    """oracle dict problem vs api.GlobalBAProblemData, bit for bit"""
+    if o is None or p is None:
+        return o is None and p is None
+    ok = o["fixed_kf_id"] == p.fixed_kf_id and o["kf_ids"] == list(p.kf_ids) and o["mp_ids"] == list(p.mp_ids)
+    ok = ok and len(o["observations"]) == len(p.observations)
+    for a, b in zip(o["observations"], p.observations):
+        ok = ok and (a["kf_id"], a["mp_id"], a["uv"]) == (b.kf_id, b.mp_id, tuple(b.observed_uv))
+    for name in ("kf_poses", "mp_positions"):
+        A, B = o[name], getattr(p, name)
+        ok = ok and set(A) == set(B) and all(np.asarray(A[k]).tobytes() == np.asarray(B[k], np.float64).tobytes() for k in A)
+    return ok
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_global_collect_matches_reference_restatement(pkg, seed):
+    m, kf_ids, mp_ids = random_map(seed)
+    snap = snapshot_of(pkg, m)
+    o = R.collect_global_ba_data(m)
+    p = snap.collect_global_ba_data()
+    assert o is not None and global_problems_equal(o, p)
+    # the stated properties: ids ascending with the smallest one fixed (:121-124); no bad keyframe / map point; every collected map point
+    # has a collected observer (:137); every observation's keyframe is collected and its feature has a keypoint
+    assert o["kf_ids"] == sorted(o["kf_ids"]) and o["fixed_kf_id"] == o["kf_ids"][0]
+    assert all(not m.keyframes[k].is_bad for k in o["kf_ids"]) and all(not m.map_points[j].is_bad for j in o["mp_ids"])
+    assert all(any(k in o["kf_ids"] for k in m.map_points[j].observations) for j in o["mp_ids"])
+    assert len(o["observations"]) > 100 and {a["kf_id"] for a in o["observations"]} <= set(o["kf_ids"])
+    # a map whose only good keyframes see nothing: None at :146-148; no keyframe at all: None at :116-118
+    for kf in m.keyframes.values():
+        kf.map_point_ids = [None] * len(kf.map_point_ids)
+    for mp in m.map_points.values():
+        mp.observations.clear()
+    assert R.collect_global_ba_data(m) is None and snapshot_of(pkg, m).collect_global_ba_data() is None
+    assert R.collect_global_ba_data(R.Map()) is None and snapshot_of(pkg, R.Map()).collect_global_ba_data() is None
+
+
+def test_global_apply_skips_deleted_and_bad(pkg):
+    m, kf_ids, mp_ids = random_map(9)
+    snap = snapshot_of(pkg, m)
+    rng = np.random.default_rng(2)
+    poses = {k: np.concatenate([[1.0, 0, 0, 0], rng.normal(0, 1, 3)]) for k in kf_ids + [123456789]}        # every keyframe, the fixed one too, one deleted meanwhile
+    points = {j: rng.normal(0, 1, 3) for j in mp_ids[:70] + [987654321]}
+    want = R.apply_global_ba_results(m, poses, points)
+    got = snap.apply_global_ba_results(pkg.GlobalBAResult(poses, points, 3, 1.0, 0.5))
+    n_ok = sum(not m.keyframes[k].is_bad for k in kf_ids) + sum(not m.map_points[j].is_bad for j in mp_ids[:70])
+    assert got == want == n_ok < len(kf_ids) + 70
+    for i, k in enumerate(snap.kf_ids):
+        assert np.array_equal(snap.kf_pose_wc[i], m.keyframes[int(k)].pose)
+    for i, j in enumerate(snap.mp_ids):
+        assert np.array_equal(snap.mp_pos[i], m.map_points[int(j)].position)
+
+
+def _read_global_problem(b):
+    some, = struct.unpack_from("<Q", b, 0)
+    if not some:
+        return None
+    fixed, nk, nm, no = struct.unpack_from("<4Q", b, 8)
+    off = 40
+    kfs = [int(x) for x in np.frombuffer(b, np.uint64, nk, off)]; off += 8 * nk
+    mps = [int(x) for x in np.frombuffer(b, np.uint64, nm, off)]; off += 8 * nm
+    obs = []
+    for _ in range(no):
+        kid, mid = struct.unpack_from("<2Q", b, off); u, v = struct.unpack_from("<2d", b, off + 16); off += 32
+        obs.append((kid, mid, (u, v)))
+    poses = {}
+    for _ in range(nk):
+        kid, present = struct.unpack_from("<2Q", b, off); p = np.frombuffer(b, np.float64, 7, off + 16).copy(); off += 72
+        if present:
+            poses[kid] = p
+    pts = {}
+    for _ in range(nm):
+        mid, present = struct.unpack_from("<2Q", b, off); p = np.frombuffer(b, np.float64, 3, off + 16).copy(); off += 40
+        if present:
+            pts[mid] = p
+    return dict(fixed=fixed, kfs=kfs, mps=mps, obs=obs, poses=poses, pts=pts)
+
+
+def test_cpp_global_collect_and_apply_match_restatement(pkg, tmp_path):
+    """include/orbx_map.hpp's collect_global_ba_data / apply_global_ba_results compiled with g++ against the restatement."""
+    pkg.load_library()
+    tmp = str(tmp_path)
+    exe = _build(tmp)
+    for seed in (1, 4):
+        m, kf_ids, mp_ids = random_map(seed)
+        snap = snapshot_of(pkg, m)
+        open(os.path.join(tmp, "snap.bin"), "wb").write(snap.to_bytes())
+        subprocess.run([exe, "gcollect", os.path.join(tmp, "snap.bin"), "0", "0", os.path.join(tmp, "gprob.bin")], check=True)
+        got = _read_global_problem(open(os.path.join(tmp, "gprob.bin"), "rb").read())
+        o = R.collect_global_ba_data(m)
+        assert got["fixed"] == o["fixed_kf_id"] and got["kfs"] == o["kf_ids"] and got["mps"] == o["mp_ids"]
+        assert got["obs"] == [(a["kf_id"], a["mp_id"], a["uv"]) for a in o["observations"]]
+        for name, key in (("poses", "kf_poses"), ("pts", "mp_positions")):
+            assert set(got[name]) == set(o[key]) and all(got[name][k].tobytes() == np.asarray(o[key][k]).tobytes() for k in o[key])
+        rng = np.random.default_rng(seed)
+        poses = {k: np.concatenate([[1.0, 0, 0, 0], rng.normal(0, 1, 3)]) for k in kf_ids + [123456789]}
+        points = {j: rng.normal(0, 1, 3) for j in mp_ids[:70] + [987654321]}
+        with open(os.path.join(tmp, "res.bin"), "wb") as f:
+            f.write(struct.pack("<2Q", len(poses), len(points)))
+            for k, p in poses.items():
+                f.write(struct.pack("<Q", k)); f.write(np.asarray(p, np.float64).tobytes())
+            for j, p in points.items():
+                f.write(struct.pack("<Q", j)); f.write(np.asarray(p, np.float64).tobytes())
+        subprocess.run([exe, "gapply", os.path.join(tmp, "snap.bin"), os.path.join(tmp, "res.bin"), os.path.join(tmp, "applied.bin")], check=True)
+        b = open(os.path.join(tmp, "applied.bin"), "rb").read()
+        updated, = struct.unpack_from("<Q", b, 0)
+        assert updated == R.apply_global_ba_results(m, poses, points)
+        kf_pose = np.frombuffer(b, np.float64, 7 * len(snap.kf_ids), 8).reshape(-1, 7)
+        mp_pos = np.frombuffer(b, np.float64, 3 * len(snap.mp_ids), 8 + 56 * len(snap.kf_ids)).reshape(-1, 3)
+        assert all(np.array_equal(kf_pose[i], m.keyframes[int(k)].pose) for i, k in enumerate(snap.kf_ids))
+        assert all(np.array_equal(mp_pos[i], m.map_points[int(j)].position) for i, j in enumerate(snap.mp_ids))
+
+
+@pytest.mark.gpu
+def test_run_global_ba_three_phases(pkg, gpu_handle, tmp_path):
+    """run_global_ba (global_ba.rs:450-500) end to end: the product's driver over flat arrays (collect -> GPU solve -> apply, unconditionally)
+    against the restatement's driver over the dict Map fed by the same GPU solve; the running flag is set on entry and cleared on every way
+    out, and clearing it from outside (LoopCloser::stop_global_ba, loop_closer.rs:285) ends the solve at the next poll.  Then the compiled C++
+    driver: same bytes."""
+    m, ids, w = _ba_map(pkg, seed=11, K=8, M=200)
+    snap = snapshot_of(pkg, m)
+    cam = pkg.CameraModel(**w["camera"])
+    before = snap.kf_pose_wc.copy()
+    running = [False]
+    res = pkg.run_global_ba(snap, cam, pkg.GlobalBAConfig(), running, handle=gpu_handle)
+    assert res is not None and res.iterations > 0 and res.final_error < res.initial_error and running == [False]
+    assert np.array_equal(snap.kf_pose_wc[0], before[0]) and not np.array_equal(snap.kf_pose_wc[1:], before[1:])   # the smallest id is the fixed keyframe
+
+    def solve(problem, should_stop):                        # the restatement's phase 2 = the same GPU solve on ITS problem
+        p = pkg.GlobalBAProblemData(problem["kf_poses"], problem["mp_positions"],
+                                    [pkg.GlobalBAObservation(o["kf_id"], o["mp_id"], o["uv"]) for o in problem["observations"]],
+                                    problem["kf_ids"], problem["mp_ids"], problem["fixed_kf_id"])
+        r = pkg.solve_global_ba(p, cam, pkg.GlobalBAConfig(), should_stop, handle=gpu_handle)
+        return None if r is None else dict(optimized_poses=r.optimized_poses, optimized_points=r.optimized_points, iterations=r.iterations)
+    flag = [False]
+    assert R.run_global_ba(m, solve, flag)["iterations"] == res.iterations and flag == [False]
+    for i, k in enumerate(snap.kf_ids):
+        assert np.array_equal(snap.kf_pose_wc[i], m.keyframes[int(k)].pose)
+    for i, j in enumerate(snap.mp_ids):
+        assert np.array_equal(snap.mp_pos[i], m.map_points[int(j)].position)
+    # stop requested from outside while it runs: the flag is what should_stop reads; the result of the iterations that ran IS applied (:486-489)
+    m2, ids2, _ = _ba_map(pkg, seed=12, K=8, M=200)
+    snap2 = snapshot_of(pkg, m2)
+
+    class Flag(list):                                        # cleared by "another thread" as soon as the solve has started
+        def __getitem__(self, i):
+            v = list.__getitem__(self, i); list.__setitem__(self, i, False); return v
+    f2 = Flag([False])
+    r2 = pkg.run_global_ba(snap2, cam, pkg.GlobalBAConfig(), f2, handle=gpu_handle)
+    assert r2 is not None and r2.iterations < res.iterations and list(f2) == [False]
+    # an empty map: None, flag cleared
+    f3 = [False]
+    assert pkg.run_global_ba(snapshot_of(pkg, R.Map()), cam, running=f3, handle=gpu_handle) is None and f3 == [False]
+    # the compiled driver
+    tmp = str(tmp_path)
+    exe = _build(tmp)
+    m3, ids3, _ = _ba_map(pkg, seed=11, K=8, M=200)
+    snap3 = snapshot_of(pkg, m3)
+    open(os.path.join(tmp, "snap.bin"), "wb").write(snap3.to_bytes())
+    subprocess.run([exe, "gba", os.path.join(tmp, "snap.bin"), "0", "0", os.path.join(tmp, "gba.bin")], check=True)
+    b = open(os.path.join(tmp, "gba.bin"), "rb").read()
+    some, iters, rl, wl, still_running = struct.unpack_from("<5q", b, 0)
+    nk, nm = len(snap3.kf_ids), len(snap3.mp_ids)
+    kf = np.frombuffer(b, np.float64, 7 * nk, 56).reshape(-1, 7)
+    mp = np.frombuffer(b, np.float64, 3 * nm, 56 + 56 * nk).reshape(-1, 3)
+    assert some == 1 and iters == res.iterations and rl == 1 and wl == 1 and still_running == 0
+    assert np.array_equal(kf, snap.kf_pose_wc) and np.array_equal(mp, snap.mp_pos)        # C++ and Python drivers: same bytes
