@@ -2039,9 +2039,10 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
   // the cut that needs the fewest 48 x 48 blur windows (a tile's blurred rectangle is 36 larger than its keypoint rectangle).  Needs every
   // level that can hold keypoints to hold a 64 x 64 window, and at most 1024 tiles per level (rank_select_kernel's counters).
   {
-    static const bool dt_off = [] { const char* e = getenv("ORBX_DESC_TILE"); return e && atoi(e) == 0; }();
-    bool ok = !dt_off;
+    static const int dt_env = [] { const char* e = getenv("ORBX_DESC_TILE"); return e ? atoi(e) : -1; }();   // 0: never, 1: whenever admissible, unset: by the rule below
+    bool ok = dt_env != 0;
     int dt = 0;
+    long windows = 0;
     auto cut = [](int k, int tmax, int margin, int& n_out, int& t_out) {
       int best = 1 << 30;
       const int n0 = (k + tmax - 1) / tmax;
@@ -2050,6 +2051,7 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
         const int wins = n * ((t + margin + 47) / 48);
         if (wins < best) { best = wins; n_out = n; t_out = t; }
       }
+      return best;
     };
     for (int l = 0; l < p.n_levels; ++l) {
       OrbLevelGeom& L = g.lv[l];
@@ -2057,13 +2059,16 @@ int orb_prepare_geometry(orbx_handle* h, int w, int h_px) {
       L.dt_nx = L.dt_ny = 0; L.dt_tw = L.dt_th = 1; L.dt_start = dt; L.dt_mx = L.dt_my = 0;
       if (kw <= 0 || kh <= 0) continue;
       if (L.w < 64 || L.h < 64) { ok = false; continue; }
-      cut(kw, DT_TW_MAX, 39, L.dt_nx, L.dt_tw);
-      cut(kh, DT_TH_MAX, 39, L.dt_ny, L.dt_th);
+      windows += (long)cut(kw, DT_TW_MAX, 39, L.dt_nx, L.dt_tw) * cut(kh, DT_TH_MAX, 39, L.dt_ny, L.dt_th);
       if (L.dt_nx * L.dt_ny > 1024) ok = false;
       L.dt_mx = (unsigned)(0x100000000ull / (unsigned)L.dt_tw) + 1u;     // floor(n / d) = umulhi(n, floor(2^32 / d) + 1) for n, d < 2^16
       L.dt_my = (unsigned)(0x100000000ull / (unsigned)L.dt_th) + 1u;
       dt += L.dt_nx * L.dt_ny;
     }
+    // The tile form blurs `windows` windows per image whatever the keypoints, the per-keypoint form one per keypoint: per 752x480 image 734 - 758
+    // windows against 2000 keypoints (0.535 against 0.680 ms per 256 pairs), per 1920x1080 image ~4400 against 4000 (0.520 against 0.363 per 64
+    // pairs).  By the measured costs — 0.45 ns per window, 0.35 against 0.66 ns per keypoint — the forms break even at windows = 0.7 n_features.
+    if (dt_env < 0 && windows * 10 > (long)p.n_features * 7) ok = false;
     g.dt_total = ok ? dt : 0;
   }
   // resize tables
@@ -2277,7 +2282,10 @@ int orb_extract_range(orbx_handle* h, hipStream_t st, const uint8_t* d_images, i
       // level 0.153; 64 / 40 / 24 / 16 blocks per image by area: 0.146 / 0.141 / 0.144 / 0.149 (profiles/r05_harris_blocks_by_area_ab.txt).
       // ORBX_HARRIS_BLOCKS=<total per image> overrides, ORBX_HARRIS_BLOCKS=0 keeps 8 per level (A/B runs).
       HarrisPlan hp{};
-      static const int hb_total = [] { const char* e = getenv("ORBX_HARRIS_BLOCKS"); const int v = e ? atoi(e) : 40; return v >= 8 && v <= 512 ? v : 0; }();
+      // (the 40 is per 2000 features: 4000 features on 1920x1080 with 40 blocks ran 0.148 against 0.128 ms per 64 pairs with round 4's 64)
+      static const int hb_env = [] { const char* e = getenv("ORBX_HARRIS_BLOCKS"); return e ? atoi(e) : -1; }();
+      const int hb_auto = std::min(512, std::max(16, (40 * h->orb.n_features + 1000) / 2000));
+      const int hb_total = hb_env < 0 ? hb_auto : (hb_env >= 8 && hb_env <= 512 ? hb_env : 0);
       if (hb_total) {
         double area = 0;
         for (int l = 0; l < nl; ++l) area += (double)g.lv[l].w * g.lv[l].h;
