@@ -469,7 +469,8 @@ def bench_extras(P, h, torch, batches, out, args, W, H):
     # three streams) -> results in pinned host memory
     host_in = batches[0].cpu().pin_memory()
     hout = P.Handle.alloc_host_outputs(args.batch, out["cap_kp"])
-    h.process_stereo_batch_host(host_in, hout)
+    for _ in range(2):                       # (the second call still first-touches part of the pinned result buffers: 15.9 ms against 7.7 at 512 pairs)
+        h.process_stereo_batch_host(host_in, hout)
     reps = 4
     per_call = []
     t0 = time.perf_counter()
