@@ -1486,7 +1486,9 @@ __constant__ __attribute__((aligned(16))) unsigned c_blur_band[6 * 64 * 4];   //
 //   (ds_write_b8_d16_hi by inline asm — as C++ byte stores the compiler merges them back into a dword with MORE VALU work — 27 v_perm_b32
 //   fewer per keypoint, 36 LDS stores instead of 9): 0.853, the LDS pipe pays more than the VALU saves;  the test pattern as f16 pairs
 //   (one v_cvt_f32_f16 per coordinate): no change, the byte table already converts with one SDWA instruction per coordinate.
-// The kernel is bound by VALU issue: per 4 keypoints ~1250 vector instructions + 108 MFMAs that hold the issue port for 8 cycles each.
+// Round 5: the tests in describe_tile_kernel's form (32 lanes per keypoint, a lane's eight tests converted once per four keypoints, no ballot):
+//   1.366 -> 1.337 ms per 512 pairs at 752x480, 0.735 -> 0.72 per 128 pairs at 1920x1080.
+// The kernel is bound by VALU issue: per 4 keypoints ~1200 vector instructions + 108 MFMAs that hold the issue port for 8 cycles each.
 
 __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, int blocks_per_img,
                                                              const unsigned long long* __restrict__ sel2,
@@ -1531,6 +1533,7 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
     const unsigned t0 = 16u * ph + (unsigned)li, r0 = (t0 * 171u) >> 10, c6 = t0 - 6u * r0;
     st_g[ph] = r0; st_l[ph] = r0 * DF_WP + 8u * c6;                         // (st_g: row; the byte offset follows from st_l)
   }
+  const int l32 = lane & 31, hf = lane >> 5;
   for (unsigned base = (bx * 4 + wave) * DG_PER_WAVE; base < total; base += blocks_per_img * DG_PER_BLOCK) {
     const unsigned pos_raw = base + grp;
     const unsigned pos = pos_raw < total ? pos_raw : base;  // idle groups shadow the wave's first keypoint
@@ -1639,30 +1642,42 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0);   // the four patches are in LDS for the whole wave
-    const unsigned char* pbb = mywin;
-    unsigned long long word[4] = {0ull, 0ull, 0ull, 0ull};
-    const desc_f2 ca2 = {ca, ca}, sa2 = {sa, sa}, magic2 = {12582912.f, 12582912.f};
-    // byte (col + 18) * 48 + row + 18 of the column-major patch from the raw float bits: the 24-bit multiply sees 0x400000 + col, the
-    // row term carries the whole 0x4B400000 + row
-    constexpr unsigned kBias = 0x400000u * DF_WP + 0x4B400000u - (18u * DF_WP + 18u);
+    // the 256 tests, two keypoints per round (32 lanes each): a lane's eight tests — test 8 l + r, its own descriptor byte — converted once per
+    // four keypoints, the sign of t0 - t1 shifted into the byte (describe_tile_kernel's form)
+    typedef float desc_f4 __attribute__((ext_vector_type(4)));
+    desc_f4 pat[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int pr = s_pat[r * 16 + li];
-      const desc_f2 X = {(float)(signed char)(pr & 0xff), (float)(signed char)((pr >> 16) & 0xff)};
-      const desc_f2 Y = {(float)(signed char)((pr >> 8) & 0xff), (float)(signed char)((pr >> 24) & 0xff)};
-      const desc_f2 fx = X * ca2 - Y * sa2 + magic2;
-      const desc_f2 fy = X * sa2 + Y * ca2 + magic2;
-      const unsigned a0 = __umul24(__float_as_uint(fx[0]), DF_WP) + __float_as_uint(fy[0]) - kBias;
-      const unsigned a1 = __umul24(__float_as_uint(fx[1]), DF_WP) + __float_as_uint(fy[1]) - kBias;
-      const int t0 = pbb[a0];
-      const int t1 = pbb[a1];
-      const unsigned long long bal = __ballot(t0 < t1);
-      const unsigned chunk = (unsigned)(bal >> (16 * grp)) & 0xffffu;        // this keypoint's bits 16r .. 16r+15
-      word[r >> 2] |= (unsigned long long)chunk << (16 * (r & 3));
+    for (int r = 0; r < 8; ++r) {
+      const int pr = s_pat[8 * l32 + r];
+      pat[r] = (desc_f4){(float)(signed char)(pr & 0xff), (float)(signed char)((pr >> 16) & 0xff), (float)(signed char)((pr >> 8) & 0xff), (float)(signed char)((pr >> 24) & 0xff)};
     }
-    if (active && li < 4) {
-      const unsigned long long wv = li == 0 ? word[0] : li == 1 ? word[1] : li == 2 ? word[2] : word[3];
-      reinterpret_cast<unsigned long long*>(desc_out + ((size_t)img * cap_kp + slot) * 32)[li] = wv;
+    const desc_f2 magic2 = {12582912.f, 12582912.f};
+    constexpr unsigned kBias = 0x400000u * DF_WP + 0x4B400000u - (18u * DF_WP + 18u);
+    const unsigned slot_a = active ? slot : 0xffffffffu;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int kp = 2 * k2 + hf;                                  // the half-wave's keypoint of this round
+      const int from = (16 * kp) << 2;
+      const float cak = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(ca)));
+      const float sak = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(sa)));
+      const unsigned slotk = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)slot_a);
+      const desc_f2 ca2 = {cak, cak}, sa2 = {sak, sak};
+      const unsigned char* pbb = wwin + kp * DF_WIN_BYTES;
+      const unsigned kbase = 0u - kBias;
+      unsigned acc = 0;
+#pragma unroll
+      for (int r = 7; r >= 0; --r) {
+        const desc_f2 X = {pat[r][0], pat[r][1]}, Y = {pat[r][2], pat[r][3]};
+        const desc_f2 fx = X * ca2 - Y * sa2 + magic2;
+        const desc_f2 fy = X * sa2 + Y * ca2 + magic2;
+        unsigned a0, a1;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a0) : "v"(__float_as_uint(fx[0])), "v"((unsigned)DF_WP), "v"(__float_as_uint(fy[0])));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a1) : "v"(__float_as_uint(fx[1])), "v"((unsigned)DF_WP), "v"(__float_as_uint(fy[1])));
+        const unsigned t0 = pbb[a0 + kbase];
+        const unsigned t1 = pbb[a1 + kbase];
+        acc = __builtin_amdgcn_alignbit(acc, t0 - t1, 31);
+      }
+      if (slotk != 0xffffffffu) desc_out[((size_t)img * cap_kp + slotk) * 32 + l32] = (uint8_t)acc;
     }
     if (active && li == 4) {
       const float sc = g.lv[l].scale;
@@ -1689,8 +1704,9 @@ __global__ __launch_bounds__(256) void describe_fused_kernel(OrbSrc s, OrbGeom g
 //      as the per-keypoint form: a window is 64 rows x 64 bytes of the level read straight from global memory as the A operands
 //      (row 16 mb + m, bytes 16 q .. 16 q + 15: no staging) and yields 48 x 48 blurred pixels (30 MFMAs); windows sit 48 apart, the last one
 //      of a row / column pulled back inside the level (it then repeats pixels of its neighbour: same integers);
-//   2. walks the tile's keypoints four per wave as before: intensity centroid from the level (global loads: the level's bytes are not staged),
-//      angle, 256 tests on the LDS tile at (kx - ox + dx) * DT_PITCH + (ky - oy + dy).
+//   2. walks the tile's keypoints in chunks of 16 per wave: intensity centroids from the level (global loads: the level's bytes are not staged) four
+//      keypoints per round, ONE evaluation of the angle and its sin / cos for the chunk, then the 256 tests on the LDS tile at
+//      (kx - ox + dx) * DT_PITCH + (ky - oy + dy) two keypoints per round, 32 lanes each, a lane's eight tests in registers as floats.
 // Same integers as the per-keypoint blur and as the whole-level specification (A.8), so the descriptors are bit-identical; tiles without
 // keypoints return at once.  Levels too small for a 64 x 64 window use describe_fused_kernel (g.dt_total == 0).
 #ifndef ORBX_DT_NWX
@@ -1715,7 +1731,7 @@ constexpr int DT_TH_MAX = 48 * DT_NWY - 39;
 static_assert(DT_NWX >= 1 && DT_NWY >= 1 && DT_TILE_BYTES + 3072 <= 65536, "LDS per workgroup");
 __constant__ __attribute__((aligned(16))) unsigned c_blur_band_t[6 * 64 * 4];   // T1 for output-column block 0..2, T2 for output-row block 0..2 (64 real k-slots)
 
-__global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void describe_tile_kernel(OrbSrc s, OrbGeom g, int n_img, XcdMap xm, const unsigned* __restrict__ tile_tab,
                                                             const uint2* __restrict__ tile_rng,
                                                             const unsigned long long* __restrict__ sel2,
                                                             const unsigned long long* __restrict__ spatial,
@@ -1723,16 +1739,46 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
                                                             orbx_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
                                                             int* __restrict__ nkp, int cap_kp, float patch_size,
                                                             unsigned* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) unsigned char s_tile[DT_TILE_BYTES + 1024 + 2 * 1024];
-  int* s_pat = reinterpret_cast<int*>(s_tile + DT_TILE_BYTES);
-  unsigned* s_ones = reinterpret_cast<unsigned*>(s_tile + DT_TILE_BYTES + 1024);
+  __shared__ __attribute__((aligned(16))) unsigned char s_tile[DT_TILE_BYTES + 3 * 1024];
+  int* s_pat = reinterpret_cast<int*>(s_tile + DT_TILE_BYTES + 2048);
+  unsigned* s_ones = reinterpret_cast<unsigned*>(s_tile + DT_TILE_BYTES);
   unsigned* s_col = s_ones + 256;
   int img, tile;
   if (!xcd_decode(xm, n_img, img, tile)) return;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int l, tx, ty;
   decode_tile(tile_tab, tile, l, tx, ty);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- the tile's rectangle of the level (block-uniform)
+  int pitch;
+  const uint8_t* src = level_ptr(s, g, img, l, pitch);
+  const int lw = g.lv[l].w, lh = g.lv[l].h;
+  const int X0 = EDGE + tx * g.lv[l].dt_tw, X1 = min(X0 + g.lv[l].dt_tw - 1, lw - EDGE - 1);
+  const int Y0 = EDGE + ty * g.lv[l].dt_th, Y1 = min(Y0 + g.lv[l].dt_th - 1, lh - EDGE - 1);
+  const int xlim = pitch - 64, ylim = lh - 64;                  // last admissible window origin (every byte a window reads lies inside the level's rows)
+  const int ox = min(X0 - 21, xlim) & ~3;                       // origin of the first window: blurred pixel (ox + 3, oy + 3) is byte 0 of the LDS tile; xlim and 48 are multiples of 4
+  int oy = min(Y0 - 21, ylim);
+  oy -= (4 - ((ylim - oy) & 3)) & 3;                            // window rows stay dword-aligned in the tile when the last one is pulled back to ylim
+  const int nwx = min((X1 + 18 - (ox + 3) + 1 + 47) / 48, DT_NWX), nwy = min((Y1 + 18 - (oy + 3) + 1 + 47) / 48, DT_NWY);
+  // ---- the first window's loads leave before anything else is waited for (the tile's keypoint range, the list entries)
+  const int m16 = lane & 15, q = lane >> 4;
+  const df_i4* band = reinterpret_cast<const df_i4*>(c_blur_band_t) + lane;
+  const int nwin = nwx * nwy;
+  // a window's origin and its A operands (the loads of window wi + 4 travel under the products of window wi)
+  const unsigned p16 = 16u * (unsigned)pitch;
+  auto origin = [&](int wi, int& c, int& r) {
+    const int wy = wi / nwx, wx = wi - wy * nwx;              // (scalar)
+    c = min(ox + 48 * wx, xlim); r = min(oy + 48 * wy, ylim);
+  };
+  auto fetch = [&](int wi, df_i4 (&a)[4]) {
+    int c, r;
+    origin(wi, c, r);
+    unsigned off = __umul24((unsigned)(r + m16), (unsigned)pitch) + (unsigned)(c + 16 * q);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) { __builtin_memcpy(&a[mb], src + off, 16); off += p16; }
+  };
+  df_i4 anx[4];
+  if (wave < nwin) fetch(wave, anx);
   unsigned lbase = 0, total = 0;
 #pragma unroll
   for (int i = 0; i < ORBX_MAX_LEVELS; ++i) {
@@ -1751,17 +1797,6 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
   s_pat[tid] = reinterpret_cast<const int*>(c_pattern)[tid];
   s_ones[tid] = c_ic_ones[tid];
   s_col[tid] = c_ic_col[tid];
-  // ---- the tile's rectangle of the level (block-uniform)
-  int pitch;
-  const uint8_t* src = level_ptr(s, g, img, l, pitch);
-  const int lw = g.lv[l].w, lh = g.lv[l].h;
-  const int X0 = EDGE + tx * g.lv[l].dt_tw, X1 = min(X0 + g.lv[l].dt_tw - 1, lw - EDGE - 1);
-  const int Y0 = EDGE + ty * g.lv[l].dt_th, Y1 = min(Y0 + g.lv[l].dt_th - 1, lh - EDGE - 1);
-  const int xlim = pitch - 64, ylim = lh - 64;                  // last admissible window origin (every byte a window reads lies inside the level's rows)
-  const int ox = min(X0 - 21, xlim) & ~3;                       // origin of the first window: blurred pixel (ox + 3, oy + 3) is byte 0 of the LDS tile; xlim and 48 are multiples of 4
-  int oy = min(Y0 - 21, ylim);
-  oy -= (4 - ((ylim - oy) & 3)) & 3;                            // window rows stay dword-aligned in the tile when the last one is pulled back to ylim
-  const int nwx = min((X1 + 18 - (ox + 3) + 1 + 47) / 48, DT_NWX), nwy = min((Y1 + 18 - (oy + 3) + 1 + 47) / 48, DT_NWY);
   const int grp = lane >> 4, li = lane & 15;
   const size_t lofs = (size_t)img * g.cand_total + g.lv[l].cand_off;
   const unsigned ngrp = (n_kp + DG_PER_WAVE - 1) / DG_PER_WAVE;
@@ -1771,26 +1806,9 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
     return sp0[pos_raw < n_kp ? pos_raw : (gi < ngrp ? gi * DG_PER_WAVE : 0u)];   // idle groups shadow the wave's first keypoint
   };
   unsigned long long ent = entry((unsigned)wave), ent_n = entry((unsigned)wave + 4u);   // (requested here: they arrive under the blur)
+  const unsigned long long ent_2 = entry((unsigned)wave + 8u), ent_3 = entry((unsigned)wave + 12u);
   // ---- 1. the blurred rectangle, one 64 x 64 window per wave and round
   {
-    const int m16 = lane & 15, q = lane >> 4;
-    const df_i4* band = reinterpret_cast<const df_i4*>(c_blur_band_t) + lane;
-    const int nwin = nwx * nwy;
-    // a window's origin and its A operands (the loads of window wi + 4 travel under the products of window wi)
-    const unsigned p16 = 16u * (unsigned)pitch;
-    auto origin = [&](int wi, int& c, int& r) {
-      const int wy = wi / nwx, wx = wi - wy * nwx;              // (scalar)
-      c = min(ox + 48 * wx, xlim); r = min(oy + 48 * wy, ylim);
-    };
-    auto fetch = [&](int wi, df_i4 (&a)[4]) {
-      int c, r;
-      origin(wi, c, r);
-      unsigned off = __umul24((unsigned)(r + m16), (unsigned)pitch) + (unsigned)(c + 16 * q);
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) { __builtin_memcpy(&a[mb], src + off, 16); off += p16; }
-    };
-    df_i4 anx[4];
-    if (wave < nwin) fetch(wave, anx);
     // (s_setprio 1 / 3 for the blur phase, 0 for the keypoint phase: 1.07 against 1.047 ms per 512 pairs — profiles/r05_describe_tile_steps.txt)
     for (int wi = wave; wi < nwin; wi += 4) {
       int c, r;
@@ -1863,79 +1881,122 @@ __global__ __launch_bounds__(256) void describe_tile_kernel(OrbSrc s, OrbGeom g,
                ((unsigned long long)__builtin_amdgcn_alignbyte(rw[it].d[2], rw[it].d[1], sh) << 32);
 #endif
   };
-  unsigned long long px[8], pxn[8];
-  pixels(ent, px);
-  for (unsigned gi = (unsigned)wave; gi < ngrp; gi += 4) {
-    const unsigned long long ent_nn = entry(gi + 8u);
-    pixels(ent_n, pxn);
-    const unsigned pos_raw = gi * DG_PER_WAVE + (unsigned)grp;
-    const int kx = (int)(ent & 0xffffu), ky = (int)((ent >> 16) & 0xffffu);
-    const unsigned j2 = (unsigned)(ent >> 32) & 0xffffu;
-    const unsigned slot = lbase + j2;
-    const bool active = pos_raw < n_kp && slot < limit;
-    const float resp = from_orderable(~(unsigned)(sel2[lofs + j2] >> 32));   // only needed for the output record
+  // Chunks of 16 keypoints per wave:
+  //  (a) the centroid sums, four keypoints per round (16 lanes each), every group's sums of round k kept by its lane k;
+  //  (b) ONE evaluation of the angle and its f64 sin / cos for the chunk (lanes 0..3 of each group), and the keypoint records from those lanes;
+  //  (c) the 256 tests, two keypoints per round (32 lanes each): a lane keeps its eight tests — test 8 l + r, the lane's own descriptor byte —
+  //      in registers as floats (32 VGPRs, read from the LDS byte table and converted ONCE per chunk: not live under the centroid's loads; the
+  //      same floats from a global table cost 0.97 against 0.895 ms per 512 pairs — a chunk's first round waits for them) and shifts the sign
+  //      of t0 - t1 into its byte: no conversions, no pattern reads and no ballot inside the rounds.
+  typedef float desc_f4 __attribute__((ext_vector_type(4)));
+  auto centroid = [&](const unsigned long long (&px)[8], int& m10, int& m01) {
     int sA = 0, sB = 0, sC = 0;
-    {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = 4 * it + (li >> 2);
-        const int r = min(row, 30);
-        const int t0 = row * 8 + 2 * (li & 3);
-        const uint2 w1 = *reinterpret_cast<const uint2*>(&s_ones[t0]);
-        const uint2 wc = *reinterpret_cast<const uint2*>(&s_col[t0]);
-        const unsigned sI = __builtin_amdgcn_udot4((unsigned)(px[it] >> 32), w1.y, __builtin_amdgcn_udot4((unsigned)px[it], w1.x, 0u, false), false);
-        sA += (int)__builtin_amdgcn_udot4((unsigned)(px[it] >> 32), wc.y, __builtin_amdgcn_udot4((unsigned)px[it], wc.x, 0u, false), false);
-        sB += (int)sI;
-        sC += (r - 15) * (int)sI;
-      }
+    for (int it = 0; it < 8; ++it) {
+      const int row = 4 * it + (li >> 2);
+      const int r = min(row, 30);
+      const int t0 = row * 8 + 2 * (li & 3);
+      const uint2 w1 = *reinterpret_cast<const uint2*>(&s_ones[t0]);
+      const uint2 wc = *reinterpret_cast<const uint2*>(&s_col[t0]);
+      const unsigned sI = __builtin_amdgcn_udot4((unsigned)(px[it] >> 32), w1.y, __builtin_amdgcn_udot4((unsigned)px[it], w1.x, 0u, false), false);
+      sA += (int)__builtin_amdgcn_udot4((unsigned)(px[it] >> 32), wc.y, __builtin_amdgcn_udot4((unsigned)px[it], wc.x, 0u, false), false);
+      sB += (int)sI;
+      sC += (r - 15) * (int)sI;
     }
     sA = row16_sum(sA); sB = row16_sum(sB); sC = row16_sum(sC);
-    const int m10 = sA - 15 * sB, m01 = sC;
-    // (the angle and its f64 sin / cos are computed by all 16 lanes of a keypoint; computing them once per FOUR rounds — 16 keypoints, one per lane —
-    // is bounded at 1.030 -> 0.985 ms per 512 pairs by a build that skips three of four evaluations, before the broadcasts it would need: not built)
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-    float ca, sa;
-    sincos_deg(angle, ca, sa);
-    unsigned long long word[4] = {0ull, 0ull, 0ull, 0ull};
-    const desc_f2 ca2 = {ca, ca}, sa2 = {sa, sa}, magic2 = {12582912.f, 12582912.f};
+    m10 = sA - 15 * sB; m01 = sC;
+  };
+  const int l32 = lane & 31, hf = lane >> 5;
+  unsigned long long e0 = ent, e1 = ent_n, e2 = ent_2, e3 = ent_3;
+  for (unsigned g0 = (unsigned)wave; g0 < ngrp; g0 += 16) {
+    int sel10, sel01;
+    {
+      unsigned long long pxa[8], pxb[8];
+      int m10, m01;
+      pixels(e0, pxa);
+      if (g0 + 4 < ngrp) pixels(e1, pxb);
+      centroid(pxa, m10, m01);
+      sel10 = m10; sel01 = m01;                                // (lane 0 of the group is what matters of round 0; lanes 1..3 are overwritten or unused)
+      if (g0 + 4 < ngrp) {
+        if (g0 + 8 < ngrp) pixels(e2, pxa);
+        centroid(pxb, m10, m01);
+        if (li == 1) { sel10 = m10; sel01 = m01; }
+        if (g0 + 8 < ngrp) {
+          if (g0 + 12 < ngrp) pixels(e3, pxb);
+          centroid(pxa, m10, m01);
+          if (li == 2) { sel10 = m10; sel01 = m01; }
+          if (g0 + 12 < ngrp) {
+            centroid(pxb, m10, m01);
+            if (li == 3) { sel10 = m10; sel01 = m01; }
+          }
+        }
+      }
+    }
+    // the lane's tests (the index goes through an empty asm so that the reads and conversions stay inside the chunk loop)
+    int pidx = 8 * l32;
+    asm volatile("" : "+v"(pidx));
+    desc_f4 pat[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int pr = s_pat[pidx + r];
+      pat[r] = (desc_f4){(float)(signed char)(pr & 0xff), (float)(signed char)((pr >> 16) & 0xff), (float)(signed char)((pr >> 8) & 0xff), (float)(signed char)((pr >> 24) & 0xff)};
+    }
+    // (b) lane k < 4 of group grp stands for the keypoint of round k of that group
+    const unsigned long long es = li == 1 ? e1 : li == 2 ? e2 : li == 3 ? e3 : e0;
+    const unsigned j2_s = (unsigned)(es >> 32) & 0xffffu;
+    const unsigned gi_s = g0 + 4u * (unsigned)(li & 3);
+    const int kx_s = (int)(es & 0xffffu), ky_s = (int)((es >> 16) & 0xffffu);
+    const unsigned slot_s = lbase + j2_s;
+    const bool active_s = li < 4 && gi_s < ngrp && gi_s * DG_PER_WAVE + (unsigned)grp < n_kp && slot_s < limit;
+    const float resp = from_orderable(~(unsigned)(sel2[lofs + j2_s] >> 32));   // only needed for the output record
+    // the next chunk's list entries travel under the tests
+    const unsigned long long n0 = entry(g0 + 16u), n1 = entry(g0 + 20u);
+    const float angle16 = fast_atan2_deg((float)sel01, (float)sel10);
+    float ca16, sa16;
+    sincos_deg(angle16, ca16, sa16);
     // byte (kx - (ox + 3) + col) * DT_PITCH + (ky - (oy + 3) + row) of the column-major tile from the raw float bits: the 24-bit multiply sees
     // 0x400000 + col, the row term carries the whole 0x4B400000 + row
     constexpr unsigned kBias = 0x400000u * DT_PITCH + 0x4B400000u;
-    const unsigned kbase = (unsigned)((kx - (ox + 3)) * DT_PITCH + (ky - (oy + 3))) - kBias;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int pr = s_pat[r * 16 + li];
-      const desc_f2 X = {(float)(signed char)(pr & 0xff), (float)(signed char)((pr >> 16) & 0xff)};
-      const desc_f2 Y = {(float)(signed char)((pr >> 8) & 0xff), (float)(signed char)((pr >> 24) & 0xff)};
-      const desc_f2 fx = X * ca2 - Y * sa2 + magic2;
-      const desc_f2 fy = X * sa2 + Y * ca2 + magic2;
-      const unsigned a0 = __umul24(__float_as_uint(fx[0]), DT_PITCH) + __float_as_uint(fy[0]) + kbase;
-      const unsigned a1 = __umul24(__float_as_uint(fx[1]), DT_PITCH) + __float_as_uint(fy[1]) + kbase;
-      const int t0 = s_tile[a0];
-      const int t1 = s_tile[a1];
-      const unsigned long long bal = __ballot(t0 < t1);
-      const unsigned chunk = (unsigned)(bal >> (16 * grp)) & 0xffffu;        // this keypoint's bits 16r .. 16r+15
-      word[r >> 2] |= (unsigned long long)chunk << (16 * (r & 3));
-    }
-    if (active && li < 4) {
-      const unsigned long long wv = li == 0 ? word[0] : li == 1 ? word[1] : li == 2 ? word[2] : word[3];
-      reinterpret_cast<unsigned long long*>(desc_out + ((size_t)img * cap_kp + slot) * 32)[li] = wv;
-    }
-    if (active && li == 4) {
+    const unsigned kbase16 = (unsigned)((kx_s - (ox + 3)) * DT_PITCH + (ky_s - (oy + 3))) - kBias;
+    const unsigned slot16 = active_s ? slot_s : 0xffffffffu;
+    if (active_s) {
       const float sc = g.lv[l].scale;
       orbx_keypoint o;
-      o.x = __fmul_rn((float)kx, sc);
-      o.y = __fmul_rn((float)ky, sc);
+      o.x = __fmul_rn((float)kx_s, sc);
+      o.y = __fmul_rn((float)ky_s, sc);
       o.size = __fmul_rn(patch_size, sc);
-      o.angle = angle;
+      o.angle = angle16;
       o.response = resp;
       o.octave = l;
       o.class_id = -1;
-      kp_out[(size_t)img * cap_kp + slot] = o;
+      kp_out[(size_t)img * cap_kp + slot_s] = o;
     }
-    ent = ent_n; ent_n = ent_nn;
+    // (c) round k2: the half-wave hf takes the chunk's keypoint 2 k2 + hf = round k2 >> 1 of group 2 (k2 & 1) + hf
 #pragma unroll
-    for (int it = 0; it < 8; ++it) px[it] = pxn[it];
+    for (int k2 = 0; k2 < 8; ++k2) {
+      if (g0 + 4u * (unsigned)(k2 >> 1) >= ngrp) break;
+      const int from = (16 * (2 * (k2 & 1) + hf) + (k2 >> 1)) << 2;
+      const float ca = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(ca16)));
+      const float sa = __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(sa16)));
+      const unsigned kbase = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)kbase16);
+      const unsigned slot = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)slot16);
+      const desc_f2 ca2 = {ca, ca}, sa2 = {sa, sa}, magic2 = {12582912.f, 12582912.f};
+      unsigned acc = 0;
+#pragma unroll
+      for (int r = 7; r >= 0; --r) {
+        const desc_f2 X = {pat[r][0], pat[r][1]}, Y = {pat[r][2], pat[r][3]};
+        const desc_f2 fx = X * ca2 - Y * sa2 + magic2;
+        const desc_f2 fy = X * sa2 + Y * ca2 + magic2;
+        unsigned a0, a1;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a0) : "v"(__float_as_uint(fx[0])), "v"((unsigned)DT_PITCH), "v"(__float_as_uint(fy[0])));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a1) : "v"(__float_as_uint(fx[1])), "v"((unsigned)DT_PITCH), "v"(__float_as_uint(fy[1])));
+        const unsigned t0 = s_tile[a0 + kbase];
+        const unsigned t1 = s_tile[a1 + kbase];
+        acc = __builtin_amdgcn_alignbit(acc, t0 - t1, 31);       // (acc << 1) | (t0 < t1): test 8 l + r ends as bit r
+      }
+      if (slot != 0xffffffffu) desc_out[((size_t)img * cap_kp + slot) * 32 + l32] = (uint8_t)acc;
+    }
+    e0 = n0; e1 = n1; e2 = entry(g0 + 24u); e3 = entry(g0 + 28u);
   }
 }
 

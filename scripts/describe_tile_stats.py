@@ -36,7 +36,7 @@ def main():
     for (w, hh) in lv:
         nx, tw = cut(w - 62, TW_MAX, 39); ny, th = cut(hh - 62, TH_MAX, 39)
         geo.append((nx, ny, tw, th))
-    win_trips = []; grp_trips = []; empty = 0; tiles = 0; windows = 0
+    win_trips = []; grp_trips = []; empty = 0; tiles = 0; windows = 0; touched = 0; kp_hist = []; chunk_rounds = np.zeros(4)
     for i in range(pairs * 2):
         k = kp[i, :nkp[i]]
         octv = np.ascontiguousarray(k).view(np.int32)[:, 5]
@@ -57,11 +57,25 @@ def main():
                     oy = min(Y0 - 21, hh - 64); oy -= (4 - ((hh - 64 - oy) & 3)) & 3
                     nwin = min((X1 + 18 - (ox + 3) + 1 + 47) // 48, NWX) * min((Y1 + 18 - (oy + 3) + 1 + 47) // 48, NWY)
                     windows += nwin
+                    # windows some keypoint's 37 x 37 patch reaches (blurred pixel (x, y) is in window ((x - ox - 3) // 48, (y - oy - 3) // 48))
+                    nwx_ = min((X1 + 18 - (ox + 3) + 1 + 47) // 48, NWX); nwy_ = nwin // nwx_
+                    m = (t == ty * nx + tx); hit = np.zeros((nwy_, nwx_), bool)
+                    for x, y in zip(kx[m], ky[m]):
+                        hit[max((y - 18 - oy - 3) // 48, 0):min((y + 18 - oy - 3) // 48, nwy_ - 1) + 1, max((x - 18 - ox - 3) // 48, 0):min((x + 18 - ox - 3) // 48, nwx_ - 1) + 1] = True
+                    touched += int(hit.sum()); kp_hist.append(n)
                     g = (n + 3) // 4
                     for wv in range(4):
                         win_trips.append(len(range(wv, nwin, 4))); grp_trips.append(len(range(wv, g, 4)))
+                        # round 6 form: a wave's groups in chunks of four rounds; chunk_rounds[j] counts the chunks that hold a round j
+                        R = len(range(wv, g, 4))
+                        for c0 in range(0, R, 4):
+                            for j in range(min(4, R - c0)):
+                                chunk_rounds[j] += 1
     print("images %d, tiles per image %.1f, empty tiles %.3f, windows per image %.1f, keypoints per image %.1f" % (pairs * 2, tiles / (pairs * 2), empty / tiles, windows / (pairs * 2), nkp.mean()))
     print("window loop trips per wave (all waves of the launch) %.4f; keypoint-group loop trips per wave %.4f; group passes per image %.1f" % (np.mean(win_trips), np.mean(grp_trips), np.sum(grp_trips) / (pairs * 2)))
+    print("windows reached by some keypoint patch: %.1f per image (%.3f of the windows); keypoints per tile: mean %.1f, median %d, p90 %d, max %d" % (touched / (pairs * 2), touched / windows, np.mean(kp_hist), np.median(kp_hist), np.percentile(kp_hist, 90), np.max(kp_hist)))
+    nw = len(grp_trips)
+    print("chunks of four rounds per wave (all waves of the launch): %.4f; of which hold a round 1 / 2 / 3: %.4f / %.4f / %.4f" % (chunk_rounds[0] / nw, chunk_rounds[1] / chunk_rounds[0], chunk_rounds[2] / chunk_rounds[0], chunk_rounds[3] / chunk_rounds[0]))
     h.close()
 
 main()

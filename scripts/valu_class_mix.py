@@ -179,6 +179,27 @@ def analyse(items, probe, weights=None):
             raise SystemExit("no forward branch to %s" % reg["skipped_to"])
         for i in range(max(srcs) + 1, b):
             wt[i] *= float(reg["weight"])
+    # stated weights of spans between two anchors (conditional rounds of an unrolled sequence that later `break`s skip, nested skips to one label):
+    # {"from": anchor, "to": anchor, "weight": w}; an anchor is {"label": L} (the label's position) or {"branch_to": L, "nth": k} (the k-th
+    # branch to L in address order, forward or backward); the instructions strictly after `from` and before `to` are executed by the
+    # fraction w of the waves that reach `from` (spans multiply where they overlap)
+    def anchor(a):
+        if "label" in a:
+            if a["label"] not in pos:
+                raise SystemExit("span label %s not in the kernel: the code changed, restate the weights" % a["label"])
+            return pos[a["label"]]
+        br = [i for i, (op, opnd) in enumerate(ins) if op.startswith(("s_cbranch", "s_branch")) and opnd.strip().split()[0] == a["branch_to"]]
+        if a["nth"] >= len(br):
+            raise SystemExit("span anchor: branch %d to %s not in the kernel: the code changed, restate the weights" % (a["nth"], a["branch_to"]))
+        return br[a["nth"]]
+    for sp in (weights or {}).get("spans", []):
+        a, b = anchor(sp["from"]), anchor(sp["to"])
+        if not a < b:
+            raise SystemExit("span %s: anchors out of order" % sp)
+        if "instructions" in sp and sp["instructions"] != b - a - 1:
+            raise SystemExit("span %s holds %d instructions, %d stated: the code changed (labels are renumbered by any edit), restate the weights" % (sp, b - a - 1, sp["instructions"]))
+        for i in range(a + 1, b):
+            wt[i] *= float(sp["weight"])
     stat = collections.Counter(); dyn = collections.Counter(); unm_s = 0; unm_d = 0.0
     ops_dyn = collections.Counter()
     salu = 0.0; lds = 0.0; vmem = 0.0
@@ -229,6 +250,7 @@ def main():
     ap.add_argument("--pmc", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "valu_class_mix.json"))
     ap.add_argument("--show", default=None, help="print the loops of one kernel (to write its weights)")
+    ap.add_argument("--skeleton", default=None, help="print the labels and branches of one kernel with their instruction indices (to write spans)")
     ap.add_argument("--kernels", default="fast_kernel<true>,blur_kernel,resize_kernel<6>,describe_kernel,describe_fused_kernel,describe_tile_kernel,harris_select_kernel,rank_select_kernel,"
                                          "stereo_match_kernel,stereo_bucket_kernel,stereo_compact_kernel")
     args = ap.parse_args()
@@ -265,6 +287,15 @@ def main():
             res["model_vs_pmc"] = dict(pmc_valu_per_wave=round(meas, 1), model_valu_per_wave=res["valu_weighted_per_wave"]["total"],
                                        ratio=round(res["valu_weighted_per_wave"]["total"] / meas, 3))
         out["kernels"][short] = res
+        if args.skeleton and args.skeleton in name:
+            n = 0
+            for kind, pz in kernels[name]:
+                if kind == "label":
+                    print("  %5d %s:" % (n, pz))
+                else:
+                    if pz[0].startswith(("s_cbranch", "s_branch", "s_barrier", "s_endpgm")):
+                        print("  %5d     %s %s" % (n, pz[0], pz[1]))
+                    n += 1
         if args.show and args.show in name:
             print(name, "static share", res["share_2cycle_static"], "weighted", res["share_2cycle"])
             for l in res["loops"]:
