@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 
 #include "orbx_internal.hpp"
 
@@ -195,6 +196,120 @@ __global__ __launch_bounds__(SM_THREADS) void stereo_match_kernel(
       const bool emit = has && (((float)b < 0.9f * (float)s) || s == TH_HIGH);   // stereo.rs:145-148
       tmp[(size_t)pair * cap + li_[r]] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
     }
+  }
+}
+
+// The same matcher with the pair's right image resident in LDS (round 5): one 1024-thread workgroup per stereo pair copies the bucket-ordered right
+// keypoints — position, index, and the DESCRIPTORS gathered into bucket order — and the row-bucket bounds into LDS (about 107 KB at 2064 keypoints),
+// then walks the left keypoints 64 per round (sixteen lanes each, as above).  What stereo_match_kernel pays per left keypoint is a chain of six
+// dependent round trips to L2; here the chain runs on LDS, the right descriptors leave HBM once per pair (the line-granular gathers of the first
+// form fetched 4.9 times the compulsory bytes), and the group reduction is four DPP row rotations instead of twelve LDS swizzles.  Same candidate
+// sets, same order-independent top-2: the matches are bit-identical (tests/test_matcher_gpu.py, test_extract_gpu.py).  Large batches only: a pair
+// occupies ONE CU for its ~31 rounds, so a call needs at least as many pairs as CUs to fill the chip (launch_stereo_match_range picks).
+constexpr int SML_THREADS = 1024;
+#ifndef ORBX_SML_LPK
+#define ORBX_SML_LPK 4
+#endif
+// lanes per left keypoint: with LDS latencies there is no chain of L2 round trips to spread over sixteen lanes, and what a round costs beside its
+// candidates (the group reduction, the ratio test, the next keypoint's loads) is paid per group — per 512 pairs, same box: stereo_match_kernel 0.1755 ms;
+// this kernel with 16 / 8 / 4 lanes per keypoint and gates + distance in one loop body 0.1455 / 0.1206 / 0.1213; with the gates into a bit mask first
+// and the row range of vl -+ 2.01 instead of seven rows 0.1428 / 0.1110 / 0.1050 (profiles/r05_stereo_match_lds.txt)
+constexpr int SML_LPK = ORBX_SML_LPK;
+constexpr int SML_LEFT_PER_ROUND = SML_THREADS / SML_LPK;
+static_assert(SML_LPK == 4 || SML_LPK == 8 || SML_LPK == 16, "lanes per left keypoint");
+template <int CTRL>
+__device__ __forceinline__ void top2_dpp_step(unsigned& b, int& bi, unsigned& s) {
+  const unsigned ob = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+  const int obi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);
+  const unsigned os = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s, CTRL, 0xf, 0xf, false);
+  merge_top2(b, bi, s, ob, obi, os);
+}
+__global__ __launch_bounds__(SML_THREADS) void stereo_match_lds_kernel(
+    const orbx_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
+    const int* __restrict__ nkp, int cap, float max_disp, float min_disp,
+    const int* __restrict__ bstart, const int* __restrict__ sidx, const float2* __restrict__ sxy,
+    int2* __restrict__ tmp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sml_smem[];
+  uint4* s_desc = reinterpret_cast<uint4*>(sml_smem);                                  // [cap][2]
+  float2* s_xy = reinterpret_cast<float2*>(sml_smem + (size_t)cap * 32);               // [cap]
+  int* s_idx = reinterpret_cast<int*>(sml_smem + (size_t)cap * 40);                    // [cap]
+  int* s_bs = s_idx + cap;                                                             // [SB_ROWS + 1]
+  const int pair = blockIdx.x;
+  const orbx_keypoint* kpL = kp + (size_t)(2 * pair) * cap;
+  const uint8_t* dL = desc + (size_t)(2 * pair) * cap * 32;
+  const uint8_t* dR = dL + (size_t)cap * 32;
+  const int nL = min(nkp[2 * pair], cap), nR = min(nkp[2 * pair + 1], cap);
+  const int tid = threadIdx.x;
+  const int gl = tid & (SML_LPK - 1);
+  const int* bs = bstart + (size_t)pair * (SB_ROWS + 1);
+  const int* si = sidx + (size_t)pair * cap;
+  const float2* sx = sxy + (size_t)pair * cap;
+  if (nL <= 0) return;
+  // the first round's left keypoint travels under the staging
+  int li = tid / SML_LPK;
+  bool live = li < nL;
+  float2 uv = make_float2(kpL[live ? li : 0].x, kpL[live ? li : 0].y);
+  Desc256 dl = load_desc(dL + (size_t)(live ? li : 0) * 32);
+  for (int i = tid; i < nR; i += SML_THREADS) {
+    const int ix = si[i];
+    const uint4* g = reinterpret_cast<const uint4*>(dR + (size_t)ix * 32);
+    const uint4 d0 = g[0], d1 = g[1];
+    s_xy[i] = sx[i]; s_idx[i] = ix;
+    s_desc[2 * i] = d0; s_desc[2 * i + 1] = d1;
+  }
+  for (int i = tid; i <= SB_ROWS; i += SML_THREADS) s_bs[i] = bs[i];
+  __syncthreads();
+  for (;;) {
+    // the next round's left keypoint
+    const int li_n = li + SML_LEFT_PER_ROUND;
+    const bool live_n = li_n < nL;
+    const float2 uv_n = make_float2(kpL[live_n ? li_n : 0].x, kpL[live_n ? li_n : 0].y);
+    const Desc256 dl_n = load_desc(dL + (size_t)(live_n ? li_n : 0) * 32);
+    const float ul = uv.x, vl = uv.y;
+    // row buckets that can hold a candidate of the vertical gate: |vl - vr| <= 2 in f32 means vr within 2.0000003 of vl, so the buckets of
+    // vl -+ 2.01 cover it (five or six rows; stereo_match_kernel scans seven) — the gates below still decide
+    const int lo = s_bs[row_bucket(vl - 2.01f)], hi = live ? s_bs[row_bucket(vl + 2.01f) + 1] : 0;
+    const float min_u = fmaxf(ul - max_disp, 0.0f);                          // stereo.rs:100
+    const float lim = ((float)nR * ul) / (float)nL;                          // stereo.rs:102
+    const float max_u = fminf(ul - min_disp, lim);                           // stereo.rs:101
+    unsigned b = TH_HIGH, s = TH_HIGH;
+    int bi = 0x7fffffff;
+    auto gates = [&](const float2& rr) -> bool {
+      return !(fabsf(vl - rr.y) > 2.0f) &&                                   // stereo.rs:117
+             !(rr.x < min_u || rr.x > max_u) &&                              // stereo.rs:122
+             !(ul <= rr.x);                                                  // stereo.rs:127
+    };
+    auto visit = [&](int t) {
+      const uint4 a0 = s_desc[2 * t], a1 = s_desc[2 * t + 1];
+      Desc256 d1;
+      d1.w[0] = a0.x | ((unsigned long long)a0.y << 32); d1.w[1] = a0.z | ((unsigned long long)a0.w << 32);
+      d1.w[2] = a1.x | ((unsigned long long)a1.y << 32); d1.w[3] = a1.z | ((unsigned long long)a1.w << 32);
+      const unsigned d = hamming(dl, d1);
+      if (d < TH_HIGH) push_top2(b, bi, s, d, s_idx[t]);                      // stereo.rs:132-141 (d >= 100 never enters)
+    };
+    // Two steps per 32 candidates of a lane: the gates of all of them into a bit mask (a third pass), then the descriptors of the set bits only —
+    // with the gates and the distance in one loop body every lane of the wave pays for a distance whenever any lane's candidate passes
+    for (int base = lo + gl; base < hi; base += 32 * SML_LPK) {
+      unsigned mask = 0;
+      int t = base;
+      for (int k = 0; k < 32 && t < hi; ++k, t += SML_LPK) mask |= gates(s_xy[t]) ? 1u << k : 0u;
+      while (mask) {
+        const int k = __ffs((int)mask) - 1;
+        mask &= mask - 1u;
+        visit(base + SML_LPK * k);
+      }
+    }
+    // all-reduce over the group's lanes on the DPP path (the sets merged at every step are disjoint)
+    if (SML_LPK == 16) { top2_dpp_step<0x128>(b, bi, s); top2_dpp_step<0x124>(b, bi, s); top2_dpp_step<0x122>(b, bi, s); top2_dpp_step<0x121>(b, bi, s); }   // row_ror 8, 4, 2, 1
+    if (SML_LPK == 8) top2_dpp_step<0x141>(b, bi, s);                          // row_half_mirror: i <-> 7 - i
+    if (SML_LPK <= 8) { top2_dpp_step<0xB1>(b, bi, s); top2_dpp_step<0x4E>(b, bi, s); }   // quad_perm [1,0,3,2], [2,3,0,1]
+    if (gl == 0 && live) {
+      const bool has = bi != 0x7fffffff;
+      const bool emit = has && (((float)b < 0.9f * (float)s) || s == TH_HIGH);   // stereo.rs:145-148
+      tmp[(size_t)pair * cap + li] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
+    }
+    if (li_n - (li_n & (SML_LEFT_PER_ROUND - 1)) >= nL) break;                  // block-uniform: the next round holds no live group
+    li = li_n; live = live_n; uv = uv_n; dl = dl_n;
   }
 }
 
@@ -777,7 +892,16 @@ int launch_stereo_match_range(orbx_handle* h, hipStream_t st, int batch_total, i
     ProfScope ps(h, "stereo_bucket_kernel", st);
     hipLaunchKernelGGL(stereo_bucket_kernel, dim3(batch), dim3(SB_THREADS), 0, st, d_kp, d_nkp, cap_kp, bstart, sidx, sxy);
   }
-  {
+  // Large batches: the pair's right image in LDS, one workgroup per pair (stereo_match_lds_kernel); ORBX_SM_LDS=0 / 1 forces the choice (A/B runs, tests)
+  const size_t lds_need = (size_t)cap_kp * 44 + (size_t)(SB_ROWS + 1) * 4;
+  static const int sm_env = [] { const char* e = getenv("ORBX_SM_LDS"); return e ? atoi(e) : -1; }();
+  static const bool sm_attr = hipFuncSetAttribute((const void*)stereo_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  const bool use_lds = sm_attr && lds_need <= 160 * 1024 && (sm_env == 1 || (sm_env < 0 && batch >= h->n_cu));
+  if (use_lds) {
+    ProfScope ps(h, "stereo_match_kernel", st, true);
+    hipLaunchKernelGGL(stereo_match_lds_kernel, dim3(batch), dim3(SML_THREADS), lds_need, st, d_kp, d_desc, d_nkp,
+                       cap_kp, max_disp, min_disp, bstart, sidx, sxy, tmp);
+  } else {
     ProfScope ps(h, "stereo_match_kernel", st, true);
     dim3 grid((cap_kp + SM_LEFT_PER_BLOCK - 1) / SM_LEFT_PER_BLOCK, batch);
     hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(SM_THREADS), 0, st, d_kp, d_desc, d_nkp,
