@@ -144,3 +144,71 @@ def test_guided_match_ties_and_empty(gpu_handle, oracle, pkg):
     assert np.all(i1 == -1)
     i1, d1 = gpu_handle.guided_match(kp, d, 752.0, 480.0, uv[:0], dq[:0], 15.0, 0)
     assert len(i1) == 0
+
+
+def test_stereo_match_crowded_rows(gpu_handle, oracle, pkg):
+    """More right keypoints in a left keypoint's rows than one pass of the LDS matcher's candidate mask holds (32 per lane, four lanes per left
+    keypoint): 1500 right keypoints in three image rows, so every left keypoint walks several chunks of 128 candidates; and row coordinates a hair's
+    breadth inside / outside the vertical gate (|vl - vr| <= 2 in f32), which the matcher's row range of vl -+ 2.01 must still reach."""
+    cam = oracle.Camera(**pkg.synth.EUROC_CAMERA)
+    rng = np.random.default_rng(21)
+    nL, nR = 400, 1500
+    kpL = np.zeros(nL, pkg.KEYPOINT); kpR = np.zeros(nR, pkg.KEYPOINT)
+    kpL["x"] = rng.uniform(300, 740, nL).astype(np.float32); kpL["y"] = rng.uniform(99.0, 103.0, nL).astype(np.float32)
+    kpR["x"] = rng.uniform(31, 700, nR).astype(np.float32); kpR["y"] = rng.uniform(100.0, 102.999, nR).astype(np.float32)
+    dL = rng.integers(0, 256, (nL, 32), dtype=np.uint8)
+    dR = dL[rng.integers(0, nL, nR)].copy(); dR[:, :4] ^= rng.integers(0, 256, (nR, 4), dtype=np.uint8)   # distances of 0..32 bits to some left descriptor
+    m0, p0, h0 = oracle.stereo_match(cam, kpL, dL, kpR, dR)
+    m1, p1, h1 = gpu_handle.stereo_match(kpL, dL, kpR, dR)
+    assert records_equal(m0, m1) and np.array_equal(h0, h1) and np.array_equal(p0[h0 == 1], p1[h1 == 1]) and len(m0) > 50
+    # the vertical gate at its edge: vr = vl + 2 exactly, the next float above and below, and the same on the other side, across a row boundary
+    vl = np.float32(200.75)
+    edge = np.array([vl + np.float32(2.0), np.nextafter(vl + np.float32(2.0), np.float32(1e9)), np.nextafter(vl + np.float32(2.0), np.float32(0)),
+                     vl - np.float32(2.0), np.nextafter(vl - np.float32(2.0), np.float32(0)), np.nextafter(vl - np.float32(2.0), np.float32(1e9)),
+                     np.float32(203.0), np.float32(198.0), np.float32(202.9999), np.float32(198.5)], np.float32)
+    kl = np.zeros(len(edge), pkg.KEYPOINT); kr = np.zeros(len(edge), pkg.KEYPOINT)
+    kl["x"] = 400.0 + 10.0 * np.arange(len(edge)); kl["y"] = vl
+    kr["x"] = kl["x"] - 20.0; kr["y"] = edge
+    d = np.zeros((len(edge), 32), np.uint8); d[:, 0] = np.arange(len(edge))          # every pair its own descriptor: who matches whom is the gates' doing
+    m0, p0, h0 = oracle.stereo_match(cam, kl, d, kr, d)
+    m1, p1, h1 = gpu_handle.stereo_match(kl, d, kr, d)
+    assert records_equal(m0, m1) and np.array_equal(h0, h1) and np.array_equal(p0[h0 == 1], p1[h1 == 1])
+
+
+def test_stereo_match_lds_form_equals_global_form(pkg, tmp_path):
+    """stereo_match_lds_kernel (the pair's right image in LDS, what large batches run and this suite forces) against stereo_match_kernel (what calls of
+    fewer pairs than CUs run; ORBX_SM_LDS=0): same candidate sets, same order-independent top-2 — the same bytes.  Two child processes: the
+    switch is read at the first stereo-match call."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import torch
+        import orb_slam3_rust_amd as P
+        cam = P.CameraModel(**P.synth.EUROC_CAMERA)
+        out = {}
+        h = P.Handle(cam, 2000, device=0, max_w=752, max_h=480, max_batch=6)
+        for i, (nL, nR) in enumerate([(2000, 2000), (1200, 1180), (1, 1), (17, 3000), (2500, 5), (257, 2049)]):
+            kpL, dL, kpR, dR = P.synth.matcher_features(30 + i, nL, nR, P.KEYPOINT)
+            m, pts, has = h.stereo_match(kpL, dL, kpR, dR)
+            out["m%%d" %% i] = np.frombuffer(m.tobytes(), np.uint8); out["p%%d" %% i] = pts; out["h%%d" %% i] = has
+        pairs = np.stack([np.stack(P.synth.stereo_pair(5, f)) for f in range(6)])
+        o = h.alloc_batch_outputs(6, 2000 + 64)
+        h.process_stereo_batch_device(torch.from_numpy(pairs).cuda(), o)
+        h.synchronize()
+        out["bm"] = o["matches"].cpu().numpy().view(np.uint8).reshape(-1); out["bn"] = o["nmatches"].cpu().numpy()
+        out["bp"] = o["points"].cpu().numpy(); out["bh"] = o["has_point"].cpu().numpy()
+        h.close()
+        np.savez(sys.argv[1], **out)
+    """ % root)
+    res = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / ("sm%s.npz" % mode))
+        env = dict(os.environ, ORBX_SM_LDS=mode)
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=env, timeout=600)
+        res[mode] = np.load(path)
+    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 22
+    for k in res["1"].files:
+        assert np.array_equal(res["1"][k], res["0"][k]), k
+    assert int(res["1"]["bn"].min()) > 300
