@@ -224,16 +224,24 @@ __device__ __forceinline__ void top2_dpp_step(unsigned& b, int& bi, unsigned& s)
   const unsigned os = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s, CTRL, 0xf, 0xf, false);
   merge_top2(b, bi, s, ob, obi, os);
 }
+// FUSED: the whole of match_features + triangulate for the pair in this one workgroup — the counting sort of the right keypoints by row (what
+// stereo_bucket_kernel does) straight into the LDS arrays, the per-left-keypoint results in LDS, and the ordered compaction + f64 triangulation (what
+// stereo_compact_kernel does) behind the last round: one launch instead of three, the bucket tables and the (best, distance) pairs never leave the CU.
+// 52 B per keypoint + 32 KB of LDS (140 KB at 2064 keypoints); above that the three-launch form with this kernel in the middle.
+template <bool FUSED>
 __global__ __launch_bounds__(SML_THREADS) void stereo_match_lds_kernel(
     const orbx_keypoint* __restrict__ kp, const uint8_t* __restrict__ desc,
     const int* __restrict__ nkp, int cap, float max_disp, float min_disp,
     const int* __restrict__ bstart, const int* __restrict__ sidx, const float2* __restrict__ sxy,
-    int2* __restrict__ tmp) {
+    int2* __restrict__ tmp, orbx_camera cam, orbx_dmatch* __restrict__ matches,
+    int* __restrict__ nmatches, double* __restrict__ points, uint8_t* __restrict__ has_point) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sml_smem[];
   uint4* s_desc = reinterpret_cast<uint4*>(sml_smem);                                  // [cap][2]
   float2* s_xy = reinterpret_cast<float2*>(sml_smem + (size_t)cap * 32);               // [cap]
   int* s_idx = reinterpret_cast<int*>(sml_smem + (size_t)cap * 40);                    // [cap]
   int* s_bs = s_idx + cap;                                                             // [SB_ROWS + 1]
+  int* s_cur = s_bs + (SB_ROWS + 1);                                                   // FUSED: [SB_ROWS] counters / cursors, then the wave totals of the compaction
+  int2* s_tmp = reinterpret_cast<int2*>(sml_smem + (((size_t)cap * 44 + (size_t)(2 * SB_ROWS + 1) * 4 + 7) & ~(size_t)7));   // FUSED: [cap]
   const int pair = blockIdx.x;
   const orbx_keypoint* kpL = kp + (size_t)(2 * pair) * cap;
   const uint8_t* dL = desc + (size_t)(2 * pair) * cap * 32;
@@ -244,20 +252,57 @@ __global__ __launch_bounds__(SML_THREADS) void stereo_match_lds_kernel(
   const int* bs = bstart + (size_t)pair * (SB_ROWS + 1);
   const int* si = sidx + (size_t)pair * cap;
   const float2* sx = sxy + (size_t)pair * cap;
-  if (nL <= 0) return;
+  if (nL <= 0) {
+    if (FUSED && tid == 0) nmatches[pair] = 0;
+    return;
+  }
   // the first round's left keypoint travels under the staging
   int li = tid / SML_LPK;
   bool live = li < nL;
   float2 uv = make_float2(kpL[live ? li : 0].x, kpL[live ? li : 0].y);
   Desc256 dl = load_desc(dL + (size_t)(live ? li : 0) * 32);
-  for (int i = tid; i < nR; i += SML_THREADS) {
-    const int ix = si[i];
-    const uint4* g = reinterpret_cast<const uint4*>(dR + (size_t)ix * 32);
-    const uint4 d0 = g[0], d1 = g[1];
-    s_xy[i] = sx[i]; s_idx[i] = ix;
-    s_desc[2 * i] = d0; s_desc[2 * i + 1] = d1;
+  if (FUSED) {
+    // counting sort of the right keypoints by image row (stereo_bucket_kernel's steps; the order inside a bucket is what the atomics give)
+    const orbx_keypoint* kpR = kpL + cap;
+    static_assert(SB_ROWS == 4 * SML_THREADS, "four counters per thread in the scan");
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < SB_ROWS; i += SML_THREADS) s_cur[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nR; i += SML_THREADS) atomicAdd(&s_cur[row_bucket(kpR[i].y)], 1);
+    __syncthreads();
+    int c[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = s_cur[4 * tid + k]; tot += c[k]; }
+    int inc = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+    int* wsum = reinterpret_cast<int*>(s_tmp);                                          // (free until the rounds write their results)
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - tot;
+    for (int wv = 0; wv < wave; ++wv) base += wsum[wv];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s_bs[4 * tid + k] = base; s_cur[4 * tid + k] = base; base += c[k]; }
+    if (tid == SML_THREADS - 1) s_bs[SB_ROWS] = base;
+    __syncthreads();
+    for (int i = tid; i < nR; i += SML_THREADS) {
+      const float x = kpR[i].x, y = kpR[i].y;
+      const uint4* g = reinterpret_cast<const uint4*>(dR + (size_t)i * 32);
+      const uint4 d0 = g[0], d1 = g[1];
+      const int pos = atomicAdd(&s_cur[row_bucket(y)], 1);
+      s_idx[pos] = i; s_xy[pos] = make_float2(x, y);
+      s_desc[2 * pos] = d0; s_desc[2 * pos + 1] = d1;
+    }
+  } else {
+    for (int i = tid; i < nR; i += SML_THREADS) {
+      const int ix = si[i];
+      const uint4* g = reinterpret_cast<const uint4*>(dR + (size_t)ix * 32);
+      const uint4 d0 = g[0], d1 = g[1];
+      s_xy[i] = sx[i]; s_idx[i] = ix;
+      s_desc[2 * i] = d0; s_desc[2 * i + 1] = d1;
+    }
+    for (int i = tid; i <= SB_ROWS; i += SML_THREADS) s_bs[i] = bs[i];
   }
-  for (int i = tid; i <= SB_ROWS; i += SML_THREADS) s_bs[i] = bs[i];
   __syncthreads();
   for (;;) {
     // the next round's left keypoint
@@ -306,10 +351,58 @@ __global__ __launch_bounds__(SML_THREADS) void stereo_match_lds_kernel(
     if (gl == 0 && live) {
       const bool has = bi != 0x7fffffff;
       const bool emit = has && (((float)b < 0.9f * (float)s) || s == TH_HIGH);   // stereo.rs:145-148
-      tmp[(size_t)pair * cap + li] = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
+      const int2 res = emit ? make_int2(bi, (int)b) : make_int2(-1, 0);
+      if (FUSED) s_tmp[li] = res; else tmp[(size_t)pair * cap + li] = res;
     }
     if (li_n - (li_n & (SML_LEFT_PER_ROUND - 1)) >= nL) break;                  // block-uniform: the next round holds no live group
     li = li_n; live = live_n; uv = uv_n; dl = dl_n;
+  }
+  if (!FUSED) return;
+  // ordered compaction of the matches and the f64 triangulation (stereo_compact_kernel's steps over 1024 threads)
+  {
+    const orbx_keypoint* kpR = kpL + cap;
+    const int lane = tid & 63, wave = tid >> 6;
+    int* wave_tot = s_cur;                                                               // (the cursors are spent)
+    int running = 0;
+    __syncthreads();
+    for (int base = 0; base < nL; base += SML_THREADS) {
+      const int lq = base + tid;
+      int2 t = make_int2(-1, 0);
+      if (lq < nL) t = s_tmp[lq];
+      const bool flag = t.x >= 0;
+      const unsigned long long m = __ballot(flag);
+      const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_tot[wave] = __popcll(m);
+      __syncthreads();
+      int off = running, all = 0;
+      for (int w = 0; w < SML_THREADS / 64; ++w) { const int wt = wave_tot[w]; off += w < wave ? wt : 0; all += wt; }
+      if (lq < nL) {
+        uint8_t hp = 0;
+        if (flag) {
+          orbx_dmatch dm;
+          dm.query_idx = lq; dm.train_idx = t.x; dm.img_idx = 0; dm.distance = (float)t.y;
+          matches[(size_t)pair * cap + off + prefix] = dm;
+          const double lx = (double)kpL[lq].x, ly = (double)kpL[lq].y, rx = (double)kpR[t.x].x;
+          const double disparity = lx - rx;                                 // stereo.rs:204
+          if (!(fabs(disparity) < 0.5)) {                                   // stereo.rs:205
+            const double z = cam.fx * cam.baseline / disparity;             // stereo.rs:208
+            const double x = (lx - cam.cx) * z / cam.fx;                    // stereo.rs:209
+            const double y = (ly - cam.cy) * z / cam.fy;                    // stereo.rs:210
+            double* P = points + ((size_t)pair * cap + lq) * 3;
+            P[0] = x; P[1] = y; P[2] = z;
+            hp = 1;
+          }
+        }
+        if (!hp) {   // None: defined contents (zeros) so that outputs are reproducible byte for byte
+          double* P = points + ((size_t)pair * cap + lq) * 3;
+          P[0] = 0.0; P[1] = 0.0; P[2] = 0.0;
+        }
+        has_point[(size_t)pair * cap + lq] = hp;
+      }
+      running += all;
+      __syncthreads();
+    }
+    if (tid == 0) nmatches[pair] = running;
   }
 }
 
@@ -888,19 +981,29 @@ int launch_stereo_match_range(orbx_handle* h, hipStream_t st, int batch_total, i
   // stereo.rs:84-90: f64 product/quotient, then `as f32`
   const float max_disp = (float)(h->cam.fx * h->cam.baseline / 0.1);
   const float min_disp = (float)(h->cam.fx * h->cam.baseline / 40.0);
+  // Large batches: the pair's right image in LDS, one workgroup per pair (stereo_match_lds_kernel); ORBX_SM_LDS=0 / 1 forces the choice (A/B runs, tests),
+  // ORBX_SM_LDS=2 the three-launch form with the LDS matcher in the middle where the fused one would fit
+  const size_t lds_need = (size_t)cap_kp * 44 + (size_t)(SB_ROWS + 1) * 4;
+  const size_t lds_fused = (((size_t)cap_kp * 44 + (size_t)(2 * SB_ROWS + 1) * 4 + 7) & ~(size_t)7) + (size_t)cap_kp * 8;
+  static const int sm_env = [] { const char* e = getenv("ORBX_SM_LDS"); return e ? atoi(e) : -1; }();
+  static const bool sm_attr = hipFuncSetAttribute((const void*)stereo_match_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                              hipFuncSetAttribute((const void*)stereo_match_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  const bool use_lds = sm_attr && lds_need <= 160 * 1024 && (sm_env >= 1 || (sm_env < 0 && batch >= h->n_cu));
+  if (use_lds && lds_fused <= 160 * 1024 && sm_env != 2) {
+    ProfScope ps(h, "stereo_match_kernel", st, true);
+    hipLaunchKernelGGL(stereo_match_lds_kernel<true>, dim3(batch), dim3(SML_THREADS), lds_fused, st, d_kp, d_desc, d_nkp,
+                       cap_kp, max_disp, min_disp, bstart, sidx, sxy, tmp, h->cam, d_matches, d_nmatches, d_points, d_has_point);
+    ORBX_HIP(h, hipGetLastError());
+    return ORBX_OK;
+  }
   {
     ProfScope ps(h, "stereo_bucket_kernel", st);
     hipLaunchKernelGGL(stereo_bucket_kernel, dim3(batch), dim3(SB_THREADS), 0, st, d_kp, d_nkp, cap_kp, bstart, sidx, sxy);
   }
-  // Large batches: the pair's right image in LDS, one workgroup per pair (stereo_match_lds_kernel); ORBX_SM_LDS=0 / 1 forces the choice (A/B runs, tests)
-  const size_t lds_need = (size_t)cap_kp * 44 + (size_t)(SB_ROWS + 1) * 4;
-  static const int sm_env = [] { const char* e = getenv("ORBX_SM_LDS"); return e ? atoi(e) : -1; }();
-  static const bool sm_attr = hipFuncSetAttribute((const void*)stereo_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-  const bool use_lds = sm_attr && lds_need <= 160 * 1024 && (sm_env == 1 || (sm_env < 0 && batch >= h->n_cu));
   if (use_lds) {
     ProfScope ps(h, "stereo_match_kernel", st, true);
-    hipLaunchKernelGGL(stereo_match_lds_kernel, dim3(batch), dim3(SML_THREADS), lds_need, st, d_kp, d_desc, d_nkp,
-                       cap_kp, max_disp, min_disp, bstart, sidx, sxy, tmp);
+    hipLaunchKernelGGL(stereo_match_lds_kernel<false>, dim3(batch), dim3(SML_THREADS), lds_need, st, d_kp, d_desc, d_nkp,
+                       cap_kp, max_disp, min_disp, bstart, sidx, sxy, tmp, h->cam, d_matches, d_nmatches, d_points, d_has_point);
   } else {
     ProfScope ps(h, "stereo_match_kernel", st, true);
     dim3 grid((cap_kp + SM_LEFT_PER_BLOCK - 1) / SM_LEFT_PER_BLOCK, batch);

@@ -252,7 +252,7 @@ def main():
     ap.add_argument("--show", default=None, help="print the loops of one kernel (to write its weights)")
     ap.add_argument("--skeleton", default=None, help="print the labels and branches of one kernel with their instruction indices (to write spans)")
     ap.add_argument("--kernels", default="fast_kernel<true>,blur_kernel,resize_kernel<6>,describe_kernel,describe_fused_kernel,describe_tile_kernel,harris_select_kernel,rank_select_kernel,"
-                                         "stereo_match_kernel,stereo_match_lds_kernel,stereo_bucket_kernel,stereo_compact_kernel")
+                                         "stereo_match_kernel,stereo_match_lds_kernel<true>,stereo_bucket_kernel,stereo_compact_kernel")
     args = ap.parse_args()
     probe = {}
     probes_used = []

@@ -15,9 +15,10 @@ if ROOT not in sys.path:
 # measured on against the oracle; the per-keypoint form is compared with it bit for bit by test_describe_tile_form_equals_per_keypoint_form
 # (child processes with ORBX_DESC_TILE=0 / 1) and runs in smoke() and bench.py's small legs.  Read by the library when it first prepares a geometry.
 os.environ.setdefault("ORBX_DESC_TILE", "1")
-# Likewise the stereo matcher: calls of fewer pairs than CUs run stereo_match_kernel, large batches stereo_match_lds_kernel (the pair's right image in
-# LDS).  The suite forces the LDS form (it steps aside by itself where a pair's 44 bytes per keypoint + 16 KB exceed 160 KB of LDS);
-# test_stereo_match_lds_form_equals_global_form compares the two bit for bit in child processes.  Read at the first stereo-match call.
+# Likewise the stereo matcher: calls of fewer pairs than CUs run stereo_bucket / stereo_match / stereo_compact_kernel, large batches the one-launch
+# stereo_match_lds_kernel (the pair's right image in LDS).  The suite forces the LDS form (it steps aside by itself where a pair's 52 bytes per
+# keypoint + 32 KB exceed 160 KB of LDS); test_stereo_match_lds_form_equals_global_form compares the forms bit for bit in child processes.  Read at
+# the first stereo-match call.
 os.environ.setdefault("ORBX_SM_LDS", "1")
 
 

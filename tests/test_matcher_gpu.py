@@ -176,9 +176,10 @@ def test_stereo_match_crowded_rows(gpu_handle, oracle, pkg):
 
 
 def test_stereo_match_lds_form_equals_global_form(pkg, tmp_path):
-    """stereo_match_lds_kernel (the pair's right image in LDS, what large batches run and this suite forces) against stereo_match_kernel (what calls of
-    fewer pairs than CUs run; ORBX_SM_LDS=0): same candidate sets, same order-independent top-2 — the same bytes.  Two child processes: the
-    switch is read at the first stereo-match call."""
+    """stereo_match_lds_kernel (the pair's right image in LDS — bucket sort, matcher, compaction and triangulation in one workgroup per pair: what large
+    batches run and this suite forces) against the three-launch form with the LDS matcher in the middle (ORBX_SM_LDS=2) and against stereo_match_kernel
+    (what calls of fewer pairs than CUs run; ORBX_SM_LDS=0): same candidate sets, same order-independent top-2 — the same bytes.  Three child
+    processes: the switch is read at the first stereo-match call."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = textwrap.dedent("""
@@ -203,12 +204,12 @@ def test_stereo_match_lds_form_equals_global_form(pkg, tmp_path):
         np.savez(sys.argv[1], **out)
     """ % root)
     res = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "2", "0"):
         path = str(tmp_path / ("sm%s.npz" % mode))
         env = dict(os.environ, ORBX_SM_LDS=mode)
         subprocess.run([sys.executable, "-c", script, path], check=True, env=env, timeout=600)
         res[mode] = np.load(path)
-    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 22
+    assert sorted(res["1"].files) == sorted(res["0"].files) == sorted(res["2"].files) and len(res["1"].files) == 22
     for k in res["1"].files:
-        assert np.array_equal(res["1"][k], res["0"][k]), k
+        assert np.array_equal(res["1"][k], res["0"][k]) and np.array_equal(res["1"][k], res["2"][k]), k
     assert int(res["1"]["bn"].min()) > 300
