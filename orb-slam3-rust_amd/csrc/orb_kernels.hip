@@ -567,7 +567,33 @@ __device__ __forceinline__ unsigned swar_ge(unsigned a, unsigned aH /* a | 0x80.
   const unsigned d = aH - bL;                      // per byte (128 + a_lo) - b_lo >= 1: no borrow crosses a byte; bit 7 = [a_lo >= b_lo]
   return ORBX_BITOP3(a, b, d, 0xB2);               // (a & ~b) | (~(a ^ b) & d): bit 7 of every byte = [a >= b] (other bits unused)
 }
-__device__ __forceinline__ unsigned swar_compass_pass(unsigned v, unsigned r0, unsigned r4, unsigned r8, unsigned r12, unsigned T) {
+#ifndef ORBX_SWAR_SATURATED
+// The thresholds WITHOUT saturation and every comparison in the form [threshold >= r], so a ring dword is prepared once (r & 0x7f..):
+//   brighter:  r > v + t.   hi8 = (v + t) mod 256 = s ^ vH; where the byte overflows (o) nothing is brighter, and o joins the combine
+//   darker:    r < v - t  <=>  v - t - 1 >= r  where v - t - 1 >= 0 (valid), nothing is darker elsewhere; T1 = (t + 1) per byte
+// 34 instead of 42 vector instructions per dword, all in the 2-cycle class; the same positions pass (tests compare with the oracle).
+__device__ __forceinline__ unsigned swar_compass_pass(unsigned v, unsigned r0, unsigned r4, unsigned r8, unsigned r12, unsigned T, unsigned T1) {
+  const unsigned H = 0x80808080u, L = 0x7f7f7f7fu;
+  const unsigned vH = v & H;
+  const unsigned s = (v & L) + T;                  // low seven bits + t <= 0xfe: no carry crosses a byte
+  const unsigned o = ORBX_BITOP3(v, s, H, 0x80);   // v & s & H: v + t >= 256 in this byte
+  const unsigned hi = s ^ vH;                      // (v + t) mod 256
+  const unsigned hiH = s | H;                      // hi | H
+  const unsigned d = (v | H) - T1;                 // (128 + v_lo) - (t + 1) >= 0
+  const unsigned w = ORBX_BITOP3(v, d, H, 0xA8);   // (v | d) & H: v - t - 1 >= 0 in this byte
+  const unsigned lo = ORBX_BITOP3(d, vH, L, 0xE0); // d & (vH | L) = v - t - 1 where valid
+  const unsigned loH = d | H;                      // lo | H
+  const unsigned q0 = r0 & L, q4 = r4 & L, q8 = r8 & L, q12 = r12 & L;
+  const unsigned g0 = ORBX_BITOP3(hi, r0, hiH - q0, 0xB2), g8 = ORBX_BITOP3(hi, r8, hiH - q8, 0xB2);      // [v + t >= r]: not brighter
+  const unsigned g4 = ORBX_BITOP3(hi, r4, hiH - q4, 0xB2), g12 = ORBX_BITOP3(hi, r12, hiH - q12, 0xB2);
+  const unsigned f0 = ORBX_BITOP3(lo, r0, loH - q0, 0xB2), f8 = ORBX_BITOP3(lo, r8, loH - q8, 0xB2);      // [v - t - 1 >= r]: darker
+  const unsigned f4 = ORBX_BITOP3(lo, r4, loH - q4, 0xB2), f12 = ORBX_BITOP3(lo, r12, loH - q12, 0xB2);
+  const unsigned nb = ORBX_BITOP3(ORBX_BITOP3(g0, g8, o, 0xEA), g4, g12, 0xF8);    // o | (g0 & g8) | (g4 & g12): no two adjacent compass points brighter
+  const unsigned dk = ORBX_BITOP3(ORBX_BITOP3(f0, f8, w, 0xA8), f4, f12, 0xE0);    // w & (f0 | f8) & (f4 | f12): two adjacent ones darker
+  return ORBX_BITOP3(nb, dk, H, 0x8A);             // (~nb | dk) & H
+}
+#else
+__device__ __forceinline__ unsigned swar_compass_pass(unsigned v, unsigned r0, unsigned r4, unsigned r8, unsigned r12, unsigned T, unsigned) {
   const unsigned H = 0x80808080u, L = 0x7f7f7f7fu;
   const unsigned vH = v & H;
   const unsigned s = (v & L) + T;                  // low seven bits + t <= 0xfe: no carry crosses a byte
@@ -584,6 +610,17 @@ __device__ __forceinline__ unsigned swar_compass_pass(unsigned v, unsigned r0, u
   const unsigned nb = ORBX_BITOP3(g0 & g8, g4, g12, 0xF8);             // (r0 <= hi and r8 <= hi) or (r4 <= hi and r12 <= hi): not brighter
   const unsigned nd = ORBX_BITOP3(e0 & e8, e4, e12, 0xF8);             // likewise not darker
   return ORBX_BITOP3(nb, nd, H, 0x2A);             // ~(nb & nd) & H: two adjacent compass points brighter than v + t, or darker than v - t
+}
+#endif
+// One returning LDS add by the calling lane(s) as written.  (atomicAdd of a wave-uniform value under `if (lane == 0)` goes through the
+// compiler's atomic optimizer all the same: mbcnt of the one-lane exec mask, s_bcnt1, a v_mul_lo_u32 of the value by the lane's rank —
+// eleven instructions around the ds_add_rtn_u32, in every round of fast_kernel's phase 1.)
+__device__ __forceinline__ int lds_add_rtn(int* p, int v) {
+  typedef __attribute__((address_space(3))) int lds_int;
+  const unsigned a = (unsigned)(size_t)(lds_int*)p;
+  int r;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a), "v"(v) : "memory");
+  return r;
 }
 // bits 7, 15, 23, 31 -> bits 0..3
 __device__ __forceinline__ unsigned swar_movemask(unsigned p) { return (p * 0x00204081u) >> 28; }
@@ -691,6 +728,7 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
     const int ntask8 = qpr8 * ah;
     const unsigned inv8 = (unsigned)(65536.f * __builtin_amdgcn_rcpf((float)qpr8)) + 1u;   // (v_rcp_f32 is within 1 ulp: the floor is the quotient's for 1..8)
     const unsigned T = (unsigned)t * 0x01010101u;
+    const unsigned T1 = T + 0x01010101u;                             // t + 1 <= 128 per byte
     for (int task0 = 0; task0 < ntask8; task0 += FT_THREADS) {
       const int task = task0 + tid;
       unsigned m8 = 0;
@@ -702,16 +740,19 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
         const unsigned* upr = reinterpret_cast<const unsigned*>(&sp[j][8 * gq + 4]);
         const unsigned* dnr = reinterpret_cast<const unsigned*>(&sp[j + 6][8 * gq + 4]);
         const unsigned up0 = upr[0], up1 = upr[1], dn0 = dnr[0], dn1 = dnr[1];
-        const unsigned p0 = swar_compass_pass(ca.y, dn0, __builtin_amdgcn_alignbyte(cb.x, ca.y, 3), up0, __builtin_amdgcn_alignbyte(ca.y, ca.x, 1), T);
-        const unsigned p1 = swar_compass_pass(cb.x, dn1, __builtin_amdgcn_alignbyte(cb.y, cb.x, 3), up1, __builtin_amdgcn_alignbyte(cb.x, ca.y, 1), T);
-        m8 = swar_movemask(p0) | (swar_movemask(p1) << 4);
+        const unsigned p0 = swar_compass_pass(ca.y, dn0, __builtin_amdgcn_alignbyte(cb.x, ca.y, 3), up0, __builtin_amdgcn_alignbyte(ca.y, ca.x, 1), T, T1);
+        const unsigned p1 = swar_compass_pass(cb.x, dn1, __builtin_amdgcn_alignbyte(cb.y, cb.x, 3), up1, __builtin_amdgcn_alignbyte(cb.x, ca.y, 1), T, T1);
+        // bits 7, 15, 23, 31 of p0 -> bits 0..3, of p1 -> bits 4..7 by ONE multiply: (p0 >> 4) | p1 holds position b at bit 8 b + 3 and
+        // position 4 + b at bit 8 b + 7, the partial products of 0x00204081 (shifts 21 - 7 b) put them at bits 24 + b and 28 + b, no two
+        // partial products share a bit and no other one reaches bits 24..31
+        m8 = (((p0 >> 4) | p1) * 0x00204081u) >> 24;
       }
       const int cnt = __popc(m8);
       const int incl = wave_scan_incl(cnt);
       const int wtot = __builtin_amdgcn_readlane(incl, 63);
       if (wtot) {                                                    // wave-uniform
         int base = 0;
-        if (lane == 0) base = atomicAdd(&s_npos, wtot);
+        if (lane == 0) base = lds_add_rtn(&s_npos, wtot);
         int off = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
         const unsigned short pbase = (unsigned short)(j * FS_W + 8 * gq);
         for (unsigned mm = m8; mm; mm &= mm - 1u) s_pos[off++] = (unsigned short)(pbase + (__ffs((int)mm) - 1));
