@@ -546,7 +546,8 @@ static_assert(FT_H >= 8 && FT_H % 2 == 0 && FT_H <= 126, "tile height: even (2x2
 static_assert(FP_PITCH >= 72 && FP_PITCH % 8 == 0, "a pixel row holds 9 aligned 8-byte chunks (positions 0..63 at bytes 4..67, ring reach +-3)");
 static_assert(FAST_ST_RPP >= 1 && FAST_ST_RPP * FAST_ST_PASS >= FP_ROWS && FAST_ST_PASS <= 4, "the staging passes cover every pixel row with at most 4 prefetch registers");
 static_assert(8 * ((FS_W + 7) / 8) * FS_H <= FS_W * FS_H && FS_W * FS_H <= 65536, "s_pos holds every position of the score region; entries are 16 bits");
-static_assert(8 * FS_H < 65536 / 8 && 16 * FS_H < 65536 / 16, "task / tasks-per-row by the 16.16 reciprocal is exact below 65536 / tasks-per-row tasks");
+static_assert(4 * FS_H < 65536 / 4 && 16 * FS_H < 65536 / 16, "task / tasks-per-row by the 16.16 reciprocal is exact below 65536 / tasks-per-row tasks");
+static_assert(FP_PITCH >= 16 * ((FS_W + 15) / 16) + 8, "the byte-parallel pre-test reads dwords 4g .. 4g+5 of a pixel row");
 static_assert((FS_W * FS_H) % 16 == 0, "the score tile is cleared with 16-byte stores");
 static_assert(FAST_LDS_BYTES <= 65536, "LDS per block (160 KB per CU / this = resident blocks: 7 at the shipped 62 x 62, 256 threads)");
 static_assert(FAST_CHAIN >= 1 && FAST_CHAIN <= 16, "tiles per block");
@@ -721,41 +722,45 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
   if (tile + 1 < tile_end) fetch(img0, tile + 1, nxt);
   const int t = g.fast_threshold;
   if (SWAR) {
-    // phase 1, byte-parallel: a task = 8 consecutive positions of a row = the two centre dwords 2g+1, 2g+2 of LDS row j+3 (position
-    // i sits at byte i+4); the positions that pass go to the list by ONE wave prefix sum per task (count per lane, DPP scan) and a
-    // short loop over each lane's set bits — no ballot per position
-    const int qpr8 = (aw + 7) >> 3;                                  // 8-position tasks per row, 1..8
-    const int ntask8 = qpr8 * ah;
-    const unsigned inv8 = (unsigned)(65536.f * __builtin_amdgcn_rcpf((float)qpr8)) + 1u;   // (v_rcp_f32 is within 1 ulp: the floor is the quotient's for 1..8)
+    // phase 1, byte-parallel: a task = 16 consecutive positions of a row = the four centre dwords 4g+1 .. 4g+4 of LDS row j+3 (position
+    // i sits at byte i+4; dwords 4g and 4g+5 supply the x-3 / x+3 neighbours), so a full tile is ONE round of the block: one wave prefix
+    // sum, one returning LDS add and one walk over each lane's set bits per 16 positions (with 8 positions per task — two rounds — those
+    // were a quarter of the phase).  The positions that pass go to the list by the prefix sum of the lanes' counts (DPP scan) and a short
+    // loop over each lane's set bits — no ballot per position
+    const int qpr16 = (aw + 15) >> 4;                                // 16-position tasks per row, 1..4
+    const int ntask16 = qpr16 * ah;
+    const unsigned inv16 = (unsigned)(65536.f * __builtin_amdgcn_rcpf((float)qpr16)) + 1u;   // (v_rcp_f32 is within 1 ulp: the floor is the quotient's for 1..4)
     const unsigned T = (unsigned)t * 0x01010101u;
     const unsigned T1 = T + 0x01010101u;                             // t + 1 <= 128 per byte
-    for (int task0 = 0; task0 < ntask8; task0 += FT_THREADS) {
+    for (int task0 = 0; task0 < ntask16; task0 += FT_THREADS) {
       const int task = task0 + tid;
-      unsigned m8 = 0;
+      unsigned m16 = 0;
       int j = 0, gq = 0;
-      if (task < ntask8) {
-        j = (int)(__umul24((unsigned)task, inv8) >> 16); gq = task - (int)__umul24((unsigned)j, (unsigned)qpr8);
-        const uint2 ca = *reinterpret_cast<const uint2*>(&sp[j + 3][8 * gq]);            // dwords 2g, 2g+1
-        const uint2 cb = *reinterpret_cast<const uint2*>(&sp[j + 3][8 * gq + 8]);        // dwords 2g+2, 2g+3
-        const unsigned* upr = reinterpret_cast<const unsigned*>(&sp[j][8 * gq + 4]);
-        const unsigned* dnr = reinterpret_cast<const unsigned*>(&sp[j + 6][8 * gq + 4]);
-        const unsigned up0 = upr[0], up1 = upr[1], dn0 = dnr[0], dn1 = dnr[1];
-        const unsigned p0 = swar_compass_pass(ca.y, dn0, __builtin_amdgcn_alignbyte(cb.x, ca.y, 3), up0, __builtin_amdgcn_alignbyte(ca.y, ca.x, 1), T, T1);
-        const unsigned p1 = swar_compass_pass(cb.x, dn1, __builtin_amdgcn_alignbyte(cb.y, cb.x, 3), up1, __builtin_amdgcn_alignbyte(cb.x, ca.y, 1), T, T1);
+      if (task < ntask16) {
+        j = (int)(__umul24((unsigned)task, inv16) >> 16); gq = task - (int)__umul24((unsigned)j, (unsigned)qpr16);
+        const uint2* crow = reinterpret_cast<const uint2*>(&sp[j + 3][16 * gq]);           // dwords 4g .. 4g+5 (8-byte aligned: the pitch is a multiple of 8)
+        const uint2 c01 = crow[0], c23 = crow[1], c45 = crow[2];
+        const unsigned* upr = reinterpret_cast<const unsigned*>(&sp[j][16 * gq + 4]);
+        const unsigned* dnr = reinterpret_cast<const unsigned*>(&sp[j + 6][16 * gq + 4]);
+        const unsigned up0 = upr[0], up1 = upr[1], up2 = upr[2], up3 = upr[3], dn0 = dnr[0], dn1 = dnr[1], dn2 = dnr[2], dn3 = dnr[3];
+        const unsigned p0 = swar_compass_pass(c01.y, dn0, __builtin_amdgcn_alignbyte(c23.x, c01.y, 3), up0, __builtin_amdgcn_alignbyte(c01.y, c01.x, 1), T, T1);
+        const unsigned p1 = swar_compass_pass(c23.x, dn1, __builtin_amdgcn_alignbyte(c23.y, c23.x, 3), up1, __builtin_amdgcn_alignbyte(c23.x, c01.y, 1), T, T1);
+        const unsigned p2 = swar_compass_pass(c23.y, dn2, __builtin_amdgcn_alignbyte(c45.x, c23.y, 3), up2, __builtin_amdgcn_alignbyte(c23.y, c23.x, 1), T, T1);
+        const unsigned p3 = swar_compass_pass(c45.x, dn3, __builtin_amdgcn_alignbyte(c45.y, c45.x, 3), up3, __builtin_amdgcn_alignbyte(c45.x, c23.y, 1), T, T1);
         // bits 7, 15, 23, 31 of p0 -> bits 0..3, of p1 -> bits 4..7 by ONE multiply: (p0 >> 4) | p1 holds position b at bit 8 b + 3 and
         // position 4 + b at bit 8 b + 7, the partial products of 0x00204081 (shifts 21 - 7 b) put them at bits 24 + b and 28 + b, no two
         // partial products share a bit and no other one reaches bits 24..31
-        m8 = (((p0 >> 4) | p1) * 0x00204081u) >> 24;
+        m16 = ((((p0 >> 4) | p1) * 0x00204081u) >> 24) | (((((p2 >> 4) | p3) * 0x00204081u) >> 16) & 0xff00u);
       }
-      const int cnt = __popc(m8);
+      const int cnt = __popc(m16);
       const int incl = wave_scan_incl(cnt);
       const int wtot = __builtin_amdgcn_readlane(incl, 63);
       if (wtot) {                                                    // wave-uniform
         int base = 0;
         if (lane == 0) base = lds_add_rtn(&s_npos, wtot);
         int off = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
-        const unsigned short pbase = (unsigned short)(j * FS_W + 8 * gq);
-        for (unsigned mm = m8; mm; mm &= mm - 1u) s_pos[off++] = (unsigned short)(pbase + (__ffs((int)mm) - 1));
+        const unsigned short pbase = (unsigned short)(j * FS_W + 16 * gq);
+        for (unsigned mm = m16; mm; mm &= mm - 1u) s_pos[off++] = (unsigned short)(pbase + (__ffs((int)mm) - 1));
       }
     }
   } else
