@@ -989,9 +989,9 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
   // parallel suffix sum over the 256 histogram bins (thread = bin)
   {
     const int lane = tid & 63, wave = tid >> 6;
-    unsigned suf = hist[(size_t)il * 256 + tid];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_down(suf, off); if (lane + off < 64) suf += o; }
+    const unsigned hv = hist[(size_t)il * 256 + tid];
+    const int incl = wave_scan_incl((int)hv);                     // (DPP; six __shfl_down steps were six LDS round trips at the head of every block's chain)
+    unsigned suf = (unsigned)(__builtin_amdgcn_readlane(incl, 63) - incl) + hv;   // suffix sum inside the wave
     if (lane == 0) sh[wave] = suf;
     if (tid == 0) s_thr = 0;
     __syncthreads();
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) void harris_select_kernel(OrbSrc s, OrbGeom g,
       const unsigned long long m = __ballot(pass);
       if (m) {
         unsigned p0 = 0;
-        if (lane == 0) p0 = atomicAdd(&s_np, (unsigned)__popcll(m));
+        if (lane == 0) p0 = (unsigned)lds_add_rtn(reinterpret_cast<int*>(&s_np), __popcll(m));   // (as written: see lds_add_rtn)
         p0 = __builtin_amdgcn_readfirstlane(p0);
         if (pass) s_pass[p0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = c;
       }

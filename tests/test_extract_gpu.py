@@ -88,6 +88,36 @@ def test_fast_candidates_bit_exact(h2000, oracle, frame0):
             assert np.array_equal(got, want), "FAST level %d: %d vs %d candidates" % (l, len(got), len(want))
 
 
+@pytest.mark.parametrize("thr", [1, 20, 64, 126, 127])
+def test_fast_pretest_byte_edges(oracle, pkg, thr):
+    """the byte-parallel compass pre-test at the ends of its arithmetic: pixels at 0 / 255 (v + t beyond 255, v - t below 0), ring values
+    exactly at v + t, v + t + 1, v - t, v - t - 1, the sign bit of a byte on either side of every comparison — candidates of every level
+    against the oracle (oracle/orb_ref.cpp A.5)"""
+    rng = np.random.default_rng(1000 + thr)
+    h_px, w_px = 240, 320
+    base = rng.choice(np.array([0, 1, thr, thr + 1, 127, 128, 129, 254 - thr, 255 - thr, 254, 255], np.int32), size=(h_px // 8, w_px // 8))
+    img = np.kron(base, np.ones((8, 8), np.int32))
+    # isolated pixels and short runs at the exact thresholds around each cell's value
+    delta = rng.choice(np.array([-thr - 1, -thr, thr, thr + 1, 0, 0, 0, 0], np.int32), size=(h_px, w_px))
+    img = np.clip(img + np.where(rng.random((h_px, w_px)) < 0.35, delta, 0), 0, 255).astype(np.uint8)
+    img[::7, ::5] = 255
+    img[3::11, 2::9] = 0
+    h = pkg.Handle(pkg.CameraModel(**pkg.synth.EUROC_CAMERA), 600, device=0, max_w=w_px, max_h=h_px, max_batch=1, orb_params=dict(fast_threshold=thr, n_levels=4))
+    p = oracle.orb_params(600)
+    p.fast_threshold = thr
+    p.n_levels = 4
+    h.process_stereo(img, img[:, ::-1].copy(), cap_kp=20000)
+    total = 0
+    for img_i, im in enumerate((img, img[:, ::-1].copy())):
+        for l in range(4):
+            want = np.sort(oracle.orb_fast_level(im, p, l))
+            got = np.sort(h.debug_candidates(img_i, l))
+            assert np.array_equal(got, want), "threshold %d, FAST level %d: %d vs %d candidates" % (thr, l, len(got), len(want))
+            total += len(want)
+    assert total > (200 if thr <= 64 else 0)
+    h.close()
+
+
 def test_process_stereo_bit_exact(h2000, oracle, pkg, frame0):
     L, R, (kpL, dL, kpR, dR, m, pts, has) = frame0
     p = oracle.orb_params(2000)
