@@ -540,12 +540,12 @@ constexpr int FAST_ST_RPP = FT_THREADS / 9;                                   //
 constexpr int FAST_ST_PASS = (FP_ROWS + FAST_ST_RPP - 1) / FAST_ST_RPP;       // passes (one 8-byte register per pass and thread)
 constexpr int FAST_LIST_CAP = ((FT_W + 1) / 2) * ((FT_H + 1) / 2);            // 3x3-NMS survivors of a tile: at most one per 2x2 positions
 constexpr int FAST_LDS_BYTES = FP_ROWS * FP_PITCH + FS_H * FS_W + 2 * FS_W * FS_H + 4 * (FAST_LIST_CAP + 1) + 12;
-static_assert(FT_W == 62 && FS_W == 64, "a position is stored as j * 64 + i and split by >> 6 / & 63; a task is 8 positions of a 64-wide row");
+static_assert(FT_W == 62 && FS_W == 64, "a position is stored as j * 64 + i and split by >> 6 / & 63; a task is 16 positions of a 64-wide row");
 static_assert(FT_THREADS % 64 == 0 && FT_THREADS >= 128 && FT_THREADS <= 1024, "whole waves; the wave-level scans and ballots assume full waves");
 static_assert(FT_H >= 8 && FT_H % 2 == 0 && FT_H <= 126, "tile height: even (2x2 NMS bound), score rows j < 128 so that j * 64 + i fits the 16-bit list");
 static_assert(FP_PITCH >= 72 && FP_PITCH % 8 == 0, "a pixel row holds 9 aligned 8-byte chunks (positions 0..63 at bytes 4..67, ring reach +-3)");
 static_assert(FAST_ST_RPP >= 1 && FAST_ST_RPP * FAST_ST_PASS >= FP_ROWS && FAST_ST_PASS <= 4, "the staging passes cover every pixel row with at most 4 prefetch registers");
-static_assert(8 * ((FS_W + 7) / 8) * FS_H <= FS_W * FS_H && FS_W * FS_H <= 65536, "s_pos holds every position of the score region; entries are 16 bits");
+static_assert(16 * ((FS_W + 15) / 16) * FS_H <= FS_W * FS_H && FS_W * FS_H <= 65536, "s_pos holds every position of the score region; entries are 16 bits");
 static_assert(4 * FS_H < 65536 / 4 && 16 * FS_H < 65536 / 16, "task / tasks-per-row by the 16.16 reciprocal is exact below 65536 / tasks-per-row tasks");
 static_assert(FP_PITCH >= 16 * ((FS_W + 15) / 16) + 8, "the byte-parallel pre-test reads dwords 4g .. 4g+5 of a pixel row");
 static_assert((FS_W * FS_H) % 16 == 0, "the score tile is cleared with 16-byte stores");
@@ -636,7 +636,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   return v;
 }
 
-// SWAR: phase 1 in the byte-parallel form, eight positions per task (fast_threshold < 128; launch_orb_extract picks the variant)
+// SWAR: phase 1 in the byte-parallel form, sixteen positions per task (fast_threshold < 128; launch_orb_extract picks the variant)
 // (waves_per_eu(8, 8) keeps the register allocator at 64 VGPRs although 21 KB of LDS admit 7 blocks per CU: with (7, 8) it takes
 // more registers and the kernel runs 0.512 instead of 0.498 ms.  The per-(image, level) retainBest thresholds precomputed by a small
 // kernel instead of in each of harris_select_kernel's eight blocks: 0.149 -> 0.146 ms, not kept.)
