@@ -689,19 +689,26 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
   if (!xcd_decode(xm, n_img, img0, chain)) return;
   const int tile0 = chain * chain_len, tile_end = min(tile0 + chain_len, n_tiles);
   fetch(img0, tile0, cur);
-  // The append of a tile's corners to its level's list needs a returning global atomic (about 2 us); it is issued when the tile's
-  // NMS is done and consumed one phase into the NEXT tile, so only the last tile of a chain waits for it.
-  int pend_cnt = 0, pend_il = 0;
-  unsigned pend_off = 0, pend_base = 0, pend_cap = 0;
-  auto flush = [&]() {
-    for (int q = tid; q < pend_cnt; q += FT_THREADS) {
+  // The corners of a chain's tiles gather in s_list and go to their level's list TOGETHER: the append needs a returning global atomic (about
+  // 2 us) — per tile it cost 0.086 of the kernel's 0.91 ms per 512 pairs (profiles/r05_fast_phase1_steps.txt) although it was consumed one phase
+  // into the next tile.  s_list holds FAST_LIST_CAP entries; before a tile's phases 2 and 3 the gathered corners are appended first if they belong
+  // to another level or might not fit beside this tile's (at most min(npos, FAST_LIST_CAP) strict maxima: every one is a pre-test survivor).
+  int acc_cnt = 0, acc_il = 0;
+  unsigned acc_off = 0, acc_cap = 0;
+  auto append = [&]() {                                              // block-uniform: every thread calls it
+    if (tid == 0) s_base = atomicAdd(&cand_count[acc_il], (unsigned)acc_cnt);
+    __syncthreads();
+    for (int q = tid; q < acc_cnt; q += FT_THREADS) {
       const unsigned c = s_list[q];
       const unsigned slot = s_base + (unsigned)q;
       // (cannot happen: a level's list is sized for the worst case of 3x3-NMS survivors — a slot beyond it is reported, never written)
-      if (slot >= pend_cap) { atomicOr(status, ORBX_ST_INTERNAL); continue; }
-      cand[(size_t)img0 * g.cand_total + pend_off + slot] = c;
-      atomicAdd(&hist[(size_t)pend_il * 256 + (c >> 24)], 1u);
+      if (slot >= acc_cap) { atomicOr(status, ORBX_ST_INTERNAL); continue; }
+      cand[(size_t)img0 * g.cand_total + acc_off + slot] = c;
+      atomicAdd(&hist[(size_t)acc_il * 256 + (c >> 24)], 1u);
     }
+    __syncthreads();                                                 // s_list is read before phase 3 appends to it again
+    if (tid == 0) s_cnt = 0;                                         // (phase 3 sits behind another barrier)
+    acc_cnt = 0;
   };
   if (tid == 0) s_cnt = 0;
   for (int tile = tile0; tile < tile_end; ++tile) {
@@ -811,10 +818,9 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
       if (pk3) s_pos[base + __builtin_amdgcn_mbcnt_hi((unsigned)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b3, 0u))] = p0 + 3;
     }
   }
-  if (tid == 0 && pend_cnt > 0) { s_base = pend_base; s_cnt = 0; }   // (the wait for the previous tile's atomic, one phase later)
   __syncthreads();
   const int npos = s_npos;
-  flush();                                                           // previous tile's corners; phase 3 below rewrites s_list
+  if (acc_cnt > 0 && (acc_il != img * g.n_levels + l || acc_cnt + min(npos, FAST_LIST_CAP) > FAST_LIST_CAP)) append();
   // phase 2: full score of the pre-test survivors
   for (int q = tid; q < npos; q += FT_THREADS) {
     const int p = s_pos[q], j = p >> 6, i = p & 63;
@@ -867,18 +873,15 @@ __global__ __launch_bounds__(FT_THREADS) void fast_kernel(OrbSrc s, OrbGeom g, i
     }
   }
   __syncthreads();
-  pend_cnt = min(s_cnt, FAST_LIST_CAP);
-  pend_il = img * g.n_levels + l;
-  pend_off = g.lv[l].cand_off;
-  pend_cap = g.lv[l].cand_cap;
-  if (tid == 0 && pend_cnt > 0) pend_base = atomicAdd(&cand_count[pend_il], (unsigned)pend_cnt);
+  acc_cnt = min(s_cnt, FAST_LIST_CAP);                               // (s_cnt keeps counting across the chain's tiles until an append resets it)
+  acc_il = img * g.n_levels + l;
+  acc_off = g.lv[l].cand_off;
+  acc_cap = g.lv[l].cand_cap;
   // (no barrier here: the next round writes pixels, scores and s_npos before its first barrier, the position list after it, and
-  // s_cnt / s_base / s_list only after the flush above)
+  // s_cnt / s_base / s_list only behind that barrier)
   cur = nxt;
   }
-  if (tid == 0 && pend_cnt > 0) s_base = pend_base;
-  __syncthreads();
-  flush();
+  if (acc_cnt > 0) append();
 }
 
 __device__ __forceinline__ unsigned ld_u32(const uint8_t* p) {   // unaligned dword load (global_load_dword)
