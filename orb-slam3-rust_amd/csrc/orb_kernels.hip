@@ -11,7 +11,7 @@
 //                         column strips (no LDS), DPP neighbours, v_dot4 / v_dot2 taps       (A.8)
 //   fast_kernel           FAST-9/16 score + 3x3 NMS + border filter on 62x62 LDS tiles, 3 tiles per block with the next
 //                         tile's pixels prefetched: byte-parallel compass pre-test (v_bitop3_b32), compacted survivors,
-//                         arc score on f16 denormals (v_pk_minimum3/maximum3_f16), deferred append; per-level
+//                         arc score on f16 denormals (v_pk_minimum3/maximum3_f16), one append per chain; per-level
 //                         candidate lists + score histograms                                  (A.5)
 //   harris_select_kernel  retainBest(2 n_l) by FAST score via the histogram, Harris response
 //                         of the survivors                                                    (A.6)
